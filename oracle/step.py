@@ -1,0 +1,93 @@
+"""Oracle (CPU, test infrastructure only): one whole training step.
+
+Restates the loop bodies of
+  * G5/train_DiGA_gta2city_warm_up.py:197-305         (warm-up)
+  * G5/train_DiGA_gta2city_self_training.py:214-387   (self-training)
+on top of the other oracle modules, with torch autograd on CPU.  Visualisation,
+logging, data loading, the kornia augmentation and the frozen translator are
+inputs/outside the path.  Pinned by tests/golden/step.npz.
+"""
+import random
+
+import torch
+
+from . import centroids as oc
+from . import classmix as ocm
+from . import deeplab as od
+from . import losses as ol
+from . import optim as oo
+
+_FROZEN = ("bn_w", "bn_b")
+_BUFFERS = ("bn_rm", "bn_rv", "bn_nbt")
+
+
+def param_keys(arch=od.RESNET101):
+    """Keys of nn.Module.parameters() in reference order (buffers excluded)."""
+    return [k for k, (_, kind) in od.state_shapes(arch).items() if kind not in _BUFFERS]
+
+
+def trainable_keys(arch=od.RESNET101):
+    return [k for k, (_, kind) in od.state_shapes(arch).items()
+            if kind not in _BUFFERS and kind not in _FROZEN]
+
+
+def multiplicity(key):
+    """How often a trainable tensor occurs in the optimizer groups that
+    G5/model/model_noaux.py:48-77 builds."""
+    if key.startswith("final."):
+        return 1                                   # 10x group: plain parameters()
+    if key.startswith("layer0."):
+        return 2                                   # Sequential + the conv itself
+    if ".downsample." in key:
+        return 4                                   # layer, block, downsample Sequential, conv
+    return 3                                       # layer, block, conv
+
+
+def lr_scale(key):
+    return 10.0 if key.startswith("final.") else 1.0
+
+
+class Trainer:
+    """Student + EMA teacher + duplicate-aware SGD, all on state dicts."""
+
+    def __init__(self, student_sd, teacher_sd, arch=od.RESNET101, base_lr=2.5e-4, max_iter=80000,
+                 power=0.9, momentum=0.9, weight_decay=5e-4, droprate_off=True):
+        self.arch = arch if not droprate_off else od.Arch(**{**arch.__dict__, "droprate": 0.0})
+        self.s, self.t = student_sd, teacher_sd
+        self.pkeys, self.tkeys = param_keys(arch), trainable_keys(arch)
+        self.bufs = {k: torch.zeros_like(self.s[k]) for k in self.tkeys}
+        self.base_lr, self.max_iter, self.power = base_lr, max_iter, power
+        self.momentum, self.wd = momentum, weight_decay
+        self.first = True
+        with torch.no_grad():                      # create_teacher_params: copy parameters only
+            for k in self.pkeys:
+                self.t[k].copy_(self.s[k])
+
+    def _keep(self, n, width=256):
+        return torch.ones(n, width)                # dropout forced off (mask of ones, p=0)
+
+    def _sgd(self, grads, it):
+        lr = oo.poly_lr(self.base_lr, it, self.max_iter, self.power)
+        ks = self.tkeys
+        oo.sgd_step_dup([self.s[k] for k in ks], [grads[k] for k in ks], [self.bufs[k] for k in ks],
+                        [multiplicity(k) for k in ks], [lr * lr_scale(k) for k in ks],
+                        self.momentum, self.wd, first_step=self.first)
+        self.first = False
+        return lr
+
+    def warmup_step(self, it, x, x_aug, rec, labels, rng=random, lambda_seg=1.0, lambda_distil=0.5):
+        B = x.shape[0]
+        oo.ema_update([self.t[k] for k in self.pkeys], [self.s[k] for k in self.pkeys], it)
+        mix, _, _ = ocm.classmix(rec, x_aug, labels, rng)
+        cat = torch.cat([x, mix])
+        leaves = {k: self.s[k].detach().requires_grad_() for k in self.tkeys}
+        sd = {**self.s, **leaves}
+        _, _, s_lr, _ = od.forward(sd, cat, self.arch, training=True, keep_mask=self._keep(2 * B),
+                                   update_stats=True)
+        with torch.no_grad():
+            _, _, t_lr, _ = od.forward(self.t, cat, self.arch, training=True,
+                                       keep_mask=self._keep(2 * B), update_stats=True)
+        total, ce, di = ol.warmup_losses_lowres(s_lr, t_lr, labels, lambda_seg, lambda_distil)
+        grads = dict(zip(leaves.keys(), torch.autograd.grad(total, list(leaves.values()))))
+        lr = self._sgd(grads, it)
+        return {"ce": float(ce), "distil": float(di), "total": float(total), "lr": lr}

@@ -1,0 +1,514 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (read-only at /root/reference)
+on PyTorch-CPU in the build container (SURVEY.md App. C recipe).
+
+Only inputs and the reference's outputs are stored; no reference source travels.
+Run from the repo root:  python tools/gen_golden.py [names...]
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/domain_adaptation/GTA5"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+# ---- import recipe: stub the absent third-party modules, neutralise .cuda() and the download
+tv = types.ModuleType("torchvision")
+tv.models = types.ModuleType("torchvision.models")
+tv.utils = types.ModuleType("torchvision.utils")
+sys.modules.update({"torchvision": tv, "torchvision.models": tv.models,
+                    "torchvision.utils": tv.utils, "kornia": types.ModuleType("kornia")})
+sys.path.insert(0, REF)
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+import torch.utils.model_zoo as mz  # noqa: E402
+
+mz.load_url = lambda *a, **k: {}
+import warnings  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+from model.model_noaux import SegModel  # noqa: E402  (reference)
+from model.seg_model_noaux import Classifier_Module2  # noqa: E402  (reference)
+from util.loss import cross_entropy2d, distillation_loss  # noqa: E402  (reference)
+from util.utils import (adjust_learning_rate, create_teacher_params,  # noqa: E402
+                        update_teacher_params)
+from util.metrics import runningScore  # noqa: E402  (reference)
+from calc_centroids import Class_Features  # noqa: E402  (reference)
+
+from oracle import detweights, synth  # noqa: E402  (build-owned generators only)
+from oracle.deeplab import RESNET101, Arch  # noqa: E402
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def striped_labels(g, shape, n_classes=19):
+    lab = torch.randint(0, n_classes, shape, generator=g)
+    lab[:, ::5, :] = 255
+    lab[:, :, 3::11] = 255
+    return lab
+
+
+# ------------------------------------------------------------------ G-ce (KAT-1)
+def gen_ce():
+    x = torch.sin(0.01 * torch.arange(608, dtype=torch.float32)).reshape(2, 19, 4, 4).requires_grad_()
+    y = (torch.arange(32) % 19).reshape(2, 4, 4)
+    y[0, 0, :] = 255
+    loss = cross_entropy2d(x, y)
+    loss.backward()
+    g = synth.gen(0)
+    xr = (3.0 * torch.randn((2, 19, 33, 33), generator=g)).requires_grad_()
+    yr = striped_labels(g, (2, 33, 33))
+    lr = cross_entropy2d(xr, yr)
+    lr.backward()
+    # all-ignored and no-ignored edge cases
+    xe = torch.randn((1, 19, 5, 7), generator=g).requires_grad_()
+    ye = torch.full((1, 5, 7), 255, dtype=torch.int64)
+    le = cross_entropy2d(xe, ye)
+    le.backward()
+    save("ce", kat_x=x, kat_y=y, kat_loss=loss, kat_grad=x.grad,
+         x=xr, y=yr, loss=lr, grad=xr.grad,
+         allign_x=xe, allign_y=ye, allign_loss=le, allign_grad=xe.grad)
+
+
+# ------------------------------------------------------------------ G-distil (KAT-2)
+def gen_distill():
+    a = torch.arange(1216, dtype=torch.float32)
+    t = torch.cos(0.01 * a).reshape(4, 19, 4, 4)
+    s = torch.sin(0.01 * a).reshape(4, 19, 4, 4).requires_grad_()
+    loss = distillation_loss(t, s)
+    loss.backward()
+    g = synth.gen(1)
+    tr = 2.0 * torch.randn((4, 19, 33, 33), generator=g)
+    sr = (2.0 * torch.randn((4, 19, 33, 33), generator=g)).requires_grad_()
+    lr = distillation_loss(tr, sr)
+    lr.backward()
+    sq = sr.detach().clone().requires_grad_()
+    lq = distillation_loss(tr, sq, scale=0.25)
+    lq.backward()
+    save("distill", kat_t=t, kat_s=s, kat_loss=loss, kat_grad=s.grad,
+         t=tr, s=sr, loss=lr, grad=sr.grad, loss_q=lq, grad_q=sq.grad)
+
+
+# ------------------------------------------------------------------ upsample + fused loss block
+def gen_upsample():
+    g = synth.gen(2)
+    x = torch.randn((2, 19, 9, 13), generator=g)
+    up = torch.nn.Upsample(size=[65, 97], mode="bilinear", align_corners=True)
+    y = up(x)
+    # warm-up loss block at the low-res boundary: warm_up.py:267-282,299 re-enacted
+    B = 2
+    stu = (2.0 * torch.randn((2 * B, 19, 9, 13), generator=g)).requires_grad_()
+    tea = 2.0 * torch.randn((2 * B, 19, 9, 13), generator=g)
+    lab = striped_labels(g, (B, 65, 97))
+    s_up, t_up = up(stu), up(tea)
+    ce = cross_entropy2d(s_up[:B], lab)
+    di = distillation_loss(t_up, s_up)
+    total = 1.0 * ce + 0.5 * di
+    total.backward()
+    save("upsample", x=x, y=y, stu=stu, tea=tea, lab=lab, ce=ce, distil=di, total=total,
+         grad_stu=stu.grad)
+
+
+# ------------------------------------------------------------------ G-ema (KAT-4)
+def gen_ema():
+    class Net(torch.nn.Module):
+        def __init__(self, seed):
+            super().__init__()
+            g = synth.gen(seed)
+            self.a = torch.nn.Parameter(torch.randn((7, 5), generator=g))
+            self.b = torch.nn.Parameter(torch.randn((1031,), generator=g))
+            self.c = torch.nn.Parameter(torch.randn((3, 4, 3, 3), generator=g))
+            self.register_buffer("buf", torch.randn((4,), generator=g))
+
+    its = [0, 1, 2, 9, 998, 999, 1000, 5000]
+    alphas = [min(1 - 1 / (i + 1), 0.999) for i in its]
+    out = {"its": np.array(its), "alphas": np.array(alphas, dtype=np.float64)}
+    stu, tea = Net(10), Net(11)
+    out.update(s_a=stu.a.detach().clone(), s_b=stu.b.detach().clone(), s_c=stu.c.detach().clone(),
+               t_a=tea.a.detach().clone(), t_b=tea.b.detach().clone(), t_c=tea.c.detach().clone(),
+               t_buf=tea.buf.clone())
+    # sequence: before update k the student moves by +0.01*(k+1) (stand-in for an SGD step)
+    for k, i in enumerate(its):
+        with torch.no_grad():
+            for p in stu.parameters():
+                p.add_(0.01 * (k + 1))
+            update_teacher_params(tea, stu, i)
+        out.update({f"t_a_{k}": tea.a.detach().clone(), f"t_b_{k}": tea.b.detach().clone(),
+                    f"t_c_{k}": tea.c.detach().clone()})
+    out["t_buf_after"] = tea.buf.clone()
+    tea2 = Net(12)
+    buf_before = tea2.buf.clone()
+    create_teacher_params(tea2, stu)
+    out.update(created_equal=np.array([bool(torch.equal(tea2.a, stu.a) and torch.equal(tea2.b, stu.b)
+                                            and torch.equal(tea2.c, stu.c))]),
+               created_buf_untouched=np.array([bool(torch.equal(tea2.buf, buf_before))]))
+    save("ema", **out)
+
+
+# ------------------------------------------------------------------ G-sgd (App. A-9)
+def gen_sgd():
+    g = synth.gen(3)
+    shapes = [(5, 3), (17,), (2, 3, 3, 3), (9,)]
+    mults = [1, 3, 4, 2]
+    groups = [0, 0, 0, 1]                       # last tensor sits in the 10x group
+    p0 = [torch.randn(s, generator=g) for s in shapes]
+    params = [torch.nn.Parameter(p.clone()) for p in p0]
+    g1x = [p for p, m, gr in zip(params, mults, groups) if gr == 0 for _ in range(m)]
+    g10x = [p for p, m, gr in zip(params, mults, groups) if gr == 1 for _ in range(m)]
+    opt = torch.optim.SGD([{"params": g1x, "lr": 2.5e-4}, {"params": g10x, "lr": 2.5e-3}],
+                          lr=2.5e-4, momentum=0.9, weight_decay=5e-4)
+    out = {"mults": np.array(mults), "groups": np.array(groups)}
+    for i, p in enumerate(p0):
+        out[f"p0_{i}"] = p
+    for step in range(3):
+        adjust_learning_rate([opt], base_lr=2.5e-4, i_iter=step, max_iter=100, power=0.9)
+        out[f"lr_{step}"] = np.array([opt.param_groups[0]["lr"], opt.param_groups[1]["lr"]])
+        for i, p in enumerate(params):
+            p.grad = torch.randn(p.shape, generator=g)
+            out[f"g{step}_{i}"] = p.grad.clone()
+        opt.step()
+        for i, p in enumerate(params):
+            out[f"p{step + 1}_{i}"] = p.detach().clone()
+            out[f"buf{step + 1}_{i}"] = opt.state[p]["momentum_buffer"].clone()
+    # scalar known-answer of App. A-9: p=1,g=2,lr=.1,wd=.01,k=3
+    q = torch.nn.Parameter(torch.ones(1))
+    o2 = torch.optim.SGD([{"params": [q, q, q]}], lr=0.1, momentum=0.9, weight_decay=0.01)
+    ka = []
+    for _ in range(2):
+        q.grad = torch.full((1,), 2.0)
+        o2.step()
+        ka.append(float(q))
+    out["kat_scalar"] = np.array(ka)
+    save("sgd", **out)
+
+
+# ------------------------------------------------------------------ G-classmix (KAT-6)
+def gen_classmix():
+    g = synth.gen(4)
+    B, H, W = 2, 64, 64
+    labels = synth.block_labels(g, B, H, W, block=8, ignore_frac=0.02)
+    labels[1][labels[1] == 255] = 3            # image 1 has no ignore pixels
+    bg = torch.randn((B, 3, H, W), generator=g)        # translated image / aug target
+    fg = torch.randn((B, 3, H, W), generator=g)        # aug source
+    bg_lab = synth.block_labels(g, B, H, W, block=16, ignore_frac=0.1)   # filtered pseudo-labels
+    random.seed(0)
+    kat6 = random.sample([0, 1, 2, 5, 8, 10, 13, 255], 4)
+    # re-enactment of the inline block (warm_up.py:240-259 / self_training.py:306-325)
+    random.seed(1234)
+    mask = torch.zeros(labels.size())
+    mixed_lab = bg_lab.clone()
+    chosen = []
+    for i in range(B):
+        present = torch.unique(labels[i]).tolist()
+        pick = random.sample(present, len(present) // 2)
+        if 255 not in pick:
+            pick.append(255)
+        chosen.append(pick)
+        for c in pick:
+            mixed_lab[i][labels[i] == c] = c
+            mask[i][labels[i] == c] = 1
+    mixed = torch.zeros(bg.size())
+    for i in range(B):
+        mixed[i] = torch.mul(bg[i], 1 - mask[i]) + torch.mul(fg[i], mask[i])
+    sel = np.full((B, 24), -1, dtype=np.int64)
+    for i, pick in enumerate(chosen):
+        sel[i, :len(pick)] = pick
+    save("classmix", labels=labels, bg=bg, fg=fg, bg_lab=bg_lab, kat6=np.array(kat6),
+         seed=np.array([1234]), sel=sel, mask=mask, mixed=mixed, mixed_lab=mixed_lab.long())
+
+
+# ------------------------------------------------------------------ G-centroid (KAT-3)
+def gen_centroid():
+    cf = Class_Features(numbers=19)
+    f = torch.sin(0.001 * torch.arange(2304, dtype=torch.float32)).reshape(1, 256, 3, 3)
+    c = torch.cos(0.01 * torch.arange(4864, dtype=torch.float32)).reshape(19, 256)
+    cf.objective_vectors = c.clone()
+    w_kat = cf.get_centroid_weight(f)
+    up5 = torch.nn.Upsample(size=[5, 5], mode="bilinear", align_corners=True)
+    kat_arg = up5(w_kat).max(1, keepdim=True)[1].squeeze(1)
+    g = synth.gen(5)
+    cents = torch.randn((19, 256), generator=g)
+    # features clustered around centroids so that weights are not degenerate
+    cls_map = torch.randint(0, 19, (2, 17, 17), generator=g)
+    feat = cents[cls_map].permute(0, 3, 1, 2).contiguous() * 0.6 + 0.7 * torch.randn((2, 256, 17, 17), generator=g)
+    cf.objective_vectors = cents.clone()
+    w = cf.get_centroid_weight(feat)
+    dist = cf.get_centroid_distance(feat)
+    up = torch.nn.Upsample(size=[128, 128], mode="bilinear", align_corners=True)
+    pseudo_prob = synth.block_labels(g, 2, 128, 128, block=8, ignore_frac=0.05)
+    # agree with the centroid label on ~half of the pixels
+    wup = up(w)
+    feat_pseudo = wup.max(1, keepdim=True)[1].squeeze(1)
+    agree = torch.rand((2, 128, 128), generator=g) < 0.5
+    pseudo_prob = torch.where(agree, feat_pseudo, pseudo_prob)
+    pseudo = pseudo_prob.clone()
+    pseudo[pseudo_prob != feat_pseudo] = 255
+    top2 = wup.topk(2, dim=1)[0]
+    save("centroid", kat_f=f, kat_c=c, kat_w=w_kat, kat_arg=kat_arg,
+         feat=feat, cents=cents, w=w, neg_dist=dist, pseudo_prob=pseudo_prob,
+         feat_pseudo=feat_pseudo, pseudo=pseudo, margin=(top2[:, 0] - top2[:, 1]))
+
+
+# ------------------------------------------------------------------ G-meanvec (KAT-5)
+def gen_meanvec():
+    g = synth.gen(6)
+    cf = Class_Features(numbers=19)
+    cents = torch.randn((19, 256), generator=g)
+    cf.objective_vectors = cents.clone()
+    cf.objective_vectors_num = torch.zeros([19])
+    N, h, w = 2, 17, 17
+    feat = torch.randn((N, 256, h, w), generator=g)
+    out = torch.randn((N, 19, h, w), generator=g)
+    # coarse class structure so that several classes pass the >=5 px rule, some don't
+    blocks = torch.randint(0, 19, (N, 5, 5), generator=g).repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :h, :w]
+    out.scatter_add_(1, blocks[:, None], torch.full((N, 1, h, w), 6.0))
+    full_lab = synth.block_labels(g, N, 128, 128, block=16, ignore_frac=0.05)
+    argm = out.argmax(1)
+    lab_lr = F.interpolate(full_lab.reshape(N, 1, 128, 128).float(), size=(h, w), mode="nearest")
+    take = torch.rand((N, 1, h, w), generator=g) < 0.3
+    lab_lr = torch.where(take, argm[:, None].float(), lab_lr)
+    res = {}
+    for tag, labels in (("nolab", None), ("lab", lab_lr)):
+        vecs, ids = cf.calculate_mean_vector(feat, out, labels)
+        res[f"{tag}_ids"] = np.array(ids, dtype=np.int64)
+        res[f"{tag}_vecs"] = (torch.stack([v.reshape(256) for v in vecs]) if vecs
+                              else torch.zeros((0, 256)))
+        cf.objective_vectors = cents.clone()
+        cf.objective_vectors_num = torch.zeros([19])
+        for t in range(len(ids)):
+            cf.update_objective_SingleVector(ids[t], vecs[t].detach(), start_mean=False)
+        res[f"{tag}_cents"] = cf.objective_vectors.clone()
+        res[f"{tag}_nums"] = cf.objective_vectors_num.clone()
+    # 'mean' mode of the offline pass (calc_centroids.py:78-79)
+    cf.objective_vectors = torch.zeros([19, 256])
+    cf.objective_vectors_num = torch.zeros([19])
+    vecs, ids = cf.calculate_mean_vector(feat, out)
+    for rep in range(2):
+        for t in range(len(ids)):
+            cf.update_objective_SingleVector(ids[t], vecs[t].detach().cpu().numpy(), "mean")
+    res["mean_cents"] = cf.objective_vectors.clone()
+    res["mean_nums"] = cf.objective_vectors_num.clone()
+    # nearest label downsample pin (App. A-3)
+    res["full_lab"] = full_lab
+    res["near_lr"] = F.interpolate(full_lab.reshape(N, 1, 128, 128).float(), size=(h, w), mode="nearest")
+    save("meanvec", feat=feat, out=out, lab_lr=lab_lr, cents=cents, **res)
+
+
+# ------------------------------------------------------------------ G-aspp
+def _fill_module(mod, prefix):
+    sd = mod.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if v.dim() == 4:
+            kind = "conv"
+        elif v.dim() == 2:
+            kind = "lin"
+        elif k.endswith("weight"):
+            kind = "gn_w"
+        else:
+            kind = "bias"
+        new[k] = detweights.fill(prefix + k, tuple(v.shape), kind)
+    mod.load_state_dict(new)
+    return new
+
+
+def gen_aspp():
+    torch.manual_seed(0)
+    head = Classifier_Module2(64, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    sd = _fill_module(head, "aspp64.")
+    head.eval()
+    g = synth.gen(7)
+    x = torch.randn((2, 64, 33, 29), generator=g).requires_grad_()
+    res = head(x, get_feat=True)
+    out, feat = res["out"], res["feat"]
+    probe = torch.randn(out.shape, generator=g)
+    probe_f = 0.1 * torch.randn(feat.shape, generator=g)
+    ((out * probe).sum() + (feat * probe_f).sum()).backward()
+    grads = {}
+    for k, p in head.named_parameters():
+        key = "gw_" + k.replace(".", "_")
+        if p.grad.numel() <= 20000:
+            grads[key] = p.grad
+        else:       # large conv weights: checksum, L1 norm and a strided sample keep the fixture small
+            grads[key + "__sum"] = np.array([synth.checksum(p.grad), float(p.grad.abs().sum())])
+            grads[key + "__sample"] = p.grad.reshape(-1)[::97].clone()
+    save("aspp", x=x, out=out, feat=feat, probe=probe, probe_f=probe_f, gx=x.grad, **grads)
+
+
+# ------------------------------------------------------------------ G-model
+def _ref_model():
+    m = SegModel()
+    sd = detweights.state_dict(RESNET101)
+    missing = set(m.state_dict().keys()) ^ set(sd.keys())
+    assert not missing, sorted(missing)[:5]
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd)
+    return m
+
+
+def gen_model():
+    m = _ref_model()
+    names = list(m.state_dict().keys())
+    pnames = [n for n, _ in m.named_parameters()]
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    m.eval()
+    g = synth.gen(8)
+    x = torch.rand((2, 3, 128, 128), generator=g) * 2 - 1
+    with torch.no_grad():
+        sh, dp, out, feat = m(x)
+    res = dict(x=x, out_eval=out, feat_eval=feat,
+               shallow_sum=np.array(synth.checksum(sh)), deep_sum=np.array(synth.checksum(dp)),
+               shallow_shape=np.array(sh.shape), deep_shape=np.array(dp.shape))
+    # train mode: batch-stat BN, dropout forced off; gradient probe
+    m.train()
+    m.final.head[0].p = 0.0
+    sh, dp, out, feat = m(x)
+    probe = torch.randn(out.shape, generator=g)
+    (out * probe).sum().backward()
+    res.update(out_train=out, feat_train=feat, probe=probe)
+    for n in ["layer0.0.weight", "layer1.0.conv1.weight", "layer2.3.conv2.weight",
+              "layer3.22.conv3.weight", "layer4.0.downsample.0.weight",
+              "final.conv2d_list.3.0.weight", "final.conv2d_list.0.1.weight",
+              "final.bottleneck.0.se.0.weight", "final.bottleneck.1.bias", "final.head.1.weight"]:
+        p = dict(m.named_parameters())[n]
+        res["g_" + n.replace(".", "_")] = np.array([synth.checksum(p.grad), float(p.grad.abs().sum())])
+    res["g_head"] = dict(m.named_parameters())["final.head.1.weight"].grad
+    res["rm_after"] = m.state_dict()["layer1.0.bn1.running_mean"]
+    res["rv_after"] = m.state_dict()["layer4.2.bn3.running_var"]
+    res["nbt_after"] = m.state_dict()["layer0.1.num_batches_tracked"]
+    # structure pins
+    res["n_state"] = np.array(len(names))
+    res["n_params"] = np.array(len(pnames))
+    res["n_trainable"] = np.array(len(trainable))
+    res["numel_params"] = np.array(sum(p.numel() for p in m.parameters()))
+    res["numel_trainable"] = np.array(sum(p.numel() for p in m.parameters() if p.requires_grad))
+    groups = m.optim_parameters(2.5e-4)
+    g1 = list(groups[0]["params"])
+    g10 = list(groups[1]["params"])
+    ids = {id(p): n for n, p in m.named_parameters()}
+    from collections import Counter
+    cnt = Counter(ids[id(p)] for p in g1)
+    res["g1_entries"] = np.array(len(g1))
+    res["g1_unique"] = np.array(len(cnt))
+    res["g1_mult_hist"] = np.array([sum(1 for v in cnt.values() if v == k) for k in range(6)])
+    res["g10_entries"] = np.array(len(g10))
+    res["g1_mult_stem"] = np.array(cnt["layer0.0.weight"])
+    res["g1_mult_block"] = np.array(cnt["layer3.5.conv2.weight"])
+    res["g1_mult_down"] = np.array(cnt["layer2.0.downsample.0.weight"])
+    res["state_keys"] = np.array(names)
+    res["param_keys"] = np.array(pnames)
+    res["g1_order"] = np.array([ids[id(p)] for p in g1])
+    res["g10_order"] = np.array([ids[id(p)] for p in g10])
+    save("model", **res)
+
+
+# ------------------------------------------------------------------ G-step (warm-up, 3 steps)
+def gen_step():
+    import torch.optim as optim
+    B, H, W = 2, 128, 128
+    student, teacher = _ref_model(), _ref_model()
+    for mdl in (student, teacher):
+        mdl.final.head[0].p = 0.0
+    opt = optim.SGD(student.optim_parameters(2.5e-4), lr=2.5e-4, momentum=0.9, weight_decay=0.0005)
+    up = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+    teacher = create_teacher_params(teacher, student)
+    random.seed(77)
+    log = {"ce": [], "distil": [], "total": [], "lr": []}
+    for it in range(3):
+        student.train()
+        adjust_learning_rate([opt], base_lr=2.5e-4, i_iter=it, max_iter=80000, power=0.9)
+        with torch.no_grad():
+            teacher = update_teacher_params(teacher, student, it)
+        x, x_aug, rec, lab = synth.warmup_batch(1000 + it, B, H, W, block=16)
+        mask = torch.zeros(lab.size())
+        for i in range(B):
+            present = torch.unique(lab[i]).tolist()
+            pick = random.sample(present, len(present) // 2)
+            if 255 not in pick:
+                pick.append(255)
+            for c in pick:
+                mask[i][lab[i] == c] = 1
+        mix = torch.zeros(rec.size())
+        for i in range(B):
+            mix[i] = torch.mul(rec[i], 1 - mask[i]) + torch.mul(x_aug[i], mask[i])
+        cat = torch.cat([x, mix])
+        _, _, s_cat, _ = student(cat)
+        s_cat = up(s_cat)
+        _, _, t_cat, _ = teacher(cat)
+        t_cat = up(t_cat)
+        ce = cross_entropy2d(s_cat[:B], lab)
+        di = distillation_loss(t_cat, s_cat)
+        total = 1.0 * ce + 0.5 * di
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        log["ce"].append(float(ce)); log["distil"].append(float(di)); log["total"].append(float(total))
+        log["lr"].append(opt.param_groups[0]["lr"])
+        print("step", it, log["ce"][-1], log["distil"][-1])
+    student.eval()
+    teacher.eval()
+    xp = synth.warmup_batch(2000, 1, H, W, block=16)[0]
+    with torch.no_grad():
+        _, _, so, _ = student(xp)
+        _, _, to, _ = teacher(xp)
+    res = {k: np.array(v, dtype=np.float64) for k, v in log.items()}
+    sd = student.state_dict()
+    td = teacher.state_dict()
+    for n in ["layer0.0.weight", "layer3.10.conv2.weight", "final.head.1.weight",
+              "final.conv2d_list.2.0.weight", "layer2.0.downsample.0.weight"]:
+        res["ps_" + n.replace(".", "_")] = np.array(synth.checksum(sd[n]))
+        res["pt_" + n.replace(".", "_")] = np.array(synth.checksum(td[n]))
+    res["student_head"] = sd["final.head.1.weight"]
+    res["teacher_head"] = td["final.head.1.weight"]
+    res["stu_rm"] = sd["layer1.0.bn1.running_mean"]
+    res["tea_rm"] = td["layer1.0.bn1.running_mean"]
+    save("step", probe_student=so, probe_teacher=to, **res)
+
+
+# ------------------------------------------------------------------ G-miou
+def gen_miou():
+    g = synth.gen(9)
+    gt = torch.randint(0, 19, (2, 64, 64), generator=g)
+    gt[torch.rand((2, 64, 64), generator=g) < 0.1] = 255
+    pred = torch.where(torch.rand((2, 64, 64), generator=g) < 0.6, gt.clamp(max=18),
+                       torch.randint(0, 19, (2, 64, 64), generator=g))
+    rs = runningScore(19)
+    import contextlib
+    import io
+    rs.update(gt.numpy(), pred.numpy())
+    with contextlib.redirect_stdout(io.StringIO()):
+        sc, cls_iu = rs.get_scores()
+    save("miou", gt=gt, pred=pred, hist=rs.confusion_matrix, miou=np.array(sc["Mean IoU : \t"]),
+         acc=np.array(sc["Overall Acc: \t"]), acc_cls=np.array(sc["Mean Acc : \t"]),
+         fwavacc=np.array(sc["FreqW Acc : \t"]), iu=np.array([cls_iu[i] for i in range(19)]))
+
+
+ALL = dict(ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+           classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
+           model=gen_model, step=gen_step, miou=gen_miou)
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    names = sys.argv[1:] or list(ALL)
+    for n in names:
+        print("==", n)
+        ALL[n]()
