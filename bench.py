@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the DiGA training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+
+A step is one full DiGA warm-up iteration (EMA teacher update, ClassMix, student forward on 2B images,
+teacher forward on 2B images, fused upsample+CE+distillation, backward, gradient all-reduce, fused SGD)
+on BASELINE.json configs[1]: ResNet-101 DeepLabV2, B=8 source crops of 768x768 per GPU, fp32, synthetic
+inputs already resident in HBM.  Rank 0 prints ONE JSON line; `value` is source crops/s over all ranks.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_* dense peak
+FWD_GFLOP_768 = 1232.9           # model forward, one 768x768 image
+FWD_GFLOP_256 = 142.6
+
+CONFIGS = {
+    # name: (arch, batch per GPU, H, W, label block, description)
+    "c2": ("RESNET101", 8, 768, 768, 32,
+           "configs[1]: ResNet-101 DeepLabV2 DiGA warm-up (student + EMA teacher, KL distill), synthetic "
+           "GTA5-shape 768x768, batch 8 per GPU"),
+    "c1": ("TINY", 2, 256, 256, 16, "configs[0] stand-in: small-backbone DeepLab, 2x256x256 warm-up step"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="override crops per GPU (debug only)")
+    ap.add_argument("--size", type=int, nargs=2, default=None, help="override crop H W (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel families with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """The oracle's warm-up step (PyTorch-CPU restatement of the reference, pinned by tests/golden) timed on
+    this box's host cores: ResNet-101, B=2 crops of 256x256, second of two steps.  Reported in 768x768-crop
+    units by the forward-FLOP ratio."""
+    from oracle import detweights, synth
+    from oracle import step as ost
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tr = ost.Trainer(detweights.state_dict(), detweights.state_dict())
+    rng = random.Random(5)
+    dt = None
+    for it in range(2):
+        batch = synth.warmup_batch(300 + it, 2, 256, 256, block=16)
+        t0 = time.perf_counter()
+        tr.warmup_step(it, *batch, rng)
+        dt = time.perf_counter() - t0
+    crops256 = 2.0 / dt
+    return {"value": crops256 * FWD_GFLOP_256 / FWD_GFLOP_768, "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"oracle warm-up step, ResNet-101, B=2 crops of 256x256 fp32, 2nd of 2 steps: {dt:.2f} s/step "
+                      f"= {crops256:.3f} 256x256-crops/s; scaled to 768x768 crops by forward FLOPs "
+                      f"({FWD_GFLOP_256}/{FWD_GFLOP_768} GFLOP)"}
+
+
+def main():
+    a = parse()
+    from diga_amd import ddp
+    rank, world, local = ddp.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = False
+
+    from diga_amd import _lib, synthetic
+    from diga_amd.model import seg_model_noaux as sm
+    from diga_amd.model.model_noaux import SegModel
+    from diga_amd.train_step import DigaTrainer
+
+    arch_name, B, H, W, block, desc = CONFIGS[a.config]
+    if a.batch:
+        B = a.batch
+    if a.size:
+        H, W = a.size
+    arch = getattr(sm, arch_name)
+
+    torch.manual_seed(0)                       # identical random-init weights on every rank
+    student, teacher = SegModel(arch=arch).to(dev), SegModel(arch=arch).to(dev)
+    ddp.broadcast_module(student)
+    teacher.train()
+    rng = random.Random(1234 + rank)           # ClassMix class choice differs per rank, reproducibly
+    tr = DigaTrainer(student, teacher, rng=rng)
+    x, x_aug, rec, labels = synthetic.warmup_batch(1234 + rank, B, H, W, block=block, device=dev)
+    n_trainable = sum(p.numel() for p in student.parameters() if p.requires_grad)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    it = 0
+    for _ in range(a.warmup):
+        tr.warmup_step(it, x, x_aug, rec, labels)
+        it += 1
+    torch.cuda.synchronize()
+    barrier()
+    if not a.no_prof:
+        _lib.call("diga_prof_reset")
+        _lib.call("diga_prof_enable", 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = tr.warmup_step(it, x, x_aug, rec, labels)
+        it += 1
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if not a.no_prof:
+        _lib.call("diga_prof_enable", 0)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t)
+    losses = {k: float(v) for k, v in out.items()}
+    if not all(v == v and abs(v) < 1e6 for v in losses.values()):
+        raise SystemExit(f"non-finite loss in the timed region: {losses}")
+
+    if rank == 0:
+        families = {}
+        if not a.no_prof:
+            for tag in _lib.PROF_TAGS:
+                n, ms = _lib.prof_query(tag)
+                if n:
+                    families[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / a.steps}
+        # roofline of the dominant own kernel: the fused duplicate-aware SGD, a pure HBM stream of
+        # 20 B per trainable parameter (read p, g, buf; write p, buf) -- DESIGN.md, "Kernels".
+        roof = None
+        if "sgd" in families:
+            alg_bytes = 20.0 * n_trainable
+            ach = alg_bytes / (families["sgd"]["avg_ms"] * 1e-3) / 1e9
+            roof = {"kernel": "sgd_multi_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                    "avg_launch_ms": families["sgd"]["avg_ms"]}
+        line = {
+            "metric": "768x768 19-class crops/sec (DiGA warm-up step)",
+            "value": world * B * a.steps / dt, "unit": "crops/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
+                       "images_per_step_per_gpu": {"student_fwd_bwd": 2 * B, "teacher_fwd": 2 * B}},
+            "roofline": roof,
+            "cpu_baseline": None if (a.no_cpu_baseline or world > 1) else cpu_baseline(),
+            "kernel_families": families, "losses_last_step": losses,
+            "model_tflop_per_step_per_gpu": (2 * B) * (3 + 1) * (FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)) / 1e3,
+        }
+        print(json.dumps(line), flush=True)
+    barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

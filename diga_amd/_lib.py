@@ -1,0 +1,119 @@
+"""ctypes binding of libdiga_hip.so (include/diga_hip.h).
+
+There is no CPU fallback: importing this module without the built library, or calling an op
+with non-GPU tensors, raises.  Build with `python -m diga_amd.build`.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiga_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the DiGA hot path has no CPU fallback. "
+        "Build the HIP extension first: python -m diga_amd.build")
+
+lib = C.CDLL(LIB_PATH)
+
+P = C.c_void_p
+I64 = C.c_int64
+F32 = C.c_float
+INT = C.c_int
+SZ = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/diga_hip.h one to one
+SIGNATURES = {
+    "diga_version": (INT, []),
+    "diga_last_error_string": (C.c_char_p, []),
+    "diga_loss_workspace_bytes": (SZ, [I64]),
+    "diga_ce2d_fwd_bwd": (INT, [P, P, P, P, P, SZ, I64, I64, I64, I64, F32, P]),
+    "diga_distill_fwd_bwd": (INT, [P, P, P, P, P, SZ, I64, I64, I64, I64, F32, F32, P]),
+    "diga_scale_inplace": (INT, [P, P, I64, P]),
+    "diga_upsample_loss_workspace_bytes": (SZ, [I64, I64, I64, I64]),
+    "diga_upsample_ce_distill_fwd_bwd": (INT, [P, P, P, P, P, P, SZ, I64, I64, I64, I64, I64, I64, F32, F32, F32, P]),
+    "diga_upsample_ce_fwd_bwd": (INT, [P, P, P, P, P, SZ, I64, I64, I64, I64, I64, I64, F32, P]),
+    "diga_upsample_bilinear_ac": (INT, [P, P, I64, I64, I64, I64, I64, P]),
+    "diga_ema_update_flat": (INT, [P, P, I64, F32, F32, P]),
+    "diga_ema_update_multi": (INT, [P, P, P, P, P, I64, I64, F32, F32, P]),
+    "diga_sgd_momentum_multi": (INT, [P, P, P, P, P, P, P, P, I64, I64, F32, F32, INT, F32, P]),
+    "diga_label_hist256": (INT, [P, P, I64, I64, P]),
+    "diga_classmix_paste": (INT, [P, P, P, P, P, P, P, I64, I64, I64, P]),
+    "diga_centroid_softmax_weights": (INT, [P, P, P, P, I64, I64, I64, I64, P]),
+    "diga_upsample_argmax_consensus": (INT, [P, P, P, P, I64, I64, I64, I64, I64, I64, P]),
+    "diga_class_mean_workspace_bytes": (SZ, [I64, I64]),
+    "diga_class_mean_vectors": (INT, [P, P, P, P, P, P, P, SZ, I64, I64, I64, I64, I64, I64, I64, P]),
+    "diga_centroid_ema_apply": (INT, [P, P, P, P, I64, I64, I64, I64, F32, INT, INT, P]),
+    "diga_confusion_matrix": (INT, [P, P, P, I64, I64, P]),
+    "diga_prof_enable": (INT, [INT]),
+    "diga_prof_reset": (INT, []),
+    "diga_prof_query": (INT, [INT, P, P]),
+}
+
+# enum order of include/diga_hip.h
+PROF_TAGS = ["ce2d", "distill", "upsample_loss", "ema", "sgd", "classmix_hist", "classmix_paste",
+             "centroid_weights", "consensus", "class_means", "centroid_apply", "conv_fwd", "conv_bwd_data",
+             "conv_bwd_weight", "norm", "elementwise"]
+
+
+def prof_query(tag):
+    """(launch count, total ms) of one kernel family since the last prof_reset."""
+    n, ms = C.c_int64(0), C.c_double(0.0)
+    call("diga_prof_query", PROF_TAGS.index(tag), C.byref(n), C.byref(ms))
+    return n.value, ms.value
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.diga_last_error_string().decode("utf-8", "replace")
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise on any non-zero status."""
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {last_error()}")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "diga_amd ops run on the GPU only (HIP kernels, no CPU fallback); got a "
+                f"{t.device} tensor")
+
+
+def contiguous(t, dtype=None):
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer owned by the PyTorch caching allocator (one per device and tag)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag,
+           torch.cuda.current_stream().cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

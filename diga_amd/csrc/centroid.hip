@@ -1,0 +1,316 @@
+// Centroid-based dynamic pseudo-label selection.
+// Reference: G5/calc_centroids.py:120-176 (Class_Features) and the bilateral-consensus block at
+// G5/train_DiGA_gta2city_self_training.py:298-304,327-341.  The reference walks the 19 classes in
+// a Python loop with a [B,256,h,w] temporary each, and issues two .item() syncs per (image,class).
+//
+// Here the feature map [N,D,hw] is streamed once per kernel:
+//   centroid_weights : lanes = pixels (coalesced plane reads), the 4 waves of a block split the D
+//                      channels, centroids sit transposed in LDS and are read as broadcasts.
+//   class_ids/sums   : argmax+label consensus to a byte map, then one wave per channel
+//                      accumulates per-class sums in lane-private LDS bins (no atomics on floats).
+//   ema_apply        : the order-dependent centroid update, sequential over images on device.
+#include "common.h"
+
+namespace diga {
+
+constexpr int kKMax = 32;
+
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void centroid_weights_kernel(const float* __restrict__ feat,
+                                                               const float* __restrict__ cent,
+                                                               float* __restrict__ weights,
+                                                               float* __restrict__ neg_dist, int D, int Krt,
+                                                               int64_t HW) {
+    constexpr int KP = (K + 3) & ~3;
+    extern __shared__ __align__(16) float smem[];
+    float* cT = smem;                 // [D][KP]  transposed centroids
+    float* part = smem + (size_t)D * KP;  // [4][K][64] per-wave partial squared distances
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < D * KP; i += 256) {
+        const int d = i / KP, k = i - d * KP;
+        cT[i] = (k < Krt) ? cent[(int64_t)k * D + d] : 0.f;
+    }
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = p < HW;
+    const int dper = (D + 3) / 4;
+    const int d0 = wv * dper, d1 = (d0 + dper < D) ? d0 + dper : D;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    const float* f = feat + ((int64_t)n * D) * HW + (live ? p : 0);
+#pragma unroll 4
+    for (int d = d0; d < d1; ++d) {
+        const float x = f[(int64_t)d * HW];
+        const float4* c4 = reinterpret_cast<const float4*>(cT + (size_t)d * KP);
+#pragma unroll
+        for (int q = 0; q < KP / 4; ++q) {
+            const float4 c = c4[q];
+            const float e0 = c.x - x, e1 = c.y - x, e2 = c.z - x, e3 = c.w - x;
+            if (q * 4 + 0 < K) acc[q * 4 + 0] += e0 * e0;
+            if (q * 4 + 1 < K) acc[q * 4 + 1] += e1 * e1;
+            if (q * 4 + 2 < K) acc[q * 4 + 2] += e2 * e2;
+            if (q * 4 + 3 < K) acc[q * 4 + 3] += e3 * e3;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) part[(wv * K + k) * 64 + lane] = acc[k];
+    __syncthreads();
+    if (wv != 0 || !live) return;
+    float dist[K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = part[(0 * K + k) * 64 + lane] + part[(1 * K + k) * 64 + lane] +
+                        part[(2 * K + k) * 64 + lane] + part[(3 * K + k) * 64 + lane];
+        dist[k] = -sqrtf(s);
+        if (k < Krt) m = fmaxf(m, dist[k]);
+    }
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k < Krt) {
+            if (neg_dist) neg_dist[((int64_t)n * Krt + k) * HW + p] = dist[k];
+            dist[k] = expf(dist[k] - m);
+            z += dist[k];
+        }
+    }
+    const float rz = 1.f / z;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (k < Krt) weights[((int64_t)n * Krt + k) * HW + p] = dist[k] * rz;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_consensus_kernel(const float* __restrict__ wts,
+                                                               const long long* __restrict__ pseudo_in,
+                                                               long long* __restrict__ pseudo_out,
+                                                               long long* __restrict__ feat_pseudo, int K, int h, int w,
+                                                               int H, int W, float sy, float sx) {
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (X >= W || Y >= H) return;
+    int i0, j0;
+    float wy, wx;
+    bilinear_cell(Y, sy, h, i0, wy);
+    bilinear_cell(X, sx, w, j0, wx);
+    const int dj = (w > 1) ? 1 : 0, di = (h > 1) ? w : 0;
+    const float* base = wts + ((int64_t)n * K) * h * w + (int64_t)i0 * w + j0;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int k = 0; k < K; ++k) {
+        const float* p = base + (int64_t)k * h * w;
+        const float v = (1.f - wy) * ((1.f - wx) * p[0] + wx * p[dj]) + wy * ((1.f - wx) * p[di] + wx * p[di + dj]);
+        if (v > best) {  // strict: first maximum wins, as torch.max
+            best = v;
+            arg = k;
+        }
+    }
+    const int64_t o = ((int64_t)n * H + Y) * W + X;
+    const long long pin = pseudo_in[o];
+    pseudo_out[o] = (pin == (long long)arg) ? pin : (long long)DIGA_IGNORE_LABEL;
+    if (feat_pseudo) feat_pseudo[o] = (long long)arg;
+}
+
+// ------------------------------------------------------------------------------------------
+// ids[n,p] = argmax_k out[n,k,p] if it agrees with the label (or no labels), else K (dead bucket)
+__global__ __launch_bounds__(256) void class_ids_kernel(const float* __restrict__ out,
+                                                        const float* __restrict__ labels_lr,
+                                                        const long long* __restrict__ labels_full,
+                                                        uint8_t* __restrict__ ids, int32_t* __restrict__ counts, int K,
+                                                        int h, int w, int H, int W, float ry, float rx) {
+    __shared__ int cnt[kKMax + 1];
+    if (threadIdx.x <= kKMax) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = blockIdx.y;
+    const int64_t hw = (int64_t)h * w;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < hw) {
+        const float* o = out + ((int64_t)n * K) * hw + p;
+        float best = o[0];
+        int arg = 0;
+        for (int k = 1; k < K; ++k) {
+            const float v = o[(int64_t)k * hw];
+            if (v > best) {
+                best = v;
+                arg = k;
+            }
+        }
+        int id = arg;
+        if (labels_lr != nullptr) {
+            const float l = labels_lr[(int64_t)n * hw + p];
+            id = (l == (float)arg) ? arg : K;
+        } else if (labels_full != nullptr) {
+            // F.interpolate(mode='nearest'): src = min(floor(dst * (in/out)), in-1), float arithmetic
+            const int y = (int)(p / w), x = (int)(p - (int64_t)y * w);
+            int sy_ = (int)floorf((float)y * ry), sx_ = (int)floorf((float)x * rx);
+            sy_ = sy_ < H - 1 ? sy_ : H - 1;
+            sx_ = sx_ < W - 1 ? sx_ : W - 1;
+            const long long l = labels_full[((int64_t)n * H + sy_) * W + sx_];
+            id = (l == (long long)arg) ? arg : K;
+        }
+        ids[(int64_t)n * hw + p] = (uint8_t)id;
+        atomicAdd(&cnt[id], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < K && cnt[threadIdx.x]) atomicAdd(&counts[(int64_t)n * K + threadIdx.x], cnt[threadIdx.x]);
+}
+
+// one wave per (image, channel): lane-private class bins in LDS, then a cross-lane sum per class
+__global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict__ feat,
+                                                         const uint8_t* __restrict__ ids, float* __restrict__ sums,
+                                                         int D, int K, int64_t hw) {
+    __shared__ float bins[4][kKMax + 1][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int d = blockIdx.x * 4 + wv;
+    const int n = blockIdx.y;
+    for (int k = 0; k <= K; ++k) bins[wv][k][lane] = 0.f;
+    if (d < D) {
+        const float* f = feat + ((int64_t)n * D + d) * hw;
+        const uint8_t* id = ids + (int64_t)n * hw;
+        for (int64_t p = lane; p < hw; p += 64) bins[wv][id[p]][lane] += f[p];
+    }
+    __syncthreads();
+    if (d < D) {
+        for (int k = 0; k < K; ++k) {
+            const float t = wave_sum(bins[wv][k][lane]);
+            if (lane == 0) sums[((int64_t)n * K + k) * D + d] = t;
+        }
+    }
+}
+
+// block = one class; threads = feature channels; sequential over images (order matters)
+__global__ __launch_bounds__(1024) void centroid_apply_kernel(float* __restrict__ cent, float* __restrict__ nums,
+                                                              const float* __restrict__ sums,
+                                                              const int32_t* __restrict__ counts, int N, int K, int D,
+                                                              float hw, float momentum, int min_pixels, int mode) {
+    __shared__ float sm[16];
+    __shared__ float vsum_s;
+    const int k = blockIdx.x;
+    const int d = threadIdx.x;
+    float c = (d < D) ? cent[(int64_t)k * D + d] : 0.f;
+    float num = nums[k];
+    for (int n = 0; n < N; ++n) {
+        const int cnt = counts[(int64_t)n * K + k];
+        if (cnt == 0 || cnt < min_pixels) continue;  // uniform over the block
+        float v = 0.f;
+        if (d < D) {
+            // adaptive_avg_pool2d(feat*mask,1) / adaptive_avg_pool2d(mask,1)
+            const float mean_fm = sums[((int64_t)n * K + k) * D + d] / hw;
+            const float mean_m = (float)cnt / hw;
+            v = mean_fm / mean_m;
+        }
+        float t = wave_sum(v);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += sm[i];
+            vsum_s = tot;
+        }
+        __syncthreads();
+        const float vsum = vsum_s;
+        __syncthreads();
+        if (vsum == 0.f) continue;
+        if (mode == 0) {
+            c = c * (1.f - momentum) + momentum * v;
+            num = fminf(num + 1.f, 3000.f);
+        } else {
+            c = c * num + v;
+            num = num + 1.f;
+            c = c / num;
+            num = fminf(num, 3000.f);
+        }
+    }
+    if (d < D) cent[(int64_t)k * D + d] = c;
+    if (threadIdx.x == 0) nums[k] = num;
+}
+
+}  // namespace diga
+
+using namespace diga;
+
+extern "C" int diga_centroid_softmax_weights(const float* feat, const float* centroids, float* weights,
+                                             float* neg_dist, int64_t N, int64_t D, int64_t K, int64_t HW,
+                                             void* stream) {
+    DIGA_REQUIRE(feat && centroids && weights, DIGA_EINVAL, "centroid_softmax_weights: null pointer");
+    DIGA_REQUIRE(N > 0 && D > 0 && D <= 1024 && K >= 1 && K <= kKMax && HW > 0, DIGA_EINVAL,
+                 "centroid_softmax_weights: bad shape N=%lld D=%lld K=%lld HW=%lld", (long long)N, (long long)D,
+                 (long long)K, (long long)HW);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_CENTROID_WEIGHTS, st);
+    dim3 grid((unsigned)ceil_div(HW, 64), (unsigned)N);
+    if (K <= 19 && K > 16) {
+        const size_t sh = ((size_t)D * 20 + 4 * 19 * 64) * sizeof(float);
+        hipLaunchKernelGGL((centroid_weights_kernel<19>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
+                           (int)D, (int)K, HW);
+    } else if (K <= 16) {
+        const size_t sh = ((size_t)D * 16 + 4 * 16 * 64) * sizeof(float);
+        hipLaunchKernelGGL((centroid_weights_kernel<16>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
+                           (int)D, (int)K, HW);
+    } else {
+        const size_t sh = ((size_t)D * 32 + 4 * 32 * 64) * sizeof(float);
+        DIGA_REQUIRE(sh <= 160 * 1024, DIGA_EINVAL, "centroid_softmax_weights: D*K too large for LDS");
+        (void)hipFuncSetAttribute((const void*)centroid_weights_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((centroid_weights_kernel<32>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
+                           (int)D, (int)K, HW);
+    }
+    return launch_status("diga_centroid_softmax_weights");
+}
+
+extern "C" int diga_upsample_argmax_consensus(const float* weights, const int64_t* pseudo_in, int64_t* pseudo_out,
+                                              int64_t* feat_pseudo, int64_t N, int64_t K, int64_t h, int64_t w,
+                                              int64_t H, int64_t W, void* stream) {
+    DIGA_REQUIRE(weights && pseudo_in && pseudo_out, DIGA_EINVAL, "upsample_argmax_consensus: null pointer");
+    DIGA_REQUIRE(N > 0 && K >= 1 && h > 0 && w > 0 && H > 0 && W > 0, DIGA_EINVAL, "upsample_argmax_consensus: bad shape");
+    dim3 grid((unsigned)ceil_div(W, 64), (unsigned)ceil_div(H, 4), (unsigned)N);
+    ProfScope prof(DIGA_PROF_CONSENSUS, (hipStream_t)stream);
+    hipLaunchKernelGGL(argmax_consensus_kernel, grid, dim3(256), 0, (hipStream_t)stream, weights,
+                       (const long long*)pseudo_in, (long long*)pseudo_out, (long long*)feat_pseudo, (int)K, (int)h,
+                       (int)w, (int)H, (int)W, ac_scale(h, H), ac_scale(w, W));
+    return launch_status("diga_upsample_argmax_consensus");
+}
+
+extern "C" size_t diga_class_mean_workspace_bytes(int64_t N, int64_t hw) {
+    return (size_t)((N * hw + 255) / 256) * 256;
+}
+
+extern "C" int diga_class_mean_vectors(const float* feat, const float* out, const float* labels_lr,
+                                       const int64_t* labels_full, float* sums, int32_t* counts, void* workspace,
+                                       size_t workspace_bytes, int64_t N, int64_t D, int64_t K, int64_t h, int64_t w,
+                                       int64_t H, int64_t W, void* stream) {
+    DIGA_REQUIRE(feat && out && sums && counts && workspace, DIGA_EINVAL, "class_mean_vectors: null pointer");
+    DIGA_REQUIRE(N > 0 && D > 0 && K >= 1 && K <= kKMax && h > 0 && w > 0, DIGA_EINVAL, "class_mean_vectors: bad shape");
+    DIGA_REQUIRE(!(labels_lr && labels_full), DIGA_EINVAL, "class_mean_vectors: give labels at one resolution only");
+    DIGA_REQUIRE(!labels_full || (H > 0 && W > 0), DIGA_EINVAL, "class_mean_vectors: full-res labels need H,W");
+    const int64_t hw = h * w;
+    DIGA_REQUIRE(workspace_bytes >= diga_class_mean_workspace_bytes(N, hw), DIGA_EWORKSPACE,
+                 "class_mean_vectors: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* ids = (uint8_t*)workspace;
+    ProfScope prof(DIGA_PROF_CLASS_MEANS, st);
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)N * K * sizeof(int32_t), st);
+    DIGA_REQUIRE(e == hipSuccess, (int)e, "class_mean_vectors: memset failed: %s", hipGetErrorString(e));
+    const float ry = labels_full ? (float)H / (float)h : 0.f, rx = labels_full ? (float)W / (float)w : 0.f;
+    hipLaunchKernelGGL(class_ids_kernel, dim3((unsigned)ceil_div(hw, 256), (unsigned)N), dim3(256), 0, st, out, labels_lr,
+                       (const long long*)labels_full, ids, counts, (int)K, (int)h, (int)w, (int)H, (int)W, ry, rx);
+    hipLaunchKernelGGL(class_sums_kernel, dim3((unsigned)ceil_div(D, 4), (unsigned)N), dim3(256), 0, st, feat, ids, sums,
+                       (int)D, (int)K, hw);
+    return launch_status("diga_class_mean_vectors");
+}
+
+extern "C" int diga_centroid_ema_apply(float* centroids, float* nums, const float* sums, const int32_t* counts,
+                                       int64_t N, int64_t K, int64_t D, int64_t hw, float momentum, int min_pixels,
+                                       int mode, void* stream) {
+    DIGA_REQUIRE(centroids && nums && sums && counts, DIGA_EINVAL, "centroid_ema_apply: null pointer");
+    DIGA_REQUIRE(N > 0 && K >= 1 && D >= 1 && D <= 1024 && hw > 0 && (mode == 0 || mode == 1), DIGA_EINVAL,
+                 "centroid_ema_apply: bad argument (D <= 1024, mode in {0,1})");
+    const int threads = (int)(ceil_div(D, 64) * 64);
+    ProfScope prof(DIGA_PROF_CENTROID_APPLY, (hipStream_t)stream);
+    hipLaunchKernelGGL(centroid_apply_kernel, dim3((unsigned)K), dim3(threads), 0, (hipStream_t)stream, centroids, nums,
+                       sums, counts, (int)N, (int)K, (int)D, (float)hw, momentum, min_pixels, mode);
+    return launch_status("diga_centroid_ema_apply");
+}

@@ -1,0 +1,112 @@
+"""Data-parallel exchange steps of the DiGA hot path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference is single-process, so this layer is new functionality:
+  * GradReducer  -- sum of the student's gradients over ranks in a few large flat buckets (xGMI is
+    point-to-point: few big ring transfers beat many small ones); the 1/world averaging is folded into
+    the fused SGD kernel's grad_scale, so no extra pass touches the gradients.
+  * gather_class_sums -- all-gather of the per-image class sums/counts of the centroid update so that
+    every rank applies the order-dependent EMA in the global (rank-major, image-major, class-minor)
+    order: bit-identical to one process that saw the concatenated batch.
+BatchNorm statistics stay local and the EMA teacher is recomputed on every rank from the (identical)
+all-reduced student, exactly as a per-rank run of the reference would.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank).  World size 1 needs no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class GradReducer:
+    """Bucketed all-reduce(sum) of the gradients of `params` (unique tensors, reverse order so the
+    buckets of the last layers -- whose gradients exist first -- go out first)."""
+
+    def __init__(self, params, bucket_bytes=128 << 20, group=None):
+        self.group = group
+        seen, uniq = set(), []
+        for p in params:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        self.params = list(reversed(uniq))
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in self.params:
+            nb = p.numel() * p.element_size()
+            if cur and cur_bytes + nb > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self.buckets.append(cur)
+        self._flat = [None] * len(self.buckets)
+
+    def reduce(self):
+        """Sum gradients over all ranks in place.  No-op for world size 1."""
+        if world_size() == 1:
+            return
+        works = []
+        for i, bucket in enumerate(self.buckets):
+            grads = [p.grad for p in bucket]
+            if any(g is None for g in grads):
+                raise RuntimeError("GradReducer: a parameter has no gradient")
+            n = sum(g.numel() for g in grads)
+            flat = self._flat[i]
+            if flat is None or flat.numel() != n or flat.device != grads[0].device:
+                flat = self._flat[i] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+            off = 0
+            for g in grads:
+                flat[off:off + g.numel()].copy_(g.reshape(-1))
+                off += g.numel()
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for i, bucket in enumerate(self.buckets):
+            works[i].wait()
+            off = 0
+            for p in bucket:
+                p.grad.copy_(self._flat[i][off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
+
+
+def gather_class_sums(sums, counts, group=None):
+    """[N,K,D] sums and [N,K] counts of every rank, concatenated rank-major along the image axis."""
+    w = world_size()
+    if w == 1:
+        return sums, counts
+    s_all = [torch.empty_like(sums) for _ in range(w)]
+    c_all = [torch.empty_like(counts) for _ in range(w)]
+    dist.all_gather(s_all, sums.contiguous(), group=group)
+    dist.all_gather(c_all, counts.contiguous(), group=group)
+    return torch.cat(s_all, 0), torch.cat(c_all, 0)
+
+
+def broadcast_module(module, src=0, group=None):
+    """Make parameters and buffers of every rank equal to rank `src`'s (start-of-training sync)."""
+    if world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

@@ -1,0 +1,164 @@
+"""DeepLabV2 / ResNet-101 (output stride 8) with the ProDA-style ASPP head -- module tree and
+state_dict keys of the reference (G5/model/seg_model_noaux.py:57-101 Bottleneck, :122-137 SEBlock,
+:140-214 Classifier_Module2, :216-261 ResNetMulti), so checkpoints are interchangeable.
+
+Semantics kept from the reference: every BatchNorm has frozen affine
+parameters but runs on batch statistics in train mode; GroupNorm(32) in the head is trainable;
+`feat` is the post-Dropout2d tensor; all Conv2d weights start as N(0, 0.01).
+"""
+from dataclasses import dataclass
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+
+@dataclass(frozen=True)
+class Arch:
+    layers: Tuple[int, ...] = (3, 4, 23, 3)
+    planes: Tuple[int, ...] = (64, 128, 256, 512)
+    strides: Tuple[int, ...] = (1, 2, 1, 1)
+    dilations: Tuple[int, ...] = (1, 1, 2, 4)
+    stem: int = 64
+    expansion: int = 4
+    aspp_dilations: Tuple[int, ...] = (6, 12, 18, 24)
+    aspp_width: int = 256
+    gn_groups: int = 32
+    se_reduction: int = 16
+    n_classes: int = 19
+    droprate: float = 0.1
+
+
+RESNET101 = Arch()
+TINY = Arch(layers=(1, 1, 2, 1), planes=(16, 32, 64, 128), stem=16)
+
+
+def _frozen_bn(channels):
+    bn = nn.BatchNorm2d(channels, affine=True)
+    for p in bn.parameters():
+        p.requires_grad = False
+    return bn
+
+
+class Bottleneck(nn.Module):
+    """1x1 (carries the stride) -> 3x3 (carries the dilation) -> 1x1, each followed by frozen-affine BN."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False)
+        self.bn1 = _frozen_bn(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = _frozen_bn(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = _frozen_bn(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        skip = x if self.downsample is None else self.downsample(x)
+        return self.relu(y + skip)
+
+
+class SEBlock(nn.Module):
+    def __init__(self, inplanes, r=16):
+        super().__init__()
+        self.global_pool = nn.AdaptiveAvgPool2d((1, 1))
+        self.se = nn.Sequential(nn.Linear(inplanes, inplanes // r), nn.ReLU(inplace=True),
+                                nn.Linear(inplanes // r, inplanes), nn.Sigmoid())
+
+    def forward(self, x):
+        gate = self.se(self.global_pool(x).flatten(1))
+        return x * gate[:, :, None, None]
+
+
+class Classifier_Module2(nn.Module):
+    """ASPP head: 1x1 + dilated 3x3 branches (conv+bias -> GN -> ReLU), concat, SE, 3x3, GN, Dropout2d, 1x1."""
+
+    def __init__(self, inplanes, dilation_series, padding_series, num_classes, droprate=0.1, use_se=True,
+                 width=256, groups=32, se_reduction=16):
+        super().__init__()
+
+        def branch(k, d, p):
+            return nn.Sequential(nn.Conv2d(inplanes, width, k, stride=1, padding=p, dilation=d, bias=True),
+                                 nn.GroupNorm(groups, width), nn.ReLU(inplace=True))
+
+        self.conv2d_list = nn.ModuleList([branch(1, 1, 0)] +
+                                         [branch(3, d, p) for d, p in zip(dilation_series, padding_series)])
+        cat = width * (len(dilation_series) + 1)
+        tail = [nn.Conv2d(cat, width, 3, stride=1, padding=1, bias=True), nn.GroupNorm(groups, width)]
+        self.bottleneck = nn.Sequential(*([SEBlock(cat, se_reduction)] if use_se else []), *tail)
+        self.head = nn.Sequential(nn.Dropout2d(droprate), nn.Conv2d(width, num_classes, 1, bias=False))
+        # Effective init of the reference (seg_model_noaux.py:173-198 + the global loop :236-242): only the
+        # 3x3 bottleneck conv gets a zero bias; branch biases and the SE linears keep torch's defaults
+        # (the reference's isinstance() tests see Sequential/SEBlock containers, not the layers inside).
+        nn.init.zeros_(self.bottleneck[-2].bias)
+
+    def forward(self, x, get_feat=True):
+        cat = torch.cat([b(x) for b in self.conv2d_list], 1)
+        y = self.bottleneck(cat)
+        if not get_feat:
+            return self.head(y)
+        feat = self.head[0](y)
+        return {'feat': feat, 'out': self.head[1](feat)}
+
+
+class ResNetMulti(nn.Module):
+    def __init__(self, block, layers, num_classes, bn_clr=False, arch=RESNET101):
+        super().__init__()
+        self.bn_clr = bn_clr
+        self.inplanes = arch.stem
+        self.conv1 = nn.Conv2d(3, arch.stem, 7, stride=2, padding=3, bias=False)
+        self.bn1 = _frozen_bn(arch.stem)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1, ceil_mode=True)
+        stages = [self._make_layer(block, arch.planes[i], layers[i], arch.strides[i], arch.dilations[i])
+                  for i in range(4)]
+        self.layer1, self.layer2, self.layer3, self.layer4 = stages
+        self.layer5 = Classifier_Module2(self.inplanes, list(arch.aspp_dilations), list(arch.aspp_dilations),
+                                         num_classes, arch.droprate, True, arch.aspp_width, arch.gn_groups,
+                                         arch.se_reduction)
+        if bn_clr:
+            self.bn_pretrain = nn.BatchNorm2d(self.inplanes, affine=True)
+        for m in self.modules():                     # the reference's global init runs after the head's own
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, 0.01)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion or dilation in (2, 4):
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                                 _frozen_bn(planes * block.expansion))
+        seq = [block(self.inplanes, planes, stride, dilation=dilation, downsample=down)]
+        self.inplanes = planes * block.expansion
+        seq += [block(self.inplanes, planes, dilation=dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        if self.bn_clr:
+            x = self.bn_pretrain(x)
+        return self.layer5(x)
+
+
+def DeeplabMulti(pretrained=True, num_classes=19, initialization=None, bn_clr=False, arch=RESNET101):
+    """Builds the network.  The reference downloads ImageNet/COCO weights here
+    (seg_model_noaux.py:7,328); there is no network on the target machines, so weights come from
+    `initialization` (a checkpoint path with a 'state_dict' entry) or stay at their N(0,0.01) init
+    until load_state_dict() is called."""
+    model = ResNetMulti(Bottleneck, list(arch.layers), num_classes, bn_clr=bn_clr, arch=arch)
+    if pretrained and initialization is not None:
+        saved = torch.load(initialization, map_location="cpu")
+        saved = saved.get('state_dict', saved)
+        own = model.state_dict()
+        own.update({k: v for k, v in saved.items() if k in own and v.shape == own[k].shape})
+        model.load_state_dict(own)
+    return model

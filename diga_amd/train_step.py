@@ -1,0 +1,91 @@
+"""The build's own driver of one DiGA training step (what the `for i_iter` bodies of the reference's
+scripts do, minus data loading, visualisation and logging):
+  warm-up        G5/train_DiGA_gta2city_warm_up.py:197-305
+  self-training  G5/train_DiGA_gta2city_self_training.py:214-387
+Inputs the reference produces outside the scoped path (kornia colour augmentation `x_aug`, frozen
+translator output `rec_s2t`) are arguments.
+
+Differences in mechanics, not in results: the loss block runs at the low-res boundary with the
+upsampling fused (no [2B,19,H,W] tensors), ClassMix costs one D->H copy per call instead of one
+per image, EMA/SGD are single launches, no per-step .cpu()/.item() syncs; the unused
+`student(tdatav)` visualisation forward (warm_up.py:265-266) is not executed.
+"""
+import random
+
+import torch
+
+from diga_amd import ddp
+from diga_amd.util import loss as L
+from diga_amd.util import utils as U
+
+
+class DigaTrainer:
+    def __init__(self, student, teacher, base_lr=2.5e-4, max_iter=80000, power=0.9, momentum=0.9,
+                 weight_decay=5e-4, rng=random, distill_scale=0.5):
+        self.student, self.teacher = student, teacher
+        self.base_lr, self.max_iter, self.power = base_lr, max_iter, power
+        self.rng = rng
+        self.distill_scale = distill_scale
+        self.world = ddp.world_size()
+        self.opt = U.DigaSGD(student.optim_parameters(base_lr), lr=base_lr, momentum=momentum,
+                             weight_decay=weight_decay, grad_scale=1.0 / self.world)
+        self.reducer = ddp.GradReducer([p for p in student.parameters() if p.requires_grad])
+        U.create_teacher_params(teacher, student)
+        for p in teacher.parameters():
+            p.requires_grad_(False)
+
+    # ------------------------------------------------------------------ common pieces
+    def _begin(self, it):
+        self.student.train()
+        U.adjust_learning_rate([self.opt], self.base_lr, it, self.max_iter, self.power)
+        with torch.no_grad():
+            U.update_teacher_params(self.teacher, self.student, it)
+
+    def _finish(self, total):
+        self.opt.zero_grad(set_to_none=True)
+        total.backward()
+        self.reducer.reduce()
+        self.opt.step()
+
+    # ------------------------------------------------------------------ warm-up step
+    def warmup_step(self, it, x, x_aug, rec_s2t, labels, lambda_seg=1.0, lambda_distil=0.5):
+        """x, x_aug, rec_s2t [B,3,H,W]; labels [B,H,W] int64.  Returns device scalars (no sync)."""
+        self._begin(it)
+        with torch.no_grad():
+            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
+            cat = torch.cat([x, mix])
+        _, _, s_lr, _ = self.student(cat)
+        with torch.no_grad():
+            _, _, t_lr, _ = self.teacher(cat)
+        total, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
+        self._finish(total)
+        return {"total": total.detach(), "ce": ce, "distil": di}
+
+    # ------------------------------------------------------------------ self-training step
+    def selftrain_step(self, it, x, x_aug, rec_s2t, labels, t_img, t_aug, pseudo_prob, class_features,
+                       lambda_seg=1.0, lambda_distil=0.25):
+        """Adds target images `t_img`, their augmented view and offline pseudo-labels; `class_features`
+        is a diga_amd.calc_centroids.Class_Features."""
+        self._begin(it)
+        B = x.shape[0]
+        with torch.no_grad():
+            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
+            cat = torch.cat([x, mix])
+        _, _, s_lr, _ = self.student(cat)
+        with torch.no_grad():
+            _, _, t_lr, t_feat = self.teacher(cat)
+            _, _, tt_lr, tt_feat = self.teacher(t_img)
+            # bilateral consensus: keep the offline pseudo-label where the centroid label agrees
+            pseudo = class_features.consensus_pseudo_labels(tt_feat, pseudo_prob)
+            cross_mix, cross_lab, _ = U.classmix(t_aug, x, labels, self.rng, bg_labels=pseudo)
+            # centroid EMA: target (filtered pseudo-labels) first, then source (teacher feats of the mixed view)
+            for feat, out, lab in ((tt_feat, tt_lr, pseudo), (t_feat[B:], t_lr[B:], labels)):
+                sums, counts = class_features._class_sums(feat, out, labels_full=lab)[:2]
+                sums, counts = ddp.gather_class_sums(sums, counts)
+                class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
+        _, _, c_lr, _ = self.student(cross_mix)
+        total_s, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
+        ce_mix = L.upsample_ce(c_lr, cross_lab, lambda_seg)
+        total = total_s + ce_mix
+        self._finish(total)
+        return {"total": total.detach(), "ce": ce, "distil": di, "ce_mix": ce_mix.detach()}

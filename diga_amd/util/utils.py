@@ -1,0 +1,317 @@
+"""Training utilities of the DiGA hot path on MI355X -- same names and call signatures as the
+reference's `util/utils.py`:
+  poly_lr_scheduler / adjust_learning_rate   G5/util/utils.py:32-41
+  save_models / load_models                  G5/util/utils.py:83-91
+  create_teacher_params / update_teacher_params   G5/util/utils.py:93-116
+  UnNormalize / Normalize                    G5/util/utils.py:126-156
+  process_label                              G5/util/utils.py:158-163
+plus what the reference inlines in its scripts and the build provides as functions:
+  classmix / classmix_select / classmix_paste   warm_up.py:240-259, self_training.py:306-325
+  DigaSGD (fused, duplicate-aware momentum SGD)  warm_up.py:156,301-305; SURVEY App. A-9
+All device work is done by libdiga_hip.so.  No CPU fallback.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+_pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.dirname(_pkg) not in sys.path:
+    sys.path.append(os.path.dirname(_pkg))
+from diga_amd import _lib  # noqa: E402
+
+CHUNK_ELEMS = 16384          # elements of one tensor handled by one 256-thread block
+
+
+# --------------------------------------------------------------------------- LR schedule
+def poly_lr_scheduler_warm(base_lr, iter, warmup=1000, max_iter=80000, power=1.0):
+    if iter <= warmup:
+        return base_lr * (iter / warmup)
+    return base_lr * ((1 - float(iter - warmup) / max_iter) ** power)
+
+
+def poly_lr_scheduler(base_lr, iter, max_iter=30000, power=0.9):
+    return base_lr * ((1 - float(iter) / max_iter) ** power)
+
+
+def _set_lr(opts, lr):
+    for opt in opts:
+        opt.param_groups[0]["lr"] = lr
+        if len(opt.param_groups) > 1:
+            opt.param_groups[1]["lr"] = lr * 10
+
+
+def adjust_learning_rate(opts, base_lr, i_iter, max_iter, power):
+    _set_lr(opts, poly_lr_scheduler(base_lr, i_iter, max_iter, power))
+
+
+def adjust_learning_rate_warm(opts, base_lr, i_iter, max_iter, power):
+    _set_lr(opts, poly_lr_scheduler_warm(base_lr, i_iter, max_iter, power))
+
+
+# --------------------------------------------------------------------------- checkpoints
+def save_models(model_dict, prefix="./"):
+    """One `<key>.pth` state_dict per entry (same on-disk format as the reference)."""
+    os.makedirs(prefix, exist_ok=True)
+    for key, value in model_dict.items():
+        torch.save(value.state_dict(), os.path.join(prefix, key + ".pth"))
+
+
+def load_models(model_dict, prefix="./"):
+    for key, value in model_dict.items():
+        value.load_state_dict(torch.load(os.path.join(prefix, key + ".pth"), map_location="cpu"))
+
+
+# --------------------------------------------------------------------------- multi-tensor tables
+class TensorTables:
+    """Device-side pointer/size/chunk tables for one list of equally shaped tensor lists."""
+
+    def __init__(self, sizes, device):
+        self.device = device
+        self.n = len(sizes)
+        self.sizes_host = list(sizes)
+        ct, cs = [], []
+        for i, n in enumerate(sizes):
+            for start in range(0, n, CHUNK_ELEMS):
+                ct.append(i)
+                cs.append(start)
+        self.n_chunks = len(ct)
+        self.sizes = torch.tensor(sizes, dtype=torch.int64, device=device)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=device)
+        self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=device)
+        self._ptrs = {}
+
+    def pointers(self, slot, tensors):
+        """Device int64 table of data pointers; re-uploaded only when a pointer changed."""
+        host = [t.data_ptr() for t in tensors]
+        cached = self._ptrs.get(slot)
+        if cached is None or cached[0] != host:
+            dev = torch.tensor(host, dtype=torch.int64, device=self.device)
+            self._ptrs[slot] = (host, dev)
+            return dev
+        return cached[1]
+
+
+def _check_param_lists(a, b, what):
+    if len(a) != len(b):
+        raise ValueError(f"{what}: {len(a)} vs {len(b)} parameters")
+    for x, y in zip(a, b):
+        if x.shape != y.shape:
+            raise ValueError(f"{what}: parameter shapes differ {tuple(x.shape)} vs {tuple(y.shape)}")
+        if x.dtype != torch.float32 or y.dtype != torch.float32:
+            raise TypeError(f"{what}: fp32 parameters expected")
+        if not (x.is_contiguous() and y.is_contiguous()):
+            raise ValueError(f"{what}: parameters must be contiguous")
+    _lib.require_gpu(*a, *b)
+
+
+_ema_tables = {}
+
+
+def _ema_multi(teacher_params, student_params, alpha):
+    t = [p.data for p in teacher_params]
+    s = [p.data for p in student_params]
+    _check_param_lists(t, s, "update_teacher_params")
+    key = tuple(x.data_ptr() for x in t) + tuple(x.data_ptr() for x in s)
+    tab = _ema_tables.get(key)
+    if tab is None:
+        _ema_tables.clear()              # one (teacher, student) pair is live at a time
+        tab = _ema_tables[key] = TensorTables([x.numel() for x in t], t[0].device)
+    tp, sp = tab.pointers("t", t), tab.pointers("s", s)
+    one_minus = float(1 - alpha)         # rounded in double first, as `(1 - alpha_teacher)` is
+    _lib.call("diga_ema_update_multi", _lib.ptr(tp), _lib.ptr(sp), _lib.ptr(tab.sizes), _lib.ptr(tab.chunk_tensor),
+              _lib.ptr(tab.chunk_start), tab.n_chunks, CHUNK_ELEMS, float(alpha), one_minus, _lib.stream())
+
+
+def ema_alpha(iteration, stage0=True, mean=False, replace=False):
+    if stage0:
+        return min(1 - 1 / (iteration + 1), 0.999)
+    if mean:
+        return 0.9
+    if replace:
+        return 0.0
+    return 0.999
+
+
+def create_teacher_params(teacher, student):
+    """Teacher := copy of the student's PARAMETERS (buffers keep their own values)."""
+    for param in teacher.parameters():
+        param.detach_()
+    with torch.no_grad():
+        for tp, sp in zip(teacher.parameters(), student.parameters()):
+            tp.data.copy_(sp.data)
+    return teacher.cuda()
+
+
+def update_teacher_params(teacher, student, iteration, stage0=True, mean=False, replace=False):
+    """theta_t <- a*theta_t + (1-a)*theta_s over parameters() (incl. frozen BN affine, not buffers),
+    a = min(1 - 1/(it+1), 0.999): one multi-tensor launch for the whole model."""
+    alpha = ema_alpha(iteration, stage0, mean, replace)
+    tflat, sflat = getattr(teacher, "flat_params", None), getattr(student, "flat_params", None)
+    if tflat is not None and sflat is not None and tflat.numel() == sflat.numel():
+        _lib.require_gpu(tflat, sflat)
+        _lib.call("diga_ema_update_flat", _lib.ptr(tflat), _lib.ptr(sflat), tflat.numel(), float(alpha),
+                  float(1 - alpha), _lib.stream())
+    else:
+        _ema_multi(list(teacher.parameters()), list(student.parameters()), alpha)
+    return teacher.cuda()
+
+
+# --------------------------------------------------------------------------- normalisation helpers
+class UnNormalize(object):
+    def __init__(self, mean, std):
+        self.mean, self.std = mean, std
+
+    def __call__(self, tensor):
+        m = torch.as_tensor(self.mean, dtype=tensor.dtype, device=tensor.device).view(1, -1, 1, 1)
+        s = torch.as_tensor(self.std, dtype=tensor.dtype, device=tensor.device).view(1, -1, 1, 1)
+        return tensor * s + m
+
+
+class Normalize(object):
+    def __init__(self, mean, std):
+        self.mean, self.std = mean, std
+
+    def __call__(self, tensor):
+        m = torch.as_tensor(self.mean, dtype=tensor.dtype, device=tensor.device).view(1, -1, 1, 1)
+        s = torch.as_tensor(self.std, dtype=tensor.dtype, device=tensor.device).view(1, -1, 1, 1)
+        return (tensor - m) / s
+
+
+def process_label(label, class_numbers=19):
+    """One-hot with a (class_numbers+1)-th bucket for everything >= class_numbers."""
+    batch, channel, w, h = label.size()
+    pred1 = torch.zeros(batch, class_numbers + 1, w, h, device=label.device)
+    idx = torch.where(label < class_numbers, label, torch.full_like(label, class_numbers))
+    return pred1.scatter_(1, idx.long(), 1)
+
+
+# --------------------------------------------------------------------------- ClassMix
+def classmix_present(labels):
+    """Per image, the ascending list of label values present (== torch.unique(img).tolist()),
+    from ONE device histogram and ONE D->H copy for the whole batch."""
+    _lib.require_gpu(labels)
+    lab = _lib.contiguous(labels, torch.int64)
+    b = lab.shape[0]
+    hist = torch.zeros((b, 256), dtype=torch.int32, device=lab.device)
+    _lib.call("diga_label_hist256", _lib.ptr(lab), _lib.ptr(hist), b, lab[0].numel(), _lib.stream())
+    present = (hist != 0).cpu().numpy()
+    return [np.nonzero(present[i])[0].tolist() for i in range(b)]
+
+
+def classmix_select(present, rng=random):
+    """Reference class choice: random.sample(half of the classes present) from Python's global RNG,
+    one call per image, then 255 is force-added (warm_up.py:247-250)."""
+    sels = []
+    for lst in present:
+        pick = rng.sample(lst, len(lst) // 2)
+        if 255 not in pick:
+            pick.append(255)
+        sels.append(pick)
+    return sels
+
+
+def classmix_paste(background, foreground, labels, selections, bg_labels=None):
+    """out = foreground where labels in selections[b] else background (mask broadcast over channels);
+    with bg_labels also the pasted label map (self_training.py:318-319)."""
+    _lib.require_gpu(background, foreground, labels)
+    bg = _lib.contiguous(background, torch.float32)
+    fg = _lib.contiguous(foreground, torch.float32)
+    lab = _lib.contiguous(labels, torch.int64)
+    b, ch = bg.shape[0], bg.shape[1]
+    hw = lab[0].numel()
+    if fg.shape != bg.shape or lab.shape[0] != b or bg[0, 0].numel() != hw:
+        raise ValueError("classmix_paste: shape mismatch")
+    lut_host = np.zeros((b, 256), dtype=np.uint8)
+    for i, sel in enumerate(selections):
+        lut_host[i, np.asarray(sel, dtype=np.int64)] = 1
+    lut = torch.from_numpy(lut_host).to(bg.device, non_blocking=True)
+    out = torch.empty_like(bg)
+    bgl = lab_out = None
+    if bg_labels is not None:
+        bgl = _lib.contiguous(bg_labels, torch.int64)
+        lab_out = torch.empty_like(lab)
+    _lib.call("diga_classmix_paste", _lib.ptr(bg), _lib.ptr(fg), _lib.ptr(lab), _lib.ptr(lut), _lib.ptr(out),
+              _lib.ptr(bgl), _lib.ptr(lab_out), b, ch, hw, _lib.stream())
+    return out if bg_labels is None else (out, lab_out)
+
+
+def classmix(background, foreground, labels, rng=random, bg_labels=None):
+    """The whole cross-domain mixture block.  Returns (mixed[, mixed_labels], selections)."""
+    sels = classmix_select(classmix_present(labels), rng)
+    res = classmix_paste(background, foreground, labels, sels, bg_labels)
+    return (res, sels) if bg_labels is None else (res[0], res[1], sels)
+
+
+# --------------------------------------------------------------------------- fused SGD
+class DigaSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(momentum, weight_decay) semantics (single-tensor path) for the param groups the
+    reference builds, where a tensor may occur k times in a group (k sequential micro-steps sharing one
+    momentum buffer; on the very first step every occurrence starts from a fresh buffer, as torch 2.x does).
+    One launch per step for the whole model; `param_groups[i]['lr']` stays the knob that
+    adjust_learning_rate() turns."""
+
+    def __init__(self, params, lr=2.5e-4, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
+        groups = []
+        for g in (params if isinstance(params, (list, tuple)) else [{"params": params}]):
+            g = dict(g) if isinstance(g, dict) else {"params": g}
+            plist = list(g["params"])
+            uniq, mult = [], {}
+            for p in plist:
+                if id(p) not in mult:
+                    uniq.append(p)
+                    mult[id(p)] = 0
+                mult[id(p)] += 1
+            g["params"] = uniq
+            g["mult"] = [mult[id(p)] for p in uniq]
+            groups.append(g)
+        super().__init__(groups, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.grad_scale = float(grad_scale)
+        self._tab = None
+        self._first = True
+
+    def _build(self):
+        self._params, self._mult, self._group_of = [], [], []
+        for gi, g in enumerate(self.param_groups):
+            for p, k in zip(g["params"], g["mult"]):
+                if p.requires_grad:
+                    self._params.append(p)
+                    self._mult.append(k)
+                    self._group_of.append(gi)
+        dev = self._params[0].device
+        _lib.require_gpu(*self._params)
+        self._bufs = [torch.zeros_like(p.data) for p in self._params]
+        self._tab = TensorTables([p.numel() for p in self._params], dev)
+        self._mult_dev = torch.tensor(self._mult, dtype=torch.int32, device=dev)
+        self._lr_host = None
+        self._lr_dev = torch.empty(len(self._params), dtype=torch.float32, device=dev)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self._tab is None:
+            self._build()
+        g0 = self.param_groups[0]
+        grads = []
+        for p in self._params:
+            if p.grad is None:
+                raise RuntimeError("DigaSGD: every trainable parameter must have a gradient")
+            grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+        lrs = [float(self.param_groups[gi]["lr"]) for gi in self._group_of]
+        if lrs != self._lr_host:
+            self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
+            self._lr_host = lrs
+        tab = self._tab
+        pp = tab.pointers("p", [p.data for p in self._params])
+        gp = tab.pointers("g", grads)
+        bp = tab.pointers("b", self._bufs)
+        _lib.call("diga_sgd_momentum_multi", _lib.ptr(pp), _lib.ptr(gp), _lib.ptr(bp), _lib.ptr(tab.sizes),
+                  _lib.ptr(self._mult_dev), _lib.ptr(self._lr_dev), _lib.ptr(tab.chunk_tensor),
+                  _lib.ptr(tab.chunk_start), tab.n_chunks, CHUNK_ELEMS, float(g0["momentum"]),
+                  float(g0["weight_decay"]), 1 if self._first else 0, self.grad_scale, _lib.stream())
+        self._first = False
+        return None
+
+    def momentum_buffers(self):
+        return {id(p): b for p, b in zip(self._params, self._bufs)} if self._tab else {}

@@ -1,0 +1,218 @@
+/*
+ * diga_hip.h -- C ABI of libdiga_hip.so: the MI355X (gfx950) kernels of the DiGA
+ * training hot path.
+ *
+ * The reference (fy-vision/DiGA) has no FFI: every function below replaces a piece of
+ * Python/torch code of the reference, cited as file:line under /root/reference with
+ *   G5/ = domain_adaptation/GTA5/.
+ * The host-side mirror of the reference interface (diga_amd/util/loss.py, util/utils.py,
+ * calc_centroids.py, model/model_noaux.py) binds these entry points with ctypes; see
+ * INTEGRATION.md for the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name starts with h_;
+ *   - tensors are contiguous; image tensors NCHW fp32 unless the name says nhwc;
+ *     labels are int64 as the reference's loaders produce them (255 = ignore);
+ *   - the caller owns every buffer, including workspaces (size queries below);
+ *     kernels never allocate, free or keep pointers past return;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*);
+ *     no entry point synchronises;
+ *   - return 0 on success, a negative DIGA_E* code on a bad argument, or the positive
+ *     hipError_t of a failed launch; diga_last_error_string() describes the last failure
+ *     of the calling thread.  Nothing throws across the ABI.
+ */
+#ifndef DIGA_HIP_H
+#define DIGA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIGA_ABI_VERSION 1
+
+#define DIGA_OK 0
+#define DIGA_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define DIGA_EALIGN (-2)   /* pointer not aligned as required             */
+#define DIGA_EWORKSPACE (-3) /* workspace too small                       */
+
+#define DIGA_IGNORE_LABEL 255
+
+int diga_version(void);
+const char* diga_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------
+ * Losses
+ * ---------------------------------------------------------------------------------- */
+
+/* Bytes of workspace the loss entry points need for `n_pixels` = N*H*W pixels. */
+size_t diga_loss_workspace_bytes(int64_t n_pixels);
+
+/* cross_entropy2d, G5/util/loss.py:48-62.
+ *   loss      = sum over pixels with target != 255 of -log_softmax(logits)[target] / (N*H*W)
+ *   grad      = d loss / d logits * grad_scale      (nullable: loss only)
+ * logits [N,C,H,W], target [N,H,W] int64, loss_out [1], C <= 32. */
+int diga_ce2d_fwd_bwd(const float* logits, const int64_t* target, float* grad, float* loss_out,
+                      void* workspace, size_t workspace_bytes,
+                      int64_t N, int64_t C, int64_t H, int64_t W, float grad_scale, void* stream);
+
+/* distillation_loss, G5/util/loss.py:125-143.  teacher/student [2B,C,H,W]; the two halves of
+ * the batch are the two views.  loss = mean_{B,H,W} sum_c -q0 log p1 + scale * mean sum_c -q1 log p0
+ * with q = softmax(teacher), p = softmax(student); grad (nullable) = d loss / d student * grad_scale. */
+int diga_distill_fwd_bwd(const float* teacher, const float* student, float* grad, float* loss_out,
+                         void* workspace, size_t workspace_bytes,
+                         int64_t B2, int64_t C, int64_t H, int64_t W, float scale, float grad_scale,
+                         void* stream);
+
+/* x *= *scale_dev, skipped entirely (no traffic) when *scale_dev == 1.  Used by the autograd
+ * wrappers to apply the upstream gradient without a host sync. */
+int diga_scale_inplace(float* x, const float* scale_dev, int64_t n, void* stream);
+
+/* Loss block of the training step at the LOW-RES boundary: bilinear(align_corners=True)
+ * upsampling of student and teacher logits to label size fused with both losses and their
+ * backward (G5/train_DiGA_gta2city_warm_up.py:173-176,267-282,299).
+ *   stu_lr, tea_lr [2B,C,h,w]; labels [B,H,W] int64
+ *   losses_out[0] = cross_entropy2d(up(stu)[:B], labels); losses_out[1] = distillation_loss(up(tea), up(stu), scale)
+ *   grad_stu_lr [2B,C,h,w] = d(lambda_seg*ce + lambda_distil*distil)/d stu_lr
+ * Deterministic (no float atomics).  Requires h,w >= 2. */
+size_t diga_upsample_loss_workspace_bytes(int64_t B2, int64_t C, int64_t h, int64_t w);
+int diga_upsample_ce_distill_fwd_bwd(const float* stu_lr, const float* tea_lr, const int64_t* labels,
+                                     float* grad_stu_lr, float* losses_out,
+                                     void* workspace, size_t workspace_bytes,
+                                     int64_t B, int64_t C, int64_t h, int64_t w, int64_t H, int64_t W,
+                                     float lambda_seg, float lambda_distil, float scale, void* stream);
+
+/* Same fusion for one cross_entropy2d term only (self-training: CE of the cross-domain mix,
+ * G5/train_DiGA_gta2city_self_training.py:343-351).  logits_lr [N,C,h,w], labels [N,H,W]. */
+int diga_upsample_ce_fwd_bwd(const float* logits_lr, const int64_t* labels, float* grad_lr,
+                             float* loss_out, void* workspace, size_t workspace_bytes,
+                             int64_t N, int64_t C, int64_t h, int64_t w, int64_t H, int64_t W,
+                             float lambda_seg, void* stream);
+
+/* nn.Upsample(size, 'bilinear', align_corners=True) forward (used for eval / drop-in callers). */
+int diga_upsample_bilinear_ac(const float* x, float* y, int64_t NC, int64_t h, int64_t w,
+                              int64_t H, int64_t W, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * EMA teacher and SGD (multi-tensor; tables are device arrays prepared by the caller)
+ * ---------------------------------------------------------------------------------- */
+
+/* update_teacher_params, G5/util/utils.py:103-116:  t <- alpha*t + (1-alpha)*s  (bit-exact to the
+ * two-multiply-one-add fp32 arithmetic of the reference).  one_minus_alpha is passed explicitly
+ * because the reference rounds (1 - alpha) in double before casting. */
+int diga_ema_update_flat(float* teacher, const float* student, int64_t n, float alpha,
+                         float one_minus_alpha, void* stream);
+
+/* Same over a list of tensors.  Chunk c covers elements [chunk_start[c], +chunk_elems) of tensor
+ * chunk_tensor[c]; sizes[i] = numel of tensor i. */
+int diga_ema_update_multi(float* const* teacher_ptrs, const float* const* student_ptrs,
+                          const int64_t* sizes, const int32_t* chunk_tensor, const int64_t* chunk_start,
+                          int64_t n_chunks, int64_t chunk_elems, float alpha, float one_minus_alpha,
+                          void* stream);
+
+/* torch.optim.SGD(momentum, weight_decay) as the reference drives it (G5/model/model_noaux.py:48-77,
+ * G5/train_DiGA_gta2city_warm_up.py:156,301-305): tensor i occurs mult[i] times in its group, so one
+ * step() is mult[i] sequential micro-steps  d = g + wd*p; buf = first_step ? d : momentum*buf + d;
+ * p -= lr[i]*buf  fused in registers.  lr[i] is a device array (per tensor; poly-LR is written there
+ * by the host each step). */
+int diga_sgd_momentum_multi(float* const* param_ptrs, const float* const* grad_ptrs, float* const* buf_ptrs,
+                            const int64_t* sizes, const int32_t* mult, const float* lr,
+                            const int32_t* chunk_tensor, const int64_t* chunk_start,
+                            int64_t n_chunks, int64_t chunk_elems,
+                            float momentum, float weight_decay, int first_step, float grad_scale,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ClassMix (G5/train_DiGA_gta2city_warm_up.py:240-259, ..._self_training.py:259-275,306-325)
+ * ---------------------------------------------------------------------------------- */
+
+/* hist[b][v] = number of pixels of image b with label v, v in 0..255 (other values are not
+ * counted).  hist [B,256] uint32 must be zeroed by the caller (hipMemsetAsync). */
+int diga_label_hist256(const int64_t* labels, uint32_t* hist, int64_t B, int64_t HW, void* stream);
+
+/* out[b,c,y,x] = lut[b][label[b,y,x]] ? fg : bg.  lut [B,256] uint8; bg, fg, out [B,CH,H*W].
+ * If labels_out != NULL also labels_out = lut ? labels : bg_labels (label paste of the
+ * self-training mix).  Labels outside 0..255 select bg. */
+int diga_classmix_paste(const float* bg, const float* fg, const int64_t* labels, const uint8_t* lut,
+                        float* out, const int64_t* bg_labels, int64_t* labels_out,
+                        int64_t B, int64_t CH, int64_t HW, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Centroid pseudo-labeler (G5/calc_centroids.py:120-176, ..._self_training.py:298-341)
+ * ---------------------------------------------------------------------------------- */
+
+/* Class_Features.get_centroid_weight: w[n,k,p] = softmax_k( -|| centroids[k] - feat[n,:,p] ||_2 ).
+ * feat [N,D,HW], centroids [K,D], weights [N,K,HW]; K <= 32.  neg_dist (nullable) receives -d. */
+int diga_centroid_softmax_weights(const float* feat, const float* centroids, float* weights,
+                                  float* neg_dist, int64_t N, int64_t D, int64_t K, int64_t HW,
+                                  void* stream);
+
+/* Bilateral consensus: argmax_k of the bilinear(align_corners) upsampling of weights to [H,W],
+ * pseudo_out = pseudo_in where it equals that argmax else 255; feat_pseudo (nullable) = argmax. */
+int diga_upsample_argmax_consensus(const float* weights, const int64_t* pseudo_in, int64_t* pseudo_out,
+                                   int64_t* feat_pseudo, int64_t N, int64_t K, int64_t h, int64_t w,
+                                   int64_t H, int64_t W, void* stream);
+
+/* Class_Features.calculate_mean_vector.  ids[n,p] = argmax_k out[n,k,p], kept only where it equals
+ * the label (labels given) and < K.  Labels come either already at feature resolution
+ * (labels_lr [N,hw] float, as the reference passes them) or at full resolution (labels_full
+ * [N,H,W] int64, nearest-downsampled here with src = floor(dst*in/out)); both NULL = no labels.
+ * sums [N,K,D] = sum of feat over member pixels, counts [N,K] (int32). */
+size_t diga_class_mean_workspace_bytes(int64_t N, int64_t hw);
+int diga_class_mean_vectors(const float* feat, const float* out, const float* labels_lr,
+                            const int64_t* labels_full, float* sums, int32_t* counts,
+                            void* workspace, size_t workspace_bytes,
+                            int64_t N, int64_t D, int64_t K, int64_t h, int64_t w, int64_t H, int64_t W,
+                            void* stream);
+
+/* update_objective_SingleVector applied sequentially in image-major / class-minor order:
+ * for n, for t: skip if counts<min_pixels or sum(v)==0; v = sums/counts;
+ *   mode 0 (moving average): c_t = c_t*(1-m) + m*v ; num_t = min(num_t+1, 3000)
+ *   mode 1 (mean):           c_t = (c_t*num_t + v)/(num_t+1) ; num_t = min(num_t+1, 3000)
+ * centroids [K,D], nums [K] float. */
+int diga_centroid_ema_apply(float* centroids, float* nums, const float* sums, const int32_t* counts,
+                            int64_t N, int64_t K, int64_t D, int64_t hw, float momentum, int min_pixels,
+                            int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Metrics (G5/util/metrics.py:32-44)
+ * ---------------------------------------------------------------------------------- */
+
+/* hist[gt*K+pred] += 1 for pixels with 0 <= gt < K.  hist [K*K] int64, accumulated into. */
+int diga_confusion_matrix(const int64_t* gt, const int64_t* pred, int64_t* hist, int64_t n, int64_t K,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Kernel-family timing (bench.py's roofline leg): when enabled, every entry point brackets its
+ * launches with HIP events recorded on the launch stream.  Not for production steps.
+ * ---------------------------------------------------------------------------------- */
+enum {
+    DIGA_PROF_CE2D = 0,
+    DIGA_PROF_DISTILL,
+    DIGA_PROF_UPSAMPLE_LOSS,
+    DIGA_PROF_EMA,
+    DIGA_PROF_SGD,
+    DIGA_PROF_CLASSMIX_HIST,
+    DIGA_PROF_CLASSMIX_PASTE,
+    DIGA_PROF_CENTROID_WEIGHTS,
+    DIGA_PROF_CONSENSUS,
+    DIGA_PROF_CLASS_MEANS,
+    DIGA_PROF_CENTROID_APPLY,
+    DIGA_PROF_CONV_FWD,
+    DIGA_PROF_CONV_BWD_DATA,
+    DIGA_PROF_CONV_BWD_WEIGHT,
+    DIGA_PROF_NORM,
+    DIGA_PROF_ELEMENTWISE,
+    DIGA_PROF_NTAGS
+};
+int diga_prof_enable(int on);
+int diga_prof_reset(void);
+/* Waits for the recorded events of `tag`; h_count = launches seen, h_total_ms = summed duration. */
+int diga_prof_query(int tag, int64_t* h_count, double* h_total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIGA_HIP_H */

@@ -1,0 +1,125 @@
+"""GPU parity of the DeepLabV2/ResNet-101 student/teacher and of whole training steps against
+the golden captures of the reference (G-model, G-step) and the CPU oracle."""
+import random
+
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import deeplab as od
+from oracle import detweights, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(arch_name="RESNET101"):
+    from diga_amd.model import seg_model_noaux as sm
+    from diga_amd.model.model_noaux import SegModel
+    m = SegModel(arch=getattr(sm, arch_name))
+    m.load_state_dict(detweights.state_dict(getattr(od, arch_name)))
+    return m.to(DEV)
+
+
+def test_structure_matches_reference(golden):
+    g = golden("model")
+    m = _model()
+    assert list(m.state_dict().keys()) == g["state_keys"].tolist()
+    assert [n for n, _ in m.named_parameters()] == g["param_keys"].tolist()
+    assert sum(p.numel() for p in m.parameters()) == int(g["numel_params"])
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == int(g["numel_trainable"])
+    names = {id(p): n for n, p in m.named_parameters()}
+    groups = m.optim_parameters(2.5e-4)
+    assert [names[id(p)] for p in groups[0]["params"]] == g["g1_order"].tolist()
+    assert [names[id(p)] for p in groups[1]["params"]] == g["g10_order"].tolist()
+    assert groups[1]["lr"] == pytest.approx(2.5e-3)
+
+
+def test_forward_eval_golden(golden):
+    g = golden("model")
+    m = _model().eval()
+    with torch.no_grad():
+        sh, dp, out, feat = m(g.t("x").to(DEV))
+    assert list(sh.shape) == g["shallow_shape"].tolist() and list(dp.shape) == g["deep_shape"].tolist()
+    # north_star tolerance: logits within 1e-3 relative of the reference's CPU path
+    assert_close(out, g.t("out_eval"), 1e-3, 1e-4, "eval logits")
+    assert_close(feat, g.t("feat_eval"), 1e-3, 1e-4, "eval feat")
+    scale = float(g.t("out_eval").abs().max())
+    assert float((out.cpu() - g.t("out_eval")).abs().max()) < 1e-3 * scale
+    assert synth.checksum(sh) == pytest.approx(float(g["shallow_sum"]), rel=1e-3, abs=5e-2)
+    assert synth.checksum(dp) == pytest.approx(float(g["deep_sum"]), rel=1e-3, abs=5e-2)
+
+
+def test_forward_backward_train_golden(golden):
+    g = golden("model")
+    m = _model().train()
+    m.final.head[0].p = 0.0                                     # dropout off, as in the capture
+    _, _, out, feat = m(g.t("x").to(DEV))
+    assert_close(out, g.t("out_train"), 1e-3, 2e-4, "train logits")
+    (out * g.t("probe").to(DEV)).sum().backward()
+    named = dict(m.named_parameters())
+    ref = g.t("g_head")
+    assert_close(named["final.head.1.weight"].grad, ref, 5e-3, 1e-3 * float(ref.abs().max()), "head grad")
+    # gradients of deep layers are discontinuous in the weights (ReLU / max-pool switches), so they are
+    # compared in L1 norm (SURVEY-level tolerance documented in DESIGN.md)
+    for n in ["layer0.0.weight", "layer1.0.conv1.weight", "layer2.3.conv2.weight", "layer3.22.conv3.weight",
+              "layer4.0.downsample.0.weight", "final.conv2d_list.3.0.weight", "final.conv2d_list.0.1.weight",
+              "final.bottleneck.0.se.0.weight", "final.bottleneck.1.bias"]:
+        l1 = g["g_" + n.replace(".", "_")].tolist()[1]
+        assert float(named[n].grad.abs().sum()) == pytest.approx(l1, rel=2e-2), n
+    sd = m.state_dict()
+    assert_close(sd["layer1.0.bn1.running_mean"], g.t("rm_after"), 1e-4, 1e-6, "running mean")
+    assert_close(sd["layer4.2.bn3.running_var"], g.t("rv_after"), 1e-3, 1e-6, "running var")
+
+
+def test_warmup_three_steps_golden(golden):
+    from diga_amd.train_step import DigaTrainer
+    g = golden("step")
+    student, teacher = _model(), _model()
+    for mdl in (student, teacher):
+        mdl.final.head[0].p = 0.0
+    teacher.train()
+    tr = DigaTrainer(student, teacher, rng=random)
+    random.seed(77)
+    for it in range(3):
+        x, x_aug, rec, lab = (t.to(DEV) for t in synth.warmup_batch(1000 + it, 2, 128, 128, block=16))
+        log = tr.warmup_step(it, x, x_aug, rec, lab)
+        assert float(log["ce"]) == pytest.approx(float(g["ce"][it]), rel=1e-3), it
+        assert float(log["distil"]) == pytest.approx(float(g["distil"][it]), rel=1e-3), it
+        assert tr.opt.param_groups[0]["lr"] == pytest.approx(float(g["lr"][it]), rel=1e-12)
+    sd, td = student.state_dict(), teacher.state_dict()
+    assert_close(sd["final.head.1.weight"], g.t("student_head"), 5e-3, 1e-5, "student head")
+    assert_close(td["final.head.1.weight"], g.t("teacher_head"), 5e-3, 1e-5, "teacher head")
+    assert_close(sd["layer1.0.bn1.running_mean"], g.t("stu_rm"), 1e-3, 1e-5, "student running mean")
+    assert_close(td["layer1.0.bn1.running_mean"], g.t("tea_rm"), 1e-3, 1e-5, "teacher running mean")
+    student.eval()
+    teacher.eval()
+    xp = synth.warmup_batch(2000, 1, 128, 128, block=16)[0].to(DEV)
+    with torch.no_grad():
+        so = student(xp)[2]
+        to = teacher(xp)[2]
+    assert_close(so, g.t("probe_student"), 5e-3, 1e-3, "student probe logits")
+    assert_close(to, g.t("probe_teacher"), 5e-3, 1e-3, "teacher probe logits")
+
+
+def test_tiny_model_train_step_vs_oracle():
+    """A small backbone (BASELINE config 1 stand-in) through one full warm-up step, against the oracle."""
+    from diga_amd.train_step import DigaTrainer
+    from oracle import step as ost
+    student, teacher = _model("TINY"), _model("TINY")
+    for mdl in (student, teacher):
+        mdl.final.head[0].p = 0.0
+    teacher.train()
+    tr = DigaTrainer(student, teacher, rng=random)
+    otr = ost.Trainer(detweights.state_dict(od.TINY), detweights.state_dict(od.TINY), arch=od.TINY)
+    for it in range(2):
+        batch = synth.warmup_batch(500 + it, 2, 96, 128, block=16)
+        random.seed(it)
+        want = otr.warmup_step(it, *batch, random)
+        random.seed(it)
+        got = tr.warmup_step(it, *(t.to(DEV) for t in batch))
+        assert float(got["ce"]) == pytest.approx(want["ce"], rel=1e-3)
+        assert float(got["distil"]) == pytest.approx(want["distil"], rel=1e-3)
+    for k in ["layer0.0.weight", "layer3.1.conv2.weight", "final.head.1.weight", "final.bottleneck.1.weight"]:
+        assert_close(student.state_dict()[k], otr.s[k], 2e-3, 2e-5, k)
+        assert_close(teacher.state_dict()[k], otr.t[k], 2e-3, 2e-5, k)

@@ -1,0 +1,226 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header declares,
+the product path refuses CPU tensors (no fallback), host logic (schedules, chunk tables, ClassMix class
+choice, optimizer groups, model structure, synthetic inputs) and the N>1 exchange layer over gloo."""
+import os
+import random
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from oracle import classmix as ocm
+from oracle import deeplab as od
+from oracle import optim as oo
+from oracle import step as ost
+from oracle import synth
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "diga_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(diga_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diga_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"{s} declared in include/diga_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in diga_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert _lib.lib.diga_version() == 1
+    assert len(_lib.PROF_TAGS) == 16
+
+
+def test_abi_argument_errors_without_gpu():
+    """Argument validation happens before any launch, so it can be exercised without a device."""
+    from diga_amd import _lib
+    rc = _lib.lib.diga_ce2d_fwd_bwd(None, None, None, None, None, 0, 1, 19, 4, 4, 1.0, None)
+    assert rc == -1 and "null" in _lib.last_error()
+    rc = _lib.lib.diga_distill_fwd_bwd(1, 1, None, 1, 1, 0, 3, 19, 4, 4, 0.5, 1.0, None)
+    assert rc == -1 and "two views" in _lib.last_error()
+    rc = _lib.lib.diga_upsample_ce_distill_fwd_bwd(1, 1, 1, 1, 1, 1, 0, 2, 19, 1, 5, 8, 8, 1.0, 0.5, 0.5, None)
+    assert rc == -1
+    assert _lib.lib.diga_upsample_loss_workspace_bytes(16, 19, 97, 97) > 16 * 96 * 96 * 78 * 4
+    assert _lib.lib.diga_loss_workspace_bytes(8 * 768 * 768) >= (8 * 768 * 768 // 256) * 4
+
+
+def test_no_cpu_fallback():
+    from diga_amd.calc_centroids import Class_Features
+    from diga_amd.model.model_noaux import SegModel
+    from diga_amd.model.seg_model_noaux import TINY
+    from diga_amd.util import loss, utils
+    x = torch.zeros(2, 19, 4, 4)
+    y = torch.zeros(2, 4, 4, dtype=torch.long)
+    for fn in (lambda: loss.cross_entropy2d(x, y), lambda: loss.distillation_loss(x, x),
+               lambda: loss.upsample_ce_distill(x, x, y[:1]),
+               lambda: utils.classmix_present(y),
+               lambda: Class_Features().get_centroid_weight(torch.zeros(1, 256, 3, 3)),
+               lambda: SegModel(arch=TINY)(torch.zeros(1, 3, 32, 32))):
+        with pytest.raises(RuntimeError, match="GPU only"):
+            fn()
+    a, b = torch.nn.Linear(3, 3), torch.nn.Linear(3, 3)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        utils.update_teacher_params(a, b, 0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "diga_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_lr_schedule_and_alpha():
+    from diga_amd.util import utils
+    for it in (0, 1, 50, 79999):
+        assert utils.poly_lr_scheduler(2.5e-4, it, 80000, 0.9) == oo.poly_lr(2.5e-4, it, 80000, 0.9)
+    for it in (0, 1, 2, 9, 998, 999, 1000, 5000):
+        assert utils.ema_alpha(it) == oo.ema_alpha(it)
+    assert utils.ema_alpha(5, stage0=False) == 0.999 and utils.ema_alpha(5, stage0=False, mean=True) == 0.9
+
+
+def test_classmix_class_choice_matches_oracle():
+    from diga_amd.util import utils
+    present = [[0, 1, 2, 5, 8, 10, 13, 255], [3, 4], [7], [0, 1, 2, 3, 4, 5]]
+    random.seed(0)
+    got = utils.classmix_select(present, random)
+    random.seed(0)
+    want = [ocm.select_classes(p, random) for p in present]
+    assert got == want and got[0] == [13, 255, 5, 0] and got[2] == [255]
+
+
+def test_chunk_tables():
+    from diga_amd.util.utils import CHUNK_ELEMS, TensorTables
+    sizes = [1, CHUNK_ELEMS, CHUNK_ELEMS + 1, 3 * CHUNK_ELEMS + 5]
+    tab = TensorTables(sizes, torch.device("cpu"))
+    ct, cs = tab.chunk_tensor.tolist(), tab.chunk_start.tolist()
+    assert tab.n_chunks == 1 + 1 + 2 + 4 == len(ct)
+    covered = {i: 0 for i in range(len(sizes))}
+    for t, s in zip(ct, cs):
+        assert s % CHUNK_ELEMS == 0 and s < sizes[t]
+        covered[t] += min(CHUNK_ELEMS, sizes[t] - s)
+    assert [covered[i] for i in range(len(sizes))] == sizes
+    a = [torch.zeros(3), torch.zeros(4)]
+    p1 = tab.pointers("x", a)
+    assert tab.pointers("x", a) is p1                       # cached while pointers are stable
+    assert tab.pointers("x", [torch.zeros(3), a[1]]) is not p1
+
+
+def test_model_structure_and_optimizer_groups(golden):
+    from diga_amd.model.model_noaux import SegModel
+    from diga_amd.util.utils import DigaSGD
+    g = golden("model")
+    m = SegModel()
+    assert list(m.state_dict().keys()) == g["state_keys"].tolist() == list(od.state_shapes().keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(od.state_shapes()[k][0]), k
+    names = {id(p): n for n, p in m.named_parameters()}
+    groups = m.optim_parameters(2.5e-4)
+    g1 = [names[id(p)] for p in groups[0]["params"]]
+    assert g1 == g["g1_order"].tolist() and len(g1) == 315
+    opt = DigaSGD(m.optim_parameters(2.5e-4), lr=2.5e-4)
+    mult = {names[id(p)]: k for grp in opt.param_groups for p, k in zip(grp["params"], grp["mult"])}
+    assert len(mult) == 104 + 29
+    for n, k in mult.items():
+        assert k == ost.multiplicity(n), n
+    assert opt.param_groups[1]["lr"] == pytest.approx(2.5e-3)
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert trainable == ost.trainable_keys()
+    w = m.state_dict()["layer3.4.conv2.weight"]
+    assert abs(float(w.std()) - 0.01) < 1e-3                 # N(0, 0.01) conv init
+    assert float(m.state_dict()["final.bottleneck.1.bias"].abs().max()) == 0.0
+
+
+def test_synthetic_inputs_match_oracle_generator():
+    from diga_amd import synthetic
+    a = synthetic.selftrain_batch(1234, 2, 64, 96, block=16)
+    b = synth.selftrain_batch(1234, 2, 64, 96, block=16)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    lab = a[3]
+    assert lab.dtype == torch.int64 and set(np.unique(lab.numpy())) <= set(range(19)) | {255}
+
+
+# ----------------------------------------------------------------------------- N > 1 over gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from diga_amd import ddp
+    r, w, _ = ddp.init_from_env("gloo")
+    assert (r, w) == (rank, world) and ddp.world_size() == world
+    g = torch.Generator().manual_seed(100)
+    shapes = [(7, 3), (1000,), (3, 3, 3, 3), (5,), (70000,)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    frozen = torch.nn.Parameter(torch.randn(4), requires_grad=False)
+    gr = torch.Generator().manual_seed(200 + rank)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=gr)
+    red = ddp.GradReducer(params + [frozen, params[0]], bucket_bytes=4096)
+    assert len(red.buckets) >= 3 and sum(len(b) for b in red.buckets) == len(params)
+    red.reduce()
+    want = []
+    for p in params:
+        acc = torch.zeros_like(p)
+        for rr in range(world):
+            gg = torch.Generator().manual_seed(200 + rr)
+            for q in params:
+                t = torch.randn(q.shape, generator=gg)
+                if q is p:
+                    acc += t
+        want.append(acc)
+    ok_grads = all(torch.allclose(p.grad, w_, rtol=1e-6, atol=1e-6) for p, w_ in zip(params, want))
+    # centroid sums: rank-major concatenation
+    sums = torch.full((2, 19, 4), float(rank))
+    sums[1] += 0.5
+    counts = torch.full((2, 19), rank, dtype=torch.int32)
+    s_all, c_all = ddp.gather_class_sums(sums, counts)
+    ok_gather = (s_all.shape == (2 * world, 19, 4)
+                 and all(float(s_all[2 * rr, 0, 0]) == rr and float(s_all[2 * rr + 1, 0, 0]) == rr + 0.5
+                         and int(c_all[2 * rr, 0]) == rr for rr in range(world)))
+    lin = torch.nn.Linear(4, 4)
+    ddp.broadcast_module(lin)
+    ref = [torch.zeros_like(lin.weight) for _ in range(world)]
+    dist.all_gather(ref, lin.weight.data)
+    ok_bcast = all(torch.equal(ref[0], t) for t in ref)
+    out[rank] = (ok_grads, ok_gather, ok_bcast)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ddp_exchange_gloo_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: (True, True, True), 1: (True, True, True)}
+
+
+def test_ddp_single_process_is_noop():
+    from diga_amd import ddp
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    ddp.GradReducer([p]).reduce()
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
+    s, c = torch.ones(1, 19, 4), torch.ones(1, 19, dtype=torch.int32)
+    assert ddp.gather_class_sums(s, c)[0] is s
+    assert ddp.world_size() == 1 and ddp.rank() == 0
