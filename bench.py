@@ -19,6 +19,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the torch ops still on the path (BatchNorm/GroupNorm/pooling) must not trigger MIOpen's exhaustive search
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import torch  # noqa: E402
 

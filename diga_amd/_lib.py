@@ -47,6 +47,10 @@ SIGNATURES = {
     "diga_class_mean_vectors": (INT, [P, P, P, P, P, P, P, SZ, I64, I64, I64, I64, I64, I64, I64, P]),
     "diga_centroid_ema_apply": (INT, [P, P, P, P, I64, I64, I64, I64, F32, INT, INT, P]),
     "diga_confusion_matrix": (INT, [P, P, P, I64, I64, P]),
+    "diga_conv2d_nhwc_f32": (INT, [P, P, P, P] + [I64] * 17 + [INT, P]),
+    "diga_conv2d_wgrad_workspace_bytes": (SZ, [I64] * 7),
+    "diga_conv2d_wgrad_nhwc_f32": (INT, [P, P, P, P, SZ] + [I64] * 17 + [P]),
+    "diga_weight_transpose": (INT, [P, P, I64, I64, I64, P]),
     "diga_prof_enable": (INT, [INT]),
     "diga_prof_reset": (INT, []),
     "diga_prof_query": (INT, [INT, P, P]),

@@ -1,0 +1,488 @@
+// Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s
+// peak on MI355X) for the DeepLabV2/ResNet-101 trunk and the ASPP head.
+// Reference: the nn.Conv2d layers of G5/model/seg_model_noaux.py:57-101 (Bottleneck 1x1 / dilated 3x3),
+// :140-172 (ASPP 1x1 + four dilated 3x3 2048->256, 3x3 1280->256, 1x1 256->19), run there through cuDNN.
+//
+// Data layout: activations NHWC fp32 ([pixel][channel], `ld` floats between pixels so that a kernel can
+// read or write a channel slice of a wider tensor, e.g. the 1280-channel ASPP concat); weights
+// [Cout][R][S][Cin] (the channels_last image of torch's [Cout,Cin,R,S]).  GEMM view: M = N*Ho*Wo output
+// pixels, N = Cout, K = R*S*Cin walked tap by tap in 32-channel steps, so one K-step reads, for every
+// output pixel of the tile, 128 contiguous bytes of one input pixel (or zeros outside the image).
+//
+//   conv_fwd_kernel   : forward, and backward-data with the roles swapped (in = dy, weights transposed
+//                       to [Cin][R][S][Cout], tap offsets negated).
+//   conv_wgrad_kernel : backward-weight, dw[k][tap][c] = sum_p dy[p][k] * x[p + off(tap)][c], split over
+//                       pixel ranges into fp32 slabs that a second kernel sums in fixed order
+//                       (deterministic: no float atomics).
+//
+// Tile: 128 x BN x 32 per 256-thread block (4 waves as 2x2, each wave TM x TN tiles of 32x32, 16
+// accumulator registers per tile); operands are staged global -> registers -> LDS (two LDS buffers, one
+// barrier per K-step; the global loads of step k+1 are in flight while step k's MFMAs issue).  LDS rows
+// are padded to 36 floats so that the ds_read_b128 fragment reads of 16 different rows land on 16
+// different 4-bank slots (conflict-free).  MFMA fragment mapping: in the 8-wide k group t of a K-step,
+// lane (i = lane&31, h = lane>>5) holds A[i][8t+4h .. 8t+4h+3] (one ds_read_b128) and feeds element j to
+// MFMA step j; B is read the same way, so both halves of the wave agree on which k they multiply.
+#include "common.h"
+
+namespace diga {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kBK = 32;
+constexpr int kLD = kBK + 4;   // padded LDS row (floats)
+
+struct ConvArgs {
+    const float* in;
+    const float* wgt;
+    const float* bias;
+    float* out;
+    int N, Hi, Wi, Cin, in_ld;
+    int Ho, Wo, Cout, out_ld;
+    int R, S, sy, sx;            // input coordinate = out*s + off0 + tap*doff
+    int oy0, ox0, ody, odx;
+    int M, tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    // blocks b and b+8 share an XCD (observed round-robin dispatch): give every XCD a contiguous range
+    // of tiles so that neighbouring tiles (shared activation rows / weight panels) hit the same L2.
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void mma_kstep(const float* __restrict__ As, const float* __restrict__ Bs, int a_row0,
+                                          int b_row0, int lane, f32x16 (&acc)[TM][TN]) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < kBK / 8; ++t) {
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = *reinterpret_cast<const float4*>(As + (a_row0 + i * 32 + li) * kLD + t * 8 + lh * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            b[j] = *reinterpret_cast<const float4*>(Bs + (b_row0 + j * 32 + li) * kLD + t * 8 + lh * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
+                    const float bv = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / backward-data
+// ---------------------------------------------------------------------------------------------
+template <int TN>   // block tile 128 x (64*TN); wave tile 64 x (32*TN)
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
+    constexpr int BM = 128, BN = 64 * TN, TM = 2;
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                     // [2][BM][kLD]
+    float* Bs = smem + 2 * BM * kLD;      // [2][BN][kLD]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // loader geometry: thread owns column chunk c4 (4 floats) of rows lr + 32*i
+    const int lr = t >> 3, c4 = (t & 7) * 4;
+    int pixbase[4], iy0[4], ix0[4];
+    bool mok[4];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lr + 32 * i;
+        mok[i] = m < a.M;
+        const int mm = mok[i] ? m : 0;
+        const int img = mm / HoWo, rem = mm - img * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        pixbase[i] = img * a.Hi * a.Wi;
+        iy0[i] = ho * a.sy + a.oy0;
+        ix0[i] = wo * a.sx + a.ox0;
+    }
+    const int RS = a.R * a.S;
+    const int cchunks = a.Cin / kBK;
+    const int ksteps = RS * cchunks;
+
+    float4 ra[4], rb[BN / 32];
+    auto gload = [&](int ks) {
+        const int tap = ks / cchunks, c0 = (ks - tap * cchunks) * kBK;
+        const int r = tap / a.S, s = tap - r * a.S;
+        const int dy = r * a.ody, dx = s * a.odx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool ok = mok[i] && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float* p = a.in + (int64_t)(pixbase[i] + iy * a.Wi + ix) * a.in_ld + c0 + c4;
+                ra[i] = *reinterpret_cast<const float4*>(p);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int co = n0 + lr + 32 * i;
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < a.Cout) {
+                const float* p = a.wgt + ((int64_t)co * RS + tap) * a.Cin + c0 + c4;
+                rb[i] = *reinterpret_cast<const float4*>(p);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* ad = As + buf * BM * kLD;
+        float* bd = Bs + buf * BN * kLD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(ad + (lr + 32 * i) * kLD + c4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<float4*>(bd + (lr + 32 * i) * kLD + c4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) gload(ks + 1);
+        mma_kstep<TM, TN>(As + cur * BM * kLD, Bs + cur * BN * kLD, wm * 64, wn * 32 * TN, lane, acc);
+        if (ks + 1 < ksteps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: accumulator register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*(lane>>5), col lane&31
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + li;
+        const bool nok = n < a.Cout;
+        const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (nok && m < a.M) a.out[(int64_t)m * a.out_ld + n] = acc[i][j][e] + bv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward-weight
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dy;     // [M][Cout] (dy_ld)
+    const float* x;      // [N][Hi][Wi][Cin] (x_ld)
+    float* slab;         // [splits][Cout][RS][Cin]
+    int N, Hi, Wi, Cin, x_ld;
+    int Ho, Wo, Cout, dy_ld;
+    int R, S, sy, sx, oy0, ox0, ody, odx;
+    int M, tiles_m, tiles_n, splits, steps_per_split;
+};
+
+constexpr int kLDW = 128 + 4;   // wgrad LDS rows: [pixel][channel], channel contiguous
+
+template <int TM, int TN>   // block tile (64*TM) couts x (64*TN) cins; wave tile (32*TM) x (32*TN)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                      // [2][kBK][kLDW]  dy tile   (pixel-major)
+    float* Bs = smem + 2 * kBK * kLDW;     // [2][kBK][kLDW]  x tile
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int RS = a.R * a.S;
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg % a.splits;
+    wg /= a.splits;
+    const int tile_n = wg % a.tiles_n;
+    wg /= a.tiles_n;
+    const int tile_m = wg % a.tiles_m;
+    const int tap = wg / a.tiles_m;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int dyo = a.oy0 + r * a.ody, dxo = a.ox0 + s * a.odx;
+    const int k0 = tile_m * BM, c0 = tile_n * BN;
+    const int HoWo = a.Ho * a.Wo;
+
+    // loader: 32 pixels x BM (or BN) channels per K-step; thread owns 4-float chunks
+    constexpr int CA = BM / 4, CB = BN / 4;          // float4 chunks per pixel row
+    constexpr int NA = (kBK * CA) / 256, NB = (kBK * CB) / 256;
+    float4 ra[NA], rb[NB];
+    const int p_begin = split * a.steps_per_split * kBK;
+    int p_end = p_begin + a.steps_per_split * kBK;
+    if (p_end > a.M) p_end = a.M;
+    const int ksteps = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
+
+    auto gload = [&](int ks) {
+        const int pb = p_begin + ks * kBK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = t + 256 * i;
+            const int pr = idx / CA, ch = (idx - pr * CA) * 4;
+            const int p = pb + pr;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < p_end && k0 + ch < a.Cout)
+                ra[i] = *reinterpret_cast<const float4*>(a.dy + (int64_t)p * a.dy_ld + k0 + ch);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = t + 256 * i;
+            const int pr = idx / CB, ch = (idx - pr * CB) * 4;
+            const int p = pb + pr;
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < p_end && c0 + ch < a.Cin) {
+                const int img = p / HoWo, rem = p - img * HoWo;
+                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                const int iy = ho * a.sy + dyo, ix = wo * a.sx + dxo;
+                if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                    rb[i] = *reinterpret_cast<const float4*>(
+                        a.x + (int64_t)((img * a.Hi + iy) * a.Wi + ix) * a.x_ld + c0 + ch);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* ad = As + buf * kBK * kLDW;
+        float* bd = Bs + buf * kBK * kLDW;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = t + 256 * i;
+            const int pr = idx / CA, ch = (idx - pr * CA) * 4;
+            *reinterpret_cast<float4*>(ad + pr * kLDW + ch) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = t + 256 * i;
+            const int pr = idx / CB, ch = (idx - pr * CB) * 4;
+            *reinterpret_cast<float4*>(bd + pr * kLDW + ch) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    if (ksteps > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) gload(ks + 1);
+        const float* Ac = As + cur * kBK * kLDW;
+        const float* Bc = Bs + cur * kBK * kLDW;
+#pragma unroll
+        for (int kk = 0; kk < kBK; kk += 2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = Ac[(kk + lh) * kLDW + wm * 32 * TM + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bc[(kk + lh) * kLDW + wn * 32 * TN + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (ks + 1 < ksteps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.slab + (int64_t)split * a.Cout * RS * a.Cin;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + wn * 32 * TN + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (k < a.Cout && c < a.Cin) out[((int64_t)k * RS + tap) * a.Cin + c] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                          int64_t n4, int splits) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = reinterpret_cast<const float4*>(slab)[i];
+    for (int k = 1; k < splits; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(slab)[(int64_t)k * n4 + i];
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = s;
+}
+
+// w [K][RS][C] -> wt [C][RS][K]   (32x32 LDS tile per tap)
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                               int K, int RS, int C) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (k < K && c < C) ? w[((int64_t)k * RS + tap) * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, k = k0 + tx;
+        if (c < C && k < K) wt[((int64_t)c * RS + tap) * K + k] = tile[tx][ty + 8 * i];
+    }
+}
+
+static int check_conv_common(const char* who, int64_t Cin, int64_t in_ld, int64_t out_ld, int64_t Cout,
+                             const void* in, const void* w, const void* out) {
+    DIGA_REQUIRE(Cin > 0 && Cin % kBK == 0, DIGA_EINVAL, "%s: Cin=%lld must be a multiple of %d", who, (long long)Cin, kBK);
+    DIGA_REQUIRE(in_ld >= Cin && in_ld % 4 == 0 && out_ld >= Cout, DIGA_EINVAL, "%s: bad leading dimensions", who);
+    DIGA_REQUIRE(aligned16(in) && aligned16(w), DIGA_EALIGN, "%s: pointers must be 16-byte aligned", who);
+    (void)out;
+    return DIGA_OK;
+}
+
+}  // namespace diga
+
+using namespace diga;
+
+extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, float* out, int64_t N,
+                                    int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo,
+                                    int64_t Cout, int64_t out_ld, int64_t R, int64_t S, int64_t stride_y,
+                                    int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
+                                    int prof_tag, void* stream) {
+    DIGA_REQUIRE(in && wgt && out, DIGA_EINVAL, "conv2d: null pointer");
+    DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d: bad shape");
+    int rc = check_conv_common("conv2d", Cin, in_ld, out_ld, Cout, in, wgt, out);
+    if (rc) return rc;
+    DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d: too many pixels for 32-bit tile indices");
+    ConvArgs a;
+    a.in = in; a.wgt = wgt; a.bias = bias; a.out = out;
+    a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.in_ld = (int)in_ld;
+    a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.out_ld = (int)out_ld;
+    a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
+    a.oy0 = (int)off_y0; a.ox0 = (int)off_x0; a.ody = (int)off_dy; a.odx = (int)off_dx;
+    a.M = (int)(N * Ho * Wo);
+    a.tiles_m = (int)ceil_div(a.M, 128);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
+    if (Cout > 64) {
+        a.tiles_n = (int)ceil_div(Cout, 128);
+        const size_t sh = (size_t)(2 * 128 * kLD + 2 * 128 * kLD) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((conv_fwd_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+    } else {
+        a.tiles_n = 1;
+        const size_t sh = (size_t)(2 * 128 * kLD + 2 * 64 * kLD) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((conv_fwd_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+    }
+    return launch_status("diga_conv2d_nhwc_f32");
+}
+
+namespace {
+struct WgradPlan {
+    int tm, tn, tiles_m, tiles_n, splits, steps_per_split;
+};
+WgradPlan plan_wgrad(int64_t M, int64_t Cout, int64_t Cin, int64_t RS) {
+    WgradPlan p;
+    p.tm = Cout > 64 ? 2 : 1;
+    p.tn = Cin > 64 ? 2 : 1;
+    p.tiles_m = (int)ceil_div(Cout, 64 * p.tm);
+    p.tiles_n = (int)ceil_div(Cin, 64 * p.tn);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * RS;
+    const int64_t ksteps = ceil_div(M, kBK);
+    int64_t splits = ceil_div(1024, tiles);            // ~4 blocks per CU in total
+    const int64_t max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;   // at least 8 K-steps per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 512) splits = 512;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (int)ceil_div(ksteps, splits);
+    p.splits = (int)ceil_div(ksteps, p.steps_per_split);
+    return p;
+}
+}  // namespace
+
+extern "C" size_t diga_conv2d_wgrad_workspace_bytes(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout, int64_t Cin,
+                                                    int64_t R, int64_t S) {
+    const WgradPlan p = plan_wgrad(N * Ho * Wo, Cout, Cin, R * S);
+    return p.splits > 1 ? (size_t)p.splits * Cout * R * S * Cin * sizeof(float) : 0;
+}
+
+extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float* dw, void* workspace,
+                                          size_t workspace_bytes, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin,
+                                          int64_t x_ld, int64_t Ho, int64_t Wo, int64_t Cout, int64_t dy_ld, int64_t R,
+                                          int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0,
+                                          int64_t off_x0, int64_t off_dy, int64_t off_dx, void* stream) {
+    DIGA_REQUIRE(dy && x && dw, DIGA_EINVAL, "conv2d_wgrad: null pointer");
+    DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_wgrad: bad shape");
+    DIGA_REQUIRE(Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 4 == 0 && x_ld >= Cin && x_ld % 4 == 0 && dy_ld >= Cout &&
+                     dy_ld % 4 == 0,
+                 DIGA_EINVAL, "conv2d_wgrad: channel counts and leading dimensions must be multiples of 4");
+    DIGA_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw), DIGA_EALIGN, "conv2d_wgrad: pointers must be 16-byte aligned");
+    DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d_wgrad: too many pixels");
+    const int64_t RS = R * S, M = N * Ho * Wo;
+    const WgradPlan p = plan_wgrad(M, Cout, Cin, RS);
+    const size_t need = p.splits > 1 ? (size_t)p.splits * Cout * RS * Cin * sizeof(float) : 0;
+    DIGA_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned16(workspace))), DIGA_EWORKSPACE,
+                 "conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    WgradArgs a;
+    a.dy = dy; a.x = x; a.slab = p.splits > 1 ? (float*)workspace : dw;
+    a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.x_ld = (int)x_ld;
+    a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.dy_ld = (int)dy_ld;
+    a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
+    a.oy0 = (int)off_y0; a.ox0 = (int)off_x0; a.ody = (int)off_dy; a.odx = (int)off_dx;
+    a.M = (int)M; a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.splits = p.splits; a.steps_per_split = p.steps_per_split;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st);
+    const unsigned grid = (unsigned)((int64_t)p.tiles_m * p.tiles_n * RS * p.splits);
+    const size_t sh = (size_t)(4 * kBK * kLDW) * sizeof(float);
+#define DIGA_WGRAD_LAUNCH(TM_, TN_)                                                                                   \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((conv_wgrad_kernel<TM_, TN_>), dim3(grid), dim3(256), sh, st, a);                            \
+    } while (0)
+    if (p.tm == 2 && p.tn == 2) DIGA_WGRAD_LAUNCH(2, 2);
+    else if (p.tm == 2) DIGA_WGRAD_LAUNCH(2, 1);
+    else if (p.tn == 2) DIGA_WGRAD_LAUNCH(1, 2);
+    else DIGA_WGRAD_LAUNCH(1, 1);
+#undef DIGA_WGRAD_LAUNCH
+    if (p.splits > 1) {
+        const int64_t n4 = Cout * RS * Cin / 4;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                           n4, p.splits);
+    }
+    return launch_status("diga_conv2d_wgrad_nhwc_f32");
+}
+
+extern "C" int diga_weight_transpose(const float* w, float* wt, int64_t K, int64_t RS, int64_t C, void* stream) {
+    DIGA_REQUIRE(w && wt && K > 0 && RS > 0 && C > 0 && RS < 65536, DIGA_EINVAL, "weight_transpose: bad argument");
+    dim3 grid((unsigned)ceil_div(C, 32), (unsigned)ceil_div(K, 32), (unsigned)RS);
+    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, (int)K, (int)RS, (int)C);
+    return launch_status("diga_weight_transpose");
+}

@@ -1,0 +1,140 @@
+"""Conv2d on the MI355X fp32 matrix cores (diga_conv2d_nhwc_f32 and friends).
+
+`DigaConv2d` is a drop-in for the nn.Conv2d layers of the reference model
+(G5/model/seg_model_noaux.py:57-101,140-172): same constructor, same parameter names and [Cout,Cin,R,S]
+shapes in the state_dict.  Inside, weights live in channels_last memory ([Cout][R][S][Cin]) and
+activations travel NHWC; tensors handed to / returned from the module are NCHW-shaped views of that
+memory (torch's channels_last format), so neighbouring torch ops see ordinary 4-D tensors.
+Channel counts that are not multiples of 32 (the 3-channel image, the 19-class head) are zero-padded.
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.dirname(_pkg) not in sys.path:
+    sys.path.append(os.path.dirname(_pkg))
+from diga_amd import _lib  # noqa: E402
+
+_TAG_FWD, _TAG_BWD_DATA = _lib.PROF_TAGS.index("conv_fwd"), _lib.PROF_TAGS.index("conv_bwd_data")
+
+
+def _pad_to(c, q=32):
+    return (c + q - 1) // q * q
+
+
+def _pad_last(t, c_to):
+    """Zero-pad the last (channel) dimension of a contiguous tensor to c_to."""
+    c = t.shape[-1]
+    if c == c_to:
+        return t
+    out = t.new_zeros(t.shape[:-1] + (c_to,))
+    out[..., :c] = t
+    return out
+
+
+def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag):
+    """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
+    out [N,Ho,Wo,K] (same rule)."""
+    n, hi, wi, cin = x.shape
+    _, ho, wo, k = out.shape
+    _, r, s, _ = w_krsc.shape
+    _lib.call("diga_conv2d_nhwc_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin,
+              x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
+              tag, _lib.stream())
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation):
+        # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
+        _lib.require_gpu(x, weight)
+        xn = x.detach().permute(0, 2, 3, 1)
+        if not xn.is_contiguous() or xn.dtype != torch.float32:
+            xn = xn.contiguous().float()
+        k, c, r, s = weight.shape
+        cp = _pad_to(c)
+        xn = _pad_last(xn, cp)
+        w = weight.detach().permute(0, 2, 3, 1)
+        if not w.is_contiguous():
+            w = w.contiguous()
+        w = _pad_last(w, cp)
+        n, hi, wi, _ = xn.shape
+        ho = (hi + 2 * padding[0] - dilation[0] * (r - 1) - 1) // stride[0] + 1
+        wo = (wi + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
+        out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
+        b = None if bias is None else bias.detach().float().contiguous()
+        _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD)
+        ctx.save_for_backward(xn, w)
+        ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xn, w = ctx.saved_tensors
+        stride, padding, dilation, c_true, has_bias, w_strides = ctx.geom
+        n, hi, wi, cp = xn.shape
+        k, r, s, _ = w.shape
+        gy = grad_out.permute(0, 2, 3, 1)
+        if not gy.is_contiguous():
+            gy = gy.contiguous()
+        _, ho, wo, _ = gy.shape
+        kp = _pad_to(k)
+        gyp = _pad_last(gy, kp)
+        dx = dw = db = None
+        st = _lib.stream()
+        if ctx.needs_input_grad[0]:
+            # backward-data = stride-1 correlation of dy with the [C][R][S][K] transpose, tap offsets negated
+            if kp == k:
+                wt = torch.empty((cp, r, s, kp), dtype=torch.float32, device=w.device)
+                _lib.call("diga_weight_transpose", _lib.ptr(w), _lib.ptr(wt), k, r * s, cp, st)
+            else:                                   # 19-class head only: tiny, padded with torch ops
+                wt = torch.zeros((cp, r, s, kp), dtype=torch.float32, device=w.device)
+                wt[..., :k] = w.permute(3, 1, 2, 0)
+            if stride == (1, 1):
+                dxn = torch.empty((n, hi, wi, cp), dtype=torch.float32, device=w.device)
+                _conv_launch(gyp, wt, None, dxn, (1, 1), (padding[0], padding[1]), (-dilation[0], -dilation[1]),
+                             _TAG_BWD_DATA)
+            else:
+                if (r, s) != (1, 1) or padding != (0, 0):
+                    raise NotImplementedError("backward-data of strided convs is only needed (and built) for 1x1")
+                dense = torch.empty((n, ho, wo, cp), dtype=torch.float32, device=w.device)
+                _conv_launch(gyp, wt, None, dense, (1, 1), (0, 0), (1, 1), _TAG_BWD_DATA)
+                dxn = torch.zeros((n, hi, wi, cp), dtype=torch.float32, device=w.device)
+                dxn[:, ::stride[0], ::stride[1]] = dense
+            dx = dxn[..., :c_true].permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.empty((kp, r, s, cp), dtype=torch.float32, device=w.device)
+            nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, cp, r, s)
+            ws = _lib.workspace(nbytes, w.device, "wgrad")
+            _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
+                      n, hi, wi, cp, xn.stride(2), ho, wo, kp, gyp.stride(2), r, s, stride[0], stride[1],
+                      -padding[0], -padding[1], dilation[0], dilation[1], st)
+            dw_krsc = dwp[:k, :, :, :c_true]
+            dw = torch.empty_strided((k, c_true, r, s), w_strides, dtype=torch.float32, device=w.device)
+            dw.copy_(dw_krsc.permute(0, 3, 1, 2))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = gy.sum(dim=(0, 1, 2))
+        return dx, dw, db, None, None, None
+
+
+class DigaConv2d(nn.Conv2d):
+    """nn.Conv2d whose compute is the HIP implicit-GEMM kernel; weights kept in channels_last memory."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.groups != 1 or self.padding_mode != "zeros":
+            raise NotImplementedError("DigaConv2d: groups=1 and zero padding only")
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        if self.weight.dim() == 4 and not self.weight.data.is_contiguous(memory_format=torch.channels_last):
+            self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+        return self
+
+    def forward(self, x):
+        return _Conv2dFn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding),
+                               tuple(self.dilation))

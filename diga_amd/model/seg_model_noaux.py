@@ -12,6 +12,8 @@ from typing import Tuple
 import torch
 import torch.nn as nn
 
+from diga_amd.model.conv import DigaConv2d
+
 
 @dataclass(frozen=True)
 class Arch:
@@ -46,11 +48,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False)
+        self.conv1 = DigaConv2d(inplanes, planes, 1, stride=stride, bias=False)
         self.bn1 = _frozen_bn(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=dilation, dilation=dilation, bias=False)
+        self.conv2 = DigaConv2d(planes, planes, 3, stride=1, padding=dilation, dilation=dilation, bias=False)
         self.bn2 = _frozen_bn(planes)
-        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.conv3 = DigaConv2d(planes, planes * self.expansion, 1, bias=False)
         self.bn3 = _frozen_bn(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -84,15 +86,15 @@ class Classifier_Module2(nn.Module):
         super().__init__()
 
         def branch(k, d, p):
-            return nn.Sequential(nn.Conv2d(inplanes, width, k, stride=1, padding=p, dilation=d, bias=True),
+            return nn.Sequential(DigaConv2d(inplanes, width, k, stride=1, padding=p, dilation=d, bias=True),
                                  nn.GroupNorm(groups, width), nn.ReLU(inplace=True))
 
         self.conv2d_list = nn.ModuleList([branch(1, 1, 0)] +
                                          [branch(3, d, p) for d, p in zip(dilation_series, padding_series)])
         cat = width * (len(dilation_series) + 1)
-        tail = [nn.Conv2d(cat, width, 3, stride=1, padding=1, bias=True), nn.GroupNorm(groups, width)]
+        tail = [DigaConv2d(cat, width, 3, stride=1, padding=1, bias=True), nn.GroupNorm(groups, width)]
         self.bottleneck = nn.Sequential(*([SEBlock(cat, se_reduction)] if use_se else []), *tail)
-        self.head = nn.Sequential(nn.Dropout2d(droprate), nn.Conv2d(width, num_classes, 1, bias=False))
+        self.head = nn.Sequential(nn.Dropout2d(droprate), DigaConv2d(width, num_classes, 1, bias=False))
         # Effective init of the reference (seg_model_noaux.py:173-198 + the global loop :236-242): only the
         # 3x3 bottleneck conv gets a zero bias; branch biases and the SE linears keep torch's defaults
         # (the reference's isinstance() tests see Sequential/SEBlock containers, not the layers inside).
@@ -112,7 +114,7 @@ class ResNetMulti(nn.Module):
         super().__init__()
         self.bn_clr = bn_clr
         self.inplanes = arch.stem
-        self.conv1 = nn.Conv2d(3, arch.stem, 7, stride=2, padding=3, bias=False)
+        self.conv1 = DigaConv2d(3, arch.stem, 7, stride=2, padding=3, bias=False)
         self.bn1 = _frozen_bn(arch.stem)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1, ceil_mode=True)
@@ -134,7 +136,7 @@ class ResNetMulti(nn.Module):
     def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion or dilation in (2, 4):
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+            down = nn.Sequential(DigaConv2d(self.inplanes, planes * block.expansion, 1, stride=stride, bias=False),
                                  _frozen_bn(planes * block.expansion))
         seq = [block(self.inplanes, planes, stride, dilation=dilation, downsample=down)]
         self.inplanes = planes * block.expansion

@@ -94,16 +94,26 @@ class TensorTables:
         return cached[1]
 
 
+def same_dense_layout(a, b):
+    """True when a and b are dense and store element (i,j,..) at the same offset, so that an
+    elementwise kernel may walk their raw memory (contiguous, or both channels_last)."""
+    if a.shape != b.shape:
+        return False
+    if a.is_contiguous() and b.is_contiguous():
+        return True
+    return (a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last)
+            and b.is_contiguous(memory_format=torch.channels_last))
+
+
 def _check_param_lists(a, b, what):
     if len(a) != len(b):
         raise ValueError(f"{what}: {len(a)} vs {len(b)} parameters")
     for x, y in zip(a, b):
-        if x.shape != y.shape:
-            raise ValueError(f"{what}: parameter shapes differ {tuple(x.shape)} vs {tuple(y.shape)}")
         if x.dtype != torch.float32 or y.dtype != torch.float32:
             raise TypeError(f"{what}: fp32 parameters expected")
-        if not (x.is_contiguous() and y.is_contiguous()):
-            raise ValueError(f"{what}: parameters must be contiguous")
+        if not same_dense_layout(x, y):
+            raise ValueError(f"{what}: parameters differ in shape or memory layout "
+                             f"({tuple(x.shape)}/{x.stride()} vs {tuple(y.shape)}/{y.stride()})")
     _lib.require_gpu(*a, *b)
 
 
@@ -297,7 +307,10 @@ class DigaSGD(torch.optim.Optimizer):
         for p in self._params:
             if p.grad is None:
                 raise RuntimeError("DigaSGD: every trainable parameter must have a gradient")
-            grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+            g = p.grad
+            if not same_dense_layout(g, p.data):          # walk raw memory: layouts must agree
+                g = torch.empty_like(p.data).copy_(g)
+            grads.append(g)
         lrs = [float(self.param_groups[gi]["lr"]) for gi in self._group_of]
         if lrs != self._lr_host:
             self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)

@@ -185,6 +185,38 @@ int diga_confusion_matrix(const int64_t* gt, const int64_t* pred, int64_t* hist,
                           void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Convolution on the fp32 matrix cores (nn.Conv2d layers of G5/model/seg_model_noaux.py:57-101,
+ * :140-172; cuDNN in the reference).  Activations NHWC fp32 with a leading dimension (`*_ld` floats
+ * between pixels, so channel slices of wider tensors can be read/written in place); weights
+ * [Cout][R][S][Cin] = the channels_last image of torch's [Cout,Cin,R,S].
+ * ---------------------------------------------------------------------------------- */
+
+/* out[n,ho,wo,k] = bias[k] + sum_{r,s,c} in[n, ho*stride_y + off_y0 + r*off_dy, wo*stride_x + off_x0 + s*off_dx, c]
+ *                                        * wgt[k][r][s][c]          (taps outside the image read zero)
+ * Forward conv: off_*0 = -padding, off_d* = dilation.  Backward-data of a stride-1 conv: in = dy,
+ * wgt = the [Cin][R][S][Cout] transpose (diga_weight_transpose), off_*0 = +padding, off_d* = -dilation.
+ * Cin % 32 == 0, in_ld % 4 == 0; bias nullable.  prof_tag: DIGA_PROF_CONV_FWD or DIGA_PROF_CONV_BWD_DATA. */
+int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, float* out,
+                         int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld,
+                         int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                         int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
+                         int64_t off_dy, int64_t off_dx, int prof_tag, void* stream);
+
+/* dw[k][r][s][c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride_y + off_y0 + r*off_dy, wo*stride_x + off_x0 + s*off_dx, c]
+ * Split over pixel ranges into fp32 slabs in `workspace`, summed in fixed order (deterministic).
+ * Cin % 4 == 0, Cout % 4 == 0. */
+size_t diga_conv2d_wgrad_workspace_bytes(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout, int64_t Cin,
+                                         int64_t R, int64_t S);
+int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes,
+                               int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t x_ld,
+                               int64_t Ho, int64_t Wo, int64_t Cout, int64_t dy_ld, int64_t R, int64_t S,
+                               int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
+                               int64_t off_dy, int64_t off_dx, void* stream);
+
+/* w [K][RS][C] -> wt [C][RS][K] (weights for backward-data). */
+int diga_weight_transpose(const float* w, float* wt, int64_t K, int64_t RS, int64_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Kernel-family timing (bench.py's roofline leg): when enabled, every entry point brackets its
  * launches with HIP events recorded on the launch stream.  Not for production steps.
  * ---------------------------------------------------------------------------------- */

@@ -79,7 +79,7 @@ def test_distill_golden(mods, golden):
         loss = mods["loss"].distillation_loss(g.t(tk).to(DEV), s, scale)
         loss.backward()
         assert_close(loss, g.t(lk), 1e-5, 1e-7, lk)
-        assert_close(s.grad, g.t(gk), 2e-5, 1e-10, gk)
+        assert_close(s.grad, g.t(gk), 2e-5, 2e-6 * float(g.t(gk).abs().max()), gk)
 
 
 @pytest.mark.parametrize("shape,C", [((4, 48, 64), 19), ((2, 33, 35), 19), ((6, 16, 16), 16), ((2, 8, 8), 5)])
@@ -95,7 +95,7 @@ def test_distill_vs_oracle(mods, shape, C):
     ld = mods["loss"].distillation_loss(t.to(DEV), sd)
     (2.0 * ld).backward()
     assert_close(ld, lo.detach(), 1e-5, 1e-7, "loss")
-    assert_close(sd.grad, 2.0 * so.grad, 2e-5, 1e-10, "grad")
+    assert_close(sd.grad, 2.0 * so.grad, 2e-5, 4e-6 * float(so.grad.abs().max()), "grad")
 
 
 # ----------------------------------------------------------------------------- fused upsample + losses

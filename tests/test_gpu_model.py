@@ -46,8 +46,8 @@ def test_forward_eval_golden(golden):
     assert_close(feat, g.t("feat_eval"), 1e-3, 1e-4, "eval feat")
     scale = float(g.t("out_eval").abs().max())
     assert float((out.cpu() - g.t("out_eval")).abs().max()) < 1e-3 * scale
-    assert synth.checksum(sh) == pytest.approx(float(g["shallow_sum"]), rel=1e-3, abs=5e-2)
-    assert synth.checksum(dp) == pytest.approx(float(g["deep_sum"]), rel=1e-3, abs=5e-2)
+    assert synth.checksum(sh.cpu()) == pytest.approx(float(g["shallow_sum"]), rel=1e-3, abs=5e-2)
+    assert synth.checksum(dp.cpu()) == pytest.approx(float(g["deep_sum"]), rel=1e-3, abs=5e-2)
 
 
 def test_forward_backward_train_golden(golden):
