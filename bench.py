@@ -145,15 +145,34 @@ def main():
                 n, ms = _lib.prof_query(tag)
                 if n:
                     families[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / a.steps}
-        # roofline of the dominant own kernel: the fused duplicate-aware SGD, a pure HBM stream of
-        # 20 B per trainable parameter (read p, g, buf; write p, buf) -- DESIGN.md, "Kernels".
-        roof = None
-        if "sgd" in families:
-            alg_bytes = 20.0 * n_trainable
-            ach = alg_bytes / (families["sgd"]["avg_ms"] * 1e-3) / 1e9
-            roof = {"kernel": "sgd_multi_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                    "avg_launch_ms": families["sgd"]["avg_ms"]}
+        # Dominant kernel: the forward implicit-GEMM convolution (MFMA-bound).  Algorithmic work of its
+        # launches in one step = model forward FLOPs (1232.9 GFLOP per 768x768 image, scaled
+        # by area) x 2B student images + 2B teacher images; achieved = that / the summed launch durations.
+        roof, roof_hbm = None, {}
+        fwd_gflop = FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)
+        if "conv_fwd" in families and arch_name == "RESNET101":
+            fam = families["conv_fwd"]
+            flops_step = 2 * (2 * B) * fwd_gflop * 1e9
+            n_launch = fam["launches"] / a.steps
+            ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
+            roof = {"kernel": "conv_fwd_kernel (fp32-MFMA implicit GEMM; all forward-conv launches of a step)",
+                    "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "algorithmic_flops_per_launch": flops_step / n_launch, "avg_launch_ms": fam["avg_ms"],
+                    "launches_per_step": n_launch}
+            for tag, mult in (("conv_bwd_data", 1.0), ("conv_bwd_weight", 1.0)):
+                if tag in families:        # backward: one pass each over the student's 2B images
+                    f = (2 * B) * fwd_gflop * 1e9 * mult
+                    roof_hbm[tag] = {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
+                                     "achieved": f / (families[tag]["ms_per_step"] * 1e-3) / 1e12}
+                    roof_hbm[tag]["frac"] = roof_hbm[tag]["achieved"] / F32_MFMA_PEAK_TFLOPS
+        for tag, bytes_per_launch in (("sgd", 20.0 * n_trainable),
+                                      ("ema", 12.0 * sum(p.numel() for p in student.parameters())),
+                                      ("classmix_paste", 44.0 * B * H * W), ("classmix_hist", 8.0 * B * H * W)):
+            if tag in families:
+                ach = bytes_per_launch / (families[tag]["avg_ms"] * 1e-3) / 1e9
+                roof_hbm[tag] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": ach,
+                                 "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch}
         line = {
             "metric": "768x768 19-class crops/sec (DiGA warm-up step)",
             "value": world * B * a.steps / dt, "unit": "crops/s", "n_gpus": world, "steps": a.steps,
@@ -161,7 +180,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
                        "images_per_step_per_gpu": {"student_fwd_bwd": 2 * B, "teacher_fwd": 2 * B}},
-            "roofline": roof,
+            "roofline": roof, "roofline_other_kernels": roof_hbm,
             "cpu_baseline": None if (a.no_cpu_baseline or world > 1) else cpu_baseline(),
             "kernel_families": families, "losses_last_step": losses,
             "model_tflop_per_step_per_gpu": (2 * B) * (3 + 1) * (FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)) / 1e3,

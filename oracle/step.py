@@ -91,3 +91,37 @@ class Trainer:
         grads = dict(zip(leaves.keys(), torch.autograd.grad(total, list(leaves.values()))))
         lr = self._sgd(grads, it)
         return {"ce": float(ce), "distil": float(di), "total": float(total), "lr": lr}
+
+    def selftrain_step(self, it, x, x_aug, rec, labels, t_img, t_aug, pseudo_prob, centroids, nums, rng=random,
+                       lambda_seg=1.0, lambda_distil=0.25, momentum=1e-4):
+        """self_training.py:214-387.  centroids [19,256] / nums [19] are updated in place."""
+        B = x.shape[0]
+        oo.ema_update([self.t[k] for k in self.pkeys], [self.s[k] for k in self.pkeys], it)
+        mix, _, _ = ocm.classmix(rec, x_aug, labels, rng)                       # :259-275
+        cat = torch.cat([x, mix])
+        leaves = {k: self.s[k].detach().requires_grad_() for k in self.tkeys}
+        sd = {**self.s, **leaves}
+        _, _, s_lr, _ = od.forward(sd, cat, self.arch, training=True, keep_mask=self._keep(2 * B),
+                                   update_stats=True)                            # :281
+        with torch.no_grad():
+            _, _, t_lr, t_feat = od.forward(self.t, cat, self.arch, training=True, keep_mask=self._keep(2 * B),
+                                            update_stats=True)                   # :286-287
+            _, _, tt_lr, tt_feat = od.forward(self.t, t_img, self.arch, training=True, keep_mask=self._keep(B),
+                                              update_stats=True)                 # :300
+            w = oc.centroid_weight(tt_feat, centroids)                           # :301
+            pseudo, _ = oc.consensus_filter(w, pseudo_prob)                      # :302-304
+            cross_mix, _, _, cross_lab = ocm.classmix(t_aug, x, labels, rng, bg_labels=pseudo)   # :306-325
+            hw = tt_feat.shape[-2:]
+            for feat, out, lab in ((tt_feat, tt_lr, pseudo), (t_feat[B:], t_lr[B:], labels)):    # :327-341
+                lab_lr = oc.nearest_downsample_labels(lab, hw)
+                vecs, ids, _ = oc.class_mean_vectors(feat, out, lab_lr)
+                oc.centroid_ema_apply(centroids, nums, vecs, ids, momentum)
+        _, _, c_lr, _ = od.forward(sd, cross_mix, self.arch, training=True, keep_mask=self._keep(B),
+                                   update_stats=True)                            # :343-344
+        total_s, ce, di = ol.warmup_losses_lowres(s_lr, t_lr, labels, lambda_seg, lambda_distil)
+        ce_mix = ol.cross_entropy2d(ol.upsample_bilinear_ac(c_lr, cross_lab.shape[-2:]), cross_lab)
+        total = total_s + lambda_seg * ce_mix                                    # :348-356,382
+        grads = dict(zip(leaves.keys(), torch.autograd.grad(total, list(leaves.values()))))
+        lr = self._sgd(grads, it)
+        return {"ce": float(ce), "distil": float(di), "ce_mix": float(ce_mix), "total": float(total), "lr": lr,
+                "kept": float((pseudo != 255).float().mean())}

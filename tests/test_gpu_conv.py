@@ -54,14 +54,16 @@ def test_conv_fwd_bwd(case):
             m.bias.copy_(b)
     m = m.to(DEV)
     assert m.weight.is_contiguous(memory_format=torch.channels_last)
-    xd = x.to(DEV).requires_grad_()
+    need_dx = stride == 1 or k == 1           # the only strided conv with k > 1 is the stem: its input is the image
+    xd = x.to(DEV).requires_grad_(need_dx)
     y = m(xd)
     assert tuple(y.shape) == tuple(yr.shape)
     scale = float(yr.abs().max())
     assert_close(y, yr, 1e-5, 2e-6 * scale, f"{name} forward")
     (y * probe.to(DEV)).sum().backward()
-    gs = float(xr.grad.abs().max())
-    assert_close(xd.grad, xr.grad, 1e-5, 3e-6 * gs, f"{name} grad input")
+    if need_dx:
+        gs = float(xr.grad.abs().max())
+        assert_close(xd.grad, xr.grad, 1e-5, 3e-6 * gs, f"{name} grad input")
     ws = float(wr.grad.abs().max())
     assert_close(m.weight.grad, wr.grad, 1e-5, 3e-6 * ws, f"{name} grad weight")
     assert m.weight.grad.stride() == m.weight.stride()

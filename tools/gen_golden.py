@@ -484,6 +484,98 @@ def gen_step():
     save("step", probe_student=so, probe_teacher=to, **res)
 
 
+# ------------------------------------------------------------------ G-selftrain (one self-training step)
+def gen_selftrain():
+    import torch.optim as optim
+    B, H, W = 2, 128, 128
+    student, teacher = _ref_model(), _ref_model()
+    for mdl in (student, teacher):
+        mdl.final.head[0].p = 0.0
+    opt = optim.SGD(student.optim_parameters(2.5e-4), lr=2.5e-4, momentum=0.9, weight_decay=0.0005)
+    up = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+    teacher = create_teacher_params(teacher, student)
+    cf = Class_Features(numbers=19)
+    cents0 = torch.randn((19, 256), generator=synth.gen(7)) * 0.3
+    cf.objective_vectors = cents0.clone()
+    random.seed(78)
+    it = 3
+    student.train()
+    adjust_learning_rate([opt], base_lr=2.5e-4, i_iter=it, max_iter=80000, power=0.9)
+    with torch.no_grad():
+        teacher = update_teacher_params(teacher, student, it)
+    x, x_aug, rec, lab, t_img, t_aug, pseudo_prob = synth.selftrain_batch(3000, B, H, W, block=16)
+    # --- self_training.py:259-275 re-enacted (ClassMix #1)
+    mask = torch.zeros(lab.size())
+    for i in range(B):
+        present = torch.unique(lab[i]).tolist()
+        pick = random.sample(present, len(present) // 2)
+        if 255 not in pick:
+            pick.append(255)
+        for c in pick:
+            mask[i][lab[i] == c] = 1
+    mix = torch.zeros(rec.size())
+    for i in range(B):
+        mix[i] = torch.mul(rec[i], 1 - mask[i]) + torch.mul(x_aug[i], mask[i])
+    cat = torch.cat([x, mix])
+    _, _, s_cat, _ = student(cat)
+    with torch.no_grad():
+        _, _, t_cat_lr, t_feat_cat = teacher(cat)
+    t_aug_raw = t_cat_lr[B:]
+    t_cat = up(t_cat_lr)
+    s_feat_tea_aug = t_feat_cat[B:]
+    # --- :298-304 bilateral consensus
+    with torch.no_grad():
+        pseudo = pseudo_prob.clone()
+        _, _, tt_pred, tt_feat = teacher(t_img)
+        fw = up(cf.get_centroid_weight(tt_feat.detach()))
+        feat_pseudo = fw.max(1, keepdim=True)[1].squeeze(1)
+        pseudo[pseudo_prob != feat_pseudo] = 255
+    # --- :306-325 ClassMix #2 with label paste
+    cross_lab = pseudo.clone()
+    mask = torch.zeros(lab.size())
+    for i in range(B):
+        present = torch.unique(lab[i]).tolist()
+        pick = random.sample(present, len(present) // 2)
+        if 255 not in pick:
+            pick.append(255)
+        for c in pick:
+            cross_lab[i][lab[i] == c] = c
+            mask[i][lab[i] == c] = 1
+    cross_mix = torch.zeros(t_aug.size())
+    for i in range(B):
+        cross_mix[i] = torch.mul(t_aug[i], 1 - mask[i]) + torch.mul(x[i], mask[i])
+    cross_lab = cross_lab.long()
+    # --- :327-341 centroid updates (target, then source)
+    with torch.no_grad():
+        nl_t = F.interpolate(pseudo.clone().reshape([B, 1, H, W]).float(), size=tt_feat.size()[2:], mode="nearest")
+        v_t, id_t = cf.calculate_mean_vector(tt_feat, tt_pred.detach(), nl_t)
+        for k in range(len(id_t)):
+            cf.update_objective_SingleVector(id_t[k], v_t[k].detach(), start_mean=False)
+        nl_s = F.interpolate(lab.clone().reshape([B, 1, H, W]).float(), size=s_feat_tea_aug.size()[2:], mode="nearest")
+        v_s, id_s = cf.calculate_mean_vector(s_feat_tea_aug, t_aug_raw.detach(), nl_s)
+        for k in range(len(id_s)):
+            cf.update_objective_SingleVector(id_s[k], v_s[k].detach(), start_mean=False)
+    _, _, c_pred, _ = student(cross_mix)
+    c_pred = up(c_pred)
+    s_up = up(s_cat)
+    ce = cross_entropy2d(s_up[:B], lab)
+    di = distillation_loss(t_cat, s_up)
+    ce_mix = cross_entropy2d(c_pred, cross_lab)
+    total = 1.0 * (ce + ce_mix) + 0.25 * di
+    opt.zero_grad()
+    total.backward()
+    opt.step()
+    sd = student.state_dict()
+    top2 = fw.topk(2, dim=1)[0]
+    save("selftrain", ce=ce, distil=di, ce_mix=ce_mix, total=total, cents0=cents0, cents=cf.objective_vectors,
+         nums=cf.objective_vectors_num, ids_t=np.array(id_t), ids_s=np.array(id_s), pseudo=pseudo,
+         feat_pseudo=feat_pseudo, margin=(top2[:, 0] - top2[:, 1]), cross_lab=cross_lab,
+         student_head=sd["final.head.1.weight"], kept=np.array(float((pseudo != 255).float().mean())),
+         ps_layer3=np.array(synth.checksum(sd["layer3.10.conv2.weight"])))
+    print("selftrain", float(ce), float(di), float(ce_mix), "kept", float((pseudo != 255).float().mean()),
+          "ids_t", id_t, "ids_s", id_s)
+
+
 # ------------------------------------------------------------------ G-miou
 def gen_miou():
     g = synth.gen(9)
@@ -504,7 +596,7 @@ def gen_miou():
 
 ALL = dict(ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
-           model=gen_model, step=gen_step, miou=gen_miou)
+           model=gen_model, step=gen_step, selftrain=gen_selftrain, miou=gen_miou)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
