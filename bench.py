@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="override crops per GPU (debug only)")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override crop H W (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the CPU leg and print its JSON")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel families with HIP events")
     return ap.parse_args()
 
@@ -57,7 +58,11 @@ def cpu_baseline():
     units by the forward-FLOP ratio."""
     from oracle import detweights, synth
     from oracle import step as ost
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))            # beyond ~32 threads torch's CPU convs stop scaling at this size
     torch.set_num_threads(cores)
     tr = ost.Trainer(detweights.state_dict(), detweights.state_dict())
     rng = random.Random(5)
@@ -74,8 +79,32 @@ def cpu_baseline():
                       f"({FWD_GFLOP_256}/{FWD_GFLOP_768} GFLOP)"}
 
 
+def cpu_baseline_subprocess(limit_s=240):
+    """Run the CPU leg in a child process (started before this process touches the GPU) so that a slow or
+    memory-hungry host cannot take the GPU measurement down with it."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
+                           text=True, timeout=limit_s)
+        for ln in reversed(r.stdout.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "unit": "crops/s", "cores": None, "kind": "port",
+                "sample": f"CPU leg failed (rc={r.returncode}): {r.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "crops/s", "cores": None, "kind": "port",
+                "sample": f"CPU leg did not finish two B=2 256x256 oracle steps within {limit_s} s"}
+
+
 def main():
     a = parse()
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_line = None
+    if world_env == 1 and not a.no_cpu_baseline:
+        cpu_line = cpu_baseline_subprocess()
     from diga_amd import ddp
     rank, world, local = ddp.init_from_env()
     if world != a.gpus:
@@ -181,7 +210,7 @@ def main():
             "config": {"workload": desc, "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
                        "images_per_step_per_gpu": {"student_fwd_bwd": 2 * B, "teacher_fwd": 2 * B}},
             "roofline": roof, "roofline_other_kernels": roof_hbm,
-            "cpu_baseline": None if (a.no_cpu_baseline or world > 1) else cpu_baseline(),
+            "cpu_baseline": cpu_line,
             "kernel_families": families, "losses_last_step": losses,
             "model_tflop_per_step_per_gpu": (2 * B) * (3 + 1) * (FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)) / 1e3,
         }

@@ -207,13 +207,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int RS = a.R * a.S;
+    // tiles fastest, pixel-range split slowest: blocks that run together (and, after the XCD remap, share an
+    // L2) read the same dy / x pixel range for different taps and channel tiles
     int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = wg % a.splits;
-    wg /= a.splits;
     const int tile_n = wg % a.tiles_n;
     wg /= a.tiles_n;
     const int tile_m = wg % a.tiles_m;
-    const int tap = wg / a.tiles_m;
+    wg /= a.tiles_m;
+    const int tap = wg % RS;
+    const int split = wg / RS;
     const int r = tap / a.S, s = tap - r * a.S;
     const int dyo = a.oy0 + r * a.ody, dxo = a.ox0 + s * a.odx;
     const int k0 = tile_m * BM, c0 = tile_n * BN;

@@ -14,6 +14,7 @@ if os.path.dirname(_pkg) not in sys.path:
     sys.path.append(os.path.dirname(_pkg))
 from diga_amd import _lib  # noqa: E402,F401  (fails loudly when the HIP library is missing)
 from diga_amd.model.seg_model_noaux import RESNET101, DeeplabMulti  # noqa: E402
+from diga_amd.model.translator import ImgDecoder, ImgEncoder  # noqa: E402,F401  (same import surface as the reference)
 
 pspnet_specs = {'n_classes': 19, 'input_size': (713, 713), 'block_config': [3, 4, 23, 3]}
 

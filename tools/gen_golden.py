@@ -576,6 +576,28 @@ def gen_selftrain():
           "ids_t", id_t, "ids_s", id_s)
 
 
+# ------------------------------------------------------------------ translator (SURVEY 8f "next" #1)
+def gen_translator():
+    from model.model_noaux import ImgDecoder, ImgEncoder  # reference
+    torch.manual_seed(0)
+    enc, dec = ImgEncoder(), ImgDecoder()
+    keys = {}
+    for tag, m in (("enc", enc), ("dec", dec)):
+        sd = m.state_dict()
+        new = {k: detweights.fill(f"translator.{tag}.{k}", tuple(v.shape), "conv" if v.dim() == 4 else "bias")
+               for k, v in sd.items()}
+        m.load_state_dict(new)
+        m.eval()
+        keys[tag] = list(sd.keys())
+    g = synth.gen(12)
+    x = torch.rand((2, 3, 64, 96), generator=g) * 2 - 1
+    with torch.no_grad():
+        feat = enc(x)
+        rec = dec(feat)
+    save("translator", x=x, feat_sum=np.array(synth.checksum(feat)), feat_shape=np.array(feat.shape), rec=rec,
+         enc_keys=np.array(keys["enc"]), dec_keys=np.array(keys["dec"]))
+
+
 # ------------------------------------------------------------------ G-miou
 def gen_miou():
     g = synth.gen(9)
@@ -596,7 +618,7 @@ def gen_miou():
 
 ALL = dict(ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
-           model=gen_model, step=gen_step, selftrain=gen_selftrain, miou=gen_miou)
+           model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
