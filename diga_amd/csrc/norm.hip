@@ -1,0 +1,682 @@
+// Normalisation / pooling kernels of the DeepLabV2 model on NHWC fp32 tensors ([pixel][channel], `ld`
+// floats between pixels): train-mode BatchNorm with frozen affine (+ReLU, +residual), GroupNorm(32)
+// (+ReLU, + per-(n,c) Dropout2d scale), SE average pool / channel gate, 3x3/2 max-pool.
+// Reference: nn.BatchNorm2d / nn.GroupNorm / SEBlock / nn.Dropout2d / nn.MaxPool2d(ceil_mode) inside
+// G5/model/seg_model_noaux.py:57-101,122-137,140-214,216-232 (cuDNN / ATen kernels there).
+//
+// All of it is HBM-bound column statistics + elementwise work.  One family of kernels serves both norms:
+//   colstats_partial : per (segment, row-chunk, channel) shifted sums  sum(x-s), sum((x-s)^2)
+//   *_finalize       : merge partials in double (Chan) -> mean / invstd -> per-(segment,channel) a, b
+//   affine_apply     : y = [relu](x*a[seg,c] + b[seg,c] [+ residual])
+//   bwd_partial      : per (segment, chunk, channel)  sum(g), sum(g*xhat),  g = dy*[y>0]
+//   *_bwd_finalize   : -> k1,k2,k3 with dx = k1*g - k2 - xhat*k3   (and dgamma/dbeta for GroupNorm)
+//   bwd_apply        : dx (and the residual gradient g)
+// A segment is the whole tensor for BatchNorm and one image for GroupNorm / SE.  Sums are merged in a
+// fixed order: deterministic, no float atomics.
+#include <initializer_list>
+
+#include "common.h"
+
+namespace diga {
+
+constexpr int kNormThreads = 256;
+
+struct ColGeom {
+    int64_t rows_per_seg;   // rows of one segment
+    int nseg, C, chunk_rows, nchunk;
+};
+
+// thread -> (channel quad q, row lane rl): tq = C/4 quads; if tq >= 256 every thread walks quads q, q+256, ...
+// over all rows of the chunk; else 256/tq row lanes share a quad and are summed through LDS.
+template <int NV, class F>
+__device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk, float* __restrict__ out, F&& f) {
+    // out: [NV][C] partial sums of this (seg, chunk); f(row_global, c, acc[NV][4]) accumulates one float4 column group
+    __shared__ float red[kNormThreads][4];
+    const int tq = g.C >> 2;
+    const int64_t r0 = (int64_t)seg * g.rows_per_seg + (int64_t)chunk * g.chunk_rows;
+    int64_t r1 = r0 + g.chunk_rows;
+    const int64_t seg_end = (int64_t)(seg + 1) * g.rows_per_seg;
+    if (r1 > seg_end) r1 = seg_end;
+    if (tq >= kNormThreads) {
+        for (int q = threadIdx.x; q < tq; q += kNormThreads) {
+            float acc[NV][4];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[v][e] = 0.f;
+            for (int64_t r = r0; r < r1; ++r) f(r, r0, q * 4, acc);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[(int64_t)v * g.C + q * 4 + e] = acc[v][e];
+        }
+    } else {
+        const int lanes = kNormThreads / tq;          // row lanes per quad (tq is a power of two <= 128 here)
+        const int q = threadIdx.x % tq, rl = threadIdx.x / tq;
+        float acc[NV][4];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[v][e] = 0.f;
+        if (rl < lanes)
+            for (int64_t r = r0 + rl; r < r1; r += lanes) f(r, r0, q * 4, acc);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[threadIdx.x][e] = acc[v][e];
+            __syncthreads();
+            if (threadIdx.x < tq) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int l = 0; l < lanes; ++l)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] += red[l * tq + threadIdx.x][e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[(int64_t)v * g.C + threadIdx.x * 4 + e] = s[e];
+            }
+        }
+    }
+}
+
+// partial[(seg*nchunk + chunk)][3][C] = { sum(x - s), sum((x - s)^2), s }, s = x[first row of the chunk]
+__global__ __launch_bounds__(kNormThreads) void colstats_partial_kernel(const float* __restrict__ x, int64_t ld,
+                                                                         ColGeom g, float* __restrict__ partial) {
+    const int chunk = blockIdx.x, seg = blockIdx.y;
+    float* out = partial + ((int64_t)seg * g.nchunk + chunk) * 3 * g.C;
+    chunk_walk<2>(g, seg, chunk, out, [&](int64_t r, int64_t r0, int c, float (&acc)[2][4]) {
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        const float4 s = *reinterpret_cast<const float4*>(x + r0 * ld + c);
+        const float d0 = v.x - s.x, d1 = v.y - s.y, d2 = v.z - s.z, d3 = v.w - s.w;
+        acc[0][0] += d0; acc[0][1] += d1; acc[0][2] += d2; acc[0][3] += d3;
+        acc[1][0] += d0 * d0; acc[1][1] += d1 * d1; acc[1][2] += d2 * d2; acc[1][3] += d3 * d3;
+    });
+    const int64_t r0 = (int64_t)seg * g.rows_per_seg + (int64_t)chunk * g.chunk_rows;
+    for (int c = threadIdx.x; c < g.C; c += kNormThreads) out[2 * g.C + c] = x[r0 * ld + c];
+}
+
+__device__ __forceinline__ int64_t chunk_count(const ColGeom& g, int chunk) {
+    const int64_t a = (int64_t)chunk * g.chunk_rows;
+    int64_t b = a + g.chunk_rows;
+    if (b > g.rows_per_seg) b = g.rows_per_seg;
+    return b - a;
+}
+
+// merge the chunk partials of one (segment, channel) -> count, mean, M2  (Chan et al., double)
+__device__ __forceinline__ void merge_channel(const float* __restrict__ partial, const ColGeom& g, int seg, int c,
+                                              double& n, double& mean, double& m2) {
+    n = 0.0; mean = 0.0; m2 = 0.0;
+    for (int k = 0; k < g.nchunk; ++k) {
+        const float* p = partial + ((int64_t)seg * g.nchunk + k) * 3 * g.C;
+        const double nb = (double)chunk_count(g, k);
+        const double sd = p[c], sd2 = p[g.C + c], sh = p[2 * g.C + c];
+        const double mb = sh + sd / nb, m2b = sd2 - sd * sd / nb;
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += m2b + delta * delta * n * nb / tot;
+        n = tot;
+    }
+}
+
+// BatchNorm: all segments form one population.  stats[0..4][C] = mean, invstd, a, b  (y = x*a + b)
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, ColGeom g, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd, float* __restrict__ ab, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.C) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int s = 0; s < g.nseg; ++s) {
+        double nb, mb, m2b;
+        merge_channel(partial, g, s, c, nb, mb, m2b);
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += m2b + delta * delta * n * nb / tot;
+        n = tot;
+    }
+    const float var = (float)(m2 / n);
+    const float invstd = 1.f / sqrtf(var + eps);
+    const float mu = (float)mean;
+    save_mean[c] = mu;
+    save_invstd[c] = invstd;
+    const float a = invstd * gamma[c];
+    ab[c] = a;
+    ab[g.C + c] = beta[c] - mu * a;
+    if (running_mean != nullptr) {
+        const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// eval-mode BatchNorm: a, b from the running statistics
+__global__ void bn_eval_ab_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                  float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ ab,
+                                  int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(running_var[c] + eps);
+    save_mean[c] = running_mean[c];
+    save_invstd[c] = invstd;
+    const float a = invstd * gamma[c];
+    ab[c] = a;
+    ab[C + c] = beta[c] - running_mean[c] * a;
+}
+
+// GroupNorm: one (image, group) population of rows_per_seg * cpg values.  save_* [N][G]; ab [2][N][C]
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, ColGeom g, int G, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const float* __restrict__ chan_scale,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ ab,
+                                   float eps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (n, group)
+    if (idx >= g.nseg * G) return;
+    const int n_img = idx / G, grp = idx - n_img * G;
+    const int cpg = g.C / G;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+        double nb, mb, m2b;
+        merge_channel(partial, g, n_img, grp * cpg + j, nb, mb, m2b);
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += m2b + delta * delta * n * nb / tot;
+        n = tot;
+    }
+    const float var = (float)(m2 / n);
+    const float invstd = 1.f / sqrtf(var + eps);
+    const float mu = (float)mean;
+    save_mean[idx] = mu;
+    save_invstd[idx] = invstd;
+    const int64_t NC = (int64_t)g.nseg * g.C;
+    for (int j = 0; j < cpg; ++j) {
+        const int c = grp * cpg + j;
+        const float s = chan_scale ? chan_scale[(int64_t)n_img * g.C + c] : 1.f;
+        const float a = invstd * gamma[c];
+        ab[(int64_t)n_img * g.C + c] = a * s;
+        ab[NC + (int64_t)n_img * g.C + c] = (beta[c] - mu * a) * s;
+    }
+}
+
+// y = [relu](x*a + b [+ res]); a,b indexed [seg*ab_seg_stride + c] (stride 0 = shared by all segments)
+__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, int64_t ld_x, float* __restrict__ y,
+                                                           int64_t ld_y, const float* __restrict__ res, int64_t ld_r,
+                                                           const float* __restrict__ a, const float* __restrict__ b,
+                                                           int64_t ab_seg_stride, int64_t rows_per_seg, int64_t rows,
+                                                           int C, int relu) {
+    const int tq = C >> 2;
+    const int64_t total = rows * tq;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / tq;
+        const int c = (int)(i - r * tq) * 4;
+        const int64_t so = (r / rows_per_seg) * ab_seg_stride + c;
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c);
+        const float4 av = *reinterpret_cast<const float4*>(a + so);
+        float4 o;
+        if (b != nullptr) {
+            const float4 bv = *reinterpret_cast<const float4*>(b + so);
+            o.x = xv.x * av.x + bv.x; o.y = xv.y * av.y + bv.y; o.z = xv.z * av.z + bv.z; o.w = xv.w * av.w + bv.w;
+        } else {
+            o.x = xv.x * av.x; o.y = xv.y * av.y; o.z = xv.z * av.z; o.w = xv.w * av.w;
+        }
+        if (res != nullptr) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + r * ld_r + c);
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(y + r * ld_y + c) = o;
+    }
+}
+
+// partial[(seg*nchunk+chunk)][2][C] = { sum g, sum g*xhat },  g = dy * [y > 0] (relu) , xhat = (x-mean)*invstd
+// mean/invstd indexed [seg*st_seg_stride + c / cdiv]  (BatchNorm: stride 0, cdiv 1; GroupNorm: stride G, cdiv cpg)
+__global__ __launch_bounds__(kNormThreads) void bwd_partial_kernel(const float* __restrict__ dy, int64_t ld_dy,
+                                                                    const float* __restrict__ x, int64_t ld_x,
+                                                                    const float* __restrict__ y, int64_t ld_y,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, int st_seg_stride,
+                                                                    int cdiv, ColGeom g, float* __restrict__ partial) {
+    const int chunk = blockIdx.x, seg = blockIdx.y;
+    float* out = partial + ((int64_t)seg * g.nchunk + chunk) * 2 * g.C;
+    chunk_walk<2>(g, seg, chunk, out, [&](int64_t r, int64_t, int c, float (&acc)[2][4]) {
+        const float4 gv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c);
+        float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+        const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (y != nullptr) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + r * ld_y + c);
+            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int si = seg * st_seg_stride + (c + e) / cdiv;
+            const float xh = (xx[e] - mean[si]) * invstd[si];
+            acc[0][e] += gg[e];
+            acc[1][e] += gg[e] * xh;
+        }
+    });
+}
+
+// BatchNorm backward coefficients: dx = k1*g - k2 - xhat*k3 ;  kk [3][C]
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, ColGeom g, const float* __restrict__ gamma,
+                                       const float* __restrict__ invstd, float* __restrict__ kk, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t k = 0; k < (int64_t)g.nseg * g.nchunk; ++k) {
+        s1 += (double)partial[k * 2 * g.C + c];
+        s2 += (double)partial[k * 2 * g.C + g.C + c];
+    }
+    const double M = (double)g.nseg * (double)g.rows_per_seg;
+    const float k1 = gamma[c] * invstd[c];
+    kk[c] = k1;
+    kk[g.C + c] = training ? (float)(k1 * (s1 / M)) : 0.f;
+    kk[2 * g.C + c] = training ? (float)(k1 * (s2 / M)) : 0.f;
+}
+
+// GroupNorm backward: per (n,group) c1 = sum_c gamma*S1 / cnt, c2 = sum_c gamma*S2 / cnt; kk [3][N][C];
+// S1/S2 already carry the Dropout2d scale through g_eff = scale*dy (applied here).  dgamma/dbeta [C].
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, ColGeom g, int G, const float* __restrict__ gamma,
+                                       const float* __restrict__ chan_scale, const float* __restrict__ invstd,
+                                       float* __restrict__ kk, float* __restrict__ chan_sums /* [2][N][C] */) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (n, group)
+    if (idx >= g.nseg * G) return;
+    const int n_img = idx / G, grp = idx - n_img * G;
+    const int cpg = g.C / G;
+    const int64_t NC = (int64_t)g.nseg * g.C;
+    double c1 = 0.0, c2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+        const int c = grp * cpg + j;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < g.nchunk; ++k) {
+            const float* p = partial + ((int64_t)n_img * g.nchunk + k) * 2 * g.C;
+            s1 += (double)p[c];
+            s2 += (double)p[g.C + c];
+        }
+        const double sc = chan_scale ? (double)chan_scale[(int64_t)n_img * g.C + c] : 1.0;
+        s1 *= sc;
+        s2 *= sc;
+        chan_sums[(int64_t)n_img * g.C + c] = (float)s1;          // d beta contribution of image n
+        chan_sums[NC + (int64_t)n_img * g.C + c] = (float)s2;     // d gamma contribution
+        c1 += (double)gamma[c] * s1;
+        c2 += (double)gamma[c] * s2;
+    }
+    const double cnt = (double)g.rows_per_seg * cpg;
+    const float is = invstd[idx];
+    for (int j = 0; j < cpg; ++j) {
+        const int c = grp * cpg + j;
+        const float sc = chan_scale ? chan_scale[(int64_t)n_img * g.C + c] : 1.f;
+        kk[(int64_t)n_img * g.C + c] = sc * gamma[c] * is;
+        kk[NC + (int64_t)n_img * g.C + c] = (float)(is * (c1 / cnt));
+        kk[2 * NC + (int64_t)n_img * g.C + c] = (float)(is * (c2 / cnt));
+    }
+}
+
+__global__ void gn_param_grad_kernel(const float* __restrict__ chan_sums, int N, int C, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float b = 0.f, gm = 0.f;
+    for (int n = 0; n < N; ++n) {
+        b += chan_sums[(int64_t)n * C + c];
+        gm += chan_sums[(int64_t)N * C + (int64_t)n * C + c];
+    }
+    dbeta[c] = b;
+    dgamma[c] = gm;
+}
+
+// dx = k1*g - k2 - xhat*k3 ; dres = g   (g = dy*[y>0])
+__global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ dy, int64_t ld_dy,
+                                                        const float* __restrict__ x, int64_t ld_x,
+                                                        const float* __restrict__ y, int64_t ld_y,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        int st_seg_stride, int cdiv, const float* __restrict__ kk,
+                                                        int64_t kk_seg_stride, int64_t kk_plane, float* __restrict__ dx,
+                                                        int64_t ld_dx, float* __restrict__ dres, int64_t ld_dr,
+                                                        int64_t rows_per_seg, int64_t rows, int C) {
+    const int tq = C >> 2;
+    const int64_t total = rows * tq;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / tq;
+        const int c = (int)(i - r * tq) * 4;
+        const int seg = (int)(r / rows_per_seg);
+        const float4 gv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c);
+        float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+        const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (y != nullptr) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + r * ld_y + c);
+            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+        }
+        const float* kb = kk + (int64_t)seg * kk_seg_stride + c;
+        const float4 k1 = *reinterpret_cast<const float4*>(kb);
+        const float4 k2 = *reinterpret_cast<const float4*>(kb + kk_plane);
+        const float4 k3 = *reinterpret_cast<const float4*>(kb + 2 * kk_plane);
+        const float k1a[4] = {k1.x, k1.y, k1.z, k1.w}, k2a[4] = {k2.x, k2.y, k2.z, k2.w}, k3a[4] = {k3.x, k3.y, k3.z, k3.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int si = seg * st_seg_stride + (c + e) / cdiv;
+            const float xh = (xx[e] - mean[si]) * invstd[si];
+            o[e] = k1a[e] * gg[e] - k2a[e] - xh * k3a[e];
+        }
+        *reinterpret_cast<float4*>(dx + r * ld_dx + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (dres != nullptr) *reinterpret_cast<float4*>(dres + r * ld_dr + c) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    }
+}
+
+// out[seg][c] = mean over the segment's rows (SE global average pool) from colstats partials
+__global__ void seg_mean_kernel(const float* __restrict__ partial, ColGeom g, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.nseg * g.C) return;
+    const int seg = idx / g.C, c = idx - seg * g.C;
+    double n, mean, m2;
+    merge_channel(partial, g, seg, c, n, mean, m2);
+    out[idx] = (float)mean;
+}
+
+// out[seg][c] = sum_rows dy*x from bwd_partial's second plane (mean = 0, invstd = 1)
+__global__ void seg_dot_kernel(const float* __restrict__ partial, ColGeom g, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.nseg * g.C) return;
+    const int seg = idx / g.C, c = idx - seg * g.C;
+    double s = 0.0;
+    for (int k = 0; k < g.nchunk; ++k) s += (double)partial[((int64_t)seg * g.nchunk + k) * 2 * g.C + g.C + c];
+    out[idx] = (float)s;
+}
+
+// ---- 3x3 stride-2 pad-1 max-pool (ceil_mode), NHWC; idx = winning tap 0..8 (first maximum in scan order)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+    const int tq = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * tq;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % tq) * 4;
+        int64_t p = i / tq;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hi = ho * 2 - 1 + t / 3, wi = wo * 2 - 1 + t % 3;
+            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+                const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)n * H + hi) * W + wi) * C + c);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (vv[e] > best[e]) {
+                        best[e] = vv[e];
+                        arg[e] = t;
+                    }
+            }
+        }
+        const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
+        *reinterpret_cast<float4*>(y + o) = make_float4(best[0], best[1], best[2], best[3]);
+        *reinterpret_cast<uint32_t*>(idx + o) = (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) |
+                                                 ((uint32_t)arg[3] << 24);
+    }
+}
+
+// gather form: every input element sums the <=4 windows that cover it and elected it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+    const int tq = C >> 2;
+    const int64_t total = (int64_t)N * H * W * tq;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % tq) * 4;
+        int64_t p = i / tq;
+        const int wi = (int)(p % W);
+        p /= W;
+        const int hi = (int)(p % H);
+        const int n = (int)(p / H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // windows ho with ho*2-1 <= hi <= ho*2+1
+        const int ho0 = hi / 2, wo0 = wi / 2;    // candidates: ho0, ho0+1 (the latter only when hi is odd)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ho = ho0 + a;
+            const int ty = hi - (ho * 2 - 1);
+            if (ho >= Ho || ty < 0 || ty > 2) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int wo = wo0 + b;
+                const int tx = wi - (wo * 2 - 1);
+                if (wo >= Wo || tx < 0 || tx > 2) continue;
+                const int tap = ty * 3 + tx;
+                const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
+                const uint32_t pk = *reinterpret_cast<const uint32_t*>(idx + o);
+                const float4 g = *reinterpret_cast<const float4*>(dy + o);
+                if ((int)(pk & 255u) == tap) acc[0] += g.x;
+                if ((int)((pk >> 8) & 255u) == tap) acc[1] += g.y;
+                if ((int)((pk >> 16) & 255u) == tap) acc[2] += g.z;
+                if ((int)(pk >> 24) == tap) acc[3] += g.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (((int64_t)n * H + hi) * W + wi) * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+static ColGeom make_geom(int64_t rows_per_seg, int64_t nseg, int64_t C) {
+    ColGeom g;
+    g.rows_per_seg = rows_per_seg;
+    g.nseg = (int)nseg;
+    g.C = (int)C;
+    // ~1024 blocks in total, at least 64 rows per chunk
+    int64_t want = ceil_div(1024, nseg);
+    int64_t chunk = ceil_div(rows_per_seg, want);
+    if (chunk < 64) chunk = 64;
+    if (chunk > rows_per_seg) chunk = rows_per_seg;
+    g.chunk_rows = (int)chunk;
+    g.nchunk = (int)ceil_div(rows_per_seg, chunk);
+    return g;
+}
+
+static unsigned ew_blocks(int64_t work) {
+    int64_t b = ceil_div(work, 256);
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+static int check_norm(const char* who, int64_t C, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
+    DIGA_REQUIRE(C > 0 && C % 4 == 0, DIGA_EINVAL, "%s: C=%lld must be a positive multiple of 4", who, (long long)C);
+    for (int64_t ld : lds) DIGA_REQUIRE(ld >= C && ld % 4 == 0, DIGA_EINVAL, "%s: leading dimension %lld invalid", who, (long long)ld);
+    for (const void* p : ptrs) DIGA_REQUIRE(p == nullptr || aligned16(p), DIGA_EALIGN, "%s: pointers must be 16-byte aligned", who);
+    return DIGA_OK;
+}
+
+}  // namespace diga
+
+using namespace diga;
+
+// workspace: partials (3*C floats per (segment, chunk)) + coefficient arrays (up to 3*nseg*C)
+extern "C" size_t diga_norm_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int64_t C) {
+    if (rows_per_seg <= 0 || nseg <= 0 || C <= 0) return 0;
+    const ColGeom g = make_geom(rows_per_seg, nseg, C);
+    return ((size_t)nseg * g.nchunk * 3 * C + (size_t)5 * nseg * C + 64) * sizeof(float);
+}
+
+extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float* save_mean, float* save_invstd, int64_t M, int64_t C, int training, int relu,
+                           float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && workspace && M > 0, DIGA_EINVAL, "bn_fwd: bad argument");
+    DIGA_REQUIRE(training || (running_mean && running_var), DIGA_EINVAL, "bn_fwd: eval mode needs running statistics");
+    int rc = check_norm("bn_fwd", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
+    if (rc) return rc;
+    DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(M, 1, C), DIGA_EWORKSPACE, "bn_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st);
+    const ColGeom g = make_geom(M, 1, C);
+    float* partial = (float*)workspace;
+    float* ab = partial + (size_t)g.nchunk * 3 * C;
+    if (training) {
+        hipLaunchKernelGGL(colstats_partial_kernel, dim3(g.nchunk, 1), dim3(kNormThreads), 0, st, x, ld_x, g, partial);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, partial, g, gamma, beta,
+                           running_mean, running_var, save_mean, save_invstd, ab, momentum, eps);
+    } else {
+        hipLaunchKernelGGL(bn_eval_ab_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, gamma, beta, running_mean,
+                           running_var, save_mean, save_invstd, ab, (int)C, eps);
+    }
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
+                       ab + C, (int64_t)0, M, M, (int)C, relu);
+    return launch_status("diga_bn_fwd");
+}
+
+extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+                           const float* gamma, const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx,
+                           float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && workspace && M > 0, DIGA_EINVAL, "bn_bwd: bad argument");
+    int rc = check_norm("bn_bwd", C, {ld_dy, ld_x, y ? ld_y : C, ld_dx, dres ? ld_dr : C}, {dy, x, y, dx, dres});
+    if (rc) return rc;
+    DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(M, 1, C), DIGA_EWORKSPACE, "bn_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st);
+    const ColGeom g = make_geom(M, 1, C);
+    float* partial = (float*)workspace;
+    float* kk = partial + (size_t)g.nchunk * 3 * C;
+    if (training)
+        hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, 1), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
+                           save_mean, save_invstd, 0, 1, g, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, partial,
+                       training ? g : ColGeom{M, 1, (int)C, (int)M, 0}, gamma, save_invstd, kk, training);
+    hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y, save_mean,
+                       save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, dres, ld_dr, M, M, (int)C);
+    return launch_status("diga_bn_bwd");
+}
+
+extern "C" int diga_gn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* gamma, const float* beta,
+                           const float* chan_scale, float* save_mean, float* save_invstd, int64_t N, int64_t HW, int64_t C,
+                           int64_t G, int relu, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && workspace && N > 0 && HW > 0, DIGA_EINVAL, "gn_fwd: bad argument");
+    DIGA_REQUIRE(G > 0 && C % G == 0, DIGA_EINVAL, "gn_fwd: C must be divisible by the group count");
+    int rc = check_norm("gn_fwd", C, {ld_x, ld_y}, {x, y});
+    if (rc) return rc;
+    DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(HW, N, C), DIGA_EWORKSPACE, "gn_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st);
+    const ColGeom g = make_geom(HW, N, C);
+    float* partial = (float*)workspace;
+    float* ab = partial + (size_t)N * g.nchunk * 3 * C;
+    hipLaunchKernelGGL(colstats_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, x, ld_x, g, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ceil_div(N * G, 64)), dim3(64), 0, st, partial, g, (int)G, gamma, beta,
+                       chan_scale, save_mean, save_invstd, ab, eps);
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y,
+                       (const float*)nullptr, (int64_t)0, ab, ab + N * C, C, HW, N * HW, (int)C, relu);
+    return launch_status("diga_gn_fwd");
+}
+
+extern "C" int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+                           const float* gamma, const float* chan_scale, const float* save_mean, const float* save_invstd,
+                           float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int64_t N, int64_t HW, int64_t C,
+                           int64_t G, void* workspace, size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace && N > 0 && HW > 0,
+                 DIGA_EINVAL, "gn_bwd: bad argument");
+    DIGA_REQUIRE(G > 0 && C % G == 0, DIGA_EINVAL, "gn_bwd: C must be divisible by the group count");
+    int rc = check_norm("gn_bwd", C, {ld_dy, ld_x, y ? ld_y : C, ld_dx}, {dy, x, y, dx});
+    if (rc) return rc;
+    DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(HW, N, C), DIGA_EWORKSPACE, "gn_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st);
+    const ColGeom g = make_geom(HW, N, C);
+    const int cpg = (int)(C / G);
+    float* partial = (float*)workspace;
+    float* kk = partial + (size_t)N * g.nchunk * 3 * C;       // [3][N][C]
+    float* chan_sums = kk + (size_t)3 * N * C;                // [2][N][C]
+    hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
+                       save_mean, save_invstd, (int)G, cpg, g, partial);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)ceil_div(N * G, 64)), dim3(64), 0, st, partial, g, (int)G, gamma,
+                       chan_scale, save_invstd, kk, chan_sums);
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, chan_sums, (int)N, (int)C,
+                       dgamma, dbeta);
+    hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
+                       save_mean, save_invstd, (int)G, cpg, kk, C, N * C, dx, ld_dx, (float*)nullptr, (int64_t)0, HW, N * HW,
+                       (int)C);
+    return launch_status("diga_gn_bwd");
+}
+
+extern "C" int diga_avgpool_nhwc(const float* x, int64_t ld_x, float* out, int64_t N, int64_t HW, int64_t C, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(x && out && workspace && N > 0 && HW > 0, DIGA_EINVAL, "avgpool: bad argument");
+    int rc = check_norm("avgpool", C, {ld_x}, {x});
+    if (rc) return rc;
+    DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(HW, N, C), DIGA_EWORKSPACE, "avgpool: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st);
+    const ColGeom g = make_geom(HW, N, C);
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(colstats_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, x, ld_x, g, partial);
+    hipLaunchKernelGGL(seg_mean_kernel, dim3((unsigned)ceil_div(N * C, 256)), dim3(256), 0, st, partial, g, out);
+    return launch_status("diga_avgpool_nhwc");
+}
+
+extern "C" int diga_channel_affine(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* a, const float* b,
+                                   int64_t N, int64_t HW, int64_t C, void* stream) {
+    DIGA_REQUIRE(x && y && a && N > 0 && HW > 0, DIGA_EINVAL, "channel_affine: bad argument");
+    int rc = check_norm("channel_affine", C, {ld_x, ld_y}, {x, y, a, b});
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y,
+                       (const float*)nullptr, (int64_t)0, a, b, C, HW, N * HW, (int)C, 0);
+    return launch_status("diga_channel_affine");
+}
+
+extern "C" int diga_channel_dot(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, float* out, int64_t N,
+                                int64_t HW, int64_t C, void* workspace, size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(dy && x && out && workspace && N > 0 && HW > 0, DIGA_EINVAL, "channel_dot: bad argument");
+    int rc = check_norm("channel_dot", C, {ld_dy, ld_x}, {dy, x});
+    if (rc) return rc;
+    DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(HW, N, C), DIGA_EWORKSPACE, "channel_dot: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st);
+    const ColGeom g = make_geom(HW, N, C);
+    float* partial = (float*)workspace;
+    float* unit = partial + (size_t)N * g.nchunk * 3 * C;     // [0] = mean 0, [1] = invstd 1
+    const float h_unit[2] = {0.f, 1.f};
+    hipError_t e = hipMemcpyAsync(unit, h_unit, sizeof(h_unit), hipMemcpyHostToDevice, st);
+    DIGA_REQUIRE(e == hipSuccess, (int)e, "channel_dot: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x,
+                       (const float*)nullptr, (int64_t)0, unit, unit + 1, 0, (int)C, g, partial);
+    hipLaunchKernelGGL(seg_dot_kernel, dim3((unsigned)ceil_div(N * C, 256)), dim3(256), 0, st, partial, g, out);
+    return launch_status("diga_channel_dot");
+}
+
+extern "C" int diga_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C,
+                                     int64_t Ho, int64_t Wo, void* stream) {
+    DIGA_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, DIGA_EINVAL, "maxpool_fwd: bad argument");
+    int rc = check_norm("maxpool_fwd", C, {}, {x, y});
+    if (rc) return rc;
+    DIGA_REQUIRE((Ho - 1) * 2 - 1 < H && (Wo - 1) * 2 - 1 < W, DIGA_EINVAL, "maxpool_fwd: last window starts outside the input");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(N * Ho * Wo * C / 4)), dim3(256), 0, st, x, y, idx, (int)N, (int)H,
+                       (int)W, (int)C, (int)Ho, (int)Wo);
+    return launch_status("diga_maxpool3x3s2_fwd");
+}
+
+extern "C" int diga_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t N, int64_t H, int64_t W,
+                                     int64_t C, int64_t Ho, int64_t Wo, void* stream) {
+    DIGA_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, DIGA_EINVAL, "maxpool_bwd: bad argument");
+    int rc = check_norm("maxpool_bwd", C, {}, {dy, dx});
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(N * H * W * C / 4)), dim3(256), 0, st, dy, idx, dx, (int)N, (int)H,
+                       (int)W, (int)C, (int)Ho, (int)Wo);
+    return launch_status("diga_maxpool3x3s2_bwd");
+}

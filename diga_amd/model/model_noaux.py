@@ -36,7 +36,8 @@ class SegModel(nn.Module):
 
     def forward(self, x):
         _lib.require_gpu(x)
-        shallow = self.layer2(self.layer1(self.layer0(x)))
+        conv1, bn1, _relu, maxpool = self.layer0              # ReLU is fused into the BN kernel
+        shallow = self.layer2(self.layer1(maxpool(bn1(conv1(x), relu=True))))
         deep = self.layer4(self.layer3(shallow))
         if self.bn_clr:
             deep = self.bn_pretrain(deep)

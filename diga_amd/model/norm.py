@@ -1,0 +1,266 @@
+"""Normalisation / pooling modules of the DeepLabV2 model on the HIP kernels of csrc/norm.hip.
+
+Drop-in subclasses (same parameters, buffers and state-dict keys) of the torch modules the reference uses
+in G5/model/seg_model_noaux.py: nn.BatchNorm2d (frozen affine, batch statistics in train mode; fused with
+the following ReLU and the residual add), nn.GroupNorm(32) (fused with ReLU / the Dropout2d channel
+scale, able to write straight into a channel slice of the ASPP concat buffer), SEBlock pieces and the
+stem max-pool.  Tensors cross module boundaries as NCHW-shaped views of NHWC memory.
+"""
+import torch
+import torch.nn as nn
+
+from diga_amd import _lib
+
+
+def nhwc(x):
+    """[N,C,H,W]-shaped tensor -> contiguous [N,H,W,C] fp32 tensor (no copy for channels_last input)."""
+    t = x.permute(0, 2, 3, 1)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def rows_ld(t):
+    """Leading dimension (floats between consecutive pixels) of an [N,H,W,C] tensor whose pixels are a dense
+    enumeration of rows of a wider [.., ld] matrix (a channel slice of a contiguous NHWC tensor), else None."""
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    if t.stride(3) == 1 and ld >= c and t.stride(1) == w * ld and t.stride(0) == h * w * ld and ld % 4 == 0 \
+            and t.data_ptr() % 16 == 0:
+        return ld
+    return None
+
+
+def as_rows(t):
+    """(tensor, ld) usable by the kernels; copies only when the layout is not row-sliceable."""
+    ld = rows_ld(t)
+    if ld is None:
+        t = t.contiguous()
+        ld = t.shape[3]
+    return t, ld
+
+
+def alias_slice(buf, lo, hi):
+    """Channel slice [.., lo:hi] of a contiguous [N,H,W,C] buffer as a fresh (non-view) tensor on the same storage."""
+    n, h, w, c = buf.shape
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+        buf.untyped_storage(), buf.storage_offset() + lo, (n, h, w, hi - lo), (h * w * c, w * c, c, 1))
+
+
+def _ws(rows_per_seg, nseg, c, device):
+    return _lib.workspace(_lib.lib.diga_norm_workspace_bytes(rows_per_seg, nseg, c), device, "norm")
+
+
+# --------------------------------------------------------------------------------------------- BatchNorm
+class _BnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, relu, momentum, eps):
+        _lib.require_gpu(x)
+        xn = nhwc(x.detach())
+        n, h, w, c = xn.shape
+        m = n * h * w
+        rn = None if residual is None else nhwc(residual.detach())
+        y = torch.empty_like(xn)
+        save_mean = torch.empty(c, dtype=torch.float32, device=xn.device)
+        save_invstd = torch.empty_like(save_mean)
+        ws = _ws(m, 1, c, xn.device)
+        _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
+                  _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd), m, c,
+                  1 if training else 0, 1 if relu else 0, float(momentum), float(eps), _lib.ptr(ws), ws.numel(),
+                  _lib.stream())
+        ctx.save_for_backward(xn, y if relu else None, weight, save_mean, save_invstd)
+        ctx.flags = (training, residual is not None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        training, has_res = ctx.flags
+        n, h, w, c = xn.shape
+        m = n * h * w
+        g, ld_g = as_rows(gy.permute(0, 2, 3, 1))
+        dx = torch.empty_like(xn)
+        dres = torch.empty_like(xn) if has_res else None
+        ws = _ws(m, 1, c, xn.device)
+        _lib.call("diga_bn_bwd", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(weight), _lib.ptr(save_mean),
+                  _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dres), c, m, c, 1 if training else 0, _lib.ptr(ws),
+                  ws.numel(), _lib.stream())
+        return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
+                None, None, None, None, None, None, None, None)
+
+
+class DigaBatchNorm2d(nn.BatchNorm2d):
+    """BatchNorm2d whose affine parameters are frozen (the reference sets requires_grad=False on every BN,
+    G5/model/seg_model_noaux.py:64-76) -- gradients flow to the input only.  forward(x, residual, relu)
+    computes relu(bn(x) + residual) in one pass."""
+
+    def forward(self, x, residual=None, relu=False):
+        if self.weight.requires_grad or self.bias.requires_grad:
+            raise RuntimeError("DigaBatchNorm2d implements the frozen-affine BN of the DiGA path; "
+                               "set requires_grad=False on weight and bias")
+        training = self.training or self.running_mean is None
+        if self.training and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return _BnFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, training, relu,
+                           self.momentum, self.eps)
+
+
+# --------------------------------------------------------------------------------------------- GroupNorm
+class _GnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu, chan_scale, out):
+        _lib.require_gpu(x)
+        xn = nhwc(x.detach())
+        n, h, w, c = xn.shape
+        y = torch.empty_like(xn) if out is None else out
+        y_, ld_y = (y, c) if out is None else (out, rows_ld(out))
+        if ld_y is None:
+            raise ValueError("GroupNorm output slice must be a channel slice of a contiguous NHWC tensor")
+        save_mean = torch.empty(n * groups, dtype=torch.float32, device=xn.device)
+        save_invstd = torch.empty_like(save_mean)
+        cs = None if chan_scale is None else chan_scale.detach().float().contiguous()
+        ws = _ws(h * w, n, c, xn.device)
+        _lib.call("diga_gn_fwd", _lib.ptr(xn), c, _lib.ptr(y_), ld_y, _lib.ptr(weight.detach()), _lib.ptr(bias.detach()),
+                  _lib.ptr(cs), _lib.ptr(save_mean), _lib.ptr(save_invstd), n, h * w, c, groups, 1 if relu else 0,
+                  float(eps), _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctx.save_for_backward(xn, y_ if relu else None, weight, cs, save_mean, save_invstd)
+        ctx.groups = groups
+        return y_.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, y, weight, cs, save_mean, save_invstd = ctx.saved_tensors
+        n, h, w, c = xn.shape
+        g, ld_g = as_rows(gy.permute(0, 2, 3, 1))
+        ld_y = rows_ld(y) if y is not None else c
+        dx = torch.empty_like(xn)
+        dgamma = torch.empty(c, dtype=torch.float32, device=xn.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = _ws(h * w, n, c, xn.device)
+        _lib.call("diga_gn_bwd", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), ld_y, _lib.ptr(weight.detach()),
+                  _lib.ptr(cs), _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dgamma),
+                  _lib.ptr(dbeta), n, h * w, c, ctx.groups, _lib.ptr(ws), ws.numel(), _lib.stream())
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None
+
+
+class DigaGroupNorm(nn.GroupNorm):
+    """GroupNorm (trainable affine) with optional fused ReLU, fused per-(n,c) scale (Dropout2d) and an
+    optional NHWC output slice to write into (the ASPP concat buffer)."""
+
+    def forward(self, x, relu=False, chan_scale=None, out=None):
+        return _GnFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, relu, chan_scale, out)
+
+
+class _AssembleFn(torch.autograd.Function):
+    """The branches already wrote their channel slices into `buf`; tie them into one differentiable tensor
+    without a copy.  Backward hands every branch the matching slice of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, buf, width, *slices):
+        ctx.width = width
+        ctx.k = len(slices)
+        return buf.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        gn = g.permute(0, 2, 3, 1)
+        if not gn.is_contiguous():
+            gn = gn.contiguous()
+        outs = [alias_slice(gn, i * ctx.width, (i + 1) * ctx.width).permute(0, 3, 1, 2) for i in range(ctx.k)]
+        return (None, None, *outs)
+
+
+def assemble(buf, width, slices):
+    return _AssembleFn.apply(buf, width, *slices)
+
+
+# --------------------------------------------------------------------------------------------- SE block
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xn = nhwc(x.detach())
+        n, h, w, c = xn.shape
+        out = torch.empty((n, c), dtype=torch.float32, device=xn.device)
+        ws = _ws(h * w, n, c, xn.device)
+        _lib.call("diga_avgpool_nhwc", _lib.ptr(xn), c, _lib.ptr(out), n, h * w, c, _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctx.shape = (n, h, w, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.shape
+        return (g / float(h * w))[:, :, None, None].expand(n, c, h, w)
+
+
+class _ChannelGateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gate):
+        xn = nhwc(x.detach())
+        n, h, w, c = xn.shape
+        gt = gate.detach().float().contiguous()
+        y = torch.empty_like(xn)
+        _lib.call("diga_channel_affine", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(gt), None, n, h * w, c, _lib.stream())
+        ctx.save_for_backward(xn, gt)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, gt = ctx.saved_tensors
+        n, h, w, c = xn.shape
+        g, ld_g = as_rows(gy.permute(0, 2, 3, 1))
+        dx = torch.empty_like(xn)
+        _lib.call("diga_channel_affine", _lib.ptr(g), ld_g, _lib.ptr(dx), c, _lib.ptr(gt), None, n, h * w, c, _lib.stream())
+        dgate = torch.empty((n, c), dtype=torch.float32, device=xn.device)
+        ws = _ws(h * w, n, c, xn.device)
+        _lib.call("diga_channel_dot", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(dgate), n, h * w, c, _lib.ptr(ws),
+                  ws.numel(), _lib.stream())
+        return dx.permute(0, 3, 1, 2), dgate
+
+
+def global_avg_pool(x):
+    return _AvgPoolFn.apply(x)
+
+
+def channel_gate(x, gate):
+    return _ChannelGateFn.apply(x, gate)
+
+
+# --------------------------------------------------------------------------------------------- max-pool
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xn = nhwc(x.detach())
+        n, h, w, c = xn.shape
+
+        def osz(i):
+            o = -(-(i + 2 - 3) // 2) + 1                   # ceil_mode
+            return o - 1 if (o - 1) * 2 - 1 >= i else o    # last window must start inside the input
+
+        ho, wo = osz(h), osz(w)
+        y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=xn.device)
+        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=xn.device)
+        _lib.call("diga_maxpool3x3s2_fwd", _lib.ptr(xn), _lib.ptr(y), _lib.ptr(idx), n, h, w, c, ho, wo, _lib.stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, h, w, c, ho, wo)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        n, h, w, c, ho, wo = ctx.shape
+        g = gy.permute(0, 2, 3, 1)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=g.device)
+        _lib.call("diga_maxpool3x3s2_bwd", _lib.ptr(g), _lib.ptr(idx), _lib.ptr(dx), n, h, w, c, ho, wo, _lib.stream())
+        return dx.permute(0, 3, 1, 2)
+
+
+class DigaMaxPool3x3s2(nn.MaxPool2d):
+    """nn.MaxPool2d(3, stride=2, padding=1, ceil_mode=True) of the stem."""
+
+    def __init__(self):
+        super().__init__(kernel_size=3, stride=2, padding=1, ceil_mode=True)
+
+    def forward(self, x):
+        return _MaxPoolFn.apply(x)

@@ -1,10 +1,16 @@
-"""DeepLabV2 / ResNet-101 (output stride 8) with the ProDA-style ASPP head -- module tree and
-state_dict keys of the reference (G5/model/seg_model_noaux.py:57-101 Bottleneck, :122-137 SEBlock,
-:140-214 Classifier_Module2, :216-261 ResNetMulti), so checkpoints are interchangeable.
+"""DeepLabV2 / ResNet-101 (output stride 8) with the ProDA-style ASPP head on the MI355X kernels --
+module tree and state_dict keys of the reference (G5/model/seg_model_noaux.py:57-101 Bottleneck, :122-137
+SEBlock, :140-214 Classifier_Module2, :216-261 ResNetMulti), so checkpoints are interchangeable.
 
-Semantics kept from the reference: every BatchNorm has frozen affine
-parameters but runs on batch statistics in train mode; GroupNorm(32) in the head is trainable;
-`feat` is the post-Dropout2d tensor; all Conv2d weights start as N(0, 0.01).
+Every layer is a drop-in subclass of the torch module the reference uses, computing with the HIP kernels
+behind include/diga_hip.h: DigaConv2d (fp32-MFMA implicit GEMM), DigaBatchNorm2d (batch statistics in train
+mode, frozen affine; fused +ReLU / +residual), DigaGroupNorm (fused +ReLU / Dropout2d scale, writes into the
+concat buffer), SE pool/gate kernels, DigaMaxPool3x3s2.  Only the two tiny SE linears (1280->80->1280 on an
+[N,1280] matrix) are library GEMMs.
+
+Semantics kept from the reference: BN uses batch statistics whenever the module is in
+train mode (the teacher always is) and updates its running statistics; GroupNorm(32) is trainable; `feat` is
+the post-Dropout2d tensor; all conv weights start as N(0, 0.01).
 """
 from dataclasses import dataclass
 from typing import Tuple
@@ -12,6 +18,7 @@ from typing import Tuple
 import torch
 import torch.nn as nn
 
+from diga_amd.model import norm as dn
 from diga_amd.model.conv import DigaConv2d
 
 
@@ -36,14 +43,15 @@ TINY = Arch(layers=(1, 1, 2, 1), planes=(16, 32, 64, 128), stem=16)
 
 
 def _frozen_bn(channels):
-    bn = nn.BatchNorm2d(channels, affine=True)
+    bn = dn.DigaBatchNorm2d(channels, affine=True)
     for p in bn.parameters():
         p.requires_grad = False
     return bn
 
 
 class Bottleneck(nn.Module):
-    """1x1 (carries the stride) -> 3x3 (carries the dilation) -> 1x1, each followed by frozen-affine BN."""
+    """1x1 (carries the stride) -> 3x3 (carries the dilation) -> 1x1, each followed by frozen-affine BN;
+    ReLU and the residual add are fused into the BN kernels."""
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
@@ -54,45 +62,45 @@ class Bottleneck(nn.Module):
         self.bn2 = _frozen_bn(planes)
         self.conv3 = DigaConv2d(planes, planes * self.expansion, 1, bias=False)
         self.bn3 = _frozen_bn(planes * self.expansion)
-        self.relu = nn.ReLU(inplace=True)
+        self.relu = nn.ReLU(inplace=True)          # kept for module-tree parity; the ReLUs run inside the BN kernels
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
+        y = self.bn1(self.conv1(x), relu=True)
+        y = self.bn2(self.conv2(y), relu=True)
         skip = x if self.downsample is None else self.downsample(x)
-        return self.relu(y + skip)
+        return self.bn3(self.conv3(y), residual=skip, relu=True)
 
 
 class SEBlock(nn.Module):
     def __init__(self, inplanes, r=16):
         super().__init__()
-        self.global_pool = nn.AdaptiveAvgPool2d((1, 1))
+        self.global_pool = nn.AdaptiveAvgPool2d((1, 1))     # module-tree parity; pooling runs in diga_avgpool_nhwc
         self.se = nn.Sequential(nn.Linear(inplanes, inplanes // r), nn.ReLU(inplace=True),
                                 nn.Linear(inplanes // r, inplanes), nn.Sigmoid())
 
     def forward(self, x):
-        gate = self.se(self.global_pool(x).flatten(1))
-        return x * gate[:, :, None, None]
+        return dn.channel_gate(x, self.se(dn.global_avg_pool(x)))
 
 
 class Classifier_Module2(nn.Module):
-    """ASPP head: 1x1 + dilated 3x3 branches (conv+bias -> GN -> ReLU), concat, SE, 3x3, GN, Dropout2d, 1x1."""
+    """ASPP head: 1x1 + dilated 3x3 branches (conv+bias -> GN -> ReLU) written side by side into one NHWC
+    buffer (no torch.cat), SE gate, 3x3 conv, GN (+ Dropout2d scale) -> feat, 1x1 -> logits."""
 
     def __init__(self, inplanes, dilation_series, padding_series, num_classes, droprate=0.1, use_se=True,
                  width=256, groups=32, se_reduction=16):
         super().__init__()
+        self.width = width
 
         def branch(k, d, p):
             return nn.Sequential(DigaConv2d(inplanes, width, k, stride=1, padding=p, dilation=d, bias=True),
-                                 nn.GroupNorm(groups, width), nn.ReLU(inplace=True))
+                                 dn.DigaGroupNorm(groups, width), nn.ReLU(inplace=True))
 
         self.conv2d_list = nn.ModuleList([branch(1, 1, 0)] +
                                          [branch(3, d, p) for d, p in zip(dilation_series, padding_series)])
         cat = width * (len(dilation_series) + 1)
-        tail = [DigaConv2d(cat, width, 3, stride=1, padding=1, bias=True), nn.GroupNorm(groups, width)]
+        tail = [DigaConv2d(cat, width, 3, stride=1, padding=1, bias=True), dn.DigaGroupNorm(groups, width)]
         self.bottleneck = nn.Sequential(*([SEBlock(cat, se_reduction)] if use_se else []), *tail)
         self.head = nn.Sequential(nn.Dropout2d(droprate), DigaConv2d(width, num_classes, 1, bias=False))
         # Effective init of the reference (seg_model_noaux.py:173-198 + the global loop :236-242): only the
@@ -100,13 +108,29 @@ class Classifier_Module2(nn.Module):
         # (the reference's isinstance() tests see Sequential/SEBlock containers, not the layers inside).
         nn.init.zeros_(self.bottleneck[-2].bias)
 
+    def _drop_scale(self, n, c, device):
+        drop = self.head[0]
+        if not drop.training or drop.p <= 0.0:
+            return None
+        keep = (torch.rand((n, c), device=device) >= drop.p).to(torch.float32)
+        return keep / (1.0 - drop.p)
+
     def forward(self, x, get_feat=True):
-        cat = torch.cat([b(x) for b in self.conv2d_list], 1)
-        y = self.bottleneck(cat)
-        if not get_feat:
-            return self.head(y)
-        feat = self.head[0](y)
-        return {'feat': feat, 'out': self.head[1](feat)}
+        n, _, h, w = x.shape
+        nb = len(self.conv2d_list)
+        buf = torch.empty((n, h, w, self.width * nb), dtype=torch.float32, device=x.device)
+        slices = []
+        for b, (conv, gn, _) in enumerate(self.conv2d_list):
+            dst = dn.alias_slice(buf, b * self.width, (b + 1) * self.width)
+            slices.append(gn(conv(x), relu=True, out=dst))
+        y = dn.assemble(buf, self.width, slices)
+        mods = list(self.bottleneck)
+        if len(mods) == 3:
+            y = mods[0](y)
+        y = mods[-2](y)
+        feat = mods[-1](y, chan_scale=self._drop_scale(n, self.width, x.device))
+        out = self.head[1](feat)
+        return {'feat': feat, 'out': out} if get_feat else out
 
 
 class ResNetMulti(nn.Module):
@@ -117,7 +141,7 @@ class ResNetMulti(nn.Module):
         self.conv1 = DigaConv2d(3, arch.stem, 7, stride=2, padding=3, bias=False)
         self.bn1 = _frozen_bn(arch.stem)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1, ceil_mode=True)
+        self.maxpool = dn.DigaMaxPool3x3s2()
         stages = [self._make_layer(block, arch.planes[i], layers[i], arch.strides[i], arch.dilations[i])
                   for i in range(4)]
         self.layer1, self.layer2, self.layer3, self.layer4 = stages
@@ -125,7 +149,9 @@ class ResNetMulti(nn.Module):
                                          num_classes, arch.droprate, True, arch.aspp_width, arch.gn_groups,
                                          arch.se_reduction)
         if bn_clr:
-            self.bn_pretrain = nn.BatchNorm2d(self.inplanes, affine=True)
+            self.bn_pretrain = dn.DigaBatchNorm2d(self.inplanes, affine=True)
+            for p in self.bn_pretrain.parameters():
+                p.requires_grad = False
         for m in self.modules():                     # the reference's global init runs after the head's own
             if isinstance(m, nn.Conv2d):
                 m.weight.data.normal_(0, 0.01)
@@ -143,9 +169,11 @@ class ResNetMulti(nn.Module):
         seq += [block(self.inplanes, planes, dilation=dilation) for _ in range(1, blocks)]
         return nn.Sequential(*seq)
 
+    def stem(self, x):
+        return self.maxpool(self.bn1(self.conv1(x), relu=True))
+
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(self.stem(x)))))
         if self.bn_clr:
             x = self.bn_pretrain(x)
         return self.layer5(x)

@@ -217,6 +217,53 @@ int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float* dw, void*
 int diga_weight_transpose(const float* w, float* wt, int64_t K, int64_t RS, int64_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Normalisation / pooling on NHWC fp32 (nn.BatchNorm2d with frozen affine in train mode, nn.GroupNorm(32),
+ * SEBlock, nn.Dropout2d, nn.MaxPool2d(3,2,1,ceil_mode) of G5/model/seg_model_noaux.py:57-101,122-137,
+ * 140-214,216-232).  x/y/... are [rows][C] with `ld_*` floats between rows; C % 4 == 0.
+ * ---------------------------------------------------------------------------------- */
+size_t diga_norm_workspace_bytes(int64_t rows_per_segment, int64_t n_segments, int64_t C);
+
+/* y = [relu]( (x - mean)*invstd*gamma + beta [+ residual] ).  training: batch statistics over the M rows
+ * (biased variance), running_mean/var updated with `momentum` (unbiased variance), statistics saved for the
+ * backward pass; eval: running statistics.  residual nullable. */
+int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
+                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                float* save_mean, float* save_invstd, int64_t M, int64_t C, int training, int relu,
+                float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*[y>0] (y nullable = no ReLU),
+ * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (nullable) = g. */
+int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+                const float* gamma, const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx,
+                float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* GroupNorm over (HW x C/G) per image and group, then y = [relu](chan_scale[n,c] * (xhat*gamma + beta));
+ * chan_scale (nullable, [N][C]) carries the Dropout2d keep/(1-p) pattern.  save_mean/invstd [N][G]. */
+int diga_gn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* gamma, const float* beta,
+                const float* chan_scale, float* save_mean, float* save_invstd, int64_t N, int64_t HW, int64_t C,
+                int64_t G, int relu, float eps, void* workspace, size_t workspace_bytes, void* stream);
+int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+                const float* gamma, const float* chan_scale, const float* save_mean, const float* save_invstd,
+                float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int64_t N, int64_t HW, int64_t C, int64_t G,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* SE block pieces: out[n][c] = mean_hw x;  y = x*a[n][c] + b[n][c] (b nullable);  out[n][c] = sum_hw dy*x. */
+int diga_avgpool_nhwc(const float* x, int64_t ld_x, float* out, int64_t N, int64_t HW, int64_t C, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int diga_channel_affine(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* a, const float* b,
+                        int64_t N, int64_t HW, int64_t C, void* stream);
+int diga_channel_dot(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, float* out, int64_t N, int64_t HW,
+                     int64_t C, void* workspace, size_t workspace_bytes, void* stream);
+
+/* 3x3 stride-2 pad-1 max-pool with ceil_mode (Ho = ceil((H-1)/2)+1 clipped so the last window starts inside);
+ * idx [N,Ho,Wo,C] uint8 = winning tap (first maximum); backward gathers, no atomics. */
+int diga_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C,
+                          int64_t Ho, int64_t Wo, void* stream);
+int diga_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t N, int64_t H, int64_t W, int64_t C,
+                          int64_t Ho, int64_t Wo, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Kernel-family timing (bench.py's roofline leg): when enabled, every entry point brackets its
  * launches with HIP events recorded on the launch stream.  Not for production steps.
  * ---------------------------------------------------------------------------------- */

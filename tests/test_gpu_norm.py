@@ -1,0 +1,191 @@
+"""GPU parity of the normalisation / pooling kernels (csrc/norm.hip) against torch's CPU ops in float64 on
+seeded inputs, and of the whole ASPP head against the capture of the reference (tests/golden/aspp.npz)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+from oracle import detweights, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cl(t):
+    """NCHW tensor -> same values in channels_last memory on the GPU (how tensors travel inside the model)."""
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 33, 29), (4, 256, 17, 17), (1, 2048, 9, 9), (2, 16, 13, 7), (3, 1024, 5, 6)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_batchnorm_train(n, c, h, w, relu, res):
+    from diga_amd.model.norm import DigaBatchNorm2d
+    g = synth.gen(n * 1000 + c + h)
+    x = torch.randn((n, c, h, w), generator=g) * 2.0 + 0.5 * torch.randn((1, c, 1, 1), generator=g) + 3.0
+    r = torch.randn((n, c, h, w), generator=g) if res else None
+    gam, bet = 1 + 0.2 * torch.randn(c, generator=g), 0.3 * torch.randn(c, generator=g)
+    rm0, rv0 = 0.1 * torch.randn(c, generator=g), 1 + 0.1 * torch.rand(c, generator=g)
+    probe = torch.randn((n, c, h, w), generator=g)
+    # float64 reference
+    xr = x.double().requires_grad_()
+    rr = r.double().requires_grad_() if res else None
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    yr = F.batch_norm(xr, rm, rv, gam.double(), bet.double(), True, 0.1, 1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    (yr * probe.double()).sum().backward()
+
+    m = DigaBatchNorm2d(c)
+    with torch.no_grad():
+        m.weight.copy_(gam), m.bias.copy_(bet), m.running_mean.copy_(rm0), m.running_var.copy_(rv0)
+    for p in m.parameters():
+        p.requires_grad = False
+    m = m.to(DEV).train()
+    xd = _cl(x).requires_grad_()
+    rd = _cl(r).requires_grad_() if res else None
+    y = m(xd, residual=rd, relu=relu)
+    assert_close(y, yr, 2e-5, 2e-5, "bn forward")
+    (y * probe.to(DEV)).sum().backward()
+    assert_close(xd.grad, xr.grad, 1e-4, 1e-5 * float(xr.grad.abs().max()) + 1e-7, "bn grad x")
+    if res:
+        assert_close(rd.grad, rr.grad, 1e-6, 1e-7, "bn grad residual")
+    assert_close(m.running_mean, rm, 1e-5, 1e-6, "running mean")
+    assert_close(m.running_var, rv, 1e-5, 1e-6, "running var")
+    assert int(m.num_batches_tracked) == 1
+    # eval mode uses the running statistics
+    m.eval()
+    with torch.no_grad():
+        ye = m(xd.detach(), relu=relu)
+    want = F.batch_norm(x.double(), rm, rv, gam.double(), bet.double(), False, 0.1, 1e-5)
+    assert_close(ye, F.relu(want) if relu else want, 2e-5, 2e-5, "bn eval forward")
+
+
+def test_batchnorm_large_mean_is_stable():
+    """Shifted sums: a channel with mean 1000 and unit variance must not lose its variance to cancellation."""
+    from diga_amd.model.norm import DigaBatchNorm2d
+    g = synth.gen(5)
+    x = torch.randn((2, 32, 64, 64), generator=g) + 1000.0
+    m = DigaBatchNorm2d(32)
+    for p in m.parameters():
+        p.requires_grad = False
+    m = m.to(DEV).train()
+    y = m(_cl(x))
+    want = F.batch_norm(x.double(), None, None, None, None, True, 0.1, 1e-5)
+    assert_close(y, want, 1e-3, 2e-3, "bn with large mean")
+
+
+@pytest.mark.parametrize("n,c,h,w,groups", [(2, 256, 17, 19, 32), (3, 64, 9, 9, 32), (1, 256, 33, 33, 32)])
+@pytest.mark.parametrize("relu,scale", [(True, False), (False, True), (False, False)])
+def test_groupnorm(n, c, h, w, groups, relu, scale):
+    from diga_amd.model.norm import DigaGroupNorm
+    g = synth.gen(n + c + h + int(relu) * 7)
+    x = torch.randn((n, c, h, w), generator=g) * 1.5 + 0.7
+    gam, bet = 1 + 0.2 * torch.randn(c, generator=g), 0.3 * torch.randn(c, generator=g)
+    cs = ((torch.rand((n, c), generator=g) >= 0.2).float() / 0.8) if scale else None
+    probe = torch.randn((n, c, h, w), generator=g)
+    xr = x.double().requires_grad_()
+    gr, br = gam.double().requires_grad_(), bet.double().requires_grad_()
+    yr = F.group_norm(xr, groups, gr, br, 1e-5)
+    if scale:
+        yr = yr * cs.double()[:, :, None, None]
+    if relu:
+        yr = F.relu(yr)
+    (yr * probe.double()).sum().backward()
+    m = DigaGroupNorm(groups, c)
+    with torch.no_grad():
+        m.weight.copy_(gam), m.bias.copy_(bet)
+    m = m.to(DEV)
+    xd = _cl(x).requires_grad_()
+    y = m(xd, relu=relu, chan_scale=None if cs is None else cs.to(DEV))
+    assert_close(y, yr, 2e-5, 2e-5, "gn forward")
+    (y * probe.to(DEV)).sum().backward()
+    assert_close(xd.grad, xr.grad, 1e-4, 1e-5 * float(xr.grad.abs().max()) + 1e-7, "gn grad x")
+    assert_close(m.weight.grad, gr.grad, 1e-4, 1e-5 * float(gr.grad.abs().max()), "gn grad gamma")
+    assert_close(m.bias.grad, br.grad, 1e-4, 1e-5 * float(br.grad.abs().max()), "gn grad beta")
+
+
+def test_groupnorm_writes_into_concat_slice():
+    from diga_amd.model import norm as dn
+    g = synth.gen(9)
+    xs = [torch.randn((2, 64, 9, 11), generator=g) for _ in range(3)]
+    gns = [dn.DigaGroupNorm(32, 64).to(DEV) for _ in range(3)]
+    buf = torch.empty((2, 9, 11, 192), device=DEV)
+    xd = [_cl(x).requires_grad_() for x in xs]
+    outs = [gn(x, relu=True, out=dn.alias_slice(buf, i * 64, (i + 1) * 64)) for i, (gn, x) in enumerate(zip(gns, xd))]
+    cat = dn.assemble(buf, 64, outs)
+    want = torch.cat([F.relu(F.group_norm(x.double(), 32, None, None, 1e-5)) for x in xs], 1)
+    assert_close(cat, want, 2e-5, 2e-5, "concat buffer")
+    probe = torch.randn(want.shape, generator=g)
+    (cat * probe.to(DEV)).sum().backward()
+    xr = [x.double().requires_grad_() for x in xs]
+    (torch.cat([F.relu(F.group_norm(x, 32, None, None, 1e-5)) for x in xr], 1) * probe.double()).sum().backward()
+    for a, b in zip(xd, xr):
+        assert_close(a.grad, b.grad, 1e-4, 1e-5 * float(b.grad.abs().max()) + 1e-7, "grad through the slice")
+
+
+def test_se_pool_and_gate():
+    from diga_amd.model import norm as dn
+    g = synth.gen(10)
+    x = torch.randn((3, 128, 13, 9), generator=g)
+    gate = torch.rand((3, 128), generator=g)
+    probe = torch.randn(x.shape, generator=g)
+    pp = torch.randn((3, 128), generator=g)
+    xr, gr = x.double().requires_grad_(), gate.double().requires_grad_()
+    ((xr * gr[:, :, None, None] * probe.double()).sum() + (xr.mean(dim=(2, 3)) * pp.double()).sum()).backward()
+    xd, gd = _cl(x).requires_grad_(), gate.to(DEV).requires_grad_()
+    pooled = dn.global_avg_pool(xd)
+    assert_close(pooled, x.double().mean(dim=(2, 3)), 1e-5, 1e-6, "avg pool")
+    y = dn.channel_gate(xd, gd)
+    assert_close(y, x.double() * gate.double()[:, :, None, None], 1e-6, 1e-7, "gate")
+    ((y * probe.to(DEV)).sum() + (pooled * pp.to(DEV)).sum()).backward()
+    assert_close(xd.grad, xr.grad, 1e-5, 1e-6, "se grad x")
+    assert_close(gd.grad, gr.grad, 1e-4, 1e-5 * float(gr.grad.abs().max()), "se grad gate")
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 384, 384), (1, 16, 65, 33), (2, 32, 64, 63), (1, 8, 7, 8)])
+def test_maxpool_ceil_mode(n, c, h, w):
+    from diga_amd.model.norm import DigaMaxPool3x3s2
+    g = synth.gen(h + w)
+    x = F.relu(torch.randn((n, c, h, w), generator=g))            # post-ReLU input: many exact zeros (ties)
+    xr = x.double().requires_grad_()
+    yr = F.max_pool2d(xr, 3, 2, 1, ceil_mode=True)
+    probe = torch.randn(yr.shape, generator=g)
+    (yr * probe.double()).sum().backward()
+    xd = _cl(x).requires_grad_()
+    y = DigaMaxPool3x3s2()(xd)
+    assert tuple(y.shape) == tuple(yr.shape)
+    assert torch.equal(y.cpu().double(), yr.detach())
+    (y * probe.to(DEV)).sum().backward()
+    # ties between equal zeros may elect a different (zero-valued) element: compare where the input is positive
+    pos = x > 0
+    assert_close(xd.grad.cpu()[pos], xr.grad[pos], 1e-6, 1e-7, "maxpool grad")
+    assert float(xd.grad.sum()) == pytest.approx(float(xr.grad.sum()), rel=1e-5, abs=1e-4)
+
+
+def test_aspp_head_golden(golden):
+    """Classifier_Module2(inplanes=64) in eval mode against the capture of the reference (G-aspp)."""
+    from diga_amd.model.seg_model_noaux import Classifier_Module2
+    g = golden("aspp")
+    head = Classifier_Module2(64, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    sd = {}
+    for k, v in head.state_dict().items():
+        kind = "conv" if v.dim() == 4 else "lin" if v.dim() == 2 else "gn_w" if k.endswith("weight") else "bias"
+        sd[k] = detweights.fill("aspp64." + k, tuple(v.shape), kind)
+    head.load_state_dict(sd)
+    head = head.to(DEV).eval()
+    x = _cl(g.t("x")).requires_grad_()
+    res = head(x, get_feat=True)
+    assert_close(res["out"], g.t("out"), 1e-3, 1e-4, "head logits")
+    assert_close(res["feat"], g.t("feat"), 1e-3, 1e-4, "head feat")
+    ((res["out"] * g.t("probe").to(DEV)).sum() + (res["feat"] * g.t("probe_f").to(DEV)).sum()).backward()
+    assert_close(x.grad, g.t("gx"), 2e-3, 2e-5, "grad x")
+    for k, p in head.named_parameters():
+        gk = "gw_" + k.replace(".", "_")
+        if gk in g:
+            ref = g.t(gk)
+            assert_close(p.grad, ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, gk)
+        else:
+            ref = g.t(gk + "__sample")
+            assert_close(p.grad.reshape(-1)[::97], ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, gk)
