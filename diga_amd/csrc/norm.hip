@@ -44,6 +44,7 @@ __device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk,
             for (int v = 0; v < NV; ++v)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[v][e] = 0.f;
+#pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) f(r, r0, q * 4, acc);
 #pragma unroll
             for (int v = 0; v < NV; ++v)
@@ -58,8 +59,17 @@ __device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk,
         for (int v = 0; v < NV; ++v)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[v][e] = 0.f;
-        if (rl < lanes)
-            for (int64_t r = r0 + rl; r < r1; r += lanes) f(r, r0, q * 4, acc);
+        if (rl < lanes) {
+            // 4 independent row loads in flight per thread: these kernels are pure HBM streams
+            int64_t r = r0 + rl;
+            for (; r + 3 * (int64_t)lanes < r1; r += 4 * (int64_t)lanes) {
+                f(r, r0, q * 4, acc);
+                f(r + lanes, r0, q * 4, acc);
+                f(r + 2 * lanes, r0, q * 4, acc);
+                f(r + 3 * lanes, r0, q * 4, acc);
+            }
+            for (; r < r1; r += lanes) f(r, r0, q * 4, acc);
+        }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             __syncthreads();
@@ -117,36 +127,6 @@ __device__ __forceinline__ void merge_channel(const float* __restrict__ partial,
     }
 }
 
-// BatchNorm: all segments form one population.  stats[0..4][C] = mean, invstd, a, b  (y = x*a + b)
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, ColGeom g, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd, float* __restrict__ ab, float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.C) return;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int s = 0; s < g.nseg; ++s) {
-        double nb, mb, m2b;
-        merge_channel(partial, g, s, c, nb, mb, m2b);
-        const double tot = n + nb, delta = mb - mean;
-        mean += delta * nb / tot;
-        m2 += m2b + delta * delta * n * nb / tot;
-        n = tot;
-    }
-    const float var = (float)(m2 / n);
-    const float invstd = 1.f / sqrtf(var + eps);
-    const float mu = (float)mean;
-    save_mean[c] = mu;
-    save_invstd[c] = invstd;
-    const float a = invstd * gamma[c];
-    ab[c] = a;
-    ab[g.C + c] = beta[c] - mu * a;
-    if (running_mean != nullptr) {
-        const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-    }
-}
 
 // eval-mode BatchNorm: a, b from the running statistics
 __global__ void bn_eval_ab_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -202,30 +182,40 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
                                                            const float* __restrict__ a, const float* __restrict__ b,
                                                            int64_t ab_seg_stride, int64_t rows_per_seg, int64_t rows,
                                                            int C, int relu) {
+    // a thread keeps its channel quad(s) and walks rows: no per-element division, coefficients in registers
     const int tq = C >> 2;
-    const int64_t total = rows * tq;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const int64_t r = i / tq;
-        const int c = (int)(i - r * tq) * 4;
-        const int64_t so = (r / rows_per_seg) * ab_seg_stride + c;
-        const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c);
-        const float4 av = *reinterpret_cast<const float4*>(a + so);
-        float4 o;
-        if (b != nullptr) {
-            const float4 bv = *reinterpret_cast<const float4*>(b + so);
+    const int tpr = tq < 256 ? tq : 256;          // threads per row
+    const int rpb = 256 / tpr;                    // rows per block iteration
+    const int q0 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    if (rl >= rpb) return;
+    const int nrows = (int)rows, rps = (int)rows_per_seg;
+    const int rstep = gridDim.x * rpb;
+    for (int q = q0; q < tq; q += tpr) {
+        const int c = q * 4;
+        float4 av = *reinterpret_cast<const float4*>(a + c);
+        float4 bv = b != nullptr ? *reinterpret_cast<const float4*>(b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int cur_seg = 0;
+        for (int r = blockIdx.x * rpb + rl; r < nrows; r += rstep) {
+            if (ab_seg_stride != 0) {
+                const int seg = r / rps;
+                if (seg != cur_seg) {
+                    cur_seg = seg;
+                    av = *reinterpret_cast<const float4*>(a + (int64_t)seg * ab_seg_stride + c);
+                    if (b != nullptr) bv = *reinterpret_cast<const float4*>(b + (int64_t)seg * ab_seg_stride + c);
+                }
+            }
+            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * ld_x + c);
+            float4 o;
             o.x = xv.x * av.x + bv.x; o.y = xv.y * av.y + bv.y; o.z = xv.z * av.z + bv.z; o.w = xv.w * av.w + bv.w;
-        } else {
-            o.x = xv.x * av.x; o.y = xv.y * av.y; o.z = xv.z * av.z; o.w = xv.w * av.w;
+            if (res != nullptr) {
+                const float4 rv = *reinterpret_cast<const float4*>(res + (int64_t)r * ld_r + c);
+                o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+            }
+            if (relu) {
+                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(y + (int64_t)r * ld_y + c) = o;
         }
-        if (res != nullptr) {
-            const float4 rv = *reinterpret_cast<const float4*>(res + r * ld_r + c);
-            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
-        }
-        if (relu) {
-            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(y + r * ld_y + c) = o;
     }
 }
 
@@ -260,22 +250,6 @@ __global__ __launch_bounds__(kNormThreads) void bwd_partial_kernel(const float* 
     });
 }
 
-// BatchNorm backward coefficients: dx = k1*g - k2 - xhat*k3 ;  kk [3][C]
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, ColGeom g, const float* __restrict__ gamma,
-                                       const float* __restrict__ invstd, float* __restrict__ kk, int training) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int64_t k = 0; k < (int64_t)g.nseg * g.nchunk; ++k) {
-        s1 += (double)partial[k * 2 * g.C + c];
-        s2 += (double)partial[k * 2 * g.C + g.C + c];
-    }
-    const double M = (double)g.nseg * (double)g.rows_per_seg;
-    const float k1 = gamma[c] * invstd[c];
-    kk[c] = k1;
-    kk[g.C + c] = training ? (float)(k1 * (s1 / M)) : 0.f;
-    kk[2 * g.C + c] = training ? (float)(k1 * (s2 / M)) : 0.f;
-}
 
 // GroupNorm backward: per (n,group) c1 = sum_c gamma*S1 / cnt, c2 = sum_c gamma*S2 / cnt; kk [3][N][C];
 // S1/S2 already carry the Dropout2d scale through g_eff = scale*dy (applied here).  dgamma/dbeta [C].
@@ -338,36 +312,61 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
                                                         int64_t ld_dx, float* __restrict__ dres, int64_t ld_dr,
                                                         int64_t rows_per_seg, int64_t rows, int C) {
     const int tq = C >> 2;
-    const int64_t total = rows * tq;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const int64_t r = i / tq;
-        const int c = (int)(i - r * tq) * 4;
-        const int seg = (int)(r / rows_per_seg);
-        const float4 gv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c);
-        const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c);
-        float gg[4] = {gv.x, gv.y, gv.z, gv.w};
-        const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
-        if (y != nullptr) {
-            const float4 yv = *reinterpret_cast<const float4*>(y + r * ld_y + c);
-            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+    const int tpr = tq < 256 ? tq : 256;
+    const int rpb = 256 / tpr;
+    const int q0 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    if (rl >= rpb) return;
+    const int nrows = (int)rows, rps = (int)rows_per_seg;
+    const int rstep = gridDim.x * rpb;
+    const bool per_seg = kk_seg_stride != 0 || st_seg_stride != 0;
+    for (int q = q0; q < tq; q += tpr) {
+        const int c = q * 4;
+        float k1a[4], k2a[4], k3a[4], mu[4], is[4];
+        auto load_coeff = [&](int seg) {
+            const float* kb = kk + (int64_t)seg * kk_seg_stride + c;
+            const float4 k1 = *reinterpret_cast<const float4*>(kb);
+            const float4 k2 = *reinterpret_cast<const float4*>(kb + kk_plane);
+            const float4 k3 = *reinterpret_cast<const float4*>(kb + 2 * kk_plane);
+            k1a[0] = k1.x; k1a[1] = k1.y; k1a[2] = k1.z; k1a[3] = k1.w;
+            k2a[0] = k2.x; k2a[1] = k2.y; k2a[2] = k2.z; k2a[3] = k2.w;
+            k3a[0] = k3.x; k3a[1] = k3.y; k3a[2] = k3.z; k3a[3] = k3.w;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
-        }
-        const float* kb = kk + (int64_t)seg * kk_seg_stride + c;
-        const float4 k1 = *reinterpret_cast<const float4*>(kb);
-        const float4 k2 = *reinterpret_cast<const float4*>(kb + kk_plane);
-        const float4 k3 = *reinterpret_cast<const float4*>(kb + 2 * kk_plane);
-        const float k1a[4] = {k1.x, k1.y, k1.z, k1.w}, k2a[4] = {k2.x, k2.y, k2.z, k2.w}, k3a[4] = {k3.x, k3.y, k3.z, k3.w};
-        float o[4];
+            for (int e = 0; e < 4; ++e) {
+                const int si = seg * st_seg_stride + (c + e) / cdiv;
+                mu[e] = mean[si];
+                is[e] = invstd[si];
+            }
+        };
+        load_coeff(0);
+        int cur_seg = 0;
+        for (int r = blockIdx.x * rpb + rl; r < nrows; r += rstep) {
+            if (per_seg) {
+                const int seg = r / rps;
+                if (seg != cur_seg) {
+                    cur_seg = seg;
+                    load_coeff(seg);
+                }
+            }
+            const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)r * ld_dy + c);
+            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * ld_x + c);
+            float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+            const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+            if (y != nullptr) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + (int64_t)r * ld_y + c);
+                const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int si = seg * st_seg_stride + (c + e) / cdiv;
-            const float xh = (xx[e] - mean[si]) * invstd[si];
-            o[e] = k1a[e] * gg[e] - k2a[e] - xh * k3a[e];
+                for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+            }
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xx[e] - mu[e]) * is[e];
+                o[e] = k1a[e] * gg[e] - k2a[e] - xh * k3a[e];
+            }
+            *reinterpret_cast<float4*>(dx + (int64_t)r * ld_dx + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (dres != nullptr)
+                *reinterpret_cast<float4*>(dres + (int64_t)r * ld_dr + c) = make_float4(gg[0], gg[1], gg[2], gg[3]);
         }
-        *reinterpret_cast<float4*>(dx + r * ld_dx + c) = make_float4(o[0], o[1], o[2], o[3]);
-        if (dres != nullptr) *reinterpret_cast<float4*>(dres + r * ld_dr + c) = make_float4(gg[0], gg[1], gg[2], gg[3]);
     }
 }
 
@@ -469,12 +468,228 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// ---- lane-parallel, division-free finalisers -------------------------------------------------------
+// Merging K chunk partials serially per channel (with double divisions) cost 0.6-0.8 ms per layer; here 8
+// lanes share a channel, the loops contain only double multiply-adds, and the two-pass form
+//   mean = sum_k (n_k*s_k + sd_k) / N ;  M2 = sum_k [ sd2_k - sd_k^2/n_k + n_k*(s_k + sd_k/n_k - mean)^2 ]
+// needs the reciprocal of just two distinct chunk sizes.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct ChunkInv {
+    double n_full, n_last, inv_full, inv_last;
+};
+__device__ __forceinline__ ChunkInv chunk_inv(const ColGeom& g) {
+    ChunkInv ci;
+    ci.n_full = (double)g.chunk_rows;
+    ci.n_last = (double)(g.rows_per_seg - (int64_t)(g.nchunk - 1) * g.chunk_rows);
+    ci.inv_full = 1.0 / ci.n_full;
+    ci.inv_last = 1.0 / ci.n_last;
+    return ci;
+}
+
+// block = kFinCh channels x kFinLn lanes; all (segment, chunk) partials of a channel form one population
+constexpr int kFinCh = 16, kFinLn = 16;
+__global__ __launch_bounds__(256) void bn_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           float* __restrict__ ab, float momentum, float eps) {
+    __shared__ double red[kFinLn][kFinCh];
+    const int cl = threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
+    const bool live = c < g.C;
+    const ChunkInv ci = chunk_inv(g);
+    const int K = g.nseg * g.nchunk;
+    double s = 0.0;
+    if (live)
+#pragma unroll 4
+        for (int k = lane; k < K; k += kFinLn) {
+            const float* p = partial + (int64_t)k * 3 * g.C;
+            const double nk = ((k % g.nchunk) == g.nchunk - 1) ? ci.n_last : ci.n_full;
+            s += nk * (double)p[2 * g.C + c] + (double)p[c];
+        }
+    red[lane][cl] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int l = 0; l < kFinLn; ++l) tot += red[l][cl];
+    const double N = (double)g.nseg * (double)g.rows_per_seg;
+    const double mean = tot / N;
+    __syncthreads();
+    double m2 = 0.0;
+    if (live)
+#pragma unroll 4
+        for (int k = lane; k < K; k += kFinLn) {
+            const float* p = partial + (int64_t)k * 3 * g.C;
+            const bool last = (k % g.nchunk) == g.nchunk - 1;
+            const double nk = last ? ci.n_last : ci.n_full, ik = last ? ci.inv_last : ci.inv_full;
+            const double sd = p[c], sd2 = p[g.C + c], sh = p[2 * g.C + c];
+            const double d = sh + sd * ik - mean;
+            m2 += sd2 - sd * sd * ik + nk * d * d;
+        }
+    red[lane][cl] = m2;
+    __syncthreads();
+    if (lane != 0 || !live) return;
+    double M2 = 0.0;
+#pragma unroll
+    for (int l = 0; l < kFinLn; ++l) M2 += red[l][cl];
+    const float var = (float)(M2 / N);
+    const float invstd = 1.f / sqrtf(var + eps);
+    const float mu = (float)mean;
+    save_mean[c] = mu;
+    save_invstd[c] = invstd;
+    const float a = invstd * gamma[c];
+    ab[c] = a;
+    ab[g.C + c] = beta[c] - mu * a;
+    if (running_mean != nullptr) {
+        const float unbiased = N > 1.0 ? (float)(M2 / (N - 1.0)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ invstd, float* __restrict__ kk,
+                                                               int training) {
+    __shared__ double red[2][kFinLn][kFinCh];
+    const int cl = threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
+    const bool live = c < g.C;
+    const int K = training ? g.nseg * g.nchunk : 0;
+    double s1 = 0.0, s2 = 0.0;
+    if (live)
+#pragma unroll 4
+        for (int k = lane; k < K; k += kFinLn) {
+            s1 += (double)partial[(int64_t)k * 2 * g.C + c];
+            s2 += (double)partial[(int64_t)k * 2 * g.C + g.C + c];
+        }
+    red[0][lane][cl] = s1;
+    red[1][lane][cl] = s2;
+    __syncthreads();
+    if (lane != 0 || !live) return;
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int l = 0; l < kFinLn; ++l) {
+        t1 += red[0][l][cl];
+        t2 += red[1][l][cl];
+    }
+    const double M = (double)g.nseg * (double)g.rows_per_seg;
+    const float k1 = gamma[c] * invstd[c];
+    kk[c] = k1;
+    kk[g.C + c] = training ? (float)(k1 * (t1 / M)) : 0.f;
+    kk[2 * g.C + c] = training ? (float)(k1 * (t2 / M)) : 0.f;
+}
+
+// one wave per (image, group): lane = (channel j = lane % cpg_pad, chunk lane); requires cpg <= 64
+__global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restrict__ partial, ColGeom g, int G,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ chan_scale, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, float* __restrict__ ab, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);     // (n, group)
+    if (idx >= g.nseg * G) return;
+    const int n_img = idx / G, grp = idx - n_img * G;
+    const int cpg = g.C / G;
+    const int lanes_per_ch = 64 / cpg > 0 ? 64 / cpg : 1;
+    const int j = lane % cpg, cl = lane / cpg;
+    const bool act = cl < lanes_per_ch;
+    const int c = grp * cpg + j;
+    const ChunkInv ci = chunk_inv(g);
+    double s = 0.0;
+    if (act)
+        for (int k = cl; k < g.nchunk; k += lanes_per_ch) {
+            const float* p = partial + ((int64_t)n_img * g.nchunk + k) * 3 * g.C;
+            const double nk = (k == g.nchunk - 1) ? ci.n_last : ci.n_full;
+            s += nk * (double)p[2 * g.C + c] + (double)p[c];
+        }
+    const double N = (double)g.rows_per_seg * cpg;
+    const double mean = wave_sum_f64(s) / N;
+    double m2 = 0.0;
+    if (act)
+        for (int k = cl; k < g.nchunk; k += lanes_per_ch) {
+            const float* p = partial + ((int64_t)n_img * g.nchunk + k) * 3 * g.C;
+            const bool last = k == g.nchunk - 1;
+            const double nk = last ? ci.n_last : ci.n_full, ik = last ? ci.inv_last : ci.inv_full;
+            const double sd = p[c], sd2 = p[g.C + c], sh = p[2 * g.C + c];
+            const double d = sh + sd * ik - mean;
+            m2 += sd2 - sd * sd * ik + nk * d * d;
+        }
+    const double M2 = wave_sum_f64(m2);
+    const float var = (float)(M2 / N);
+    const float invstd = 1.f / sqrtf(var + eps);
+    const float mu = (float)mean;
+    if (lane == 0) {
+        save_mean[idx] = mu;
+        save_invstd[idx] = invstd;
+    }
+    if (lane < cpg) {
+        const int64_t NC = (int64_t)g.nseg * g.C;
+        const int cc = grp * cpg + lane;
+        const float sc = chan_scale ? chan_scale[(int64_t)n_img * g.C + cc] : 1.f;
+        const float a = invstd * gamma[cc];
+        ab[(int64_t)n_img * g.C + cc] = a * sc;
+        ab[NC + (int64_t)n_img * g.C + cc] = (beta[cc] - mu * a) * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g, int G,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ chan_scale,
+                                                               const float* __restrict__ invstd, float* __restrict__ kk,
+                                                               float* __restrict__ chan_sums) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= g.nseg * G) return;
+    const int n_img = idx / G, grp = idx - n_img * G;
+    const int cpg = g.C / G;
+    const int lanes_per_ch = 64 / cpg > 0 ? 64 / cpg : 1;
+    const int j = lane % cpg, cl = lane / cpg;
+    const bool act = cl < lanes_per_ch;
+    const int c = grp * cpg + j;
+    double s1 = 0.0, s2 = 0.0;
+    if (act)
+        for (int k = cl; k < g.nchunk; k += lanes_per_ch) {
+            const float* p = partial + ((int64_t)n_img * g.nchunk + k) * 2 * g.C;
+            s1 += (double)p[c];
+            s2 += (double)p[g.C + c];
+        }
+    // per-channel totals: sum over the chunk lanes (lanes with equal j), kept in every lane of that channel
+    for (int o = cpg; o < 64; o <<= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    const double sc = chan_scale ? (double)chan_scale[(int64_t)n_img * g.C + c] : 1.0;
+    s1 *= sc;
+    s2 *= sc;
+    const int64_t NC = (int64_t)g.nseg * g.C;
+    if (lane < cpg) {
+        chan_sums[(int64_t)n_img * g.C + c] = (float)s1;
+        chan_sums[NC + (int64_t)n_img * g.C + c] = (float)s2;
+    }
+    double c1 = lane < cpg ? (double)gamma[c] * s1 : 0.0;
+    double c2 = lane < cpg ? (double)gamma[c] * s2 : 0.0;
+    c1 = wave_sum_f64(c1);
+    c2 = wave_sum_f64(c2);
+    const double cnt = (double)g.rows_per_seg * cpg;
+    const float is = invstd[idx];
+    if (lane < cpg) {
+        kk[(int64_t)n_img * g.C + c] = (float)sc * gamma[c] * is;
+        kk[NC + (int64_t)n_img * g.C + c] = (float)(is * (c1 / cnt));
+        kk[2 * NC + (int64_t)n_img * g.C + c] = (float)(is * (c2 / cnt));
+    }
+}
+
 static ColGeom make_geom(int64_t rows_per_seg, int64_t nseg, int64_t C) {
     ColGeom g;
     g.rows_per_seg = rows_per_seg;
     g.nseg = (int)nseg;
     g.C = (int)C;
-    // ~1024 blocks in total, at least 64 rows per chunk
+    // ~1024 blocks in total (4 per CU, 4 row loads in flight per thread), at least 64 rows per chunk
     int64_t want = ceil_div(1024, nseg);
     int64_t chunk = ceil_div(rows_per_seg, want);
     if (chunk < 64) chunk = 64;
@@ -525,7 +740,7 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     float* ab = partial + (size_t)g.nchunk * 3 * C;
     if (training) {
         hipLaunchKernelGGL(colstats_partial_kernel, dim3(g.nchunk, 1), dim3(kNormThreads), 0, st, x, ld_x, g, partial);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, partial, g, gamma, beta,
+        hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
                            running_mean, running_var, save_mean, save_invstd, ab, momentum, eps);
     } else {
         hipLaunchKernelGGL(bn_eval_ab_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, gamma, beta, running_mean,
@@ -552,8 +767,8 @@ extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     if (training)
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, 1), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
                            save_mean, save_invstd, 0, 1, g, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, partial,
-                       training ? g : ColGeom{M, 1, (int)C, (int)M, 0}, gamma, save_invstd, kk, training);
+    hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma,
+                       save_invstd, kk, training);
     hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y, save_mean,
                        save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, dres, ld_dr, M, M, (int)C);
     return launch_status("diga_bn_bwd");
@@ -573,8 +788,13 @@ extern "C" int diga_gn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     float* partial = (float*)workspace;
     float* ab = partial + (size_t)N * g.nchunk * 3 * C;
     hipLaunchKernelGGL(colstats_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, x, ld_x, g, partial);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ceil_div(N * G, 64)), dim3(64), 0, st, partial, g, (int)G, gamma, beta,
-                       chan_scale, save_mean, save_invstd, ab, eps);
+    const int cpg_f = (int)(C / G);
+    if (cpg_f <= 64 && (cpg_f & (cpg_f - 1)) == 0)
+        hipLaunchKernelGGL(gn_finalize2_kernel, dim3((unsigned)ceil_div(N * G, 4)), dim3(256), 0, st, partial, g, (int)G, gamma,
+                           beta, chan_scale, save_mean, save_invstd, ab, eps);
+    else
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ceil_div(N * G, 64)), dim3(64), 0, st, partial, g, (int)G, gamma,
+                           beta, chan_scale, save_mean, save_invstd, ab, eps);
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y,
                        (const float*)nullptr, (int64_t)0, ab, ab + N * C, C, HW, N * HW, (int)C, relu);
     return launch_status("diga_gn_fwd");
@@ -599,8 +819,12 @@ extern "C" int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     float* chan_sums = kk + (size_t)3 * N * C;                // [2][N][C]
     hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
                        save_mean, save_invstd, (int)G, cpg, g, partial);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)ceil_div(N * G, 64)), dim3(64), 0, st, partial, g, (int)G, gamma,
-                       chan_scale, save_invstd, kk, chan_sums);
+    if (cpg <= 64 && (cpg & (cpg - 1)) == 0)
+        hipLaunchKernelGGL(gn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(N * G, 4)), dim3(256), 0, st, partial, g, (int)G,
+                           gamma, chan_scale, save_invstd, kk, chan_sums);
+    else
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)ceil_div(N * G, 64)), dim3(64), 0, st, partial, g, (int)G,
+                           gamma, chan_scale, save_invstd, kk, chan_sums);
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, chan_sums, (int)N, (int)C,
                        dgamma, dbeta);
     hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y,

@@ -160,7 +160,7 @@ def test_maxpool_ceil_mode(n, c, h, w):
     (y * probe.to(DEV)).sum().backward()
     # ties between equal zeros may elect a different (zero-valued) element: compare where the input is positive
     pos = x > 0
-    assert_close(xd.grad.cpu()[pos], xr.grad[pos], 1e-6, 1e-7, "maxpool grad")
+    assert_close(xd.grad.cpu()[pos], xr.grad[pos], 1e-5, 1e-6, "maxpool grad")   # <=4 fp32 addends, any order
     assert float(xd.grad.sum()) == pytest.approx(float(xr.grad.sum()), rel=1e-5, abs=1e-4)
 
 
