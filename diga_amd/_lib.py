@@ -51,6 +51,7 @@ SIGNATURES = {
     "diga_conv2d_wgrad_workspace_bytes": (SZ, [I64] * 7),
     "diga_conv2d_wgrad_nhwc_f32": (INT, [P, P, P, P, SZ] + [I64] * 17 + [P]),
     "diga_weight_transpose": (INT, [P, P, I64, I64, I64, P]),
+    "diga_im2col_nchw": (INT, [P, P] + [I64] * 11 + [P]),
     "diga_norm_workspace_bytes": (SZ, [I64, I64, I64]),
     "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, I64, I64, INT, INT, F32, F32, P, SZ, P]),
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, I64, P, I64, I64, I64, INT, P, SZ, P]),

@@ -22,6 +22,8 @@
 // different 4-bank slots (conflict-free).  MFMA fragment mapping: in the 8-wide k group t of a K-step,
 // lane (i = lane&31, h = lane>>5) holds A[i][8t+4h .. 8t+4h+3] (one ds_read_b128) and feeds element j to
 // MFMA step j; B is read the same way, so both halves of the wave agree on which k they multiply.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace diga {
@@ -50,19 +52,20 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int BK>
 __device__ __forceinline__ void mma_kstep(const float* __restrict__ As, const float* __restrict__ Bs, int a_row0,
                                           int b_row0, int lane, f32x16 (&acc)[TM][TN]) {
+    constexpr int LD = BK + 4;
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < kBK / 8; ++t) {
+    for (int t = 0; t < BK / 8; ++t) {
         float4 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-            a[i] = *reinterpret_cast<const float4*>(As + (a_row0 + i * 32 + li) * kLD + t * 8 + lh * 4);
+            a[i] = *reinterpret_cast<const float4*>(As + (a_row0 + i * 32 + li) * LD + t * 8 + lh * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            b[j] = *reinterpret_cast<const float4*>(Bs + (b_row0 + j * 32 + li) * kLD + t * 8 + lh * 4);
+            b[j] = *reinterpret_cast<const float4*>(Bs + (b_row0 + j * 32 + li) * LD + t * 8 + lh * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -80,26 +83,32 @@ __device__ __forceinline__ void mma_kstep(const float* __restrict__ As, const fl
 // ---------------------------------------------------------------------------------------------
 // forward / backward-data
 // ---------------------------------------------------------------------------------------------
-template <int TN>   // block tile 128 x (64*TN); wave tile 64 x (32*TN)
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
+// block tile 128 x (64*TN) x BK; wave tile 64 x (32*TN).  BK = 32: 2 blocks per CU (74 KB LDS each);
+// BK = 16: 37 KB LDS, 3 blocks per CU (register-limited) -> a third wave per SIMD to cover barrier stalls.
+template <int TN, int BK>
+__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_fwd_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 64 * TN, TM = 2;
+    constexpr int LD = BK + 4;
+    constexpr int CPR = BK / 4;          // float4 chunks per LDS row
+    constexpr int RPP = 256 / CPR;       // rows staged per pass of the block
+    constexpr int NPA = BM / RPP, NPB = BN / RPP;
     extern __shared__ __align__(16) float smem[];
-    float* As = smem;                     // [2][BM][kLD]
-    float* Bs = smem + 2 * BM * kLD;      // [2][BN][kLD]
+    float* As = smem;                    // [2][BM][LD]
+    float* Bs = smem + 2 * BM * LD;      // [2][BN][LD]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // loader geometry: thread owns column chunk c4 (4 floats) of rows lr + 32*i
-    const int lr = t >> 3, c4 = (t & 7) * 4;
-    int pixbase[4], iy0[4], ix0[4];
-    bool mok[4];
+    // loader geometry: thread owns column chunk c4 (4 floats) of rows lr + RPP*i
+    const int lr = t / CPR, c4 = (t % CPR) * 4;
+    int pixbase[NPA], iy0[NPA], ix0[NPA];
+    bool mok[NPA];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + lr + 32 * i;
+    for (int i = 0; i < NPA; ++i) {
+        const int m = m0 + lr + RPP * i;
         mok[i] = m < a.M;
         const int mm = mok[i] ? m : 0;
         const int img = mm / HoWo, rem = mm - img * HoWo;
@@ -109,41 +118,53 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         ix0[i] = wo * a.sx + a.ox0;
     }
     const int RS = a.R * a.S;
-    const int cchunks = a.Cin / kBK;
+    const int cchunks = a.Cin / BK;
     const int ksteps = RS * cchunks;
 
-    float4 ra[4], rb[BN / 32];
+    // Branch-free loader: out-of-image taps / rows beyond M read a clamped (valid) address and are zeroed by a
+    // select afterwards, so the 8 loads of a K-step issue back to back instead of through 8 exec-masked branches.
+    float4 ra[NPA], rb[NPB];
+    float fa[NPA], fb[NPB];
+    int cob[NPB];
+    bool cok[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int co = n0 + lr + RPP * i;
+        cok[i] = co < a.Cout;
+        cob[i] = cok[i] ? co : a.Cout - 1;
+        fb[i] = cok[i] ? 1.f : 0.f;
+    }
     auto gload = [&](int ks) {
-        const int tap = ks / cchunks, c0 = (ks - tap * cchunks) * kBK;
+        const int tap = ks / cchunks, c0 = (ks - tap * cchunks) * BK;
         const int r = tap / a.S, s = tap - r * a.S;
         const int dy = r * a.ody, dx = s * a.odx;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPA; ++i) {
             const int iy = iy0[i] + dy, ix = ix0[i] + dx;
             const bool ok = mok[i] && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const float* p = a.in + (int64_t)(pixbase[i] + iy * a.Wi + ix) * a.in_ld + c0 + c4;
-                ra[i] = *reinterpret_cast<const float4*>(p);
-            }
+            const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+            const float* p = a.in + (int64_t)(pixbase[i] + cy * a.Wi + cx) * a.in_ld + c0 + c4;
+            ra[i] = *reinterpret_cast<const float4*>(p);
+            fa[i] = ok ? 1.f : 0.f;               // applied at LDS-store time (a multiply: hipcc turns a select
+                                                  // back into a branch around the load)
         }
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            const int co = n0 + lr + 32 * i;
-            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < a.Cout) {
-                const float* p = a.wgt + ((int64_t)co * RS + tap) * a.Cin + c0 + c4;
-                rb[i] = *reinterpret_cast<const float4*>(p);
-            }
+        for (int i = 0; i < NPB; ++i) {
+            const float* p = a.wgt + ((int64_t)cob[i] * RS + tap) * a.Cin + c0 + c4;
+            rb[i] = *reinterpret_cast<const float4*>(p);
         }
     };
     auto lstore = [&](int buf) {
-        float* ad = As + buf * BM * kLD;
-        float* bd = Bs + buf * BN * kLD;
+        float* ad = As + buf * BM * LD;
+        float* bd = Bs + buf * BN * LD;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(ad + (lr + 32 * i) * kLD + c4) = ra[i];
+        for (int i = 0; i < NPA; ++i)
+            *reinterpret_cast<float4*>(ad + (lr + RPP * i) * LD + c4) =
+                make_float4(ra[i].x * fa[i], ra[i].y * fa[i], ra[i].z * fa[i], ra[i].w * fa[i]);
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<float4*>(bd + (lr + 32 * i) * kLD + c4) = rb[i];
+        for (int i = 0; i < NPB; ++i)
+            *reinterpret_cast<float4*>(bd + (lr + RPP * i) * LD + c4) =
+                make_float4(rb[i].x * fb[i], rb[i].y * fb[i], rb[i].z * fb[i], rb[i].w * fb[i]);
     };
 
     f32x16 acc[TM][TN];
@@ -160,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     for (int ks = 0; ks < ksteps; ++ks) {
         const int cur = ks & 1;
         if (ks + 1 < ksteps) gload(ks + 1);
-        mma_kstep<TM, TN>(As + cur * BM * kLD, Bs + cur * BN * kLD, wm * 64, wn * 32 * TN, lane, acc);
+        mma_kstep<TM, TN, BK>(As + cur * BM * LD, Bs + cur * BN * LD, wm * 64, wn * 32 * TN, lane, acc);
         if (ks + 1 < ksteps) lstore(cur ^ 1);
         __syncthreads();
     }
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
 
 static int check_conv_common(const char* who, int64_t Cin, int64_t in_ld, int64_t out_ld, int64_t Cout,
                              const void* in, const void* w, const void* out) {
-    DIGA_REQUIRE(Cin > 0 && Cin % kBK == 0, DIGA_EINVAL, "%s: Cin=%lld must be a multiple of %d", who, (long long)Cin, kBK);
+    DIGA_REQUIRE(Cin > 0 && Cin % 32 == 0, DIGA_EINVAL, "%s: Cin=%lld must be a multiple of 32", who, (long long)Cin);
     DIGA_REQUIRE(in_ld >= Cin && in_ld % 4 == 0 && out_ld >= Cout, DIGA_EINVAL, "%s: bad leading dimensions", who);
     DIGA_REQUIRE(aligned16(in) && aligned16(w), DIGA_EALIGN, "%s: pointers must be 16-byte aligned", who);
     (void)out;
@@ -393,17 +414,23 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
     a.tiles_m = (int)ceil_div(a.M, 128);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
+    static const int bk_env = [] { const char* e = getenv("DIGA_CONV_BK"); return e ? atoi(e) : 32; }();
+    const int bk = (bk_env == 16) ? 16 : 32;
+#define DIGA_FWD_LAUNCH(TN_, BK_)                                                                                      \
+    do {                                                                                                               \
+        const size_t sh = (size_t)(2 * 128 * (BK_ + 4) + 2 * 64 * TN_ * (BK_ + 4)) * sizeof(float);                     \
+        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<TN_, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                  (int)sh);                                                                            \
+        hipLaunchKernelGGL((conv_fwd_kernel<TN_, BK_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a); \
+    } while (0)
     if (Cout > 64) {
         a.tiles_n = (int)ceil_div(Cout, 128);
-        const size_t sh = (size_t)(2 * 128 * kLD + 2 * 128 * kLD) * sizeof(float);
-        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((conv_fwd_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+        if (bk == 16) DIGA_FWD_LAUNCH(2, 16); else DIGA_FWD_LAUNCH(2, 32);
     } else {
         a.tiles_n = 1;
-        const size_t sh = (size_t)(2 * 128 * kLD + 2 * 64 * kLD) * sizeof(float);
-        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((conv_fwd_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+        if (bk == 16) DIGA_FWD_LAUNCH(1, 16); else DIGA_FWD_LAUNCH(1, 32);
     }
+#undef DIGA_FWD_LAUNCH
     return launch_status("diga_conv2d_nhwc_f32");
 }
 
@@ -487,4 +514,59 @@ extern "C" int diga_weight_transpose(const float* w, float* wt, int64_t K, int64
     dim3 grid((unsigned)ceil_div(C, 32), (unsigned)ceil_div(K, 32), (unsigned)RS);
     hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, (int)K, (int)RS, (int)C);
     return launch_status("diga_weight_transpose");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem (7x7/2 on the 3-channel image): gather the R*S*C inputs of every output pixel into one row of
+// Kpad floats (k = (r*S + s)*C + c, zero padded), so that the conv becomes a 1x1 conv with Cin = Kpad
+// on the kernels above (forward and backward-weight; the image needs no gradient).  Zero-padding the 3
+// channels to the 32-channel K-step instead costs 10x the FLOPs.
+// ---------------------------------------------------------------------------------------------
+namespace diga {
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int N,
+                                                          int C, int H, int W, int R, int S, int stride, int pad, int Ho,
+                                                          int Wo, int Kpad) {
+    const int kq = Kpad >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * kq;
+    const int64_t gstride = (int64_t)gridDim.x * 256;
+    const int K = R * S * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const int k0 = (int)(i % kq) * 4;
+        int64_t m = i / kq;
+        const int wo = (int)(m % Wo);
+        m /= Wo;
+        const int ho = (int)(m % Ho);
+        const int n = (int)(m / Ho);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            v[e] = 0.f;
+            if (k < K) {
+                const int c = k % C, tap = k / C;
+                const int r = tap / S, s = tap - r * S;
+                const int hi = ho * stride - pad + r, wi = wo * stride - pad + s;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                    v[e] = x[(((int64_t)n * C + c) * H + hi) * W + wi];
+            }
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+}  // namespace diga
+
+extern "C" int diga_im2col_nchw(const float* x, float* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t R,
+                                int64_t S, int64_t stride, int64_t pad, int64_t Ho, int64_t Wo, int64_t Kpad,
+                                void* stream) {
+    DIGA_REQUIRE(x && out && N > 0 && C > 0 && H > 0 && W > 0 && R > 0 && S > 0 && stride > 0 && Ho > 0 && Wo > 0,
+                 DIGA_EINVAL, "im2col: bad argument");
+    DIGA_REQUIRE(Kpad % 4 == 0 && Kpad >= R * S * C && aligned16(out), DIGA_EINVAL, "im2col: Kpad must be a multiple of 4 >= R*S*C");
+    const int64_t total = N * Ho * Wo * (Kpad / 4);
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
+    hipLaunchKernelGGL(im2col_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, out, (int)N, (int)C, (int)H, (int)W,
+                       (int)R, (int)S, (int)stride, (int)pad, (int)Ho, (int)Wo, (int)Kpad);
+    return launch_status("diga_im2col_nchw");
 }

@@ -46,6 +46,57 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag):
               tag, _lib.stream())
 
 
+class _StemConvFn(torch.autograd.Function):
+    """Few-channel conv (the 7x7/2 stem on the 3-channel image): im2col into rows of R*S*C (padded to 32)
+    floats, then a 1x1 conv on the GEMM kernels.  No gradient wrt the input (it is the image)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation):
+        _lib.require_gpu(x, weight)
+        xc = x.detach().float().contiguous()                      # NCHW
+        n, c, h, w_ = xc.shape
+        k, _, r, s = weight.shape
+        ho = (h + 2 * padding[0] - (r - 1) - 1) // stride[0] + 1
+        wo = (w_ + 2 * padding[1] - (s - 1) - 1) // stride[1] + 1
+        kk = r * s * c
+        kp = _pad_to(kk)
+        xcol = torch.empty((n, ho, wo, kp), dtype=torch.float32, device=x.device)
+        _lib.call("diga_im2col_nchw", _lib.ptr(xc), _lib.ptr(xcol), n, c, h, w_, r, s, stride[0], padding[0], ho, wo, kp,
+                  _lib.stream())
+        w2 = _pad_last(weight.detach().permute(0, 2, 3, 1).reshape(k, 1, 1, kk).contiguous(), kp)
+        out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
+        b = None if bias is None else bias.detach().float().contiguous()
+        _conv_launch(xcol, w2, b, out, (1, 1), (0, 0), (1, 1), _TAG_FWD)
+        ctx.save_for_backward(xcol)
+        ctx.geom = (k, c, r, s, kk, kp, bias is not None, weight.stride())
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (xcol,) = ctx.saved_tensors
+        k, c, r, s, kk, kp, has_bias, w_strides = ctx.geom
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("the stem conv path does not produce a gradient wrt its (image) input")
+        n, ho, wo, _ = xcol.shape
+        gy = grad_out.permute(0, 2, 3, 1)
+        if not gy.is_contiguous():
+            gy = gy.contiguous()
+        kq = _pad_to(k)
+        gyp = _pad_last(gy, kq)
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dwp = torch.empty((kq, 1, 1, kp), dtype=torch.float32, device=xcol.device)
+            nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kq, kp, 1, 1)
+            ws = _lib.workspace(nbytes, xcol.device, "wgrad")
+            _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xcol), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
+                      n, ho, wo, kp, kp, ho, wo, kq, kq, 1, 1, 1, 1, 0, 0, 1, 1, _lib.stream())
+            dw = torch.empty_strided((k, c, r, s), w_strides, dtype=torch.float32, device=xcol.device)
+            dw.copy_(dwp[:k, 0, 0, :kk].reshape(k, r, s, c).permute(0, 3, 1, 2))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = gy.sum(dim=(0, 1, 2))
+        return None, dw, db, None, None, None
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
@@ -136,5 +187,8 @@ class DigaConv2d(nn.Conv2d):
         return self
 
     def forward(self, x):
-        return _Conv2dFn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding),
-                               tuple(self.dilation))
+        fn = _Conv2dFn
+        if (self.in_channels < 8 and not x.requires_grad and tuple(self.dilation) == (1, 1)
+                and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]):
+            fn = _StemConvFn           # image-like input: gather the few channels of all taps into the K dimension
+        return fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation))

@@ -213,6 +213,12 @@ int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float* dw, void*
                                int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
                                int64_t off_dy, int64_t off_dx, void* stream);
 
+/* Stem (7x7/2 on the 3-channel NCHW image, G5/model/seg_model_noaux.py:221): out[n,ho,wo][(r*S+s)*C + c] =
+ * x[n,c,ho*stride-pad+r,wo*stride-pad+s] (zero outside / beyond R*S*C up to Kpad), after which the conv is a
+ * 1x1 conv with Cin = Kpad on the kernels above. */
+int diga_im2col_nchw(const float* x, float* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t R, int64_t S,
+                     int64_t stride, int64_t pad, int64_t Ho, int64_t Wo, int64_t Kpad, void* stream);
+
 /* w [K][RS][C] -> wt [C][RS][K] (weights for backward-data). */
 int diga_weight_transpose(const float* w, float* wt, int64_t K, int64_t RS, int64_t C, void* stream);
 
