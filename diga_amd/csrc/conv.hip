@@ -23,6 +23,9 @@
 // lane (i = lane&31, h = lane>>5) holds A[i][8t+4h .. 8t+4h+3] (one ds_read_b128) and feeds element j to
 // MFMA step j; B is read the same way, so both halves of the wave agree on which k they multiply.
 #include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
 
 #include "common.h"
 
@@ -205,6 +208,179 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_fwd_kernel(ConvA
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward / backward-data on the bf16 matrix cores with split operands ("bf16x3")
+//
+// Every fp32 operand x is split while it is staged into LDS into hi = bf16(x) and lo = bf16(x - hi)
+// (x = hi + lo up to 2^-18 relative) and a*b is evaluated as hi*hi + hi*lo + lo*hi with
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 3 MFMAs of 32 cycles per 16 k instead of 8 fp32 MFMAs of
+// 64 cycles -- 5.3x less matrix-pipe time at ~1e-5 relative error per product (the dropped lo*lo term
+// and the split residual are each <= 2^-18), well inside the path's 1e-3 logit tolerance.
+// Same tiling, loader and epilogue as conv_fwd_kernel; LDS rows are 32 bf16 (64 B) + 16 B of padding so
+// that the 16 lanes of a ds_read_b128 group fall on 16 different 16-byte slots.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);   // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// 4 fp32 -> 4 bf16 hi (8 B) + 4 bf16 lo (8 B)
+__device__ __forceinline__ void split4(const float4 v, const float f, uint2& hi, uint2& lo) {
+    const float x0 = v.x * f, x1 = v.y * f, x2 = v.z * f, x3 = v.w * f;
+    hi.x = pack_bf16(x0, x1);
+    hi.y = pack_bf16(x2, x3);
+    const float h0 = __uint_as_float(hi.x << 16), h1 = __uint_as_float(hi.x & 0xffff0000u);
+    const float h2 = __uint_as_float(hi.y << 16), h3 = __uint_as_float(hi.y & 0xffff0000u);
+    lo.x = pack_bf16(x0 - h0, x1 - h1);
+    lo.y = pack_bf16(x2 - h2, x3 - h3);
+}
+
+constexpr int kRowB = 80;   // bytes per LDS row: 32 bf16 + 16 B pad
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_fwd_x3_kernel(ConvArgs a) {
+    constexpr int BM = 128, BN = 64 * TN, TM = 2, BK = 32;
+    constexpr int CPR = BK / 4, RPP = 256 / CPR, NPA = BM / RPP, NPB = BN / RPP;
+    constexpr int A_PLANE = BM * kRowB, B_PLANE = BN * kRowB, BUF = 2 * A_PLANE + 2 * B_PLANE;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int lr = t / CPR, c4 = (t % CPR) * 4;
+    int pixbase[NPA], iy0[NPA], ix0[NPA];
+    bool mok[NPA];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int m = m0 + lr + RPP * i;
+        mok[i] = m < a.M;
+        const int mm = mok[i] ? m : 0;
+        const int img = mm / HoWo, rem = mm - img * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        pixbase[i] = img * a.Hi * a.Wi;
+        iy0[i] = ho * a.sy + a.oy0;
+        ix0[i] = wo * a.sx + a.ox0;
+    }
+    const int RS = a.R * a.S;
+    const int cchunks = a.Cin / BK;
+    const int ksteps = RS * cchunks;
+
+    float4 ra[NPA], rb[NPB];
+    float fa[NPA], fb[NPB];
+    int cob[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int co = n0 + lr + RPP * i;
+        const bool ok = co < a.Cout;
+        cob[i] = ok ? co : a.Cout - 1;
+        fb[i] = ok ? 1.f : 0.f;
+    }
+    auto gload = [&](int ks) {
+        const int tap = ks / cchunks, c0 = (ks - tap * cchunks) * BK;
+        const int r = tap / a.S, s = tap - r * a.S;
+        const int dy = r * a.ody, dx = s * a.odx;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool ok = mok[i] && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+            ra[i] = *reinterpret_cast<const float4*>(a.in + (int64_t)(pixbase[i] + cy * a.Wi + cx) * a.in_ld + c0 + c4);
+            fa[i] = ok ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i)
+            rb[i] = *reinterpret_cast<const float4*>(a.wgt + ((int64_t)cob[i] * RS + tap) * a.Cin + c0 + c4);
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* base = smem_b + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            uint2 hi, lo;
+            split4(ra[i], fa[i], hi, lo);
+            const int off = (lr + RPP * i) * kRowB + c4 * 2;
+            *reinterpret_cast<uint2*>(base + off) = hi;
+            *reinterpret_cast<uint2*>(base + A_PLANE + off) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            uint2 hi, lo;
+            split4(rb[i], fb[i], hi, lo);
+            const int off = (lr + RPP * i) * kRowB + c4 * 2;
+            *reinterpret_cast<uint2*>(base + 2 * A_PLANE + off) = hi;
+            *reinterpret_cast<uint2*>(base + 2 * A_PLANE + B_PLANE + off) = lo;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) gload(ks + 1);
+        const unsigned char* Ah = smem_b + cur * BUF;
+        const unsigned char* Al = Ah + A_PLANE;
+        const unsigned char* Bh = Ah + 2 * A_PLANE;
+        const unsigned char* Bl = Bh + B_PLANE;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int off = (wm * 64 + i * 32 + li) * kRowB + s * 32 + lh * 16;
+                ah[i] = *reinterpret_cast<const bf16x8_t*>(Ah + off);
+                al[i] = *reinterpret_cast<const bf16x8_t*>(Al + off);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int off = (wn * 32 * TN + j * 32 + li) * kRowB + s * 32 + lh * 16;
+                bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + off);
+                bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (ks + 1 < ksteps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + li;
+        const bool nok = n < a.Cout;
+        const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (nok && m < a.M) a.out[(int64_t)m * a.out_ld + n] = acc[i][j][e] + bv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward-weight
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -346,6 +522,155 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward-weight with split-bf16 operands.  The contraction index is the pixel, but both operands sit
+// pixel-major in memory ([pixel][channel]); a thread therefore loads a 4-pixel x 4-channel block (4 float4),
+// transposes it in registers and writes, per channel, the 4 consecutive pixels as 8 B of hi and 8 B of lo
+// into LDS rows [channel][32 pixels]: the MFMA fragment reads are then exactly those of conv_fwd_x3_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int A_PLANE = BM * kRowB, B_PLANE = BN * kRowB, BUF = 2 * A_PLANE + 2 * B_PLANE;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int RS = a.R * a.S;
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n;
+    wg /= a.tiles_n;
+    const int tile_m = wg % a.tiles_m;
+    wg /= a.tiles_m;
+    const int tap = wg % RS;
+    const int split = wg / RS;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int dyo = a.oy0 + r * a.ody, dxo = a.ox0 + s * a.odx;
+    const int k0 = tile_m * BM, c0 = tile_n * BN;
+    const int HoWo = a.Ho * a.Wo;
+
+    // loader: thread -> (channel quad cq, pixel quad pq) of each operand tile (BM or BN channels x 32 pixels)
+    const int pq = t & 7, cq = t >> 3;                // 8 pixel quads x 32 channel quads
+    const bool a_on = cq < BM / 4, b_on = cq < BN / 4;
+    const int p_begin = split * a.steps_per_split * kBK;
+    int p_end = p_begin + a.steps_per_split * kBK;
+    if (p_end > a.M) p_end = a.M;
+    const int ksteps = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
+
+    float4 ra[4], rb[4];
+    float fa[4], fb[4];
+    auto gload = [&](int ks) {
+        const int pb = p_begin + ks * kBK + pq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = pb + j;
+            const bool inr = p < p_end;
+            const int pc = inr ? p : p_begin;            // clamped: always a valid pixel
+            const int ka = min(k0 + cq * 4, a.Cout - 4);
+            ra[j] = *reinterpret_cast<const float4*>(a.dy + (int64_t)pc * a.dy_ld + ka);
+            fa[j] = (inr && a_on && k0 + cq * 4 < a.Cout) ? 1.f : 0.f;
+            const int img = pc / HoWo, rem = pc - img * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int iy = ho * a.sy + dyo, ix = wo * a.sx + dxo;
+            const bool ok = inr && b_on && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi &&
+                            c0 + cq * 4 < a.Cin;
+            const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+            const int cb = min(c0 + cq * 4, a.Cin - 4);
+            rb[j] = *reinterpret_cast<const float4*>(a.x + (int64_t)((img * a.Hi + cy) * a.Wi + cx) * a.x_ld + cb);
+            fb[j] = ok ? 1.f : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* base = smem_b + buf * BUF;
+        if (a_on) {
+            const float va[4][4] = {{ra[0].x, ra[1].x, ra[2].x, ra[3].x}, {ra[0].y, ra[1].y, ra[2].y, ra[3].y},
+                                    {ra[0].z, ra[1].z, ra[2].z, ra[3].z}, {ra[0].w, ra[1].w, ra[2].w, ra[3].w}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint2 hi, lo;
+                split4(make_float4(va[e][0] * fa[0], va[e][1] * fa[1], va[e][2] * fa[2], va[e][3] * fa[3]), 1.f, hi, lo);
+                const int off = (cq * 4 + e) * kRowB + pq * 8;
+                *reinterpret_cast<uint2*>(base + off) = hi;
+                *reinterpret_cast<uint2*>(base + A_PLANE + off) = lo;
+            }
+        }
+        if (b_on) {
+            const float vb[4][4] = {{rb[0].x, rb[1].x, rb[2].x, rb[3].x}, {rb[0].y, rb[1].y, rb[2].y, rb[3].y},
+                                    {rb[0].z, rb[1].z, rb[2].z, rb[3].z}, {rb[0].w, rb[1].w, rb[2].w, rb[3].w}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint2 hi, lo;
+                split4(make_float4(vb[e][0] * fb[0], vb[e][1] * fb[1], vb[e][2] * fb[2], vb[e][3] * fb[3]), 1.f, hi, lo);
+                const int off = (cq * 4 + e) * kRowB + pq * 8;
+                *reinterpret_cast<uint2*>(base + 2 * A_PLANE + off) = hi;
+                *reinterpret_cast<uint2*>(base + 2 * A_PLANE + B_PLANE + off) = lo;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    if (ksteps > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) gload(ks + 1);
+        const unsigned char* Ah = smem_b + cur * BUF;
+        const unsigned char* Al = Ah + A_PLANE;
+        const unsigned char* Bh = Ah + 2 * A_PLANE;
+        const unsigned char* Bl = Bh + B_PLANE;
+#pragma unroll
+        for (int sl = 0; sl < kBK / 16; ++sl) {
+            bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int off = (wm * 32 * TM + i * 32 + li) * kRowB + sl * 32 + lh * 16;
+                ah[i] = *reinterpret_cast<const bf16x8_t*>(Ah + off);
+                al[i] = *reinterpret_cast<const bf16x8_t*>(Al + off);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int off = (wn * 32 * TN + j * 32 + li) * kRowB + sl * 32 + lh * 16;
+                bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + off);
+                bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (ks + 1 < ksteps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.slab + (int64_t)split * a.Cout * RS * a.Cin;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + wn * 32 * TN + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (k < a.Cout && c < a.Cin) out[((int64_t)k * RS + tap) * a.Cin + c] = acc[i][j][e];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                           int64_t n4, int splits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -380,6 +705,13 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
         if (c < C && k < K) wt[((int64_t)c * RS + tap) * K + k] = tile[tx][ty + 8 * i];
     }
 }
+
+// process-wide arithmetic of the forward / backward-data kernels (diga_set_conv_math); the default can be
+// chosen with DIGA_CONV_MATH=bf16x3 in the environment
+static std::atomic<int> g_conv_math{[] {
+    const char* e = getenv("DIGA_CONV_MATH");
+    return (e && (strcmp(e, "bf16x3") == 0 || strcmp(e, "1") == 0)) ? DIGA_CONV_MATH_BF16X3 : DIGA_CONV_MATH_F32;
+}()};
 
 static int check_conv_common(const char* who, int64_t Cin, int64_t in_ld, int64_t out_ld, int64_t Cout,
                              const void* in, const void* w, const void* out) {
@@ -423,16 +755,37 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
                                   (int)sh);                                                                            \
         hipLaunchKernelGGL((conv_fwd_kernel<TN_, BK_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a); \
     } while (0)
+#define DIGA_X3_LAUNCH(TN_)                                                                                            \
+    do {                                                                                                               \
+        const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 64 * TN_ * kRowB);                                         \
+        (void)hipFuncSetAttribute((const void*)conv_fwd_x3_kernel<TN_>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)sh);                                                                            \
+        hipLaunchKernelGGL((conv_fwd_x3_kernel<TN_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);   \
+    } while (0)
+    const bool x3 = g_conv_math.load(std::memory_order_relaxed) == DIGA_CONV_MATH_BF16X3;
     if (Cout > 64) {
         a.tiles_n = (int)ceil_div(Cout, 128);
-        if (bk == 16) DIGA_FWD_LAUNCH(2, 16); else DIGA_FWD_LAUNCH(2, 32);
+        if (x3) DIGA_X3_LAUNCH(2);
+        else if (bk == 16) DIGA_FWD_LAUNCH(2, 16);
+        else DIGA_FWD_LAUNCH(2, 32);
     } else {
         a.tiles_n = 1;
-        if (bk == 16) DIGA_FWD_LAUNCH(1, 16); else DIGA_FWD_LAUNCH(1, 32);
+        if (x3) DIGA_X3_LAUNCH(1);
+        else if (bk == 16) DIGA_FWD_LAUNCH(1, 16);
+        else DIGA_FWD_LAUNCH(1, 32);
     }
 #undef DIGA_FWD_LAUNCH
+#undef DIGA_X3_LAUNCH
     return launch_status("diga_conv2d_nhwc_f32");
 }
+
+extern "C" int diga_set_conv_math(int mode) {
+    DIGA_REQUIRE(mode == DIGA_CONV_MATH_F32 || mode == DIGA_CONV_MATH_BF16X3, DIGA_EINVAL, "set_conv_math: unknown mode %d", mode);
+    g_conv_math.store(mode, std::memory_order_relaxed);
+    return DIGA_OK;
+}
+
+extern "C" int diga_get_conv_math(void) { return g_conv_math.load(std::memory_order_relaxed); }
 
 namespace {
 struct WgradPlan {
@@ -496,10 +849,24 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((conv_wgrad_kernel<TM_, TN_>), dim3(grid), dim3(256), sh, st, a);                            \
     } while (0)
-    if (p.tm == 2 && p.tn == 2) DIGA_WGRAD_LAUNCH(2, 2);
-    else if (p.tm == 2) DIGA_WGRAD_LAUNCH(2, 1);
-    else if (p.tn == 2) DIGA_WGRAD_LAUNCH(1, 2);
-    else DIGA_WGRAD_LAUNCH(1, 1);
+#define DIGA_WGRAD_X3_LAUNCH(TM_, TN_)                                                                                \
+    do {                                                                                                               \
+        const size_t shx = (size_t)2 * (2 * 64 * TM_ * kRowB + 2 * 64 * TN_ * kRowB);                                   \
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx); \
+        hipLaunchKernelGGL((conv_wgrad_x3_kernel<TM_, TN_>), dim3(grid), dim3(256), shx, st, a);                        \
+    } while (0)
+    if (g_conv_math.load(std::memory_order_relaxed) == DIGA_CONV_MATH_BF16X3) {
+        if (p.tm == 2 && p.tn == 2) DIGA_WGRAD_X3_LAUNCH(2, 2);
+        else if (p.tm == 2) DIGA_WGRAD_X3_LAUNCH(2, 1);
+        else if (p.tn == 2) DIGA_WGRAD_X3_LAUNCH(1, 2);
+        else DIGA_WGRAD_X3_LAUNCH(1, 1);
+    } else {
+        if (p.tm == 2 && p.tn == 2) DIGA_WGRAD_LAUNCH(2, 2);
+        else if (p.tm == 2) DIGA_WGRAD_LAUNCH(2, 1);
+        else if (p.tn == 2) DIGA_WGRAD_LAUNCH(1, 2);
+        else DIGA_WGRAD_LAUNCH(1, 1);
+    }
+#undef DIGA_WGRAD_X3_LAUNCH
 #undef DIGA_WGRAD_LAUNCH
     if (p.splits > 1) {
         const int64_t n4 = Cout * RS * Cin / 4;

@@ -202,6 +202,15 @@ int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, f
                          int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
                          int64_t off_dy, int64_t off_dx, int prof_tag, void* stream);
 
+/* Arithmetic of diga_conv2d_nhwc_f32 (process-wide; default from the environment variable DIGA_CONV_MATH):
+ *   DIGA_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, exact fp32 (k-ordered fmaf chain)            [default]
+ *   DIGA_CONV_MATH_BF16X3 operands split into bf16 hi+lo while staged, hi*hi + hi*lo + lo*hi on
+ *                         v_mfma_f32_32x32x16_bf16 with fp32 accumulate (~1e-5 relative per product) */
+#define DIGA_CONV_MATH_F32 0
+#define DIGA_CONV_MATH_BF16X3 1
+int diga_set_conv_math(int mode);
+int diga_get_conv_math(void);
+
 /* dw[k][r][s][c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride_y + off_y0 + r*off_dy, wo*stride_x + off_x0 + s*off_dx, c]
  * Split over pixel ranges into fp32 slabs in `workspace`, summed in fixed order (deterministic).
  * Cin % 4 == 0, Cout % 4 == 0. */

@@ -71,6 +71,68 @@ def test_conv_fwd_bwd(case):
         assert_close(m.bias.grad, br.grad, 1e-5, 1e-5 * float(br.grad.abs().max()), f"{name} grad bias")
 
 
+@pytest.fixture
+def bf16x3():
+    from diga_amd import _lib
+    _lib.call("diga_set_conv_math", 1)
+    yield
+    _lib.call("diga_set_conv_math", 0)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16x3_mode(case, bf16x3):
+    """Split-bf16 arithmetic (hi*hi + hi*lo + lo*hi on the bf16 matrix cores) of forward and backward-data:
+    errors stay at the 1e-5 level of the output scale, two orders inside the path's 1e-3 logit tolerance."""
+    from diga_amd import _lib
+    from diga_amd.model.conv import DigaConv2d
+    assert _lib.lib.diga_get_conv_math() == 1
+    name, n, cin, h, w, cout, k, stride, pad, dil, bias = case
+    g = synth.gen(zlib.crc32(name.encode()) % 10000 + 1)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+    yr = F.conv2d(xr, wr, None, stride, pad, dil)
+    probe = torch.randn(yr.shape, generator=g)
+    (yr * probe.double()).sum().backward()
+    m = DigaConv2d(cin, cout, k, stride=stride, padding=pad, dilation=dil, bias=False)
+    with torch.no_grad():
+        m.weight.copy_(wt)
+    m = m.to(DEV)
+    need_dx = stride == 1 or k == 1
+    xd = x.to(DEV).requires_grad_(need_dx)
+    y = m(xd)
+    err = float((y.detach().cpu().double() - yr.detach()).abs().max()) / float(yr.detach().abs().max())
+    assert err < 3e-5, f"{name}: forward max error {err:.2e} of the output scale"
+    (y * probe.to(DEV)).sum().backward()
+    if need_dx:
+        gerr = float((xd.grad.cpu().double() - xr.grad).abs().max()) / float(xr.grad.abs().max())
+        assert gerr < 3e-5, f"{name}: grad-input max error {gerr:.2e}"
+    werr = float((m.weight.grad.cpu().double() - wr.grad).abs().max()) / float(wr.grad.abs().max())
+    assert werr < 3e-5, f"{name}: grad-weight max error {werr:.2e}"
+
+
+def test_model_logits_bf16x3_within_tolerance(golden, bf16x3):
+    """north_star tolerance on the whole network in the split-bf16 mode: logits within 1e-3 of the reference."""
+    from diga_amd.model.model_noaux import SegModel
+    from oracle import deeplab as od
+    from oracle import detweights
+    g = golden("model")
+    m = SegModel()
+    m.load_state_dict(detweights.state_dict(od.RESNET101))
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        out = m(g.t("x").to(DEV))[2]
+    scale = float(g.t("out_eval").abs().max())
+    assert float((out.cpu() - g.t("out_eval")).abs().max()) < 1e-3 * scale
+    m.train()
+    m.final.head[0].p = 0.0
+    with torch.no_grad():
+        out = m(g.t("x").to(DEV))[2]
+    scale = float(g.t("out_train").abs().max())
+    err = float((out.cpu() - g.t("out_train")).abs().max())
+    assert err < 1e-3 * scale, f"train-mode logits off by {err / scale:.2e} of scale"
+
+
 def test_conv_wgrad_is_deterministic():
     from diga_amd.model.conv import DigaConv2d
     g = synth.gen(3)

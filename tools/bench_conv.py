@@ -52,7 +52,9 @@ def main():
     ap.add_argument("--images", type=int, default=16)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"])
     a = ap.parse_args()
+    _lib.call("diga_set_conv_math", 1 if a.math == "bf16x3" else 0)
     dev = "cuda"
     rows, tot = [], {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     for name, count, cin, cout, k, stride, dil, hw in SHAPES:
