@@ -6,8 +6,14 @@
 
 A step is one full DiGA warm-up iteration (EMA teacher update, ClassMix, student forward on 2B images,
 teacher forward on 2B images, fused upsample+CE+distillation, backward, gradient all-reduce, fused SGD)
-on BASELINE.json configs[1]: ResNet-101 DeepLabV2, B=8 source crops of 768x768 per GPU, fp32, synthetic
-inputs already resident in HBM.  Rank 0 prints ONE JSON line; `value` is source crops/s over all ranks.
+on BASELINE.json configs[1]: ResNet-101 DeepLabV2, B=8 source crops of 768x768 per GPU, synthetic inputs
+already resident in HBM.  Rank 0 prints ONE JSON line; `value` is source crops/s over all ranks.
+
+Arithmetic (`--precision`): the convolutions run either in exact fp32 on the fp32 matrix cores ("f32") or
+with fp32 operands split into bf16 hi+lo and three bf16 MFMAs per product, fp32 accumulate ("bf16x3",
+default: ~1e-5 relative per product, the whole network stays within the path's 1e-3 logit tolerance --
+tests/test_gpu_conv.py).  Everything else is fp32.  The other mode is timed too (2 steps) and reported
+under "other_precision".
 """
 import argparse
 import json
@@ -19,14 +25,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# the torch ops still on the path (BatchNorm/GroupNorm/pooling) must not trigger MIOpen's exhaustive search
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # only the two SE linears reach a vendor library
 
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-F32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_* dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_*_bf16 dense peak
+F32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak
 FWD_GFLOP_768 = 1232.9           # model forward, one 768x768 image
 FWD_GFLOP_256 = 142.6
 
@@ -37,6 +42,9 @@ CONFIGS = {
            "GTA5-shape 768x768, batch 8 per GPU"),
     "c1": ("TINY", 2, 256, 256, 16, "configs[0] stand-in: small-backbone DeepLab, 2x256x256 warm-up step"),
 }
+DTYPE = {"f32": "f32",
+         "bf16x3": "bf16x3 (conv operands = f32 split into bf16 hi+lo, 3 bf16 MFMAs per product, f32 accumulate; "
+                   "all other kernels f32)"}
 
 
 def parse():
@@ -47,11 +55,11 @@ def parse():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="override crops per GPU (debug only)")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override crop H W (debug only)")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--no-other-precision", action="store_true", help="skip the short run of the other arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the CPU leg and print its JSON")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel families with HIP events")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
-                    help="conv arithmetic: exact fp32 MFMA (default, the headline) or split-bf16 on the bf16 MFMA")
     return ap.parse_args()
 
 
@@ -99,6 +107,115 @@ def cpu_baseline_subprocess(limit_s=240):
                 "sample": f"CPU leg did not finish two B=2 256x256 oracle steps within {limit_s} s"}
 
 
+def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
+    """Build student/teacher, run `warmup` + `steps` warm-up iterations; returns (seconds for `steps` = max over
+    ranks, kernel families, last losses, parameter counts)."""
+    from diga_amd import _lib, ddp, synthetic
+    from diga_amd.model import seg_model_noaux as sm
+    from diga_amd.model.model_noaux import SegModel
+    from diga_amd.train_step import DigaTrainer
+
+    _lib.call("diga_set_conv_math", 1 if precision == "bf16x3" else 0)
+    arch_name, B, H, W, block, _ = CONFIGS[a.config]
+    B = a.batch or B
+    if a.size:
+        H, W = a.size
+    arch = getattr(sm, arch_name)
+    torch.manual_seed(0)                       # identical random-init weights on every rank
+    student, teacher = SegModel(arch=arch).to(dev), SegModel(arch=arch).to(dev)
+    ddp.broadcast_module(student)
+    teacher.train()
+    rng = random.Random(1234 + rank)           # ClassMix class choice differs per rank, reproducibly
+    tr = DigaTrainer(student, teacher, rng=rng)
+    x, x_aug, rec, labels = synthetic.warmup_batch(1234 + rank, B, H, W, block=block, device=dev)
+    counts = (sum(p.numel() for p in student.parameters() if p.requires_grad),
+              sum(p.numel() for p in student.parameters()))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    it = 0
+    for _ in range(warmup):
+        tr.warmup_step(it, x, x_aug, rec, labels)
+        it += 1
+    torch.cuda.synchronize()
+    barrier()
+    if prof:
+        _lib.call("diga_prof_reset")
+        _lib.call("diga_prof_enable", 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.warmup_step(it, x, x_aug, rec, labels)
+        it += 1
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if prof:
+        _lib.call("diga_prof_enable", 0)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    losses = {k: float(v) for k, v in out.items()}
+    if not all(v == v and abs(v) < 1e6 for v in losses.values()):
+        raise SystemExit(f"non-finite loss in the timed region: {losses}")
+    families = {}
+    if prof and rank == 0:
+        for tag in _lib.PROF_TAGS:
+            n, ms = _lib.prof_query(tag)
+            if n:
+                families[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / steps}
+    del tr, student, teacher
+    torch.cuda.empty_cache()
+    return float(t), families, losses, counts, (B, H, W, arch_name)
+
+
+def rooflines(a, precision, families, steps, counts, geom):
+    """Dominant kernel: the forward implicit-GEMM convolution (MFMA-bound).  Algorithmic work of its launches in
+    one step = model forward FLOPs (1232.9 GFLOP per 768x768 image, scaled by area) x 2B
+    student + 2B teacher images; achieved = that / the summed HIP-event durations of those launches."""
+    B, H, W, arch_name = geom
+    n_trainable, n_params = counts
+    roof, other = None, {}
+    fwd_gflop = FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)
+    # bf16x3: three bf16 MFMAs (2.5 PFLOP/s dense) per algorithmic multiply-add
+    peak = F32_MFMA_PEAK_TFLOPS if precision == "f32" else BF16_MFMA_PEAK_TFLOPS / 3.0
+    pmc = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
+            pmc = json.load(fh)["kernels"]
+    except (OSError, ValueError, KeyError):
+        pass
+    if "conv_fwd" in families and arch_name == "RESNET101":
+        fam = families["conv_fwd"]
+        flops_step = 2 * (2 * B) * fwd_gflop * 1e9
+        n_launch = fam["launches"] / steps
+        ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
+        kname = "conv_fwd_kernel" if precision == "f32" else "conv_fwd_x3_kernel"
+        traffic = None
+        if pmc and precision == "f32" and (B, H, W) == (8, 768, 768):
+            ent = pmc.get("diga::conv_fwd_kernel<2>")
+            traffic = ent["hbm_bytes_per_launch_corrected"] if ent else None
+        roof = {"kernel": f"{kname} (implicit-GEMM convolution on the "
+                          f"{'fp32' if precision == 'f32' else 'bf16'} matrix cores; all forward-conv launches of a step)",
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                "algorithmic_flops_per_launch": flops_step / n_launch, "avg_launch_ms": fam["avg_ms"],
+                "launches_per_step": n_launch}
+        for tag in ("conv_bwd_data", "conv_bwd_weight"):
+            if tag in families:        # backward: one pass each over the student's 2B images
+                f = (2 * B) * fwd_gflop * 1e9
+                v = f / (families[tag]["ms_per_step"] * 1e-3) / 1e12
+                other[tag] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": v, "frac": v / peak}
+    for tag, nbytes in (("sgd", 20.0 * n_trainable), ("ema", 12.0 * n_params),
+                        ("classmix_paste", 44.0 * B * H * W), ("classmix_hist", 8.0 * B * H * W)):
+        if tag in families:
+            v = nbytes / (families[tag]["avg_ms"] * 1e-3) / 1e9
+            other[tag] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": v, "frac": v / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": nbytes}
+    return roof, other
+
+
 def main():
     a = parse()
     if a.cpu_baseline_only:
@@ -116,117 +233,34 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = False
 
-    from diga_amd import _lib, synthetic
-    from diga_amd.model import seg_model_noaux as sm
-    from diga_amd.model.model_noaux import SegModel
-    from diga_amd.train_step import DigaTrainer
-
-    _lib.call("diga_set_conv_math", 1 if a.precision == "bf16x3" else 0)
-    arch_name, B, H, W, block, desc = CONFIGS[a.config]
-    if a.batch:
-        B = a.batch
-    if a.size:
-        H, W = a.size
-    arch = getattr(sm, arch_name)
-
-    torch.manual_seed(0)                       # identical random-init weights on every rank
-    student, teacher = SegModel(arch=arch).to(dev), SegModel(arch=arch).to(dev)
-    ddp.broadcast_module(student)
-    teacher.train()
-    rng = random.Random(1234 + rank)           # ClassMix class choice differs per rank, reproducibly
-    tr = DigaTrainer(student, teacher, rng=rng)
-    x, x_aug, rec, labels = synthetic.warmup_batch(1234 + rank, B, H, W, block=block, device=dev)
-    n_trainable = sum(p.numel() for p in student.parameters() if p.requires_grad)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    it = 0
-    for _ in range(a.warmup):
-        tr.warmup_step(it, x, x_aug, rec, labels)
-        it += 1
-    torch.cuda.synchronize()
-    barrier()
-    if not a.no_prof:
-        _lib.call("diga_prof_reset")
-        _lib.call("diga_prof_enable", 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = tr.warmup_step(it, x, x_aug, rec, labels)
-        it += 1
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if not a.no_prof:
-        _lib.call("diga_prof_enable", 0)
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t)
-    losses = {k: float(v) for k, v in out.items()}
-    if not all(v == v and abs(v) < 1e6 for v in losses.values()):
-        raise SystemExit(f"non-finite loss in the timed region: {losses}")
+    dt, families, losses, counts, geom = run_steps(a, a.precision, a.steps, a.warmup, rank, world, dev, not a.no_prof)
+    B, H, W, _ = geom
+    other_line = None
+    if not a.no_other_precision and world == 1:
+        oprec = "f32" if a.precision == "bf16x3" else "bf16x3"
+        odt, ofam, olosses, _, _ = run_steps(a, oprec, 2, 1, rank, world, dev, not a.no_prof)
+        oroof, _ = rooflines(a, oprec, ofam, 2, counts, geom)
+        other_line = {"dtype": DTYPE[oprec], "value": world * B * 2 / odt, "unit": "crops/s", "steps": 2, "warmup": 1,
+                      "ms_per_step": 1e3 * odt / 2, "roofline": oroof, "losses_last_step": olosses}
 
     if rank == 0:
-        families = {}
-        if not a.no_prof:
-            for tag in _lib.PROF_TAGS:
-                n, ms = _lib.prof_query(tag)
-                if n:
-                    families[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / a.steps}
-        # Dominant kernel: the forward implicit-GEMM convolution (MFMA-bound).  Algorithmic work of its
-        # launches in one step = model forward FLOPs (1232.9 GFLOP per 768x768 image, scaled
-        # by area) x 2B student images + 2B teacher images; achieved = that / the summed launch durations.
-        roof, roof_hbm = None, {}
-        fwd_gflop = FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)
-        # bf16x3: three bf16 MFMAs (2.5 PFLOP/s dense) per algorithmic multiply-add
-        conv_peak = F32_MFMA_PEAK_TFLOPS if a.precision == "f32" else BF16_MFMA_PEAK_TFLOPS / 3.0
-        if "conv_fwd" in families and arch_name == "RESNET101":
-            fam = families["conv_fwd"]
-            flops_step = 2 * (2 * B) * fwd_gflop * 1e9
-            n_launch = fam["launches"] / a.steps
-            ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
-            roof = {"kernel": ("conv_fwd_kernel (fp32-MFMA implicit GEMM" if a.precision == "f32" else
-                               "conv_fwd_x3_kernel (split-bf16 MFMA implicit GEMM") + "; all forward-conv launches of a step)",
-                    "bound": "mfma", "achieved": ach, "peak": conv_peak, "unit": "TFLOP/s",
-                    "frac": ach / conv_peak, "traffic": None,
-                    "algorithmic_flops_per_launch": flops_step / n_launch, "avg_launch_ms": fam["avg_ms"],
-                    "launches_per_step": n_launch}
-            for tag, mult in (("conv_bwd_data", 1.0), ("conv_bwd_weight", 1.0)):
-                if tag in families:        # backward: one pass each over the student's 2B images
-                    f = (2 * B) * fwd_gflop * 1e9 * mult
-                    roof_hbm[tag] = {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
-                                     "achieved": f / (families[tag]["ms_per_step"] * 1e-3) / 1e12}
-                    roof_hbm[tag]["frac"] = roof_hbm[tag]["achieved"] / F32_MFMA_PEAK_TFLOPS
-        for tag, bytes_per_launch in (("sgd", 20.0 * n_trainable),
-                                      ("ema", 12.0 * sum(p.numel() for p in student.parameters())),
-                                      ("classmix_paste", 44.0 * B * H * W), ("classmix_hist", 8.0 * B * H * W)):
-            if tag in families:
-                ach = bytes_per_launch / (families[tag]["avg_ms"] * 1e-3) / 1e9
-                roof_hbm[tag] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": ach,
-                                 "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch}
+        roof, other = rooflines(a, a.precision, families, a.steps, counts, geom)
         line = {
             "metric": "768x768 19-class crops/sec (DiGA warm-up step)",
             "value": world * B * a.steps / dt, "unit": "crops/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if a.precision == "f32" else "f32 operands split into bf16 hi+lo (3 bf16 MFMAs, fp32 accumulate) "
-                                                        "in the convolutions; exact f32 elsewhere",
-            "data": "synthetic",
-            "config": {"workload": desc, "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
+            "vs_baseline": None, "dtype": DTYPE[a.precision], "data": "synthetic",
+            "config": {"workload": CONFIGS[a.config][5], "global_batch": world * B, "crop": [H, W],
+                       "parallelism": f"dp{world}",
                        "images_per_step_per_gpu": {"student_fwd_bwd": 2 * B, "teacher_fwd": 2 * B}},
-            "roofline": roof, "roofline_other_kernels": roof_hbm,
-            "cpu_baseline": cpu_line,
-            "kernel_families": families, "losses_last_step": losses,
-            "model_tflop_per_step_per_gpu": (2 * B) * (3 + 1) * (FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)) / 1e3,
+            "roofline": roof, "roofline_other_kernels": other, "cpu_baseline": cpu_line,
+            "other_precision": other_line, "kernel_families": families, "losses_last_step": losses,
+            "model_tflop_per_step_per_gpu": (2 * B) * 4 * (FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)) / 1e3,
         }
         print(json.dumps(line), flush=True)
-    barrier()
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
