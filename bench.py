@@ -181,9 +181,11 @@ def rooflines(a, precision, families, steps, counts, geom):
     fwd_gflop = FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)
     # bf16x3: three bf16 MFMAs (2.5 PFLOP/s dense) per algorithmic multiply-add
     peak = F32_MFMA_PEAK_TFLOPS if precision == "f32" else BF16_MFMA_PEAK_TFLOPS / 3.0
+    # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled
+    # as MI355X_MICROARCH.md prescribes), condensed by tools/summarize_prof.py into profiles/
     pmc = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", f"r01_{precision}_pmc_summary.json")) as fh:
             pmc = json.load(fh)["kernels"]
     except (OSError, ValueError, KeyError):
         pass
@@ -194,8 +196,8 @@ def rooflines(a, precision, families, steps, counts, geom):
         ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
         kname = "conv_fwd_kernel" if precision == "f32" else "conv_fwd_x3_kernel"
         traffic = None
-        if pmc and precision == "f32" and (B, H, W) == (8, 768, 768):
-            ent = pmc.get("diga::conv_fwd_kernel<2>")
+        if pmc and (B, H, W) == (8, 768, 768):
+            ent = pmc.get("diga::conv_fwd_kernel<2>" if precision == "f32" else "diga::conv_fwd_x3_kernel<2>")
             traffic = ent["hbm_bytes_per_launch_corrected"] if ent else None
         roof = {"kernel": f"{kname} (implicit-GEMM convolution on the "
                           f"{'fp32' if precision == 'f32' else 'bf16'} matrix cores; all forward-conv launches of a step)",
