@@ -41,6 +41,9 @@ CONFIGS = {
            "configs[1]: ResNet-101 DeepLabV2 DiGA warm-up (student + EMA teacher, KL distill), synthetic "
            "GTA5-shape 768x768, batch 8 per GPU"),
     "c1": ("TINY", 2, 256, 256, 16, "configs[0] stand-in: small-backbone DeepLab, 2x256x256 warm-up step"),
+    "c4": ("RESNET101", 8, 512, 1024, 32,
+           "configs[3]: self-training step (centroid pseudo-labeler + two ClassMix blocks + centroid EMA), synthetic "
+           "Cityscapes-shape 512x1024, 8 source + 8 target crops per GPU"),
 }
 DTYPE = {"f32": "f32",
          "bf16x3": "bf16x3 (conv operands = f32 split into bf16 hi+lo, 3 bf16 MFMAs per product, f32 accumulate; "
@@ -127,7 +130,21 @@ def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
     teacher.train()
     rng = random.Random(1234 + rank)           # ClassMix class choice differs per rank, reproducibly
     tr = DigaTrainer(student, teacher, rng=rng)
-    x, x_aug, rec, labels = synthetic.warmup_batch(1234 + rank, B, H, W, block=block, device=dev)
+    if a.config == "c4":
+        from diga_amd.calc_centroids import Class_Features
+        batch = synthetic.selftrain_batch(1234 + rank, B, H, W, block=block, device=dev)
+        cf = Class_Features(numbers=19)
+        g7 = torch.Generator(device="cpu")
+        g7.manual_seed(7)
+        cf.objective_vectors = torch.randn((19, 256), generator=g7).to(dev)
+
+        def one_step(i):
+            return tr.selftrain_step(i, *batch, cf)
+    else:
+        batch = synthetic.warmup_batch(1234 + rank, B, H, W, block=block, device=dev)
+
+        def one_step(i):
+            return tr.warmup_step(i, *batch)
     counts = (sum(p.numel() for p in student.parameters() if p.requires_grad),
               sum(p.numel() for p in student.parameters()))
 
@@ -137,7 +154,7 @@ def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
 
     it = 0
     for _ in range(warmup):
-        tr.warmup_step(it, x, x_aug, rec, labels)
+        one_step(it)
         it += 1
     torch.cuda.synchronize()
     barrier()
@@ -147,7 +164,7 @@ def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = tr.warmup_step(it, x, x_aug, rec, labels)
+        out = one_step(it)
         it += 1
     torch.cuda.synchronize()
     barrier()
@@ -166,7 +183,7 @@ def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
             n, ms = _lib.prof_query(tag)
             if n:
                 families[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / steps}
-    del tr, student, teacher
+    del tr, student, teacher, batch, one_step
     torch.cuda.empty_cache()
     return float(t), families, losses, counts, (B, H, W, arch_name)
 
@@ -191,7 +208,8 @@ def rooflines(a, precision, families, steps, counts, geom):
         pass
     if "conv_fwd" in families and arch_name == "RESNET101":
         fam = families["conv_fwd"]
-        flops_step = 2 * (2 * B) * fwd_gflop * 1e9
+        imgs_fwd = (2 * (2 * B)) if a.config != "c4" else (2 * (3 * B))      # student + teacher forward images
+        flops_step = imgs_fwd * fwd_gflop * 1e9
         n_launch = fam["launches"] / steps
         ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
         kname = "conv_fwd_kernel" if precision == "f32" else "conv_fwd_x3_kernel"
@@ -206,7 +224,7 @@ def rooflines(a, precision, families, steps, counts, geom):
                 "launches_per_step": n_launch}
         for tag in ("conv_bwd_data", "conv_bwd_weight"):
             if tag in families:        # backward: one pass each over the student's 2B images
-                f = (2 * B) * fwd_gflop * 1e9
+                f = ((2 * B) if a.config != "c4" else (3 * B)) * fwd_gflop * 1e9
                 v = f / (families[tag]["ms_per_step"] * 1e-3) / 1e12
                 other[tag] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": v, "frac": v / peak}
     for tag, nbytes in (("sgd", 20.0 * n_trainable), ("ema", 12.0 * n_params),
@@ -249,7 +267,8 @@ def main():
     if rank == 0:
         roof, other = rooflines(a, a.precision, families, a.steps, counts, geom)
         line = {
-            "metric": "768x768 19-class crops/sec (DiGA warm-up step)",
+            "metric": ("768x768 19-class crops/sec (DiGA warm-up step)" if a.config != "c4" else
+                       "512x1024 19-class (source,target) crop pairs/sec (DiGA self-training step)"),
             "value": world * B * a.steps / dt, "unit": "crops/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE[a.precision], "data": "synthetic",

@@ -48,6 +48,8 @@ SIGNATURES = {
     "diga_centroid_ema_apply": (INT, [P, P, P, P, I64, I64, I64, I64, F32, INT, INT, P]),
     "diga_confusion_matrix": (INT, [P, P, P, I64, I64, P]),
     "diga_conv2d_nhwc_f32": (INT, [P, P, P, P] + [I64] * 17 + [INT, P]),
+    "diga_split_bf16": (INT, [P, P, P, I64, P]),
+    "diga_conv2d_nhwc_bf16x3": (INT, [P, P, P, P, P] + [I64] * 17 + [INT, P]),
     "diga_set_conv_math": (INT, [INT]),
     "diga_get_conv_math": (INT, []),
     "diga_conv2d_wgrad_workspace_bytes": (SZ, [I64] * 7),

@@ -39,6 +39,8 @@ constexpr int kLD = kBK + 4;   // padded LDS row (floats)
 struct ConvArgs {
     const float* in;
     const float* wgt;
+    const uint16_t* wgt_hi;   // split-bf16 weights (conv_fwd_x3p_kernel), else null
+    const uint16_t* wgt_lo;
     const float* bias;
     float* out;
     int N, Hi, Wi, Cin, in_ld;
@@ -377,6 +379,175 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3_kernel(ConvArgs a) {
                 if (nok && m < a.M) a.out[(int64_t)m * a.out_ld + n] = acc[i][j][e] + bv;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 forward / backward-data, tuned variant: weights arrive already split (two bf16 arrays written
+// once per step by split_bf16_kernel, so the B operand is staged with two 8-byte copies and no VALU work),
+// and the K loop walks tap-major with per-row pointers that are recomputed only when the tap changes
+// (one 64-bit add per load instead of a clamp + multiply-add chain).  Rows beyond M / columns beyond Cout
+// read clamped addresses and are simply never stored; only out-of-image taps are zeroed.
+// ---------------------------------------------------------------------------------------------
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_fwd_x3p_kernel(ConvArgs a) {
+    constexpr int BM = 128, BN = 64 * TN, TM = 2, BK = 32;
+    constexpr int CPR = BK / 4, RPP = 256 / CPR, NPA = BM / RPP, NPB = BN / RPP;
+    constexpr int A_PLANE = BM * kRowB, B_PLANE = BN * kRowB, BUF = 2 * A_PLANE + 2 * B_PLANE;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int lr = t / CPR, c4 = (t % CPR) * 4;
+    int pixbase[NPA], iy0[NPA], ix0[NPA];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int m = min(m0 + lr + RPP * i, a.M - 1);
+        const int img = m / HoWo, rem = m - img * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        pixbase[i] = img * a.Hi * a.Wi;
+        iy0[i] = ho * a.sy + a.oy0;
+        ix0[i] = wo * a.sx + a.ox0;
+    }
+    const int RS = a.R * a.S;
+    const int cchunks = a.Cin / BK;
+    const int ksteps = RS * cchunks;
+    const int64_t wrow = (int64_t)RS * a.Cin;       // elements per output channel of the weight arrays
+    int64_t wbase[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) wbase[i] = (int64_t)min(n0 + lr + RPP * i, a.Cout - 1) * wrow + c4;
+
+    // loader state: (l_tap, l_cc) of the NEXT K-step to fetch
+    const float* pa[NPA];
+    float ftap[NPA];
+    int l_tap = 0, l_cc = 0;
+    auto set_tap = [&](int tap) {
+        const int r = tap / a.S, s = tap - r * a.S;
+        const int dy = r * a.ody, dx = s * a.odx;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+            pa[i] = a.in + (int64_t)(pixbase[i] + cy * a.Wi + cx) * a.in_ld + c4;
+            ftap[i] = ok ? 1.f : 0.f;
+        }
+    };
+    float4 ra[NPA];
+    float fa[NPA];
+    uint2 rbh[NPB], rbl[NPB];
+    auto gload = [&]() {
+        const int koff = l_tap * a.Cin + l_cc * BK;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            ra[i] = *reinterpret_cast<const float4*>(pa[i] + l_cc * BK);
+            fa[i] = ftap[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            rbh[i] = *reinterpret_cast<const uint2*>(a.wgt_hi + wbase[i] + koff);
+            rbl[i] = *reinterpret_cast<const uint2*>(a.wgt_lo + wbase[i] + koff);
+        }
+        if (++l_cc == cchunks) {
+            l_cc = 0;
+            if (++l_tap < RS) set_tap(l_tap);
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* base = smem_b + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            uint2 hi, lo;
+            split4(ra[i], fa[i], hi, lo);
+            const int off = (lr + RPP * i) * kRowB + c4 * 2;
+            *reinterpret_cast<uint2*>(base + off) = hi;
+            *reinterpret_cast<uint2*>(base + A_PLANE + off) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int off = (lr + RPP * i) * kRowB + c4 * 2;
+            *reinterpret_cast<uint2*>(base + 2 * A_PLANE + off) = rbh[i];
+            *reinterpret_cast<uint2*>(base + 2 * A_PLANE + B_PLANE + off) = rbl[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    set_tap(0);
+    gload();
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) gload();
+        const unsigned char* Ah = smem_b + cur * BUF;
+        const unsigned char* Al = Ah + A_PLANE;
+        const unsigned char* Bh = Ah + 2 * A_PLANE;
+        const unsigned char* Bl = Bh + B_PLANE;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int off = (wm * 64 + i * 32 + li) * kRowB + s * 32 + lh * 16;
+                ah[i] = *reinterpret_cast<const bf16x8_t*>(Ah + off);
+                al[i] = *reinterpret_cast<const bf16x8_t*>(Al + off);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int off = (wn * 32 * TN + j * 32 + li) * kRowB + s * 32 + lh * 16;
+                bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + off);
+                bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (ks + 1 < ksteps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + li;
+        const bool nok = n < a.Cout;
+        const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (nok && m < a.M) a.out[(int64_t)m * a.out_ld + n] = acc[i][j][e] + bv;
+            }
+        }
+    }
+}
+
+// x[n] -> hi[n] = bf16(x), lo[n] = bf16(x - hi)   (weights, once per optimizer step)
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
+                                                         uint16_t* __restrict__ lo, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        uint2 h, l;
+        split4(reinterpret_cast<const float4*>(x)[i], 1.f, h, l);
+        reinterpret_cast<uint2*>(hi)[i] = h;
+        reinterpret_cast<uint2*>(lo)[i] = l;
     }
 }
 
@@ -737,7 +908,7 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
     if (rc) return rc;
     DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d: too many pixels for 32-bit tile indices");
     ConvArgs a;
-    a.in = in; a.wgt = wgt; a.bias = bias; a.out = out;
+    a.in = in; a.wgt = wgt; a.wgt_hi = nullptr; a.wgt_lo = nullptr; a.bias = bias; a.out = out;
     a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.in_ld = (int)in_ld;
     a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.out_ld = (int)out_ld;
     a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
@@ -777,6 +948,50 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
 #undef DIGA_FWD_LAUNCH
 #undef DIGA_X3_LAUNCH
     return launch_status("diga_conv2d_nhwc_f32");
+}
+
+extern "C" int diga_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, void* stream) {
+    DIGA_REQUIRE(x && hi && lo && n > 0 && n % 4 == 0, DIGA_EINVAL, "split_bf16: n must be a positive multiple of 4");
+    DIGA_REQUIRE(aligned16(x) && ((uintptr_t)hi & 7u) == 0 && ((uintptr_t)lo & 7u) == 0, DIGA_EALIGN, "split_bf16: alignment");
+    int64_t blocks = ceil_div(n / 4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, hi, lo, n / 4);
+    return launch_status("diga_split_bf16");
+}
+
+extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, const float* bias,
+                                       float* out, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld,
+                                       int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                                       int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
+                                       int64_t off_dx, int prof_tag, void* stream) {
+    DIGA_REQUIRE(in && wgt_hi && wgt_lo && out, DIGA_EINVAL, "conv2d_bf16x3: null pointer");
+    DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_bf16x3: bad shape");
+    int rc = check_conv_common("conv2d_bf16x3", Cin, in_ld, out_ld, Cout, in, in, out);
+    if (rc) return rc;
+    DIGA_REQUIRE(((uintptr_t)wgt_hi & 7u) == 0 && ((uintptr_t)wgt_lo & 7u) == 0, DIGA_EALIGN, "conv2d_bf16x3: weight alignment");
+    DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d_bf16x3: too many pixels");
+    ConvArgs a;
+    a.in = in; a.wgt = nullptr; a.wgt_hi = wgt_hi; a.wgt_lo = wgt_lo; a.bias = bias; a.out = out;
+    a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.in_ld = (int)in_ld;
+    a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.out_ld = (int)out_ld;
+    a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
+    a.oy0 = (int)off_y0; a.ox0 = (int)off_x0; a.ody = (int)off_dy; a.odx = (int)off_dx;
+    a.M = (int)(N * Ho * Wo);
+    a.tiles_m = (int)ceil_div(a.M, 128);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
+    if (Cout > 64) {
+        a.tiles_n = (int)ceil_div(Cout, 128);
+        const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 128 * kRowB);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_x3p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((conv_fwd_x3p_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+    } else {
+        a.tiles_n = 1;
+        const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 64 * kRowB);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((conv_fwd_x3p_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+    }
+    return launch_status("diga_conv2d_nhwc_bf16x3");
 }
 
 extern "C" int diga_set_conv_math(int mode) {

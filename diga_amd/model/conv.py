@@ -41,6 +41,16 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag):
     n, hi, wi, cin = x.shape
     _, ho, wo, k = out.shape
     _, r, s, _ = w_krsc.shape
+    if _lib.lib.diga_get_conv_math() == 1:
+        # split-bf16 arithmetic: the weights are split once here (two bf16 arrays), the activations inside the kernel
+        nel = w_krsc.numel()
+        w_hi = torch.empty(nel, dtype=torch.int16, device=w_krsc.device)
+        w_lo = torch.empty(nel, dtype=torch.int16, device=w_krsc.device)
+        _lib.call("diga_split_bf16", _lib.ptr(w_krsc), _lib.ptr(w_hi), _lib.ptr(w_lo), nel, _lib.stream())
+        _lib.call("diga_conv2d_nhwc_bf16x3", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(bias), _lib.ptr(out),
+                  n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
+                  doff[0], doff[1], tag, _lib.stream())
+        return
     _lib.call("diga_conv2d_nhwc_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin,
               x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
               tag, _lib.stream())

@@ -211,6 +211,16 @@ int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, f
 int diga_set_conv_math(int mode);
 int diga_get_conv_math(void);
 
+/* Tuned split-bf16 forward / backward-data: same contract as diga_conv2d_nhwc_f32 in DIGA_CONV_MATH_BF16X3, but the
+ * weights are passed already split (diga_split_bf16 of the [Cout][R][S][Cin] array, once per step), so the kernel
+ * stages them without arithmetic.  hi/lo are bf16 bit patterns; n % 4 == 0. */
+int diga_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
+int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, const float* bias, float* out,
+                            int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld,
+                            int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                            int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
+                            int64_t off_dy, int64_t off_dx, int prof_tag, void* stream);
+
 /* dw[k][r][s][c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride_y + off_y0 + r*off_dy, wo*stride_x + off_x0 + s*off_dx, c]
  * Split over pixel ranges into fp32 slabs in `workspace`, summed in fixed order (deterministic).
  * Cin % 4 == 0, Cout % 4 == 0. */
