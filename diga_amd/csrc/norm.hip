@@ -44,7 +44,7 @@ __device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk,
             for (int v = 0; v < NV; ++v)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[v][e] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
             for (int64_t r = r0; r < r1; ++r) f(r, r0, q * 4, acc);
 #pragma unroll
             for (int v = 0; v < NV; ++v)
@@ -60,13 +60,11 @@ __device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk,
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[v][e] = 0.f;
         if (rl < lanes) {
-            // 4 independent row loads in flight per thread: these kernels are pure HBM streams
+            // 8 independent row loads in flight per thread: these kernels are pure HBM streams
             int64_t r = r0 + rl;
-            for (; r + 3 * (int64_t)lanes < r1; r += 4 * (int64_t)lanes) {
-                f(r, r0, q * 4, acc);
-                f(r + lanes, r0, q * 4, acc);
-                f(r + 2 * lanes, r0, q * 4, acc);
-                f(r + 3 * lanes, r0, q * 4, acc);
+            for (; r + 7 * (int64_t)lanes < r1; r += 8 * (int64_t)lanes) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f(r + u * (int64_t)lanes, r0, q * 4, acc);
             }
             for (; r < r1; r += lanes) f(r, r0, q * 4, acc);
         }
@@ -689,8 +687,8 @@ static ColGeom make_geom(int64_t rows_per_seg, int64_t nseg, int64_t C) {
     g.rows_per_seg = rows_per_seg;
     g.nseg = (int)nseg;
     g.C = (int)C;
-    // ~1024 blocks in total (4 per CU, 4 row loads in flight per thread), at least 64 rows per chunk
-    int64_t want = ceil_div(1024, nseg);
+    // ~512 blocks in total (2 per CU, 8 row loads in flight per thread), at least 64 rows per chunk
+    int64_t want = ceil_div(512, nseg);
     int64_t chunk = ceil_div(rows_per_seg, want);
     if (chunk < 64) chunk = 64;
     if (chunk > rows_per_seg) chunk = rows_per_seg;
