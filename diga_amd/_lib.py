@@ -47,6 +47,7 @@ SIGNATURES = {
     "diga_class_mean_vectors": (INT, [P, P, P, P, P, P, P, SZ, I64, I64, I64, I64, I64, I64, I64, P]),
     "diga_centroid_ema_apply": (INT, [P, P, P, P, I64, I64, I64, I64, F32, INT, INT, P]),
     "diga_confusion_matrix": (INT, [P, P, P, I64, I64, P]),
+    "diga_two_scale_confusion": (INT, [P, I64, I64, P, I64, I64, P, P, P, I64, I64, I64, I64, P]),
     "diga_conv2d_nhwc_f32": (INT, [P, P, P, P] + [I64] * 17 + [INT, P]),
     "diga_split_bf16": (INT, [P, P, P, I64, P]),
     "diga_conv2d_nhwc_bf16x3": (INT, [P, P, P, P, P] + [I64] * 17 + [INT, P]),

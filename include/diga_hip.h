@@ -184,6 +184,13 @@ int diga_centroid_ema_apply(float* centroids, float* nums, const float* sums, co
 int diga_confusion_matrix(const int64_t* gt, const int64_t* pred, int64_t* hist, int64_t n, int64_t K,
                           void* stream);
 
+/* Two-scale evaluation (G5/train_DiGA_gta2city_warm_up.py:346-359, G5/evaluate_val.py:73-93): per label pixel,
+ * argmax_k max(up(pred_a)[k], up(pred_b)[k]) with up = bilinear align_corners upsampling to [H,W]; pred_out
+ * (nullable) receives it, hist (nullable, [K*K] int64, accumulated) the confusion against gt (nullable). */
+int diga_two_scale_confusion(const float* pred_a, int64_t ha, int64_t wa, const float* pred_b, int64_t hb, int64_t wb,
+                             const int64_t* gt, int64_t* pred_out, int64_t* hist, int64_t N, int64_t K, int64_t H,
+                             int64_t W, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Convolution on the fp32 matrix cores (nn.Conv2d layers of G5/model/seg_model_noaux.py:57-101,
  * :140-172; cuDNN in the reference).  Activations NHWC fp32 with a leading dimension (`*_ld` floats
