@@ -51,3 +51,30 @@ def evaluate_two_scale(model, images, labels, running, ds_size=None, want_pred=F
     pred = model(images)[2]
     pred_ds = model(image_ds)[2]
     return two_scale_prediction(pred, pred_ds, (H, W), labels, running, want_pred)
+
+
+@torch.no_grad()
+def generate_pseudo_labels(model, images, size=None, ds_size=None):
+    """Offline pseudo-label pass (G5/pseudolabel_generator.py:69-86): argmax of the softmax of the two-scale
+    max-logits (softmax is monotone, so the argmax is taken on the fused logits directly) as uint8 train ids,
+    ready to be written as palette PNGs by the caller."""
+    size = size or tuple(images.shape[-2:])
+    ds_size = ds_size or (images.shape[-2] // 2, images.shape[-1] // 2)
+    pred = model(images)[2]
+    pred_ds = model(resize_bilinear_ac(images, ds_size))[2]
+    return two_scale_prediction(pred, pred_ds, size).to(torch.uint8)
+
+
+@torch.no_grad()
+def initial_centroids(model, target_batches, class_features=None, epochs=5):
+    """Initial class centroids on the target domain (G5/calc_centroids.py:17-81, target branch): per batch the
+    class-mean feature vectors of the model's own predictions update the bank in 'mean' mode.  `target_batches`
+    is a re-iterable of image tensors; returns the Class_Features (its objective_vectors is what the reference
+    torch.save()s to <centroid_dir>/feat_centroids)."""
+    from diga_amd.calc_centroids import Class_Features
+    cf = class_features or Class_Features(numbers=19)
+    for _ in range(epochs):
+        for images in target_batches:
+            _, _, out, feat = model(images)
+            cf.update_from_batch(feat, out, name='mean')
+    return cf

@@ -12,8 +12,20 @@ if os.path.dirname(_pkg) not in sys.path:
     sys.path.append(os.path.dirname(_pkg))
 from diga_amd import _lib  # noqa: E402
 
-label = ['road', 'sidewalk', 'building', 'wall', 'fence', 'pole', 'light', 'sign', 'vegetation', 'terrain',
-         'sky', 'person', 'rider', 'car', 'truck', 'bus', 'train', 'motorcycle', 'bycycle']
+# Cityscapes train-id names, printed with the per-class IoU exactly as the reference does
+label = ("road sidewalk building wall fence pole light sign vegetation terrain sky person rider car truck bus "
+         "train motorcycle bycycle").split()
+
+
+def _summary(conf):
+    """Accuracy, class accuracy, IoU, frequency-weighted IoU of a confusion matrix (rows = ground truth)."""
+    tp = np.diag(conf)
+    per_gt, per_pred = conf.sum(axis=1), conf.sum(axis=0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = tp / (per_gt + per_pred - tp)
+        freq = per_gt / conf.sum()
+        return (tp.sum() / conf.sum(), np.nanmean(tp / per_gt), (freq[freq > 0] * iou[freq > 0]).sum(),
+                np.nanmean(iou), iou)
 
 
 class runningScore(object):
@@ -47,17 +59,10 @@ class runningScore(object):
         return self._hist.cpu().numpy().reshape(self.n_classes, self.n_classes).astype(np.float64)
 
     def get_scores(self):
-        hist = self.confusion_matrix
-        with np.errstate(divide="ignore", invalid="ignore"):
-            acc = np.diag(hist).sum() / hist.sum()
-            acc_cls = np.nanmean(np.diag(hist) / hist.sum(axis=1))
-            iu = np.diag(hist) / (hist.sum(axis=1) + hist.sum(axis=0) - np.diag(hist))
-            if self.verbose:
-                for i in range(min(self.n_classes, len(label))):
-                    print('===>' + label[i] + ':' + str(iu[i]))
-            mean_iu = np.nanmean(iu)
-            freq = hist.sum(axis=1) / hist.sum()
-            fwavacc = (freq[freq > 0] * iu[freq > 0]).sum()
+        acc, acc_cls, fwavacc, mean_iu, iu = _summary(self.confusion_matrix)
+        if self.verbose:
+            for i in range(min(self.n_classes, len(label))):
+                print('===>' + label[i] + ':' + str(iu[i]))
         cls_iu = dict(zip(range(self.n_classes), iu))
         return {'Overall Acc: \t': acc, 'Mean Acc : \t': acc_cls, 'FreqW Acc : \t': fwavacc,
                 'Mean IoU : \t': mean_iu}, cls_iu
