@@ -48,9 +48,10 @@ SIGNATURES = {
     "diga_centroid_ema_apply": (INT, [P, P, P, P, I64, I64, I64, I64, F32, INT, INT, P]),
     "diga_confusion_matrix": (INT, [P, P, P, I64, I64, P]),
     "diga_two_scale_confusion": (INT, [P, I64, I64, P, I64, I64, P, P, P, I64, I64, I64, I64, P]),
-    "diga_conv2d_nhwc_f32": (INT, [P, P, P, P] + [I64] * 17 + [INT, P]),
+    "diga_conv2d_nhwc_f32": (INT, [P, P, P, P] + [I64] * 17 + [P, INT, P]),
+    "diga_conv2d_stats_floats": (SZ, [I64, I64, I64, I64]),
     "diga_split_bf16": (INT, [P, P, P, I64, P]),
-    "diga_conv2d_nhwc_bf16x3": (INT, [P, P, P, P, P] + [I64] * 17 + [INT, P]),
+    "diga_conv2d_nhwc_bf16x3": (INT, [P, P, P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_set_conv_math": (INT, [INT]),
     "diga_get_conv_math": (INT, []),
     "diga_conv2d_wgrad_workspace_bytes": (SZ, [I64] * 7),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "diga_im2col_nchw": (INT, [P, P] + [I64] * 11 + [P]),
     "diga_norm_workspace_bytes": (SZ, [I64, I64, I64]),
     "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, I64, I64, INT, INT, F32, F32, P, SZ, P]),
+    "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, I64, I64, INT, F32, F32, P, I64, P, SZ, P]),
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, I64, P, I64, I64, I64, INT, P, SZ, P]),
     "diga_gn_fwd": (INT, [P, I64, P, I64, P, P, P, P, P, I64, I64, I64, I64, INT, F32, P, SZ, P]),
     "diga_gn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, P, SZ, P]),

@@ -43,6 +43,7 @@ struct ConvArgs {
     const uint16_t* wgt_lo;
     const float* bias;
     float* out;
+    float* stats;             // nullable: per-(128-row tile, channel) shifted sums for the BatchNorm that follows
     int N, Hi, Wi, Cin, in_ld;
     int Ho, Wo, Cout, out_ld;
     int R, S, sy, sx;            // input coordinate = out*s + off0 + tap*doff
@@ -55,6 +56,87 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     // of tiles so that neighbouring tiles (shared activation rows / weight panels) hit the same L2.
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// Epilogue shared by the forward kernels: the block's 128 x BN accumulator tile is staged through LDS (the operand
+// buffers are free after the K loop) and written with 16-byte stores, whole 512-byte (256-byte for BN=64) row
+// segments at a time, instead of 64 scalar stores per lane that touch 128-byte pieces.  On the way out it can emit
+// what the BatchNorm after the conv needs -- per channel sum(y - s), sum((y - s)^2) and s = the tile's first row,
+// over the tile's valid rows -- in exactly the layout colstats_partial_kernel produces with 128-row chunks, so the
+// BN forward skips its own statistics pass over the conv output.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_tile(f32x16 (&acc)[TM][TN], float* __restrict__ stage, const ConvArgs& a,
+                                              int m0, int n0, int wm, int wn, int lane, int t, int tile_m) {
+    constexpr int BN = 64 * TN, LDS_LD = BN + 4;
+    constexpr int CQ = BN / 4;            // column quads per row
+    constexpr int RG = 256 / CQ;          // row groups (threads sharing a column quad)
+    constexpr int RPT = 128 / RG;         // rows per thread
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[(wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDS_LD + wn * 32 * TN + j * 32 + li] =
+                    acc[i][j][e];
+    __syncthreads();
+    const int cq = t % CQ, rg = t / CQ;
+    const int n = n0 + cq * 4;
+    const bool vec_ok = (a.out_ld & 3) == 0 && n + 3 < a.Cout && ((uintptr_t)a.out & 15u) == 0;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias != nullptr) {
+        bv.x = n + 0 < a.Cout ? a.bias[n + 0] : 0.f;
+        bv.y = n + 1 < a.Cout ? a.bias[n + 1] : 0.f;
+        bv.z = n + 2 < a.Cout ? a.bias[n + 2] : 0.f;
+        bv.w = n + 3 < a.Cout ? a.bias[n + 3] : 0.f;
+    }
+    const float4 s0 = *reinterpret_cast<const float4*>(stage + cq * 4);       // tile row 0 (always a valid row)
+    const float4 sh = make_float4(s0.x + bv.x, s0.y + bv.y, s0.z + bv.z, s0.w + bv.w);
+    float sd[4] = {0.f, 0.f, 0.f, 0.f}, sd2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rg + RG * k;
+        const int m = m0 + r;
+        if (m < a.M) {
+            float4 v = *reinterpret_cast<const float4*>(stage + r * LDS_LD + cq * 4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            float* o = a.out + (int64_t)m * a.out_ld + n;
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(o) = v;
+            } else {
+                if (n + 0 < a.Cout) o[0] = v.x;
+                if (n + 1 < a.Cout) o[1] = v.y;
+                if (n + 2 < a.Cout) o[2] = v.z;
+                if (n + 3 < a.Cout) o[3] = v.w;
+            }
+            const float d0 = v.x - sh.x, d1 = v.y - sh.y, d2 = v.z - sh.z, d3 = v.w - sh.w;
+            sd[0] += d0; sd[1] += d1; sd[2] += d2; sd[3] += d3;
+            sd2[0] += d0 * d0; sd2[1] += d1 * d1; sd2[2] += d2 * d2; sd2[3] += d3 * d3;
+        }
+    }
+    if (a.stats == nullptr) return;        // uniform over the grid
+    __syncthreads();                       // everyone is done reading the staged tile
+    float* red = stage;                    // [2][RG][BN]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[(0 * RG + rg) * BN + cq * 4 + e] = sd[e];
+        red[(1 * RG + rg) * BN + cq * 4 + e] = sd2[e];
+    }
+    if (rg == 0) *reinterpret_cast<float4*>(red + 2 * RG * BN + cq * 4) = sh;      // the shift of these 4 columns
+    __syncthreads();
+    if (t < BN && n0 + t < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            t1 += red[(0 * RG + g) * BN + t];
+            t2 += red[(1 * RG + g) * BN + t];
+        }
+        float* sp = a.stats + (int64_t)tile_m * 3 * a.Cout + n0 + t;
+        sp[0] = t1;
+        sp[a.Cout] = t2;
+        sp[2 * a.Cout] = red[2 * RG * BN + t];
+    }
 }
 
 template <int TM, int TN, int BK>
@@ -192,18 +274,22 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_fwd_kernel(ConvA
     }
 
     // epilogue: accumulator register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*(lane>>5), col lane&31
-    const int li = lane & 31, lh = lane >> 5;
+    if constexpr (BK == 32) {
+        epilogue_tile<TM, TN>(acc, smem, a, m0, n0, wm, wn, lane, t, tile_m);
+    } else {
+        const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * 32 * TN + j * 32 + li;
-        const bool nok = n < a.Cout;
-        const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 32 * TN + j * 32 + li;
+            const bool nok = n < a.Cout;
+            const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (nok && m < a.M) a.out[(int64_t)m * a.out_ld + n] = acc[i][j][e] + bv;
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (nok && m < a.M) a.out[(int64_t)m * a.out_ld + n] = acc[i][j][e] + bv;
+                }
             }
         }
     }
@@ -366,20 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * 32 * TN + j * 32 + li;
-        const bool nok = n < a.Cout;
-        const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (nok && m < a.M) a.out[(int64_t)m * a.out_ld + n] = acc[i][j][e] + bv;
-            }
-        }
-    }
+    epilogue_tile<TM, TN>(acc, reinterpret_cast<float*>(smem_b), a, m0, n0, wm, wn, lane, t, tile_m);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -523,20 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3p_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * 32 * TN + j * 32 + li;
-        const bool nok = n < a.Cout;
-        const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (nok && m < a.M) a.out[(int64_t)m * a.out_ld + n] = acc[i][j][e] + bv;
-            }
-        }
-    }
+    epilogue_tile<TM, TN>(acc, reinterpret_cast<float*>(smem_b), a, m0, n0, wm, wn, lane, t, tile_m);
 }
 
 // x[n] -> hi[n] = bf16(x), lo[n] = bf16(x - hi)   (weights, once per optimizer step)
@@ -901,14 +961,14 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
                                     int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo,
                                     int64_t Cout, int64_t out_ld, int64_t R, int64_t S, int64_t stride_y,
                                     int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
-                                    int prof_tag, void* stream) {
+                                    float* stats_partial, int prof_tag, void* stream) {
     DIGA_REQUIRE(in && wgt && out, DIGA_EINVAL, "conv2d: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d: bad shape");
     int rc = check_conv_common("conv2d", Cin, in_ld, out_ld, Cout, in, wgt, out);
     if (rc) return rc;
     DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d: too many pixels for 32-bit tile indices");
     ConvArgs a;
-    a.in = in; a.wgt = wgt; a.wgt_hi = nullptr; a.wgt_lo = nullptr; a.bias = bias; a.out = out;
+    a.in = in; a.wgt = wgt; a.wgt_hi = nullptr; a.wgt_lo = nullptr; a.bias = bias; a.out = out; a.stats = stats_partial;
     a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.in_ld = (int)in_ld;
     a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.out_ld = (int)out_ld;
     a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
@@ -918,7 +978,7 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
     static const int bk_env = [] { const char* e = getenv("DIGA_CONV_BK"); return e ? atoi(e) : 32; }();
-    const int bk = (bk_env == 16) ? 16 : 32;
+    const int bk = (bk_env == 16 && stats_partial == nullptr) ? 16 : 32;
 #define DIGA_FWD_LAUNCH(TN_, BK_)                                                                                      \
     do {                                                                                                               \
         const size_t sh = (size_t)(2 * 128 * (BK_ + 4) + 2 * 64 * TN_ * (BK_ + 4)) * sizeof(float);                     \
@@ -963,7 +1023,7 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
                                        float* out, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld,
                                        int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
                                        int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
-                                       int64_t off_dx, int prof_tag, void* stream) {
+                                       int64_t off_dx, float* stats_partial, int prof_tag, void* stream) {
     DIGA_REQUIRE(in && wgt_hi && wgt_lo && out, DIGA_EINVAL, "conv2d_bf16x3: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_bf16x3: bad shape");
     int rc = check_conv_common("conv2d_bf16x3", Cin, in_ld, out_ld, Cout, in, in, out);
@@ -971,7 +1031,7 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
     DIGA_REQUIRE(((uintptr_t)wgt_hi & 7u) == 0 && ((uintptr_t)wgt_lo & 7u) == 0, DIGA_EALIGN, "conv2d_bf16x3: weight alignment");
     DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d_bf16x3: too many pixels");
     ConvArgs a;
-    a.in = in; a.wgt = nullptr; a.wgt_hi = wgt_hi; a.wgt_lo = wgt_lo; a.bias = bias; a.out = out;
+    a.in = in; a.wgt = nullptr; a.wgt_hi = wgt_hi; a.wgt_lo = wgt_lo; a.bias = bias; a.out = out; a.stats = stats_partial;
     a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.in_ld = (int)in_ld;
     a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.out_ld = (int)out_ld;
     a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
@@ -992,6 +1052,10 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
         hipLaunchKernelGGL((conv_fwd_x3p_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
     }
     return launch_status("diga_conv2d_nhwc_bf16x3");
+}
+
+extern "C" size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout) {
+    return (size_t)ceil_div(N * Ho * Wo, 128) * 3 * (size_t)Cout;
 }
 
 extern "C" int diga_set_conv_math(int mode) {

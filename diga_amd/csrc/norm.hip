@@ -550,6 +550,40 @@ __global__ __launch_bounds__(256) void bn_finalize2_kernel(const float* __restri
     }
 }
 
+// Folds `group` consecutive row-chunk partials {sum d, sum d^2, shift} (each over `g.chunk_rows` rows, the last
+// one ragged) into one partial per group, re-based on the shift of the group's first chunk.  Block = 4 chunk
+// lanes x 64 channels, so every load is a coalesced 256-byte row piece; sums are formed in double.
+__global__ __launch_bounds__(256) void merge_partials_kernel(const float* __restrict__ partial, ColGeom g, int group,
+                                                             float* __restrict__ merged) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const bool live = c < g.C;
+    const int k0 = blockIdx.x * group;
+    const int k1 = min(k0 + group, g.nchunk);
+    const ChunkInv ci = chunk_inv(g);
+    double s1 = 0.0, s2 = 0.0;
+    float base = 0.f;
+    if (live) {
+        base = partial[((int64_t)k0 * 3 + 2) * g.C + c];
+        for (int k = k0 + lane; k < k1; k += 4) {
+            const float* p = partial + (int64_t)k * 3 * g.C;
+            const double nk = (k == g.nchunk - 1) ? ci.n_last : ci.n_full;
+            const double sd = p[c], sd2 = p[g.C + c], dl = (double)p[2 * g.C + c] - (double)base;
+            s1 += sd + nk * dl;
+            s2 += sd2 + 2.0 * dl * sd + nk * dl * dl;
+        }
+    }
+    red[0][lane][cl] = s1;
+    red[1][lane][cl] = s2;
+    __syncthreads();
+    if (lane != 0 || !live) return;
+    float* o = merged + (int64_t)blockIdx.x * 3 * g.C;
+    o[c] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    o[g.C + c] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+    o[2 * g.C + c] = base;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ invstd, float* __restrict__ kk,
@@ -747,6 +781,45 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
                        ab + C, (int64_t)0, M, M, (int)C, relu);
     return launch_status("diga_bn_fwd");
+}
+
+extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
+                                    int64_t ld_r, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float* save_mean, float* save_invstd, int64_t M, int64_t C,
+                                    int relu, float momentum, float eps, const float* partial, int64_t chunk_rows,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0 && chunk_rows > 0,
+                 DIGA_EINVAL, "bn_fwd_partials: bad argument");
+    int rc = check_norm("bn_fwd_partials", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st);
+    ColGeom g;
+    g.rows_per_seg = M;
+    g.nseg = 1;
+    g.C = (int)C;
+    g.chunk_rows = (int)chunk_rows;
+    g.nchunk = (int)ceil_div(M, chunk_rows);
+    // the finaliser walks all chunks of a channel with 16 lanes: beyond a few hundred chunks fold them first
+    const int group = g.nchunk > 512 ? (int)ceil_div(g.nchunk, 384) : 1;
+    const int ngroup = (int)ceil_div(g.nchunk, group);
+    const size_t need = ((group > 1 ? (size_t)ngroup * 3 * C : 0) + (size_t)2 * C) * sizeof(float);
+    DIGA_REQUIRE(workspace_bytes >= need, DIGA_EWORKSPACE, "bn_fwd_partials: workspace too small (%zu < %zu)",
+                 workspace_bytes, need);
+    float* ab = (float*)workspace;
+    if (group > 1) {
+        float* merged = ab + 2 * C;
+        hipLaunchKernelGGL(merge_partials_kernel, dim3(ngroup, (unsigned)ceil_div(C, 64)), dim3(256), 0, st, partial, g, group,
+                           merged);
+        partial = merged;
+        g.chunk_rows = (int)(chunk_rows * group);
+        g.nchunk = ngroup;
+    }
+    hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, ab, momentum, eps);
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
+                       ab + C, (int64_t)0, M, M, (int)C, relu);
+    return launch_status("diga_bn_fwd_partials");
 }
 
 extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,

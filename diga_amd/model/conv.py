@@ -35,7 +35,7 @@ def _pad_last(t, c_to):
     return out
 
 
-def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag):
+def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule)."""
     n, hi, wi, cin = x.shape
@@ -49,11 +49,11 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag):
         _lib.call("diga_split_bf16", _lib.ptr(w_krsc), _lib.ptr(w_hi), _lib.ptr(w_lo), nel, _lib.stream())
         _lib.call("diga_conv2d_nhwc_bf16x3", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(bias), _lib.ptr(out),
                   n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
-                  doff[0], doff[1], tag, _lib.stream())
+                  doff[0], doff[1], _lib.ptr(stats), tag, _lib.stream())
         return
     _lib.call("diga_conv2d_nhwc_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin,
               x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
-              tag, _lib.stream())
+              _lib.ptr(stats), tag, _lib.stream())
 
 
 class _StemConvFn(torch.autograd.Function):
@@ -61,7 +61,7 @@ class _StemConvFn(torch.autograd.Function):
     floats, then a 1x1 conv on the GEMM kernels.  No gradient wrt the input (it is the image)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None):
         _lib.require_gpu(x, weight)
         xc = x.detach().float().contiguous()                      # NCHW
         n, c, h, w_ = xc.shape
@@ -76,7 +76,7 @@ class _StemConvFn(torch.autograd.Function):
         w2 = _pad_last(weight.detach().permute(0, 2, 3, 1).reshape(k, 1, 1, kk).contiguous(), kp)
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
-        _conv_launch(xcol, w2, b, out, (1, 1), (0, 0), (1, 1), _TAG_FWD)
+        _conv_launch(xcol, w2, b, out, (1, 1), (0, 0), (1, 1), _TAG_FWD, stats)
         ctx.save_for_backward(xcol)
         ctx.geom = (k, c, r, s, kk, kp, bias is not None, weight.stride())
         return out.permute(0, 3, 1, 2)
@@ -104,12 +104,12 @@ class _StemConvFn(torch.autograd.Function):
             dw.copy_(dwp[:k, 0, 0, :kk].reshape(k, r, s, c).permute(0, 3, 1, 2))
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return None, dw, db, None, None, None
+        return None, dw, db, None, None, None, None
 
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         xn = x.detach().permute(0, 2, 3, 1)
@@ -127,7 +127,7 @@ class _Conv2dFn(torch.autograd.Function):
         wo = (wi + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
-        _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD)
+        _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats)
         ctx.save_for_backward(xn, w)
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         return out.permute(0, 3, 1, 2)
@@ -178,7 +178,7 @@ class _Conv2dFn(torch.autograd.Function):
             dw.copy_(dw_krsc.permute(0, 3, 1, 2))
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -188,6 +188,7 @@ class DigaConv2d(nn.Conv2d):
         super().__init__(*args, **kwargs)
         if self.groups != 1 or self.padding_mode != "zeros":
             raise NotImplementedError("DigaConv2d: groups=1 and zero padding only")
+        self.emit_bn_stats = False      # set by the model on convs that feed a train-mode BatchNorm
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def _apply(self, fn, *a, **k):
@@ -201,4 +202,14 @@ class DigaConv2d(nn.Conv2d):
         if (self.in_channels < 8 and not x.requires_grad and tuple(self.dilation) == (1, 1)
                 and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]):
             fn = _StemConvFn           # image-like input: gather the few channels of all taps into the K dimension
-        return fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation))
+        stats = None
+        if self.emit_bn_stats and self.training and self.out_channels % 4 == 0:
+            n, _, h, w = x.shape
+            ho = (h + 2 * self.padding[0] - self.dilation[0] * (self.kernel_size[0] - 1) - 1) // self.stride[0] + 1
+            wo = (w + 2 * self.padding[1] - self.dilation[1] * (self.kernel_size[1] - 1) - 1) // self.stride[1] + 1
+            stats = torch.empty(_lib.lib.diga_conv2d_stats_floats(n, ho, wo, self.out_channels), dtype=torch.float32,
+                                device=x.device)
+        y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats)
+        if stats is not None:
+            y._diga_bn_partials = (stats, 128)       # picked up by the DigaBatchNorm2d that consumes y
+        return y

@@ -54,7 +54,8 @@ def _ws(rows_per_seg, nseg, c, device):
 # --------------------------------------------------------------------------------------------- BatchNorm
 class _BnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, relu, momentum, eps):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, relu, momentum, eps,
+                partials=None):
         _lib.require_gpu(x)
         xn = nhwc(x.detach())
         n, h, w, c = xn.shape
@@ -64,10 +65,17 @@ class _BnFn(torch.autograd.Function):
         save_mean = torch.empty(c, dtype=torch.float32, device=xn.device)
         save_invstd = torch.empty_like(save_mean)
         ws = _ws(m, 1, c, xn.device)
-        _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
-                  _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd), m, c,
-                  1 if training else 0, 1 if relu else 0, float(momentum), float(eps), _lib.ptr(ws), ws.numel(),
-                  _lib.stream())
+        if partials is not None and training:
+            # the producing conv already reduced its output tile by tile: finalise + apply only
+            _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
+                      _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
+                      _lib.ptr(save_invstd), m, c, 1 if relu else 0, float(momentum), float(eps), _lib.ptr(partials[0]),
+                      int(partials[1]), _lib.ptr(ws), ws.numel(), _lib.stream())
+        else:
+            _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
+                      _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd), m, c,
+                      1 if training else 0, 1 if relu else 0, float(momentum), float(eps), _lib.ptr(ws), ws.numel(),
+                      _lib.stream())
         ctx.save_for_backward(xn, y if relu else None, weight, save_mean, save_invstd)
         ctx.flags = (training, residual is not None)
         return y.permute(0, 3, 1, 2)
@@ -86,7 +94,7 @@ class _BnFn(torch.autograd.Function):
                   _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dres), c, m, c, 1 if training else 0, _lib.ptr(ws),
                   ws.numel(), _lib.stream())
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 class DigaBatchNorm2d(nn.BatchNorm2d):
@@ -102,7 +110,7 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
         if self.training and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
         return _BnFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, training, relu,
-                           self.momentum, self.eps)
+                           self.momentum, self.eps, getattr(x, "_diga_bn_partials", None))
 
 
 # --------------------------------------------------------------------------------------------- GroupNorm

@@ -65,6 +65,8 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)          # kept for module-tree parity; the ReLUs run inside the BN kernels
         self.downsample = downsample
         self.stride = stride
+        for conv in (self.conv1, self.conv2, self.conv3) + ((downsample[0],) if downsample is not None else ()):
+            conv.emit_bn_stats = True              # BN statistics come out of the conv epilogue
 
     def forward(self, x):
         y = self.bn1(self.conv1(x), relu=True)
@@ -140,6 +142,7 @@ class ResNetMulti(nn.Module):
         self.inplanes = arch.stem
         self.conv1 = DigaConv2d(3, arch.stem, 7, stride=2, padding=3, bias=False)
         self.bn1 = _frozen_bn(arch.stem)
+        self.conv1.emit_bn_stats = True
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = dn.DigaMaxPool3x3s2()
         stages = [self._make_layer(block, arch.planes[i], layers[i], arch.strides[i], arch.dilations[i])

@@ -207,7 +207,12 @@ int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, f
                          int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld,
                          int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
                          int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
-                         int64_t off_dy, int64_t off_dx, int prof_tag, void* stream);
+                         int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream);
+
+/* stats_partial (nullable, diga_conv2d_stats_floats(N,Ho,Wo,Cout) floats): the epilogue also writes, per 128-pixel
+ * tile and channel, sum(y - s), sum((y - s)^2), s -- the column-statistics partials of the BatchNorm that follows the
+ * conv (diga_bn_fwd_partials), which then needs no statistics pass of its own over y. */
+size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout);
 
 /* Arithmetic of diga_conv2d_nhwc_f32 (process-wide; default from the environment variable DIGA_CONV_MATH):
  *   DIGA_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, exact fp32 (k-ordered fmaf chain)            [default]
@@ -226,7 +231,7 @@ int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, const uint1
                             int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld,
                             int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
                             int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
-                            int64_t off_dy, int64_t off_dx, int prof_tag, void* stream);
+                            int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream);
 
 /* dw[k][r][s][c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride_y + off_y0 + r*off_dy, wo*stride_x + off_x0 + s*off_dx, c]
  * Split over pixel ranges into fp32 slabs in `workspace`, summed in fixed order (deterministic).
@@ -262,6 +267,14 @@ int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const floa
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                 float* save_mean, float* save_invstd, int64_t M, int64_t C, int training, int relu,
                 float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Train-mode diga_bn_fwd whose statistics pass is replaced by partials the producing conv already wrote
+ * (`partial` = stats_partial of diga_conv2d_nhwc_*, `chunk_rows` = 128). */
+int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float* save_mean, float* save_invstd, int64_t M, int64_t C, int relu, float momentum,
+                         float eps, const float* partial, int64_t chunk_rows, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*[y>0] (y nullable = no ReLU),
  * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (nullable) = g. */

@@ -151,3 +151,49 @@ def test_conv_rejects_cpu():
     m = DigaConv2d(32, 32, 1)
     with pytest.raises(RuntimeError, match="GPU only"):
         m(torch.zeros(1, 32, 4, 4))
+
+
+@pytest.mark.parametrize("math", [0, 1], ids=["f32", "bf16x3"])
+@pytest.mark.parametrize("case", [c for c in CASES if c[5] % 4 == 0 and not c[10]] +
+                         [("stats_merge", 2, 32, 192, 193, 64, 1, 1, 0, 1, False)],     # > 512 tiles: merge stage
+                         ids=lambda c: c[0])
+def test_conv_epilogue_bn_statistics(case, math):
+    """Train-mode BN fed by the per-tile {sum d, sum d^2, shift} partials the conv epilogue emits equals BN that
+    re-reads the conv output (and a float64 reference), including running-stat updates; the input carries a large
+    mean so a naive sum-of-squares would lose the variance."""
+    from diga_amd import _lib
+    from diga_amd.model.conv import DigaConv2d
+    from diga_amd.model.norm import DigaBatchNorm2d
+    name, n, cin, h, w, cout, k, stride, pad, dil, _ = case
+    g = synth.gen(zlib.crc32(name.encode()) % 10000 + 7)
+    x = torch.randn((n, cin, h, w), generator=g) + 3.0
+    wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    conv = DigaConv2d(cin, cout, k, stride=stride, padding=pad, dilation=dil, bias=False)
+    bn_a, bn_b = DigaBatchNorm2d(cout), DigaBatchNorm2d(cout)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, cout))
+            for p in bn.parameters():
+                p.requires_grad = False
+    conv, bn_a, bn_b = conv.to(DEV).train(), bn_a.to(DEV).train(), bn_b.to(DEV).train()
+    prev = _lib.lib.diga_get_conv_math()
+    _lib.lib.diga_set_conv_math(math)
+    try:
+        conv.emit_bn_stats = True
+        y = conv(x.to(DEV))
+        assert hasattr(y, "_diga_bn_partials")
+        fused = bn_a(y, relu=True)
+        plain = bn_b(y.detach().clone(), relu=True)          # no partials attached: statistics re-read y
+    finally:
+        _lib.lib.diga_set_conv_math(prev)
+    yd = y.detach().double().cpu()
+    mean, var = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
+    ref = torch.relu((yd - mean[None, :, None, None]) / torch.sqrt(var + bn_a.eps)[None, :, None, None]
+                     * bn_a.weight.double().cpu()[None, :, None, None] + bn_a.bias.double().cpu()[None, :, None, None])
+    assert_close(fused.cpu(), ref, rtol=2e-5, atol=2e-5, what=f"{name} fused BN")
+    assert_close(fused.cpu(), plain.cpu(), rtol=1e-5, atol=1e-5, what=f"{name} fused vs plain BN")
+    cnt = yd.numel() // cout
+    assert_close(bn_a.running_mean.cpu(), 0.1 * mean, rtol=1e-5, atol=1e-6, what="running_mean")
+    assert_close(bn_a.running_var.cpu(), 0.9 + 0.1 * var * cnt / (cnt - 1), rtol=1e-5, atol=1e-6, what="running_var")
