@@ -65,12 +65,12 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // over the tile's valid rows -- in exactly the layout colstats_partial_kernel produces with 128-row chunks, so the
 // BN forward skips its own statistics pass over the conv output.
 template <int TM, int TN>
+__device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArgs& a, int m0, int n0, int t, int tile_m);
+
+template <int TM, int TN>
 __device__ __forceinline__ void epilogue_tile(f32x16 (&acc)[TM][TN], float* __restrict__ stage, const ConvArgs& a,
                                               int m0, int n0, int wm, int wn, int lane, int t, int tile_m) {
     constexpr int BN = 64 * TN, LDS_LD = BN + 4;
-    constexpr int CQ = BN / 4;            // column quads per row
-    constexpr int RG = 256 / CQ;          // row groups (threads sharing a column quad)
-    constexpr int RPT = 128 / RG;         // rows per thread
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -81,6 +81,18 @@ __device__ __forceinline__ void epilogue_tile(f32x16 (&acc)[TM][TN], float* __re
                 stage[(wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDS_LD + wn * 32 * TN + j * 32 + li] =
                     acc[i][j][e];
     __syncthreads();
+    drain_stage<TM, TN>(stage, a, m0, n0, t, tile_m);
+}
+
+// Second half of the epilogue: 128 staged rows x 64*TN columns (row stride 64*TN + 4 floats) -> global memory
+// (+ bias, + BatchNorm partials for 128-row chunk `tile_m`).  Entered after a barrier that follows the stage writes.
+template <int TM, int TN>
+__device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArgs& a, int m0, int n0, int t, int tile_m) {
+    float* stage = const_cast<float*>(stage_in);
+    constexpr int BN = 64 * TN, LDS_LD = BN + 4;
+    constexpr int CQ = BN / 4;            // column quads per row
+    constexpr int RG = 256 / CQ;          // row groups (threads sharing a column quad)
+    constexpr int RPT = 128 / RG;         // rows per thread
     const int cq = t % CQ, rg = t / CQ;
     const int n = n0 + cq * 4;
     const bool vec_ok = (a.out_ld & 3) == 0 && n + 3 < a.Cout && ((uintptr_t)a.out & 15u) == 0;
@@ -599,6 +611,199 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3p_kernel(ConvArgs a) {
     epilogue_tile<TM, TN>(acc, reinterpret_cast<float*>(smem_b), a, m0, n0, wm, wn, lane, t, tile_m);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 forward / backward-data, wide variant: 256 x (64*TN) block tile, 4 waves as 2 x 2, wave tile
+// 128 x (32*TN) built from v_mfma_f32_16x16x32_bf16 (8 x 2*TN accumulator tiles of 4 registers).
+//
+// Why: on the 128^2 kernel the LDS is as busy as the matrix pipe (per 32-deep K-step: 32 KB of ds_write_b64 at
+// ~75 B/clk + 64 KB of ds_read_b128 at 256 B/clk ~= the 768 MFMA cycles of a wave).  Doubling the rows a wave owns
+// halves the B-operand traffic per flop and cuts the A-operand re-reads by the wave grid: per flop 0.75x the
+// LDS writes and 0.75x the reads; the 16x16x32 shape also holds a higher clock than 32x32x16 on this chip.
+//
+// LDS image: four planes (A hi, A lo, B hi, B lo) of 64-byte rows (one pixel / output channel x 32 k), the four
+// 16-byte k-slots of row r stored at slot ^ swz(r), swz(r) = G[(r>>2)&3] ^ 2*((r>>1)&1), G = {0,2,3,1}: the
+// ds_read_b128 of a 16x16x32 fragment (lane l: row l&15, slot l>>4) then touches 16 distinct slots of the
+// 256-byte bank row in each of its four lane groups, and the staging ds_write_b64 (16 lanes = 4 rows x 4 half
+// slots) is conflict-free too.  One LDS buffer (two barriers per K-step), two blocks per CU.
+// ---------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ int lds_swz(int r) { return ((0x78 >> (((r >> 2) & 3) * 2)) & 3) ^ (((r >> 1) & 1) << 1); }
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
+    constexpr int BM = 256, BN = 64 * TN, NT = 2 * TN, MT = 8;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // loader: thread = (row lr + 64 p, float4 chunks q and q + 4 of the 32-deep K slice).  Per-row state is kept
+    // small (the accumulators own half the register file): image base, packed (y, x) origin, 32-bit element offsets.
+    const int q = t & 3, lr = t >> 2;
+    int pixbase[4], yx0[4];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = min(m0 + lr + 64 * p, a.M - 1);
+        const int img = m / HoWo, rem = m - img * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        pixbase[p] = img * a.Hi * a.Wi;
+        yx0[p] = ((ho * a.sy + a.oy0) << 16) | ((wo * a.sx + a.ox0) & 0xffff);
+    }
+    const int RS = a.R * a.S;
+    const int cchunks = a.Cin / 32;
+    const int ksteps = RS * cchunks;
+    const int wrow = RS * a.Cin;
+    int wbase[TN];
+#pragma unroll
+    for (int p = 0; p < TN; ++p) wbase[p] = min(n0 + lr + 64 * p, a.Cout - 1) * wrow + 4 * q;
+
+    int po[4];                       // element offset of (pixel of the current tap, channel 4 q)
+    unsigned tapmask = 0, ldmask = 0; // bit p: the tap lies inside the image for row p (current tap / loaded data)
+    int l_tap = 0, l_cc = 0;
+    auto set_tap = [&](int tap) {
+        const int r = tap / a.S, s = tap - r * a.S;
+        const int dy = r * a.ody, dx = s * a.odx;
+        tapmask = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int iy = (yx0[p] >> 16) + dy, ix = (int)(short)(yx0[p] & 0xffff) + dx;
+            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+            po[p] = (pixbase[p] + cy * a.Wi + cx) * a.in_ld + 4 * q;
+            tapmask |= ok ? (1u << p) : 0u;
+        }
+    };
+    float4 ra[4][2];
+    uint2 rbh[TN][2], rbl[TN][2];
+    auto gload = [&]() {
+        const int koff = l_tap * a.Cin + l_cc * 32;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float* src = a.in + po[p] + l_cc * 32;
+            ra[p][0] = *reinterpret_cast<const float4*>(src);
+            ra[p][1] = *reinterpret_cast<const float4*>(src + 16);
+        }
+        ldmask = tapmask;
+#pragma unroll
+        for (int p = 0; p < TN; ++p) {
+            rbh[p][0] = *reinterpret_cast<const uint2*>(a.wgt_hi + wbase[p] + koff);
+            rbh[p][1] = *reinterpret_cast<const uint2*>(a.wgt_hi + wbase[p] + koff + 16);
+            rbl[p][0] = *reinterpret_cast<const uint2*>(a.wgt_lo + wbase[p] + koff);
+            rbl[p][1] = *reinterpret_cast<const uint2*>(a.wgt_lo + wbase[p] + koff + 16);
+        }
+        if (++l_cc == cchunks) {
+            l_cc = 0;
+            if (++l_tap < RS) set_tap(l_tap);
+        }
+    };
+    // staging offsets: row lr + 64 p keeps lr's swizzle (64 p does not touch bits 1..3)
+    const int wsw = lds_swz(lr);
+    const int woff0 = lr * 64 + ((((q >> 1)) ^ wsw) << 4) + ((q & 1) << 3);
+    const int woff1 = lr * 64 + ((((q >> 1) | 2) ^ wsw) << 4) + ((q & 1) << 3);
+    auto lstore = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint2 hi, lo;
+            const float f = (ldmask >> p) & 1u ? 1.f : 0.f;
+            split4(ra[p][0], f, hi, lo);
+            *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff0) = hi;
+            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff0) = lo;
+            split4(ra[p][1], f, hi, lo);
+            *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff1) = hi;
+            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff1) = lo;
+        }
+#pragma unroll
+        for (int p = 0; p < TN; ++p) {
+            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + p * 4096 + woff0) = rbh[p][0];
+            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + p * 4096 + woff1) = rbh[p][1];
+            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + B_PLANE + p * 4096 + woff0) = rbl[p][0];
+            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + B_PLANE + p * 4096 + woff1) = rbl[p][1];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offset of this lane inside a 16-row tile
+    const int frow = lane & 15;
+    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
+    const unsigned char* Ah = smem_b + wm * 128 * 64 + foff;
+    const unsigned char* Al = Ah + A_PLANE;
+    const unsigned char* Bh = smem_b + 2 * A_PLANE + wn * 32 * TN * 64 + foff;
+    const unsigned char* Bl = Bh + B_PLANE;
+
+    set_tap(0);
+    gload();
+    lstore();
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const bool more = ks + 1 < ksteps;
+        if (more) gload();
+        // fragment reads run one 16-row tile ahead of the MFMAs that consume them (hipcc otherwise parks every read
+        // directly in front of its first use and drains lgkmcnt(0) sixteen times per K-step)
+        bf16x8_t bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
+            bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
+        }
+        bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(Ah);
+        bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(Al);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 2, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            bf16x8_t ahn = ah, aln = al;
+            if (i + 1 < MT) {
+                ahn = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 1) * 1024);
+                aln = *reinterpret_cast<const bf16x8_t*>(Al + (i + 1) * 1024);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
+            ah = ahn;
+            al = aln;
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: the two 128-row halves of the tile go through the 128 x (BN + 4) float stage one after the other
+    float* stage = reinterpret_cast<float*>(smem_b);
+    constexpr int LDS_LD = BN + 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (m0 + h * 128 >= a.M) break;              // uniform over the block
+        if (h) __syncthreads();
+        if (wm == h) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        stage[(i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 32 * TN + j * 16 + (lane & 15)] = acc[i][j][e];
+        }
+        __syncthreads();
+        drain_stage<2, TN>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
+    }
+}
+
 // x[n] -> hi[n] = bf16(x), lo[n] = bf16(x - hi)   (weights, once per optimizer step)
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
                                                          uint16_t* __restrict__ lo, int64_t n4) {
@@ -1040,13 +1245,30 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
     a.tiles_m = (int)ceil_div(a.M, 128);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
-    if (Cout > 64) {
-        a.tiles_n = (int)ceil_div(Cout, 128);
+    static const bool narrow = [] {
+        const char* e = getenv("DIGA_CONV_X3_TILE");          // "128": the 128-row kernel (A/B runs)
+        return e != nullptr && atoi(e) == 128;
+    }();
+    const int tn = Cout > 64 ? 2 : 1;
+    a.tiles_n = (int)ceil_div(Cout, 64 * tn);
+    // the wide kernel addresses the input and the weights with 32-bit element offsets
+    const bool fits32 = N * Hi * Wi * in_ld < (1ll << 31) && Cout * R * S * Cin < (1ll << 31);
+    if (!narrow && fits32) {
+        a.tiles_m = (int)ceil_div(a.M, 256);
+        const size_t loop = (size_t)2 * 256 * 64 + (size_t)2 * 64 * tn * 64, stage = (size_t)128 * (64 * tn + 4) * sizeof(float);
+        const size_t sh = loop > stage ? loop : stage;
+        if (tn == 2) {
+            (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL((conv_fwd_x3w_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL((conv_fwd_x3w_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+        }
+    } else if (tn == 2) {
         const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 128 * kRowB);
         (void)hipFuncSetAttribute((const void*)conv_fwd_x3p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((conv_fwd_x3p_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
     } else {
-        a.tiles_n = 1;
         const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 64 * kRowB);
         (void)hipFuncSetAttribute((const void*)conv_fwd_x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((conv_fwd_x3p_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
