@@ -630,7 +630,17 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ int lds_swz(int r) { return ((0x78 >> (((r >> 2) & 3) * 2)) & 3) ^ (((r >> 1) & 1) << 1); }
 
-template <int TN>
+// STAMP = diagnostic build (DIGA_CONV_STAMP=1): per block, wave 0 accumulates s_memtime deltas of the K-loop phases
+// {issue loads + MFMA, barrier 1, wait for the global loads, split + ds_write, barrier 2, steps} into a.stats[8 * block]
+// instead of BatchNorm partials.  Never used by the product path.
+__device__ __forceinline__ uint64_t stamp() {
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t v = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return v;
+}
+
+template <int TN, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
     constexpr int BM = 256, BN = 64 * TN, NT = 2 * TN, MT = 8;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
@@ -710,12 +720,30 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
         for (int p = 0; p < 4; ++p) {
             uint2 hi, lo;
             const float f = (ldmask >> p) & 1u ? 1.f : 0.f;
-            split4(ra[p][0], f, hi, lo);
-            *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff0) = hi;
-            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff0) = lo;
-            split4(ra[p][1], f, hi, lo);
-            *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff1) = hi;
-            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff1) = lo;
+            if constexpr (ABL == 1) {          // ablation: no split arithmetic (wrong results)
+                hi = make_uint2(__float_as_uint(ra[p][0].x), __float_as_uint(ra[p][0].y));
+                lo = make_uint2(__float_as_uint(ra[p][0].z), __float_as_uint(ra[p][0].w));
+            } else {
+                split4(ra[p][0], f, hi, lo);
+            }
+            if constexpr (ABL == 2) {          // ablation: no ds_write of A (wrong results)
+                asm volatile("" ::"v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y));
+            } else {
+                *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff0) = hi;
+                *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff0) = lo;
+            }
+            if constexpr (ABL == 1) {
+                hi = make_uint2(__float_as_uint(ra[p][1].x), __float_as_uint(ra[p][1].y));
+                lo = make_uint2(__float_as_uint(ra[p][1].z), __float_as_uint(ra[p][1].w));
+            } else {
+                split4(ra[p][1], f, hi, lo);
+            }
+            if constexpr (ABL == 2) {
+                asm volatile("" ::"v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y));
+            } else {
+                *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff1) = hi;
+                *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff1) = lo;
+            }
         }
 #pragma unroll
         for (int p = 0; p < TN; ++p) {
@@ -740,13 +768,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
     const unsigned char* Bh = smem_b + 2 * A_PLANE + wn * 32 * TN * 64 + foff;
     const unsigned char* Bl = Bh + B_PLANE;
 
+    uint64_t tacc[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     set_tap(0);
     gload();
     lstore();
     __syncthreads();
     for (int ks = 0; ks < ksteps; ++ks) {
         const bool more = ks + 1 < ksteps;
-        if (more) gload();
+        if constexpr (STAMP) t0 = stamp();
+        if (more && ABL != 3) gload();
         // fragment reads run one 16-row tile ahead of the MFMAs that consume them (hipcc otherwise parks every read
         // directly in front of its first use and drains lgkmcnt(0) sixteen times per K-step)
         bf16x8_t bh[NT], bl[NT];
@@ -776,11 +806,41 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
             ah = ahn;
             al = aln;
         }
-        __syncthreads();
-        if (more) {
-            lstore();
-            __syncthreads();
+        if constexpr (STAMP) {
+            t1 = stamp();
+            tacc[0] += t1 - t0;
         }
+        __syncthreads();
+        if constexpr (STAMP) {
+            t0 = stamp();
+            tacc[1] += t0 - t1;
+        }
+        if (more) {
+            if constexpr (STAMP) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                t1 = stamp();
+                tacc[2] += t1 - t0;
+            }
+            if constexpr (ABL != 3) lstore();
+            if constexpr (STAMP) {
+                t0 = stamp();
+                tacc[3] += t0 - t1;
+            }
+            __syncthreads();
+            if constexpr (STAMP) {
+                t1 = stamp();
+                tacc[4] += t1 - t0;
+            }
+        }
+    }
+    if constexpr (STAMP) {
+        if (t == 0) {
+            float* d = a.stats + (int64_t)blockIdx.x * 8;
+#pragma unroll
+            for (int e = 0; e < 5; ++e) d[e] = (float)tacc[e];
+            d[5] = (float)ksteps;
+        }
+        a.stats = nullptr;
     }
 
     // epilogue: the two 128-row halves of the tile go through the 128 x (BN + 4) float stage one after the other
@@ -1257,7 +1317,22 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
         a.tiles_m = (int)ceil_div(a.M, 256);
         const size_t loop = (size_t)2 * 256 * 64 + (size_t)2 * 64 * tn * 64, stage = (size_t)128 * (64 * tn + 4) * sizeof(float);
         const size_t sh = loop > stage ? loop : stage;
-        if (tn == 2) {
+        static const bool stamped = getenv("DIGA_CONV_STAMP") != nullptr;      // diagnostic: see the kernel
+        if (stamped && tn == 2 && a.stats != nullptr) {
+            const int abl = atoi(getenv("DIGA_CONV_STAMP"));                     // 10 + n: ablation n (wrong results)
+#define DIGA_STAMP_LAUNCH(ABL_)                                                                                         \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2, true, ABL_>,                                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                \
+        hipLaunchKernelGGL((conv_fwd_x3w_kernel<2, true, ABL_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256),    \
+                           sh, st, a);                                                                                 \
+    } while (0)
+            if (abl == 11) DIGA_STAMP_LAUNCH(1);
+            else if (abl == 12) DIGA_STAMP_LAUNCH(2);
+            else if (abl == 13) DIGA_STAMP_LAUNCH(3);
+            else DIGA_STAMP_LAUNCH(0);
+#undef DIGA_STAMP_LAUNCH
+        } else if (tn == 2) {
             (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             hipLaunchKernelGGL((conv_fwd_x3w_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
         } else {
