@@ -1083,17 +1083,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
     int p_end = p_begin + a.steps_per_split * kBK;
     if (p_end > a.M) p_end = a.M;
     const int ksteps = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
+    const int ka = min(k0 + cq * 4, a.Cout - 4), cb = min(c0 + cq * 4, a.Cin - 4);
 
     float4 ra[4], rb[4];
     float fa[4], fb[4];
-    auto gload = [&](int ks) {
+    // General loader (any geometry, ragged last step): per pixel two integer divisions and clamps -- ~90 VALU
+    // instructions per pixel, 3x the matrix-pipe time of a K-step.  Used for the first step, the ragged last step
+    // and tiny maps only.
+    auto gload_slow = [&](int ks) {
         const int pb = p_begin + ks * kBK + pq * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = pb + j;
             const bool inr = p < p_end;
             const int pc = inr ? p : p_begin;            // clamped: always a valid pixel
-            const int ka = min(k0 + cq * 4, a.Cout - 4);
             ra[j] = *reinterpret_cast<const float4*>(a.dy + (int64_t)pc * a.dy_ld + ka);
             fa[j] = (inr && a_on && k0 + cq * 4 < a.Cout) ? 1.f : 0.f;
             const int img = pc / HoWo, rem = pc - img * HoWo;
@@ -1102,12 +1105,70 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
             const bool ok = inr && b_on && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi &&
                             c0 + cq * 4 < a.Cin;
             const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
-            const int cb = min(c0 + cq * 4, a.Cin - 4);
             rb[j] = *reinterpret_cast<const float4*>(a.x + (int64_t)((img * a.Hi + cy) * a.Wi + cx) * a.x_ld + cb);
             fb[j] = ok ? 1.f : 0.f;
         }
     };
-    auto lstore = [&](int buf) {
+    // Fast loader (full steps of maps at least 32 wide): the thread's first pixel is tracked as (image, row, column)
+    // and advanced by 32 per step; its three neighbours are derived with one wrap test each.  Only the x operand is
+    // masked (a zero on either side kills the product; rows / columns beyond Cout / Cin are never stored), and a
+    // pointwise layer (1x1, stride 1, no offset: x pixel == dy pixel) needs neither coordinates nor a mask.
+    const bool pointwise = RS == 1 && a.sy == 1 && a.sx == 1 && dyo == 0 && dxo == 0 && a.Hi == a.Ho && a.Wi == a.Wo;
+    // (measured on the C2 layer shapes: pointwise layers +7..10 % with the fast loader, 3x3 layers -5..10 % -- their
+    // coordinate arithmetic in front of the pinned load slots delays the loads -- so only pointwise layers take it)
+    const bool fast_ok = pointwise && a.Wo >= kBK && a.Ho >= 2;
+    int f_img, f_ho, f_wo;        // coordinates of pixel f_p = p_begin + (step) * 32 + pq * 4
+    int64_t f_p;
+    auto fast_init = [&](int ks) {
+        f_p = p_begin + ks * kBK + pq * 4;
+        const int pc = (int)min((int64_t)a.M - 1, f_p);
+        f_img = pc / HoWo;
+        const int rem = pc - f_img * HoWo;
+        f_ho = rem / a.Wo;
+        f_wo = rem - f_ho * a.Wo;
+    };
+    auto gload_fast = [&]() {
+        // addresses first (the only control flow), then the eight loads in straight-line code so that they can be
+        // scheduled between the MFMAs of the step
+        const float* xa[4];
+        if (pointwise) {
+            const float* xp = a.x + f_p * a.x_ld + cb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xa[j] = xp + (int64_t)j * a.x_ld;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int wo = f_wo + j, ho = f_ho, img = f_img;
+                const bool wrap = wo >= a.Wo;
+                wo = wrap ? wo - a.Wo : wo;
+                ho = wrap ? ho + 1 : ho;
+                const bool wrap2 = ho >= a.Ho;
+                ho = wrap2 ? 0 : ho;
+                img = wrap2 ? img + 1 : img;
+                const int iy = ho * a.sy + dyo, ix = wo * a.sx + dxo;
+                const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+                const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+                xa[j] = a.x + (int64_t)((img * a.Hi + cy) * a.Wi + cx) * a.x_ld + cb;
+                fb[j] = ok ? 1.f : 0.f;
+            }
+        }
+        const float* dyp = a.dy + f_p * a.dy_ld + ka;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = *reinterpret_cast<const float4*>(dyp + (int64_t)j * a.dy_ld);
+            rb[j] = *reinterpret_cast<const float4*>(xa[j]);
+        }
+        f_p += kBK;
+        f_wo += kBK;
+        const bool w1 = f_wo >= a.Wo;
+        f_wo = w1 ? f_wo - a.Wo : f_wo;
+        f_ho = w1 ? f_ho + 1 : f_ho;
+        const bool w2 = f_ho >= a.Ho;
+        f_ho = w2 ? 0 : f_ho;
+        f_img = w2 ? f_img + 1 : f_img;
+    };
+    // transposing stores: per channel e of the thread's channel quad, its 4 consecutive pixels -> 8 B hi + 8 B lo
+    auto lstore = [&](int buf, bool fast) {
         unsigned char* base = smem_b + buf * BUF;
         if (a_on) {
             const float va[4][4] = {{ra[0].x, ra[1].x, ra[2].x, ra[3].x}, {ra[0].y, ra[1].y, ra[2].y, ra[3].y},
@@ -1115,7 +1176,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 uint2 hi, lo;
-                split4(make_float4(va[e][0] * fa[0], va[e][1] * fa[1], va[e][2] * fa[2], va[e][3] * fa[3]), 1.f, hi, lo);
+                if (fast) split4_nomask(make_float4(va[e][0], va[e][1], va[e][2], va[e][3]), hi, lo);
+                else split4_nomask(make_float4(va[e][0] * fa[0], va[e][1] * fa[1], va[e][2] * fa[2], va[e][3] * fa[3]), hi, lo);
                 const int off = (cq * 4 + e) * kRowB + pq * 8;
                 *reinterpret_cast<uint2*>(base + off) = hi;
                 *reinterpret_cast<uint2*>(base + A_PLANE + off) = lo;
@@ -1127,7 +1189,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 uint2 hi, lo;
-                split4(make_float4(vb[e][0] * fb[0], vb[e][1] * fb[1], vb[e][2] * fb[2], vb[e][3] * fb[3]), 1.f, hi, lo);
+                if (fast && pointwise) split4_nomask(make_float4(vb[e][0], vb[e][1], vb[e][2], vb[e][3]), hi, lo);
+                else split4_nomask(make_float4(vb[e][0] * fb[0], vb[e][1] * fb[1], vb[e][2] * fb[2], vb[e][3] * fb[3]), hi, lo);
                 const int off = (cq * 4 + e) * kRowB + pq * 8;
                 *reinterpret_cast<uint2*>(base + 2 * A_PLANE + off) = hi;
                 *reinterpret_cast<uint2*>(base + 2 * A_PLANE + B_PLANE + off) = lo;
@@ -1144,14 +1207,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int li = lane & 31, lh = lane >> 5;
-    if (ksteps > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < ksteps) gload(ks + 1);
+    auto compute = [&](int cur, bool with_loads) {
         const unsigned char* Ah = smem_b + cur * BUF;
         const unsigned char* Al = Ah + A_PLANE;
         const unsigned char* Bh = Ah + 2 * A_PLANE;
@@ -1171,6 +1227,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
                 bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + off);
                 bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + off);
             }
+            // issue order: this sub-step's fragment reads, half of the next step's global loads, then the MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+            if (with_loads) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1179,8 +1238,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM * TN, 0);
         }
-        if (ks + 1 < ksteps) lstore(cur ^ 1);
+    };
+
+    if (ksteps > 0) {
+        gload_slow(0);
+        lstore(0, false);
+    }
+    __syncthreads();
+    const bool ragged = (p_end - p_begin) % kBK != 0;
+    // steps [0, nfast) prefetch their successor with the fast loader in the same basic block as the MFMAs
+    const int nfast = fast_ok ? max(0, ksteps - (ragged ? 2 : 1)) : 0;
+    if (nfast > 0) fast_init(1);
+    int ks = 0;
+    for (; ks < nfast; ++ks) {
+        const int cur = ks & 1;
+        gload_fast();
+        compute(cur, true);
+        lstore(cur ^ 1, true);
+        __syncthreads();
+    }
+    for (; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) gload_slow(ks + 1);
+        compute(cur, false);
+        if (ks + 1 < ksteps) lstore(cur ^ 1, false);
         __syncthreads();
     }
 
