@@ -743,11 +743,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
         for (int p = 0; p < 4; ++p) {
             uint2 hi, lo;
             const float f = (ldmask >> p) & 1u ? 1.f : 0.f;
-            if (a.all_inside) {                // uniform
-                split4_nomask(ra[p][0], hi, lo);
-            } else if constexpr (ABL == 1) {          // ablation: no split arithmetic (wrong results)
+            if constexpr (ABL == 1) {          // ablation: no split arithmetic (wrong results)
                 hi = make_uint2(__float_as_uint(ra[p][0].x), __float_as_uint(ra[p][0].y));
                 lo = make_uint2(__float_as_uint(ra[p][0].z), __float_as_uint(ra[p][0].w));
+            } else if (a.all_inside) {         // uniform
+                split4_nomask(ra[p][0], hi, lo);
             } else {
                 split4(ra[p][0], f, hi, lo);
             }
@@ -757,11 +757,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
                 *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff0) = hi;
                 *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff0) = lo;
             }
-            if (a.all_inside) {
-                split4_nomask(ra[p][1], hi, lo);
-            } else if constexpr (ABL == 1) {
+            if constexpr (ABL == 1) {
                 hi = make_uint2(__float_as_uint(ra[p][1].x), __float_as_uint(ra[p][1].y));
                 lo = make_uint2(__float_as_uint(ra[p][1].z), __float_as_uint(ra[p][1].w));
+            } else if (a.all_inside) {
+                split4_nomask(ra[p][1], hi, lo);
             } else {
                 split4(ra[p][1], f, hi, lo);
             }
@@ -919,6 +919,9 @@ struct WgradArgs {
     int Ho, Wo, Cout, dy_ld;
     int R, S, sy, sx, oy0, ox0, ody, odx;
     int M, tiles_m, tiles_n, splits, steps_per_split;
+    const int* ptab;     // conv_wgrad_x3w_kernel: [R*S][M_pad] x-pixel index of (tap, output pixel), -1 = outside the image
+    const float* zeros;  // 16 bytes of zeros (what an outside tap loads)
+    int M_pad;
 };
 
 constexpr int kLDW = 128 + 4;   // wgrad LDS rows: [pixel][channel], channel contiguous
@@ -1282,6 +1285,189 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward-weight, split-bf16, wide variant: 256 output channels x (64*TN) input channels per block (wave tile
+// 128 x 32*TN), one LDS buffer, two blocks per CU.  Both operands are split in-kernel, so per MFMA the 128^2 kernel
+// does twice the split arithmetic of the forward kernel and is bound by the vector-issue port (it reaches 0.23 of
+// the MFMA peak); doubling the Cout extent of the tile halves the x-operand work per MFMA: per 32-pixel K-step a
+// thread stages 48 values for 48 MFMAs instead of 32 for 24.
+// The (tap, output pixel) -> input pixel map comes from a table built by wgrad_pixtab_kernel (one int per pixel and
+// tap, -1 outside the image), so the loader has no divisions, no coordinate arithmetic and no masks: an outside
+// tap or a pixel past the block's range loads 16 bytes of zeros for the x operand (a zero on one side kills the
+// product; rows / columns beyond Cout / Cin are never stored).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_pixtab_kernel(int* __restrict__ tab, float* __restrict__ zeros, int M,
+                                                           int M_pad, int Ho, int Wo, int Hi, int Wi, int S, int sy, int sx,
+                                                           int oy0, int ox0, int ody, int odx) {
+    const int p = blockIdx.x * 256 + threadIdx.x, tap = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) zeros[threadIdx.x] = 0.f;
+    if (p >= M_pad) return;
+    int v = -1;
+    if (p < M) {
+        const int r = tap / S, s = tap - r * S;
+        const int img = p / (Ho * Wo), rem = p - img * Ho * Wo;
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        const int iy = ho * sy + oy0 + r * ody, ix = wo * sx + ox0 + s * odx;
+        if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) v = (img * Hi + iy) * Wi + ix;
+    }
+    tab[(int64_t)tap * M_pad + p] = v;
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3w_kernel(WgradArgs a) {
+    constexpr int BM = 256, BN = 64 * TN, TM = 4;
+    constexpr int A_PLANE = BM * kRowB, B_PLANE = BN * kRowB;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int RS = a.R * a.S;
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n;
+    wg /= a.tiles_n;
+    const int tile_m = wg % a.tiles_m;
+    wg /= a.tiles_m;
+    const int tap = wg % RS;
+    const int split = wg / RS;
+    const int k0 = tile_m * BM, c0 = tile_n * BN;
+
+    const int pq = t & 7, cq = t >> 3;                // 8 pixel quads x 32 channel quads (two passes over dy)
+    const bool b_on = cq < BN / 4;
+    const int p_begin = split * a.steps_per_split * kBK;
+    int p_end = p_begin + a.steps_per_split * kBK;
+    if (p_end > a.M) p_end = a.M;
+    const int ksteps = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
+    const int ka0 = min(k0 + cq * 4, a.Cout - 4), ka1 = min(k0 + 128 + cq * 4, a.Cout - 4);
+    const int cb = min(c0 + cq * 4, a.Cin - 4);
+    const int* tab = a.ptab + (int64_t)tap * a.M_pad;
+
+    float4 ra[2][4], rb[4];
+    int4 idx;                       // x-pixel indices of the quad that the next gload() fetches
+    auto load_idx = [&](int p) { idx = *reinterpret_cast<const int4*>(tab + min(p, a.M_pad - 4)); };
+    auto gload = [&](int p) {       // p = first pixel of this thread's quad
+        const int xi[4] = {idx.x, idx.y, idx.z, idx.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* dyp = a.dy + (int64_t)min(p + j, a.M - 1) * a.dy_ld;
+            ra[0][j] = *reinterpret_cast<const float4*>(dyp + ka0);
+            ra[1][j] = *reinterpret_cast<const float4*>(dyp + ka1);
+            const bool ok = xi[j] >= 0 && p + j < p_end;
+            const float* xp = ok ? a.x + (int64_t)xi[j] * a.x_ld + cb : a.zeros;
+            rb[j] = *reinterpret_cast<const float4*>(xp);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float va[4][4] = {{ra[i][0].x, ra[i][1].x, ra[i][2].x, ra[i][3].x}, {ra[i][0].y, ra[i][1].y, ra[i][2].y, ra[i][3].y},
+                                    {ra[i][0].z, ra[i][1].z, ra[i][2].z, ra[i][3].z}, {ra[i][0].w, ra[i][1].w, ra[i][2].w, ra[i][3].w}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint2 hi, lo;
+                split4_nomask(make_float4(va[e][0], va[e][1], va[e][2], va[e][3]), hi, lo);
+                const int off = (i * 128 + cq * 4 + e) * kRowB + pq * 8;
+                *reinterpret_cast<uint2*>(smem_b + off) = hi;
+                *reinterpret_cast<uint2*>(smem_b + A_PLANE + off) = lo;
+            }
+        }
+        if (b_on) {
+            const float vb[4][4] = {{rb[0].x, rb[1].x, rb[2].x, rb[3].x}, {rb[0].y, rb[1].y, rb[2].y, rb[3].y},
+                                    {rb[0].z, rb[1].z, rb[2].z, rb[3].z}, {rb[0].w, rb[1].w, rb[2].w, rb[3].w}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint2 hi, lo;
+                split4_nomask(make_float4(vb[e][0], vb[e][1], vb[e][2], vb[e][3]), hi, lo);
+                const int off = (cq * 4 + e) * kRowB + pq * 8;
+                *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + off) = hi;
+                *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + B_PLANE + off) = lo;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned char* Ab = smem_b + (wm * 128 + li) * kRowB + lh * 16;
+    const unsigned char* Bb = smem_b + 2 * A_PLANE + (wn * 32 * TN + li) * kRowB + lh * 16;
+    int p = p_begin + pq * 4;
+    if (ksteps > 0) {
+        load_idx(p);
+        gload(p);
+        load_idx(p + kBK);
+        lstore();
+    }
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const bool more = ks + 1 < ksteps;
+        p = more ? p + kBK : p;          // the last step re-reads its own pixels (loads stay unconditional so that they
+        gload(p);                        // share a basic block with the MFMAs)
+        load_idx(p + kBK);
+#pragma unroll
+        for (int sl = 0; sl < kBK / 16; ++sl) {
+            bf16x8_t bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * kRowB + sl * 32);
+                bl[j] = *reinterpret_cast<const bf16x8_t*>(Bb + B_PLANE + j * 32 * kRowB + sl * 32);
+            }
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                bf16x8_t ah[2], al[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ah[u] = *reinterpret_cast<const bf16x8_t*>(Ab + (ip * 2 + u) * 32 * kRowB + sl * 32);
+                    al[u] = *reinterpret_cast<const bf16x8_t*>(Ab + A_PLANE + (ip * 2 + u) * 32 * kRowB + sl * 32);
+                }
+                // issue order: fragment reads, a quarter of the next step's 13 global loads, MFMAs
+                if (ip == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * TN, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                if (sl == 0 && ip == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh[j], acc[ip * 2 + u][j], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[j], acc[ip * 2 + u][j], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh[j], acc[ip * 2 + u][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    float* out = a.slab + (int64_t)split * a.Cout * RS * a.Cin;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + wn * 32 * TN + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (k < a.Cout && c < a.Cin) out[((int64_t)k * RS + tap) * a.Cin + c] = acc[i][j][e];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                           int64_t n4, int splits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1453,6 +1639,9 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
             else if (abl == 13) DIGA_STAMP_LAUNCH(3);
             else DIGA_STAMP_LAUNCH(0);
 #undef DIGA_STAMP_LAUNCH
+        } else if (tn == 2 && getenv("DIGA_CONV_ABL1") != nullptr) {     // timing experiment only (wrong results)
+            (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL((conv_fwd_x3w_kernel<2, false, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
         } else if (tn == 2) {
             (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             hipLaunchKernelGGL((conv_fwd_x3w_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
@@ -1488,15 +1677,17 @@ namespace {
 struct WgradPlan {
     int tm, tn, tiles_m, tiles_n, splits, steps_per_split;
 };
-WgradPlan plan_wgrad(int64_t M, int64_t Cout, int64_t Cin, int64_t RS) {
+WgradPlan plan_wgrad(int64_t M, int64_t Cout, int64_t Cin, int64_t RS, bool x3) {
     WgradPlan p;
     p.tm = Cout > 64 ? 2 : 1;
+    if (x3 && Cout >= 256) p.tm = 4;                   // conv_wgrad_x3w_kernel: 256 output channels per block
     p.tn = Cin > 64 ? 2 : 1;
     p.tiles_m = (int)ceil_div(Cout, 64 * p.tm);
     p.tiles_n = (int)ceil_div(Cin, 64 * p.tn);
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * RS;
     const int64_t ksteps = ceil_div(M, kBK);
     int64_t splits = ceil_div(1024, tiles);            // ~4 blocks per CU in total
+    if (p.tm == 4) splits = 512 / tiles > 0 ? 512 / tiles : 1;   // wide kernel: one full round of 2 blocks per CU
     const int64_t max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;   // at least 8 K-steps per block
     if (splits > max_splits) splits = max_splits;
     if (splits > 512) splits = 512;
@@ -1505,12 +1696,20 @@ WgradPlan plan_wgrad(int64_t M, int64_t Cout, int64_t Cin, int64_t RS) {
     p.splits = (int)ceil_div(ksteps, p.steps_per_split);
     return p;
 }
+int64_t wgrad_mpad(int64_t M) { return ceil_div(M, kBK) * kBK + 2 * kBK; }
+size_t wgrad_slab_bytes(const WgradPlan& p, int64_t Cout, int64_t Cin, int64_t RS) {
+    return p.splits > 1 ? (size_t)p.splits * Cout * RS * Cin * sizeof(float) : 0;
+}
 }  // namespace
 
+// workspace = [split-K slabs][(tap, pixel) -> input pixel table of the wide split-bf16 kernel][16 zero bytes]; sized
+// for either conv arithmetic so that a query and the call may straddle a diga_set_conv_math()
 extern "C" size_t diga_conv2d_wgrad_workspace_bytes(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout, int64_t Cin,
                                                     int64_t R, int64_t S) {
-    const WgradPlan p = plan_wgrad(N * Ho * Wo, Cout, Cin, R * S);
-    return p.splits > 1 ? (size_t)p.splits * Cout * R * S * Cin * sizeof(float) : 0;
+    const int64_t M = N * Ho * Wo, RS = R * S;
+    const size_t s0 = wgrad_slab_bytes(plan_wgrad(M, Cout, Cin, RS, false), Cout, Cin, RS);
+    const size_t s1 = wgrad_slab_bytes(plan_wgrad(M, Cout, Cin, RS, true), Cout, Cin, RS);
+    return (s0 > s1 ? s0 : s1) + (size_t)RS * wgrad_mpad(M) * sizeof(int) + 64;
 }
 
 extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float* dw, void* workspace,
@@ -1526,8 +1725,12 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
     DIGA_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw), DIGA_EALIGN, "conv2d_wgrad: pointers must be 16-byte aligned");
     DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d_wgrad: too many pixels");
     const int64_t RS = R * S, M = N * Ho * Wo;
-    const WgradPlan p = plan_wgrad(M, Cout, Cin, RS);
-    const size_t need = p.splits > 1 ? (size_t)p.splits * Cout * RS * Cin * sizeof(float) : 0;
+    const bool x3 = g_conv_math.load(std::memory_order_relaxed) == DIGA_CONV_MATH_BF16X3;
+    const WgradPlan p = plan_wgrad(M, Cout, Cin, RS, x3);
+    const bool wide = p.tm == 4;
+    const size_t slab_bytes = wgrad_slab_bytes(p, Cout, Cin, RS);
+    const int64_t M_pad = wgrad_mpad(M);
+    const size_t need = slab_bytes + (wide ? (size_t)RS * M_pad * sizeof(int) + 64 : 0);
     DIGA_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned16(workspace))), DIGA_EWORKSPACE,
                  "conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     WgradArgs a;
@@ -1537,9 +1740,28 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
     a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
     a.oy0 = (int)off_y0; a.ox0 = (int)off_x0; a.ody = (int)off_dy; a.odx = (int)off_dx;
     a.M = (int)M; a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.splits = p.splits; a.steps_per_split = p.steps_per_split;
+    a.ptab = nullptr; a.zeros = nullptr; a.M_pad = (int)M_pad;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st);
     const unsigned grid = (unsigned)((int64_t)p.tiles_m * p.tiles_n * RS * p.splits);
+    if (wide) {
+        int* tab = reinterpret_cast<int*>(static_cast<char*>(workspace) + slab_bytes);
+        float* zeros = reinterpret_cast<float*>(tab + RS * M_pad);
+        hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3((unsigned)ceil_div(M_pad, 256), (unsigned)RS), dim3(256), 0, st, tab, zeros,
+                           (int)M, (int)M_pad, (int)Ho, (int)Wo, (int)Hi, (int)Wi, (int)S, (int)stride_y, (int)stride_x,
+                           (int)off_y0, (int)off_x0, (int)off_dy, (int)off_dx);
+        a.ptab = tab;
+        a.zeros = zeros;
+        const size_t shw = (size_t)2 * (256 + 64 * p.tn) * kRowB;
+        if (p.tn == 2) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw);
+            hipLaunchKernelGGL((conv_wgrad_x3w_kernel<2>), dim3(grid), dim3(256), shw, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_x3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw);
+            hipLaunchKernelGGL((conv_wgrad_x3w_kernel<1>), dim3(grid), dim3(256), shw, st, a);
+        }
+    } else
+    {
     const size_t sh = (size_t)(4 * kBK * kLDW) * sizeof(float);
 #define DIGA_WGRAD_LAUNCH(TM_, TN_)                                                                                   \
     do {                                                                                                               \
@@ -1552,7 +1774,7 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
         (void)hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx); \
         hipLaunchKernelGGL((conv_wgrad_x3_kernel<TM_, TN_>), dim3(grid), dim3(256), shx, st, a);                        \
     } while (0)
-    if (g_conv_math.load(std::memory_order_relaxed) == DIGA_CONV_MATH_BF16X3) {
+    if (x3) {
         if (p.tm == 2 && p.tn == 2) DIGA_WGRAD_X3_LAUNCH(2, 2);
         else if (p.tm == 2) DIGA_WGRAD_X3_LAUNCH(2, 1);
         else if (p.tn == 2) DIGA_WGRAD_X3_LAUNCH(1, 2);
@@ -1565,6 +1787,7 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
     }
 #undef DIGA_WGRAD_X3_LAUNCH
 #undef DIGA_WGRAD_LAUNCH
+    }
     if (p.splits > 1) {
         const int64_t n4 = Cout * RS * Cin / 4;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
