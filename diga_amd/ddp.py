@@ -46,9 +46,15 @@ def rank():
 
 class GradReducer:
     """Bucketed all-reduce(sum) of the gradients of `params` (unique tensors, reverse order so the
-    buckets of the last layers -- whose gradients exist first -- go out first)."""
+    buckets of the last layers -- whose gradients exist first -- go out first).
 
-    def __init__(self, params, bucket_bytes=128 << 20, group=None):
+    With more than one rank every parameter carries a post-accumulate-grad hook: the moment the last
+    gradient of a bucket exists (inside backward) the bucket is packed by one multi-tensor copy and its
+    all-reduce is started asynchronously on RCCL's stream, so all but the last bucket travel under the
+    rest of the backward pass; `reduce()` starts whatever is still pending (gradients that were set by
+    hand), waits, and unpacks with one multi-tensor copy per bucket."""
+
+    def __init__(self, params, bucket_bytes=128 << 20, group=None, overlap=True):
         self.group = group
         seen, uniq = set(), []
         for p in params:
@@ -67,31 +73,51 @@ class GradReducer:
         if cur:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._ready = [0] * len(self.buckets)
+        self._hooks = []
+        if overlap and world_size() > 1:
+            for i, bucket in enumerate(self.buckets):
+                for p in bucket:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        def hook(_param):
+            self._ready[i] += 1
+            if self._ready[i] == len(self.buckets[i]) and self._work[i] is None:
+                self._launch(i)
+        return hook
+
+    def _views(self, i):
+        flat, views, off = self._flat[i], [], 0
+        for p in self.buckets[i]:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return views
+
+    def _launch(self, i):
+        grads = [p.grad for p in self.buckets[i]]
+        if any(g is None for g in grads):
+            raise RuntimeError("GradReducer: a parameter has no gradient")
+        n = sum(g.numel() for g in grads)
+        flat = self._flat[i]
+        if flat is None or flat.numel() != n or flat.device != grads[0].device:
+            self._flat[i] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        torch._foreach_copy_(self._views(i), [g.detach() for g in grads])
+        self._work[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def reduce(self):
         """Sum gradients over all ranks in place.  No-op for world size 1."""
         if world_size() == 1:
             return
-        works = []
+        for i in range(len(self.buckets)):
+            if self._work[i] is None:
+                self._launch(i)
         for i, bucket in enumerate(self.buckets):
-            grads = [p.grad for p in bucket]
-            if any(g is None for g in grads):
-                raise RuntimeError("GradReducer: a parameter has no gradient")
-            n = sum(g.numel() for g in grads)
-            flat = self._flat[i]
-            if flat is None or flat.numel() != n or flat.device != grads[0].device:
-                flat = self._flat[i] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
-            off = 0
-            for g in grads:
-                flat[off:off + g.numel()].copy_(g.reshape(-1))
-                off += g.numel()
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for i, bucket in enumerate(self.buckets):
-            works[i].wait()
-            off = 0
-            for p in bucket:
-                p.grad.copy_(self._flat[i][off:off + p.numel()].view_as(p.grad))
-                off += p.numel()
+            self._work[i].wait()
+            torch._foreach_copy_([p.grad for p in bucket], self._views(i))
+            self._work[i] = None
+            self._ready[i] = 0
 
 
 def gather_class_sums(sums, counts, group=None):

@@ -188,6 +188,20 @@ def _worker(rank, world, port, out):
                     acc += t
         want.append(acc)
     ok_grads = all(torch.allclose(p.grad, w_, rtol=1e-6, atol=1e-6) for p, w_ in zip(params, want))
+    # gradients that come out of backward(): the per-parameter hooks start every bucket's all-reduce from inside
+    # autograd (overlap with the rest of backward); two steps in a row exercise the counter reset
+    ok_hooks = True
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        loss = sum(float((rank + 1 + step) * (i + 1)) * p.sum() for i, p in enumerate(params))
+        loss.backward()
+        ok_hooks &= all(w_ is not None for w_ in red._work)          # all launched before reduce()
+        red.reduce()
+        tot = sum(rr + 1 + step for rr in range(world))
+        ok_hooks &= all(torch.allclose(p.grad, torch.full_like(p, float(tot * (i + 1)))) for i, p in enumerate(params))
+        ok_hooks &= all(w_ is None for w_ in red._work)
+    ok_grads = ok_grads and ok_hooks
     # centroid sums: rank-major concatenation
     sums = torch.full((2, 19, 4), float(rank))
     sums[1] += 0.5
