@@ -30,6 +30,8 @@ SIGNATURES = {
     "diga_last_error_string": (C.c_char_p, []),
     "diga_loss_workspace_bytes": (SZ, [I64]),
     "diga_ce2d_fwd_bwd": (INT, [P, P, P, P, P, SZ, I64, I64, I64, I64, F32, P]),
+    "diga_ohem_ce_workspace_bytes": (SZ, [I64, I64, I64]),
+    "diga_ohem_ce_fwd_bwd": (INT, [P, P, P, P, P, SZ, I64, I64, I64, I64, I64, F32, I64, F32, P]),
     "diga_distill_fwd_bwd": (INT, [P, P, P, P, P, SZ, I64, I64, I64, I64, F32, F32, P]),
     "diga_scale_inplace": (INT, [P, P, I64, P]),
     "diga_upsample_loss_workspace_bytes": (SZ, [I64, I64, I64, I64]),

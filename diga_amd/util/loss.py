@@ -16,7 +16,7 @@ if os.path.dirname(_pkg) not in sys.path:          # drop-in use: only .../diga_
     sys.path.append(os.path.dirname(_pkg))
 from diga_amd import _lib  # noqa: E402
 
-__all__ = ["cross_entropy2d", "distillation_loss", "upsample_ce_distill", "upsample_ce"]
+__all__ = ["cross_entropy2d", "distillation_loss", "upsample_ce_distill", "upsample_ce", "OhemCrossEntropy"]
 
 
 def _f32c(t):
@@ -66,6 +66,52 @@ def cross_entropy2d(input, target, weight=None, size_average=True):
         n, _, h, w = input.shape
         loss = loss * float(n * h * w)
     return loss
+
+
+class _OhemCrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, score, target, ignore_label, thresh, min_kept):
+        _lib.require_gpu(score, target)
+        x = _f32c(score.detach())
+        t = _lib.contiguous(target, torch.int64)
+        n, c, h, w = x.shape
+        if tuple(t.shape) != (n, h, w):
+            raise ValueError(f"OhemCrossEntropy: target shape {tuple(t.shape)} does not match score {tuple(x.shape)}")
+        grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(_lib.lib.diga_ohem_ce_workspace_bytes(n, h, w), x.device, "ohem")
+        _lib.call("diga_ohem_ce_fwd_bwd", _lib.ptr(x), _lib.ptr(t), _lib.ptr(grad), _lib.ptr(loss), _lib.ptr(ws), ws.numel(),
+                  n, c, h, w, int(ignore_label), float(thresh), int(min_kept), 1.0, _lib.stream())
+        ctx.grad = grad
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad, ctx.grad = ctx.grad, None
+        if grad is None:
+            raise RuntimeError("OhemCrossEntropy: backward called twice (the fused gradient is consumed once)")
+        return _apply_upstream(grad, grad_out), None, None, None, None
+
+
+class OhemCrossEntropy(torch.nn.Module):
+    """Hard-pixel cross entropy with the reference's constructor and call signature (G5/util/loss.py:65-122; the
+    Synthia / semi-supervised scripts' `seg_loss`).  Scores at another resolution than the labels are upsampled
+    (bilinear, align_corners) first, as the reference does; the selection threshold comes from an exact on-device
+    radix select instead of a sort (`diga_ohem_ce_fwd_bwd`)."""
+
+    def __init__(self, ignore_label=255, thres=0.7, min_kept=100000, weight=None):
+        super().__init__()
+        if weight is not None:
+            raise NotImplementedError("OhemCrossEntropy: class weights are not used on the DiGA path")
+        self.thresh = thres
+        self.min_kept = max(1, min_kept)
+        self.ignore_label = ignore_label
+
+    def forward(self, score, target):
+        if tuple(score.shape[-2:]) != tuple(target.shape[-2:]):
+            score = torch.nn.functional.interpolate(score, size=tuple(target.shape[-2:]), mode="bilinear",
+                                                    align_corners=True)
+        return _OhemCrossEntropy.apply(score, target, self.ignore_label, self.thresh, self.min_kept)
 
 
 class _Distillation(torch.autograd.Function):

@@ -58,6 +58,18 @@ int diga_ce2d_fwd_bwd(const float* logits, const int64_t* target, float* grad, f
                       void* workspace, size_t workspace_bytes,
                       int64_t N, int64_t C, int64_t H, int64_t W, float grad_scale, void* stream);
 
+/* OhemCrossEntropy (hard-pixel CE of the Synthia / semi-supervised trees), G5/util/loss.py:65-122
+ * (`_ohem_forward` :91-109): over pixels with target != ignore_label, p_t = softmax(logits)[target];
+ * kth = the min(min_kept, n_valid-1)-th smallest p_t (0-based); thr = max(kth, thresh);
+ *   loss = mean of -log_softmax(logits)[target] over the valid pixels with p_t < thr   (NaN if there are none)
+ *   grad = d loss / d logits * grad_scale                                               (nullable: loss only)
+ * logits [N,C,H,W] at label resolution, target [N,H,W] int64, loss_out [1].  The order statistic is found by an
+ * exact radix select on the device (no sort, no host sync). */
+size_t diga_ohem_ce_workspace_bytes(int64_t N, int64_t H, int64_t W);
+int diga_ohem_ce_fwd_bwd(const float* logits, const int64_t* target, float* grad, float* loss_out,
+                         void* workspace, size_t workspace_bytes, int64_t N, int64_t C, int64_t H, int64_t W,
+                         int64_t ignore_label, float thresh, int64_t min_kept, float grad_scale, void* stream);
+
 /* distillation_loss, G5/util/loss.py:125-143.  teacher/student [2B,C,H,W]; the two halves of
  * the batch are the two views.  loss = mean_{B,H,W} sum_c -q0 log p1 + scale * mean sum_c -q1 log p0
  * with q = softmax(teacher), p = softmax(student); grad (nullable) = d loss / d student * grad_scale. */

@@ -57,6 +57,29 @@ def cross_entropy2d(logits, target, size_average=True):
     return loss
 
 
+def ohem_cross_entropy(score, target, thresh=0.7, min_kept=100000, ignore_label=IGNORE):
+    """OhemCrossEntropy._ohem_forward, G5/util/loss.py:91-109, restated without the sort: over valid pixels
+    p_t = softmax(score)[target]; kth = the min(min_kept, n_valid-1)-th smallest p_t; threshold = max(kth, thresh);
+    the loss is the mean CE of the valid pixels with p_t < threshold.  Scores at another resolution are first
+    upsampled (bilinear, align_corners), :92-96.  Returns (loss, kept mask [N,H,W], threshold)."""
+    if tuple(score.shape[-2:]) != tuple(target.shape[-2:]):
+        score = upsample_bilinear_ac(score, tuple(target.shape[-2:]))
+    min_kept = max(1, int(min_kept))
+    logp = F.log_softmax(score, dim=1)
+    valid = target != ignore_label
+    idx = torch.where(valid, target, torch.zeros_like(target)).unsqueeze(1)
+    ce = -logp.gather(1, idx).squeeze(1)
+    pt = F.softmax(score, dim=1).gather(1, idx).squeeze(1)
+    pv = pt[valid]
+    if pv.numel() == 0:
+        return score.sum() * float("nan"), torch.zeros_like(valid), float("nan")
+    k = min(min_kept, pv.numel() - 1)
+    kth = torch.kthvalue(pv.detach().reshape(-1), k + 1).values       # 0-based rank k
+    threshold = max(float(kth), float(thresh))
+    kept = valid & (pt < threshold)
+    return ce[kept].mean(), kept, threshold
+
+
 def distillation_loss(teacher_out, student_out, scale=0.5):
     """G5/util/loss.py:125-143.  Views are the two halves of the batch; teacher
     of view 0 supervises student of view 1 (weight 1) and teacher of view 1

@@ -70,6 +70,60 @@ def test_ce_upstream_scale_and_loss_only(mods):
     assert_close(ls, ol.cross_entropy2d(x, y, size_average=False), 1e-5, 1e-4)
 
 
+# ----------------------------------------------------------------------------- OhemCrossEntropy ("next" row 4)
+def _ohem_check(loss, grad, want_loss, want_grad, what):
+    assert_close(loss, want_loss, 2e-5, 1e-7, what + " loss")
+    # a pixel whose probability is within an ulp of the threshold may fall on the other side: compare in norm too
+    scale = float(want_grad.abs().max())
+    err = (grad.cpu() - want_grad).abs()
+    assert float((err > 2e-5 * scale + 1e-9).float().mean()) < 1e-3, what + " grad: too many pixels differ"
+    assert float(err.norm() / max(float(want_grad.norm()), 1e-30)) < 1e-3, what + " grad norm"
+
+
+@pytest.mark.parametrize("tag,kw", [("a", dict(min_kept=50)), ("b", dict(min_kept=600)), ("c", dict(min_kept=100000)),
+                                    ("d", dict(min_kept=300, thres=0.5))])
+def test_ohem_golden(mods, golden, tag, kw):
+    g = golden("ohem")
+    src = "b" if tag == "c" else tag
+    x = g.t(src + "_x").to(DEV).requires_grad_()
+    loss = mods["loss"].OhemCrossEntropy(**kw)(x, g.t(src + "_y").to(DEV))
+    loss.backward()
+    _ohem_check(loss, x.grad, g.t(tag + "_loss"), g.t(tag + "_grad"), f"ohem {tag}")
+
+
+@pytest.mark.parametrize("shape,C,min_kept,conf", [((2, 96, 128), 19, 5000, 5.0), ((3, 37, 53), 19, 100000, 0.0),
+                                                  ((1, 64, 64), 16, 100, 8.0), ((2, 128, 256), 19, 20000, 3.0)])
+def test_ohem_vs_oracle(mods, shape, C, min_kept, conf):
+    g = synth.gen(sum(shape) + C + min_kept)
+    n, h, w = shape
+    y = torch.randint(0, C, shape, generator=g)
+    x = torch.randn((n, C, h, w), generator=g)
+    x = x + conf * torch.nn.functional.one_hot(y, C).permute(0, 3, 1, 2).float() * (torch.rand((n, 1, h, w), generator=g) < 0.8)
+    y[torch.rand(shape, generator=g) < 0.1] = 255
+    xo = x.clone().requires_grad_()
+    lo, kept, thr = ol.ohem_cross_entropy(xo, y, min_kept=min_kept)
+    lo.backward()
+    xd = x.to(DEV).requires_grad_()
+    loss = mods["loss"].OhemCrossEntropy(min_kept=min_kept)(xd, y.to(DEV))
+    (2.0 * loss).backward()
+    _ohem_check(loss, xd.grad / 2.0, lo.detach(), xo.grad, f"ohem {shape}")
+    # bit-reproducible: integer-atomic histograms and fixed-order sums
+    xe = x.to(DEV).requires_grad_()
+    loss2 = mods["loss"].OhemCrossEntropy(min_kept=min_kept)(xe, y.to(DEV))
+    (2.0 * loss2).backward()
+    assert torch.equal(loss, loss2) and torch.equal(xd.grad, xe.grad)
+
+
+def test_ohem_all_ignored_is_nan_with_zero_grad(mods):
+    x = torch.randn((1, 19, 8, 8)).to(DEV).requires_grad_()
+    y = torch.full((1, 8, 8), 255, dtype=torch.int64, device=DEV)
+    loss = mods["loss"].OhemCrossEntropy()(x, y)
+    loss.backward()
+    assert torch.isnan(loss) and float(x.grad.abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        mods["loss"].OhemCrossEntropy(weight=torch.ones(19))
+
+
 # ----------------------------------------------------------------------------- distillation_loss
 def test_distill_golden(mods, golden):
     g = golden("distill")

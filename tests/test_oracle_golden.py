@@ -42,6 +42,22 @@ def test_cross_entropy_random_and_all_ignored(golden):
     assert_close(xe.grad, g.t("allign_grad"), 0, 0, "all-ignored grad")
 
 
+@pytest.mark.parametrize("tag,kw", [("a", dict(min_kept=50)), ("b", dict(min_kept=600)), ("c", dict(min_kept=100000)),
+                                    ("d", dict(min_kept=300, thresh=0.5))])
+def test_ohem_cross_entropy(golden, tag, kw):
+    """OhemCrossEntropy of the reference in its regimes: threshold = thresh, threshold = k-th smallest probability,
+    k clamped to n_valid - 1, low-res scores upsampled by the module."""
+    g = golden("ohem")
+    src = "b" if tag == "c" else tag
+    x = g.t(src + "_x").clone().requires_grad_()
+    loss, kept, thr = ol.ohem_cross_entropy(x, g.t(src + "_y"), **kw)
+    loss.backward()
+    assert_close(loss, g.t(tag + "_loss"), 1e-6, 1e-7, f"ohem {tag} loss")
+    assert_close(x.grad, g.t(tag + "_grad"), 1e-5, 1e-9, f"ohem {tag} grad")
+    if tag == "b":
+        assert int(kept.sum()) == 600 and thr > 0.7          # exactly min_kept pixels lie below sorted[min_kept]
+
+
 def test_kat2_distillation(golden):
     g = golden("distill")
     s = g.t("kat_s").requires_grad_()

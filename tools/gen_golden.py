@@ -37,7 +37,7 @@ warnings.filterwarnings("ignore")
 
 from model.model_noaux import SegModel  # noqa: E402  (reference)
 from model.seg_model_noaux import Classifier_Module2  # noqa: E402  (reference)
-from util.loss import cross_entropy2d, distillation_loss  # noqa: E402  (reference)
+from util.loss import OhemCrossEntropy, cross_entropy2d, distillation_loss  # noqa: E402  (reference)
 from util.utils import (adjust_learning_rate, create_teacher_params,  # noqa: E402
                         update_teacher_params)
 from util.metrics import runningScore  # noqa: E402  (reference)
@@ -616,7 +616,42 @@ def gen_miou():
          fwavacc=np.array(sc["FreqW Acc : \t"]), iu=np.array([cls_iu[i] for i in range(19)]))
 
 
-ALL = dict(ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+# ------------------------------------------------------------------ G-ohem ("next" row 4)
+def gen_ohem():
+    """OhemCrossEntropy (G5/util/loss.py:65-122) in its three regimes: threshold = thresh (many uncertain
+    pixels), threshold = k-th smallest probability (confident predictions, min_kept larger than the number of
+    uncertain pixels), and low-res scores that the module upsamples itself."""
+    g = synth.gen(11)
+    out = {}
+    # (a) near-uniform predictions: the k-th smallest p_t is far below 0.7 -> threshold 0.7
+    xa = torch.randn((2, 19, 33, 33), generator=g).requires_grad_()
+    ya = striped_labels(g, (2, 33, 33))
+    la = OhemCrossEntropy(min_kept=50)(xa, ya)
+    la.backward()
+    out.update(a_x=xa, a_y=ya, a_loss=la, a_grad=xa.grad, a_min_kept=np.array(50))
+    # (b) confident predictions: most p_t > 0.7, so sorted[min_kept] > 0.7 becomes the threshold
+    yb = striped_labels(g, (2, 33, 33))
+    xb = torch.randn((2, 19, 33, 33), generator=g)
+    onehot = F.one_hot(yb.clamp(max=18), 19).permute(0, 3, 1, 2).float()
+    xb = (xb + 6.0 * onehot * (torch.rand((2, 1, 33, 33), generator=g) < 0.9)).requires_grad_()
+    lb = OhemCrossEntropy(min_kept=600)(xb, yb)
+    lb.backward()
+    out.update(b_x=xb, b_y=yb, b_loss=lb, b_grad=xb.grad, b_min_kept=np.array(600))
+    # (c) min_kept beyond the number of valid pixels: k = n_valid - 1 (the largest probability), everything below it kept
+    lc_x = xb.detach().clone().requires_grad_()
+    lc = OhemCrossEntropy(min_kept=100000)(lc_x, yb)
+    lc.backward()
+    out.update(c_loss=lc, c_grad=lc_x.grad)
+    # (d) low-res scores: the module upsamples (bilinear, align_corners) to the label size first
+    xd = (2.0 * torch.randn((2, 19, 9, 9), generator=g)).requires_grad_()
+    yd = striped_labels(g, (2, 65, 65))
+    ld = OhemCrossEntropy(min_kept=300, thres=0.5)(xd, yd)
+    ld.backward()
+    out.update(d_x=xd, d_y=yd, d_loss=ld, d_grad=xd.grad, d_min_kept=np.array(300), d_thres=np.array(0.5))
+    save("ohem", **out)
+
+
+ALL = dict(ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou)
 
