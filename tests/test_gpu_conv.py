@@ -28,6 +28,9 @@ CASES = [
     ("stem_7x7", 2, 3, 65, 63, 64, 7, 2, 3, 1, False),
     ("head_19", 2, 256, 17, 17, 19, 1, 1, 0, 1, False),
     ("big_m", 4, 64, 97, 97, 64, 1, 1, 0, 1, False),
+    ("wide_ragged_cout", 1, 96, 19, 23, 320, 3, 1, 1, 1, False),    # 256-channel wgrad tile with a partial second tile
+    ("wide_stride2", 2, 128, 33, 31, 512, 1, 2, 0, 1, False),         # pixel-index table with a stride
+    ("wide_many_splits", 3, 64, 97, 97, 256, 1, 1, 0, 1, False),      # split-K over a ragged pixel range
 ]
 
 
