@@ -32,6 +32,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak
+SERIAL_STEPS = 2          # steps of the serialised-stream pass that times kernels for the roofline
 FWD_GFLOP_768 = 1232.9           # model forward, one 768x768 image
 FWD_GFLOP_256 = 142.6
 
@@ -63,6 +64,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the CPU leg and print its JSON")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel families with HIP events")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="run the whole step on one stream (no teacher / weight-gradient side stream): the mode the "
+                         "per-kernel roofline durations are measured in; profiles/*_serial_* are rocprofv3 runs of it")
     return ap.parse_args()
 
 
@@ -177,15 +181,44 @@ def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
     losses = {k: float(v) for k, v in out.items()}
     if not all(v == v and abs(v) < 1e6 for v in losses.values()):
         raise SystemExit(f"non-finite loss in the timed region: {losses}")
-    families = {}
-    if prof and rank == 0:
+    def query(nsteps):
+        fam = {}
         for tag in _lib.PROF_TAGS:
             n, ms = _lib.prof_query(tag)
             if n:
-                families[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / steps}
+                fam[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / nsteps}
+        return fam
+
+    families_overlapped = query(steps) if prof else {}
+    families = families_overlapped
+    if prof and not a.serial_streams:
+        # Kernel durations for the roofline: the timed region runs the teacher forward and the weight gradients on a
+        # second stream, so the HIP events of a launch there span other kernels sharing the GPU.  Two more steps
+        # with the streams serialised time every kernel on its own (all ranks, the step has a collective).
+        saved = {k: os.environ.get(k) for k in ("DIGA_TEACHER_STREAM", "DIGA_WGRAD_STREAM")}
+        os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
+        try:
+            one_step(it)
+            it += 1
+            torch.cuda.synchronize()
+            _lib.call("diga_prof_reset")
+            _lib.call("diga_prof_enable", 1)
+            for _ in range(SERIAL_STEPS):
+                one_step(it)
+                it += 1
+            torch.cuda.synchronize()
+            _lib.call("diga_prof_enable", 0)
+            families = query(SERIAL_STEPS)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        barrier()
     del tr, student, teacher, batch, one_step
     torch.cuda.empty_cache()
-    return float(t), families, losses, counts, (B, H, W, arch_name)
+    return float(t), (families, families_overlapped), losses, counts, (B, H, W, arch_name)
 
 
 def rooflines(a, precision, families, steps, counts, geom):
@@ -255,18 +288,27 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    dt, families, losses, counts, geom = run_steps(a, a.precision, a.steps, a.warmup, rank, world, dev, not a.no_prof)
+    if a.serial_streams:
+        os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
+    dt, (families, families_ov), losses, counts, geom = run_steps(a, a.precision, a.steps, a.warmup, rank, world, dev,
+                                                                  not a.no_prof)
+    fam_steps = a.steps if (a.serial_streams or a.no_prof) else SERIAL_STEPS
     B, H, W, _ = geom
     other_line = None
     if not a.no_other_precision and world == 1:
         oprec = "f32" if a.precision == "bf16x3" else "bf16x3"
-        odt, ofam, olosses, _, _ = run_steps(a, oprec, 2, 1, rank, world, dev, not a.no_prof)
-        oroof, _ = rooflines(a, oprec, ofam, 2, counts, geom)
+        odt, (ofam, _), olosses, _, _ = run_steps(a, oprec, 2, 1, rank, world, dev, not a.no_prof)
+        oroof, _ = rooflines(a, oprec, ofam, 2 if (a.serial_streams or a.no_prof) else SERIAL_STEPS, counts, geom)
         other_line = {"dtype": DTYPE[oprec], "value": world * B * 2 / odt, "unit": "crops/s", "steps": 2, "warmup": 1,
                       "ms_per_step": 1e3 * odt / 2, "roofline": oroof, "losses_last_step": olosses}
 
     if rank == 0:
-        roof, other = rooflines(a, a.precision, families, a.steps, counts, geom)
+        roof, other = rooflines(a, a.precision, families, fam_steps, counts, geom)
+        if roof is not None:
+            roof["measured"] = ("HIP events around every launch, on the launch stream; "
+                                + ("timed region (single stream)" if a.serial_streams else
+                                   f"{SERIAL_STEPS} extra steps with the teacher / weight-gradient side streams serialised "
+                                   "(in the timed region they overlap other kernels; see kernel_families_overlapped)"))
         line = {
             "metric": ("768x768 19-class crops/sec (DiGA warm-up step)" if a.config != "c4" else
                        "512x1024 19-class (source,target) crop pairs/sec (DiGA self-training step)"),
@@ -277,7 +319,8 @@ def main():
                        "parallelism": f"dp{world}",
                        "images_per_step_per_gpu": {"student_fwd_bwd": 2 * B, "teacher_fwd": 2 * B}},
             "roofline": roof, "roofline_other_kernels": other, "cpu_baseline": cpu_line,
-            "other_precision": other_line, "kernel_families": families, "losses_last_step": losses,
+            "other_precision": other_line, "kernel_families": families,
+            "kernel_families_overlapped": None if a.serial_streams else families_ov, "losses_last_step": losses,
             "model_tflop_per_step_per_gpu": (2 * B) * 4 * (FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)) / 1e3,
         }
         print(json.dumps(line), flush=True)

@@ -132,6 +132,31 @@ def contiguous(t, dtype=None):
 _workspaces = {}
 
 
+# ---- optional second stream for work that is off the critical path (weight gradients during backward)
+_side_streams = {}
+_side_dirty = set()
+side_overlap = False          # switched on by the step driver around backward(); plain autograd users stay in line
+
+
+def side_stream(device):
+    """The per-device side stream when overlap is switched on, else None."""
+    if not side_overlap or os.environ.get("DIGA_WGRAD_STREAM", "1") == "0":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    _side_dirty.add(idx)
+    return st
+
+
+def join_side():
+    """Make the current stream of every device that used its side stream wait for it."""
+    for idx in list(_side_dirty):
+        torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
+    _side_dirty.clear()
+
+
 def workspace(nbytes, device, tag="default"):
     """Grow-only scratch buffer owned by the PyTorch caching allocator (one per device and tag)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), tag,

@@ -103,6 +103,9 @@ class GradReducer:
         flat = self._flat[i]
         if flat is None or flat.numel() != n or flat.device != grads[0].device:
             self._flat[i] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        if grads[0].is_cuda:
+            from diga_amd import _lib
+            _lib.join_side()              # weight gradients may still be in flight on the side stream
         torch._foreach_copy_(self._views(i), [g.detach() for g in grads])
         self._work[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 

@@ -168,14 +168,27 @@ class _Conv2dFn(torch.autograd.Function):
             dx = dxn[..., :c_true].permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dwp = torch.empty((kp, r, s, cp), dtype=torch.float32, device=w.device)
-            nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, cp, r, s)
-            ws = _lib.workspace(nbytes, w.device, "wgrad")
-            _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
-                      n, hi, wi, cp, xn.stride(2), ho, wo, kp, gyp.stride(2), r, s, stride[0], stride[1],
-                      -padding[0], -padding[1], dilation[0], dilation[1], st)
-            dw_krsc = dwp[:k, :, :, :c_true]
             dw = torch.empty_strided((k, c_true, r, s), w_strides, dtype=torch.float32, device=w.device)
-            dw.copy_(dw_krsc.permute(0, 3, 1, 2))
+
+            def run():
+                nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, cp, r, s)
+                ws = _lib.workspace(nbytes, w.device, "wgrad")
+                _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
+                          n, hi, wi, cp, xn.stride(2), ho, wo, kp, gyp.stride(2), r, s, stride[0], stride[1],
+                          -padding[0], -padding[1], dilation[0], dilation[1], _lib.stream())
+                dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
+
+            # The weight gradient is a leaf of the backward graph: under the step driver it runs on a second stream
+            # next to the backward-data / BatchNorm chain (the driver joins the streams before the optimizer step).
+            side = _lib.side_stream(w.device)
+            if side is None:
+                run()
+            else:
+                side.wait_stream(torch.cuda.current_stream(w.device))
+                with torch.cuda.stream(side):
+                    run()
+                for tns in (gyp, xn, dwp, dw):
+                    tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
         return dx, dw, db, None, None, None, None

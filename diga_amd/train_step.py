@@ -10,11 +10,12 @@ upsampling fused (no [2B,19,H,W] tensors), ClassMix costs one D->H copy per call
 per image, EMA/SGD are single launches, no per-step .cpu()/.item() syncs; the unused
 `student(tdatav)` visualisation forward (warm_up.py:265-266) is not executed.
 """
+import os
 import random
 
 import torch
 
-from diga_amd import ddp
+from diga_amd import _lib, ddp
 from diga_amd.util import loss as L
 from diga_amd.util import utils as U
 
@@ -30,6 +31,7 @@ class DigaTrainer:
         self.opt = U.DigaSGD(student.optim_parameters(base_lr), lr=base_lr, momentum=momentum,
                              weight_decay=weight_decay, grad_scale=1.0 / self.world)
         self.reducer = ddp.GradReducer([p for p in student.parameters() if p.requires_grad])
+        self._side = None
         U.create_teacher_params(teacher, student)
         for p in teacher.parameters():
             p.requires_grad_(False)
@@ -41,9 +43,37 @@ class DigaTrainer:
         with torch.no_grad():
             U.update_teacher_params(self.teacher, self.student, it)
 
+    def _teacher_async(self, cat):
+        """Teacher forward (no grad) on a second HIP stream, concurrent with the student's forward on the current
+        one: the two passes are independent, and kernels of one fill the CUs that the tile tails of the other
+        leave idle (DIGA_TEACHER_STREAM=0 runs it in line)."""
+        if not (cat.is_cuda and os.environ.get("DIGA_TEACHER_STREAM", "1") != "0"):
+            with torch.no_grad():
+                return self.teacher(cat)[2]
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=cat.device)
+        main = torch.cuda.current_stream(cat.device)
+        self._side.wait_stream(main)                 # EMA update of the teacher and `cat` are ready
+        with torch.cuda.stream(self._side), torch.no_grad():
+            t_lr = self.teacher(cat)[2]
+        cat.record_stream(self._side)
+        return t_lr
+
+    def _teacher_join(self, t_lr):
+        if self._side is not None and t_lr.is_cuda:
+            main = torch.cuda.current_stream(t_lr.device)
+            main.wait_stream(self._side)
+            t_lr.record_stream(main)
+        return t_lr
+
     def _finish(self, total):
         self.opt.zero_grad(set_to_none=True)
-        total.backward()
+        _lib.side_overlap = True          # weight gradients on the side stream (diga_amd/model/conv.py)
+        try:
+            total.backward()
+        finally:
+            _lib.side_overlap = False
+            _lib.join_side()
         self.reducer.reduce()
         self.opt.step()
 
@@ -54,9 +84,9 @@ class DigaTrainer:
         with torch.no_grad():
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
             cat = torch.cat([x, mix])
+        t_lr = self._teacher_async(cat)
         _, _, s_lr, _ = self.student(cat)
-        with torch.no_grad():
-            _, _, t_lr, _ = self.teacher(cat)
+        t_lr = self._teacher_join(t_lr)
         total, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
         self._finish(total)
         return {"total": total.detach(), "ce": ce, "distil": di}
