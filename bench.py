@@ -235,7 +235,8 @@ def rooflines(a, precision, families, steps, counts, geom):
     # as MI355X_MICROARCH.md prescribes), condensed by tools/summarize_prof.py into profiles/
     pmc = None
     try:
-        with open(os.path.join(ROOT, "profiles", f"r01_{precision}_pmc_summary.json")) as fh:
+        tag = "r01_f32" if precision == "f32" else "r01_bf16x3_serial"      # rocprofv3 --pmc runs of bench.py --serial-streams
+        with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")) as fh:
             pmc = json.load(fh)["kernels"]
     except (OSError, ValueError, KeyError):
         pass

@@ -59,7 +59,7 @@ def main():
                       "hbm_bytes_per_launch_corrected": (2.0 * f_kb + w_kb) * 1024.0}
     with open(os.path.join(out, f"{tag}_pmc_summary.json"), "w") as fh:
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
-                           "bench.py --steps 1 --warmup 1 (config c2); FETCH_SIZE doubled per MI355X_MICROARCH.md",
+                           "bench.py --steps 1 --warmup 1 --serial-streams (config c2); FETCH_SIZE doubled per MI355X_MICROARCH.md",
                    "kernels": summary}, fh, indent=1)
     print("wrote", out)
 
