@@ -123,3 +123,36 @@ def test_tiny_model_train_step_vs_oracle():
     for k in ["layer0.0.weight", "layer3.1.conv2.weight", "final.head.1.weight", "final.bottleneck.1.weight"]:
         assert_close(student.state_dict()[k], otr.s[k], 2e-3, 2e-5, k)
         assert_close(teacher.state_dict()[k], otr.t[k], 2e-3, 2e-5, k)
+
+
+def test_tiny_model_16_class_step_vs_oracle():
+    """16-class mode of the Synthia tree: the same step with a 16-way head -- exercises the
+    C = 16 instantiations of the fused loss block -- against the oracle."""
+    import dataclasses
+    from diga_amd.model import seg_model_noaux as sm
+    from diga_amd.model.model_noaux import SegModel
+    from diga_amd.train_step import DigaTrainer
+    from oracle import step as ost
+    arch_p = dataclasses.replace(sm.TINY, n_classes=16)
+    arch_o = dataclasses.replace(od.TINY, n_classes=16)
+    sd = detweights.state_dict(arch_o)
+    student, teacher = SegModel(arch=arch_p), SegModel(arch=arch_p)
+    for mdl in (student, teacher):
+        mdl.load_state_dict(sd)
+        mdl.to(DEV)
+        mdl.final.head[0].p = 0.0
+    teacher.train()
+    assert student(torch.zeros((1, 3, 64, 64), device=DEV))[2].shape[1] == 16
+    tr = DigaTrainer(student, teacher, rng=random)
+    otr = ost.Trainer(detweights.state_dict(arch_o), detweights.state_dict(arch_o), arch=arch_o)
+    for it in range(2):
+        x, x_aug, rec, lab = synth.warmup_batch(700 + it, 2, 96, 128, block=16)
+        lab = torch.where(lab < 16, lab, torch.full_like(lab, 255))           # Synthia: classes 16..18 do not exist
+        random.seed(it)
+        want = otr.warmup_step(it, x, x_aug, rec, lab, random)
+        random.seed(it)
+        got = tr.warmup_step(it, *(t.to(DEV) for t in (x, x_aug, rec, lab)))
+        assert float(got["ce"]) == pytest.approx(want["ce"], rel=1e-3)
+        assert float(got["distil"]) == pytest.approx(want["distil"], rel=1e-3)
+    for k in ["layer0.0.weight", "final.head.1.weight", "final.bottleneck.1.weight"]:
+        assert_close(student.state_dict()[k], otr.s[k], 2e-3, 2e-5, k)
