@@ -61,7 +61,7 @@ class _StemConvFn(torch.autograd.Function):
     floats, then a 1x1 conv on the GEMM kernels.  No gradient wrt the input (it is the image)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None):
         _lib.require_gpu(x, weight)
         xc = x.detach().float().contiguous()                      # NCHW
         n, c, h, w_ = xc.shape
@@ -104,12 +104,12 @@ class _StemConvFn(torch.autograd.Function):
             dw.copy_(dwp[:k, 0, 0, :kk].reshape(k, r, s, c).permute(0, 3, 1, 2))
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return None, dw, db, None, None, None, None
+        return None, dw, db, None, None, None, None, None
 
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         xn = x.detach().permute(0, 2, 3, 1)
@@ -130,6 +130,7 @@ class _Conv2dFn(torch.autograd.Function):
         _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats)
         ctx.save_for_backward(xn, w)
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
+        ctx.uses = uses
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -180,7 +181,16 @@ class _Conv2dFn(torch.autograd.Function):
 
             # The weight gradient is a leaf of the backward graph: under the step driver it runs on a second stream
             # next to the backward-data / BatchNorm chain (the driver joins the streams before the optimizer step).
-            side = _lib.side_stream(w.device)
+            # A weight that entered the graph more than once (the self-training step runs the student twice) gets its
+            # contributions summed by autograd on the main stream: only the first one of a backward pass may still be
+            # in flight on the side stream when it is handed over, the later ones run in line after a join.
+            later = False
+            if ctx.uses is not None:
+                later = ctx.uses[0] > 0
+                ctx.uses[0] += 1
+            if later:
+                _lib.join_side()
+            side = None if later else _lib.side_stream(w.device)
             if side is None:
                 run()
             else:
@@ -191,7 +201,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -202,6 +212,7 @@ class DigaConv2d(nn.Conv2d):
         if self.groups != 1 or self.padding_mode != "zeros":
             raise NotImplementedError("DigaConv2d: groups=1 and zero padding only")
         self.emit_bn_stats = False      # set by the model on convs that feed a train-mode BatchNorm
+        self._bw_seen = [0]
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def _apply(self, fn, *a, **k):
@@ -222,7 +233,12 @@ class DigaConv2d(nn.Conv2d):
             wo = (w + 2 * self.padding[1] - self.dilation[1] * (self.kernel_size[1] - 1) - 1) // self.stride[1] + 1
             stats = torch.empty(_lib.lib.diga_conv2d_stats_floats(n, ho, wo, self.out_channels), dtype=torch.float32,
                                 device=x.device)
-        y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats)
+        uses = None
+        if torch.is_grad_enabled() and self.weight.requires_grad:
+            if self._bw_seen[0] > 0:          # a backward pass has consumed the previous graph(s)
+                self._bw_seen[0] = 0
+            uses = self._bw_seen              # [weight-gradient calls of the current backward pass]
+        y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses)
         if stats is not None:
             y._diga_bn_partials = (stats, 128)       # picked up by the DigaBatchNorm2d that consumes y
         return y

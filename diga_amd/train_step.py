@@ -43,28 +43,35 @@ class DigaTrainer:
         with torch.no_grad():
             U.update_teacher_params(self.teacher, self.student, it)
 
-    def _teacher_async(self, cat):
-        """Teacher forward (no grad) on a second HIP stream, concurrent with the student's forward on the current
-        one: the two passes are independent, and kernels of one fill the CUs that the tile tails of the other
-        leave idle (DIGA_TEACHER_STREAM=0 runs it in line)."""
-        if not (cat.is_cuda and os.environ.get("DIGA_TEACHER_STREAM", "1") != "0"):
+    def _teacher_async(self, *inputs):
+        """Teacher forward(s) (no grad) on a second HIP stream, concurrent with the student's forward on the current
+        one: the passes are independent, and kernels of one fill the CUs that the tile tails of the other leave
+        idle (DIGA_TEACHER_STREAM=0 runs them in line).  Returns one (logits, feat) pair per input; call
+        `_teacher_join` on the result before using it."""
+        dev = inputs[0].device
+        if not (inputs[0].is_cuda and os.environ.get("DIGA_TEACHER_STREAM", "1") != "0"):
             with torch.no_grad():
-                return self.teacher(cat)[2]
+                return [self.teacher(x)[2:4] for x in inputs]
         if self._side is None:
-            self._side = torch.cuda.Stream(device=cat.device)
-        main = torch.cuda.current_stream(cat.device)
-        self._side.wait_stream(main)                 # EMA update of the teacher and `cat` are ready
+            self._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        self._side.wait_stream(main)                 # EMA update of the teacher and the inputs are ready
         with torch.cuda.stream(self._side), torch.no_grad():
-            t_lr = self.teacher(cat)[2]
-        cat.record_stream(self._side)
-        return t_lr
+            outs = [self.teacher(x)[2:4] for x in inputs]
+        for x in inputs:
+            x.record_stream(self._side)
+        self._pending_join = True
+        return outs
 
-    def _teacher_join(self, t_lr):
-        if self._side is not None and t_lr.is_cuda:
-            main = torch.cuda.current_stream(t_lr.device)
+    def _teacher_join(self, outs):
+        if getattr(self, "_pending_join", False):
+            main = torch.cuda.current_stream(outs[0][0].device)
             main.wait_stream(self._side)
-            t_lr.record_stream(main)
-        return t_lr
+            for pair in outs:
+                for t in pair:
+                    t.record_stream(main)
+            self._pending_join = False
+        return outs
 
     def _finish(self, total):
         self.opt.zero_grad(set_to_none=True)
@@ -84,9 +91,9 @@ class DigaTrainer:
         with torch.no_grad():
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
             cat = torch.cat([x, mix])
-        t_lr = self._teacher_async(cat)
+        pending = self._teacher_async(cat)
         _, _, s_lr, _ = self.student(cat)
-        t_lr = self._teacher_join(t_lr)
+        (t_lr, _), = self._teacher_join(pending)
         total, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
         self._finish(total)
         return {"total": total.detach(), "ce": ce, "distil": di}
@@ -101,10 +108,10 @@ class DigaTrainer:
         with torch.no_grad():
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
             cat = torch.cat([x, mix])
+        pending = self._teacher_async(cat, t_img)
         _, _, s_lr, _ = self.student(cat)
+        (t_lr, t_feat), (tt_lr, tt_feat) = self._teacher_join(pending)
         with torch.no_grad():
-            _, _, t_lr, t_feat = self.teacher(cat)
-            _, _, tt_lr, tt_feat = self.teacher(t_img)
             # bilateral consensus: keep the offline pseudo-label where the centroid label agrees
             pseudo = class_features.consensus_pseudo_labels(tt_feat, pseudo_prob)
             cross_mix, cross_lab, _ = U.classmix(t_aug, x, labels, self.rng, bg_labels=pseudo)
