@@ -204,7 +204,10 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
             }
             const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * ld_x + c);
             float4 o;
-            o.x = xv.x * av.x + bv.x; o.y = xv.y * av.y + bv.y; o.z = xv.z * av.z + bv.z; o.w = xv.w * av.w + bv.w;
+            // explicit fma: the backward kernels re-derive the ReLU mask of a residual-free BatchNorm from x with the
+            // same expression instead of re-reading y
+            o.x = __builtin_fmaf(xv.x, av.x, bv.x); o.y = __builtin_fmaf(xv.y, av.y, bv.y);
+            o.z = __builtin_fmaf(xv.z, av.z, bv.z); o.w = __builtin_fmaf(xv.w, av.w, bv.w);
             if (res != nullptr) {
                 const float4 rv = *reinterpret_cast<const float4*>(res + (int64_t)r * ld_r + c);
                 o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
@@ -224,7 +227,9 @@ __global__ __launch_bounds__(kNormThreads) void bwd_partial_kernel(const float* 
                                                                     const float* __restrict__ y, int64_t ld_y,
                                                                     const float* __restrict__ mean,
                                                                     const float* __restrict__ invstd, int st_seg_stride,
-                                                                    int cdiv, ColGeom g, float* __restrict__ partial) {
+                                                                    int cdiv, ColGeom g, float* __restrict__ partial,
+                                                                    const float* __restrict__ relu_ab) {
+    // relu_ab (BatchNorm without residual, y == nullptr): [2][C] forward coefficients; mask = fma(x, a, b) > 0
     const int chunk = blockIdx.x, seg = blockIdx.y;
     float* out = partial + ((int64_t)seg * g.nchunk + chunk) * 2 * g.C;
     chunk_walk<2>(g, seg, chunk, out, [&](int64_t r, int64_t, int c, float (&acc)[2][4]) {
@@ -237,6 +242,10 @@ __global__ __launch_bounds__(kNormThreads) void bwd_partial_kernel(const float* 
             const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+        } else if (relu_ab != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                gg[e] = __builtin_fmaf(xx[e], relu_ab[c + e], relu_ab[g.C + c + e]) > 0.f ? gg[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -308,7 +317,8 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
                                                         int st_seg_stride, int cdiv, const float* __restrict__ kk,
                                                         int64_t kk_seg_stride, int64_t kk_plane, float* __restrict__ dx,
                                                         int64_t ld_dx, float* __restrict__ dres, int64_t ld_dr,
-                                                        int64_t rows_per_seg, int64_t rows, int C) {
+                                                        int64_t rows_per_seg, int64_t rows, int C,
+                                                        const float* __restrict__ relu_ab) {
     const int tq = C >> 2;
     const int tpr = tq < 256 ? tq : 256;
     const int rpb = 256 / tpr;
@@ -320,6 +330,14 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
     for (int q = q0; q < tq; q += tpr) {
         const int c = q * 4;
         float k1a[4], k2a[4], k3a[4], mu[4], is[4];
+        float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (relu_ab != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ra[e] = relu_ab[c + e];
+                rb[e] = relu_ab[C + c + e];
+            }
+        }
         auto load_coeff = [&](int seg) {
             const float* kb = kk + (int64_t)seg * kk_seg_stride + c;
             const float4 k1 = *reinterpret_cast<const float4*>(kb);
@@ -354,6 +372,9 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
                 const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+            } else if (relu_ab != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gg[e] = __builtin_fmaf(xx[e], ra[e], rb[e]) > 0.f ? gg[e] : 0.f;
             }
             float o[4];
 #pragma unroll
@@ -758,8 +779,8 @@ extern "C" size_t diga_norm_workspace_bytes(int64_t rows_per_seg, int64_t nseg, 
 
 extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
-                           float* save_mean, float* save_invstd, int64_t M, int64_t C, int training, int relu,
-                           float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+                           float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int training,
+                           int relu, float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && workspace && M > 0, DIGA_EINVAL, "bn_fwd: bad argument");
     DIGA_REQUIRE(training || (running_mean && running_var), DIGA_EINVAL, "bn_fwd: eval mode needs running statistics");
     int rc = check_norm("bn_fwd", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
@@ -769,7 +790,7 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     ProfScope prof(DIGA_PROF_NORM, st);
     const ColGeom g = make_geom(M, 1, C);
     float* partial = (float*)workspace;
-    float* ab = partial + (size_t)g.nchunk * 3 * C;
+    float* ab = save_ab != nullptr ? save_ab : partial + (size_t)g.nchunk * 3 * C;     // [2][C] y = fma(x, a, b)
     if (training) {
         hipLaunchKernelGGL(colstats_partial_kernel, dim3(g.nchunk, 1), dim3(kNormThreads), 0, st, x, ld_x, g, partial);
         hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
@@ -785,8 +806,8 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
 
 extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
                                     int64_t ld_r, const float* gamma, const float* beta, float* running_mean,
-                                    float* running_var, float* save_mean, float* save_invstd, int64_t M, int64_t C,
-                                    int relu, float momentum, float eps, const float* partial, int64_t chunk_rows,
+                                    float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
+                                    int64_t C, int relu, float momentum, float eps, const float* partial, int64_t chunk_rows,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0 && chunk_rows > 0,
                  DIGA_EINVAL, "bn_fwd_partials: bad argument");
@@ -806,9 +827,9 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
     const size_t need = ((group > 1 ? (size_t)ngroup * 3 * C : 0) + (size_t)2 * C) * sizeof(float);
     DIGA_REQUIRE(workspace_bytes >= need, DIGA_EWORKSPACE, "bn_fwd_partials: workspace too small (%zu < %zu)",
                  workspace_bytes, need);
-    float* ab = (float*)workspace;
+    float* ab = save_ab != nullptr ? save_ab : (float*)workspace;
     if (group > 1) {
-        float* merged = ab + 2 * C;
+        float* merged = (float*)workspace + 2 * C;
         hipLaunchKernelGGL(merge_partials_kernel, dim3(ngroup, (unsigned)ceil_div(C, 64)), dim3(256), 0, st, partial, g, group,
                            merged);
         partial = merged;
@@ -823,7 +844,8 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
 }
 
 extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
-                           const float* gamma, const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx,
+                           const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd,
+                           float* dx, int64_t ld_dx,
                            float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, void* workspace,
                            size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && workspace && M > 0, DIGA_EINVAL, "bn_bwd: bad argument");
@@ -835,13 +857,14 @@ extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     const ColGeom g = make_geom(M, 1, C);
     float* partial = (float*)workspace;
     float* kk = partial + (size_t)g.nchunk * 3 * C;
+    DIGA_REQUIRE(!(y && relu_ab), DIGA_EINVAL, "bn_bwd: pass y or relu_ab, not both");
     if (training)
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, 1), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
-                           save_mean, save_invstd, 0, 1, g, partial);
+                           save_mean, save_invstd, 0, 1, g, partial, relu_ab);
     hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma,
                        save_invstd, kk, training);
     hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y, save_mean,
-                       save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, dres, ld_dr, M, M, (int)C);
+                       save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, dres, ld_dr, M, M, (int)C, relu_ab);
     return launch_status("diga_bn_bwd");
 }
 
@@ -889,7 +912,7 @@ extern "C" int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     float* kk = partial + (size_t)N * g.nchunk * 3 * C;       // [3][N][C]
     float* chan_sums = kk + (size_t)3 * N * C;                // [2][N][C]
     hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
-                       save_mean, save_invstd, (int)G, cpg, g, partial);
+                       save_mean, save_invstd, (int)G, cpg, g, partial, (const float*)nullptr);
     if (cpg <= 64 && (cpg & (cpg - 1)) == 0)
         hipLaunchKernelGGL(gn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(N * G, 4)), dim3(256), 0, st, partial, g, (int)G,
                            gamma, chan_scale, save_invstd, kk, chan_sums);
@@ -900,7 +923,7 @@ extern "C" int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
                        dgamma, dbeta);
     hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
                        save_mean, save_invstd, (int)G, cpg, kk, C, N * C, dx, ld_dx, (float*)nullptr, (int64_t)0, HW, N * HW,
-                       (int)C);
+                       (int)C, (const float*)nullptr);
     return launch_status("diga_gn_bwd");
 }
 
@@ -946,7 +969,7 @@ extern "C" int diga_channel_dot(const float* dy, int64_t ld_dy, const float* x, 
     hipError_t e = hipMemcpyAsync(unit, h_unit, sizeof(h_unit), hipMemcpyHostToDevice, st);
     DIGA_REQUIRE(e == hipSuccess, (int)e, "channel_dot: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x,
-                       (const float*)nullptr, (int64_t)0, unit, unit + 1, 0, (int)C, g, partial);
+                       (const float*)nullptr, (int64_t)0, unit, unit + 1, 0, (int)C, g, partial, (const float*)nullptr);
     hipLaunchKernelGGL(seg_dot_kernel, dim3((unsigned)ceil_div(N * C, 256)), dim3(256), 0, st, partial, g, out);
     return launch_status("diga_channel_dot");
 }

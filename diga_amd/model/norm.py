@@ -64,25 +64,27 @@ class _BnFn(torch.autograd.Function):
         y = torch.empty_like(xn)
         save_mean = torch.empty(c, dtype=torch.float32, device=xn.device)
         save_invstd = torch.empty_like(save_mean)
+        # ReLU without residual: the backward re-derives the mask from x and the forward coefficients (no y read)
+        save_ab = torch.empty(2 * c, dtype=torch.float32, device=xn.device) if (relu and residual is None) else None
         ws = _ws(m, 1, c, xn.device)
         if partials is not None and training:
             # the producing conv already reduced its output tile by tile: finalise + apply only
             _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
-                      _lib.ptr(save_invstd), m, c, 1 if relu else 0, float(momentum), float(eps), _lib.ptr(partials[0]),
-                      int(partials[1]), _lib.ptr(ws), ws.numel(), _lib.stream())
+                      _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, float(momentum), float(eps),
+                      _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(), _lib.stream())
         else:
             _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
-                      _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd), m, c,
-                      1 if training else 0, 1 if relu else 0, float(momentum), float(eps), _lib.ptr(ws), ws.numel(),
-                      _lib.stream())
-        ctx.save_for_backward(xn, y if relu else None, weight, save_mean, save_invstd)
+                      _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd),
+                      _lib.ptr(save_ab), m, c, 1 if training else 0, 1 if relu else 0, float(momentum), float(eps),
+                      _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctx.save_for_backward(xn, y if (relu and save_ab is None) else None, weight, save_mean, save_invstd, save_ab)
         ctx.flags = (training, residual is not None)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
-        xn, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        xn, y, weight, save_mean, save_invstd, save_ab = ctx.saved_tensors
         training, has_res = ctx.flags
         n, h, w, c = xn.shape
         m = n * h * w
@@ -90,9 +92,9 @@ class _BnFn(torch.autograd.Function):
         dx = torch.empty_like(xn)
         dres = torch.empty_like(xn) if has_res else None
         ws = _ws(m, 1, c, xn.device)
-        _lib.call("diga_bn_bwd", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(weight), _lib.ptr(save_mean),
-                  _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dres), c, m, c, 1 if training else 0, _lib.ptr(ws),
-                  ws.numel(), _lib.stream())
+        _lib.call("diga_bn_bwd", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(save_ab), _lib.ptr(weight),
+                  _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dres), c, m, c,
+                  1 if training else 0, _lib.ptr(ws), ws.numel(), _lib.stream())
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
                 None, None, None, None, None, None, None, None, None)
 

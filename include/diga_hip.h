@@ -272,27 +272,30 @@ int diga_weight_transpose(const float* w, float* wt, int64_t K, int64_t RS, int6
  * ---------------------------------------------------------------------------------- */
 size_t diga_norm_workspace_bytes(int64_t rows_per_segment, int64_t n_segments, int64_t C);
 
-/* y = [relu]( (x - mean)*invstd*gamma + beta [+ residual] ).  training: batch statistics over the M rows
- * (biased variance), running_mean/var updated with `momentum` (unbiased variance), statistics saved for the
- * backward pass; eval: running statistics.  residual nullable. */
+/* y = [relu]( fma(x, a, b) [+ residual] ), a = invstd*gamma, b = beta - mean*a.  training: batch statistics over the
+ * M rows (biased variance), running_mean/var updated with `momentum` (unbiased variance), statistics saved for the
+ * backward pass; eval: running statistics.  residual nullable.  save_ab (nullable, [2][C]) receives a and b: passed
+ * back to diga_bn_bwd as `relu_ab` it lets the backward of a residual-free BN+ReLU re-derive the ReLU mask from x
+ * instead of reading y. */
 int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
-                float* save_mean, float* save_invstd, int64_t M, int64_t C, int training, int relu,
+                float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int training, int relu,
                 float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Train-mode diga_bn_fwd whose statistics pass is replaced by partials the producing conv already wrote
  * (`partial` = stats_partial of diga_conv2d_nhwc_*, `chunk_rows` = 128). */
 int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
-                         float* save_mean, float* save_invstd, int64_t M, int64_t C, int relu, float momentum,
-                         float eps, const float* partial, int64_t chunk_rows, void* workspace, size_t workspace_bytes,
-                         void* stream);
+                         float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
+                         float momentum, float eps, const float* partial, int64_t chunk_rows, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
-/* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*[y>0] (y nullable = no ReLU),
- * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (nullable) = g. */
+/* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*mask, mask = [y>0] when y is given,
+ * [fma(x, a, b) > 0] when relu_ab = save_ab of the forward is given instead (BN without residual), 1 when both are
+ * null (no ReLU); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (nullable) = g. */
 int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
-                const float* gamma, const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx,
-                float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, void* workspace,
+                const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
+                int64_t ld_dx, float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, void* workspace,
                 size_t workspace_bytes, void* stream);
 
 /* GroupNorm over (HW x C/G) per image and group, then y = [relu](chan_scale[n,c] * (xhat*gamma + beta));
