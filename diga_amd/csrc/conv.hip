@@ -641,7 +641,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3p_kernel(ConvArgs a) {
 // Measured alternatives (C2 layer shapes, sum of forward convs of one pass: 128^2 kernel 85.2 ms, this kernel
 // 68.2 ms): the same tile on 32x32x16 MFMAs 88.9 ms; a wave-specialised build (4 MFMA waves + 4 loader waves, double
 // buffered, one barrier per step) 87.9 ms; tap-inner K order (L2 reuse across taps) no gain; s_setprio around the
-// staging phase no gain; 4 instead of 2 global loads per MFMA group 77.5 ms.
+// staging phase no gain; 4 (3) instead of 2 global loads per MFMA group 77.5 (73.8) ms; weight tiles pre-arranged as LDS
+// images and copied by LDS-DMA (global_load_lds_dwordx4, double-buffered B, no registers / ds_writes on the weight
+// side) 71.8 vs 70.9 ms -- the weight side of the staging is not what bounds the kernel.
 // ---------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
