@@ -170,6 +170,57 @@ def test_conv_fullsize_linearity_and_adjoint():
     assert rhs_w == pytest.approx(lhs, rel=1e-4)
 
 
+@pytest.mark.parametrize("geom", [(256, 256, 3, 2), (1024, 256, 1, 1), (256, 1024, 1, 1)], ids=["l3.conv2", "l3.conv1", "l3.conv3"])
+def test_conv_fullsize_split_bf16_vs_exact_fp32(geom):
+    """The three layer-3 bottleneck convolutions at the true C2 geometry (16 images, 97x97): the split-bf16 kernels
+    (256-row forward / backward-data tile on 1178+ blocks, 256-channel backward-weight tile with the pixel table and
+    the one-round split-K plan) against the exact-fp32 MFMA kernels on the same inputs, the fused BatchNorm statistics
+    against a direct reduction, and run-to-run bit reproducibility."""
+    from diga_amd import _lib
+    from diga_amd.model.conv import DigaConv2d
+    cin, cout, k, dil = geom
+    g = synth.gen(60 + cin // 64 + k)
+    n, hw = 16, 97
+    m = DigaConv2d(cin, cout, k, padding=dil * (k // 2), dilation=dil, bias=False).to(DEV)
+    with torch.no_grad():
+        m.weight.mul_(5.0)
+    x0 = torch.randn((n, cin, hw, hw), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    yy = torch.randn((n, cout, hw, hw), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+
+    def run(mode):
+        prev = _lib.lib.diga_get_conv_math()
+        _lib.lib.diga_set_conv_math(mode)
+        try:
+            m.weight.grad = None
+            m.emit_bn_stats = True
+            m.train()
+            x = x0.clone().requires_grad_()
+            y = m(x)
+            stats = y._diga_bn_partials[0].clone()
+            (y * yy).sum().backward()
+            return y.detach(), x.grad.detach(), m.weight.grad.detach().clone(), stats
+        finally:
+            _lib.lib.diga_set_conv_math(prev)
+
+    y1, dx1, dw1, st1 = run(1)
+    y0, dx0, dw0, _ = run(0)
+    for a, b, what in ((y1, y0, "y"), (dx1, dx0, "dx"), (dw1, dw0, "dw")):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) < 1e-4 * scale, what
+        assert float((a - b).norm() / b.norm()) < 3e-5, what
+    # fused statistics: sum over the 128-row chunks of {sum d, shift} reproduces the column sums of y
+    M = n * hw * hw
+    nchunk = (M + 127) // 128
+    st = st1.view(nchunk, 3, cout).double()
+    rows = torch.full((nchunk,), 128.0, dtype=torch.float64, device=DEV)
+    rows[-1] = M - 128 * (nchunk - 1)
+    col_sum = (st[:, 0] + st[:, 2] * rows[:, None]).sum(0)
+    want = y1.permute(0, 2, 3, 1).reshape(M, cout).double().sum(0)
+    assert float((col_sum - want).abs().max()) < 1e-6 * float(y1.abs().max()) * M
+    y2, dx2, dw2, st2 = run(1)
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2) and torch.equal(dw1, dw2) and torch.equal(st1, st2)
+
+
 def test_batchnorm_fullsize_statistics():
     """Train-mode BN on a c2-sized layer1 tensor: the output has zero mean / unit variance per channel and the
     gradient is orthogonal to constants and to the normalised input (the two projections BN backward removes)."""
