@@ -33,6 +33,13 @@ def init_from_env(backend=None):
             local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "gloo" and torch.cuda.is_available():
+            # gloo reduces GPU tensors through host-synchronous copies on its own streams; next to the step driver's
+            # side streams (teacher forward, weight gradients) that degenerates to seconds per step on this stack
+            # (measured: 2 ranks on one GPU 15 s vs 0.13 s).  gloo is the smoke-test backend only -- run it on one
+            # stream.  The RCCL path is stream-ordered and keeps the side streams (tools/nccl_1rank_proxy.py).
+            os.environ["DIGA_TEACHER_STREAM"] = "0"
+            os.environ["DIGA_WGRAD_STREAM"] = "0"
     return rank, world, local
 
 
@@ -76,7 +83,7 @@ class GradReducer:
         self._work = [None] * len(self.buckets)
         self._ready = [0] * len(self.buckets)
         self._hooks = []
-        if overlap and world_size() > 1:
+        if overlap and world_size() > 1 and os.environ.get("DIGA_DDP_OVERLAP", "1") != "0":
             for i, bucket in enumerate(self.buckets):
                 for p in bucket:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One-GPU proxy for the N>1 RCCL path:  python tools/nccl_1rank_proxy.py <B> <crop>   (e.g. 8 768)."""
+# Proxy for the N>1 RCCL path on one GPU: a 1-rank "nccl" process group with the gradient reducer forced on, so that every
+# step runs hook-driven RCCL all-reduces (RCCL stream + events) next to the teacher / weight-gradient side streams.
+import os, sys, time, random
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+from diga_amd import ddp, synthetic, _lib
+ddp.world_size = lambda: 2            # make the reducer (and its hooks) believe there are peers; all-reduce runs on RCCL
+from diga_amd.model import seg_model_noaux as sm
+from diga_amd.model.model_noaux import SegModel
+from diga_amd.train_step import DigaTrainer
+_lib.call("diga_set_conv_math", 1)
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+student, teacher = SegModel(arch=sm.RESNET101).to(dev), SegModel(arch=sm.RESNET101).to(dev)
+teacher.train()
+tr = DigaTrainer(student, teacher, rng=random.Random(1))
+B, H, W = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[2])
+batch = synthetic.warmup_batch(1234, B, H, W, block=32, device=dev)
+for it in range(2):
+    out = tr.warmup_step(it, *batch)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for it in range(2, 6):
+    out = tr.warmup_step(it, *batch)
+torch.cuda.synchronize()
+print(f"nccl-1rank proxy: {1e3 * (time.perf_counter() - t0) / 4:.1f} ms/step  hooks={len(tr.reducer._hooks)} buckets={len(tr.reducer.buckets)} loss={float(out['total']):.4f}", flush=True)
+dist.destroy_process_group()
