@@ -54,6 +54,10 @@ SIGNATURES = {
     "diga_conv2d_stats_floats": (SZ, [I64, I64, I64, I64]),
     "diga_split_bf16": (INT, [P, P, P, I64, P]),
     "diga_conv2d_nhwc_bf16x3": (INT, [P, P, P, P, P] + [I64] * 17 + [P, INT, P]),
+    "diga_make_twin": (INT, [P, I64, P, I64, I64, P]),
+    "diga_split_bf16_image_bytes": (SZ, [I64, I64, I64]),
+    "diga_split_bf16_image": (INT, [P, P, I64, I64, I64, P]),
+    "diga_conv2d_nhwc_twin": (INT, [P, P, P, P] + [I64] * 16 + [P, INT, P]),
     "diga_set_conv_math": (INT, [INT]),
     "diga_get_conv_math": (INT, []),
     "diga_conv2d_wgrad_workspace_bytes": (SZ, [I64] * 7),

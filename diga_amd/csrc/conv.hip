@@ -42,6 +42,7 @@ struct ConvArgs {
     const float* wgt;
     const uint16_t* wgt_hi;   // split-bf16 weights (conv_fwd_x3p_kernel), else null
     const uint16_t* wgt_lo;
+    const unsigned char* wgt_img;   // conv_fwd_x3t_kernel: split weights pre-arranged as LDS images (split_image_kernel)
     const float* bias;
     float* out;
     float* stats;             // nullable: per-(128-row tile, channel) shifted sums for the BatchNorm that follows
@@ -911,6 +912,248 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-bf16 forward / backward-data without register staging ("twin" path).
+//
+// In-kernel stamps of conv_fwd_x3w_kernel: a loop that only reads fragments and issues MFMAs runs a K-step in 2.4 k
+// cycles, the real kernel in 5.5 k -- the global -> register -> split -> ds_write -> barrier staging costs more than
+// the MFMAs.  Here both operands arrive already split and are copied global -> LDS by LDS-DMA loads
+// (global_load_lds_dwordx4: no registers, no VALU, no ds_write) into a two-stage ring, one barrier per K-step:
+//   * activations as a "twin": per pixel and group of 8 channels 16 B of bf16 hi + 16 B of bf16 lo (4 B per element,
+//     the size of the fp32 tensor), written by make_twin_kernel;
+//   * weights as LDS images (split_image_kernel): per 128/64-channel tile and K-step the hi and lo planes exactly as
+//     they sit in LDS.
+// An LDS-DMA instruction writes 64 x 16 B linearly from a wave-uniform LDS base, so the swizzle of the image is applied
+// to the per-lane SOURCE address (lane l fills row l >> 2, slot l & 3 and therefore fetches k-slot (l & 3) ^ swz(row));
+// outside taps fetch 16 zero bytes.  Same tile, MFMA loop and epilogue as conv_fwd_x3w_kernel; 144 KB of LDS, one block
+// (4 waves) per CU.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned char g_zero16[16];
+
+// x [M][ld] fp32 (C channels) -> twin [M][C/8][hi8 | lo8]
+__global__ __launch_bounds__(256) void make_twin_kernel(const float* __restrict__ x, int64_t ld, unsigned char* __restrict__ twin,
+                                                        int64_t M, int C8) {
+    const int64_t total = M * C8, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int64_t m = i / C8;
+        const int g = (int)(i - m * C8);
+        const float* src = x + m * ld + g * 8;
+        uint2 h0, l0, h1, l1;
+        split4_nomask(*reinterpret_cast<const float4*>(src), h0, l0);
+        split4_nomask(*reinterpret_cast<const float4*>(src + 4), h1, l1);
+        uint4* dst = reinterpret_cast<uint4*>(twin + i * 32);
+        dst[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        dst[1] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+// Weights [K][RS][C] fp32 -> LDS images: for every tile of `bn` output channels and every 32-channel K-step (tap-major,
+// the kernel's K order) 2 * bn * 64 bytes = hi plane then lo plane, one 64-byte row per output channel (rows past K
+// repeat the last channel: never stored), the four 16-byte k-slots of row r at slot ^ lds_swz(r).
+__global__ __launch_bounds__(256) void split_image_kernel(const float* __restrict__ w, unsigned char* __restrict__ img,
+                                                          int K, int RS, int C, int bn, int64_t total) {
+    const int cchunks = C / 32, ksteps = RS * cchunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int s = (int)(i & 3);
+        const int r = (int)((i >> 2) % bn);
+        const int64_t tk = (i >> 2) / bn;               // tile * ksteps + ks
+        const int ks = (int)(tk % ksteps), tile = (int)(tk / ksteps);
+        const int tap = ks / cchunks, cc = ks - tap * cchunks;
+        const int n = min(tile * bn + r, K - 1);
+        const float* src = w + ((int64_t)n * RS + tap) * C + cc * 32 + 8 * s;
+        uint2 h0, l0, h1, l1;
+        split4_nomask(*reinterpret_cast<const float4*>(src), h0, l0);
+        split4_nomask(*reinterpret_cast<const float4*>(src + 4), h1, l1);
+        unsigned char* dst = img + tk * (2 * (int64_t)bn * 64) + r * 64 + ((s ^ lds_swz(r)) << 4);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(dst + (int64_t)bn * 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+template <int TN>
+__global__ __launch_bounds__(512, 1) void conv_fwd_x3t_kernel(ConvArgs a) {
+    constexpr int BM = 256, BN = 64 * TN, NT = 2 * TN, MT = 8;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    // 8 waves: 0-3 read fragments and issue MFMAs, 4-7 (one per SIMD, next to an MFMA wave) only issue the LDS-DMA loads
+    // -- an LDS-DMA instruction costs its wave 60-185 cycles of issue time, which a lone in-order wave cannot overlap
+    // with its own MFMAs (measured: one wave per SIMD doing both keeps the matrix pipe 45 % busy)
+    const int t = threadIdx.x & 255, lane = t & 63, wv = t >> 6;
+    const bool loader = threadIdx.x >= 256;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const unsigned char* twin = reinterpret_cast<const unsigned char*>(a.in);
+
+    // LDS-DMA geometry of this lane: A rows wv*64 + 16 j + (lane >> 2), j = 0..3, destination slot lane & 3
+    const int lrow = lane >> 2;
+    const int kslot = (lane & 3) ^ lds_swz(lrow);             // 64 wv + 16 j leave bits 1..3 of the row untouched
+    int pixbase[4], yx0[4];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = min(m0 + wv * 64 + 16 * j + lrow, a.M - 1);
+        const int img = m / HoWo, rem = m - img * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        pixbase[j] = img * a.Hi * a.Wi;
+        yx0[j] = ((ho * a.sy + a.oy0) << 16) | ((wo * a.sx + a.ox0) & 0xffff);
+    }
+    const int RS = a.R * a.S;
+    const int cchunks = a.Cin / 32;
+    const int ksteps = RS * cchunks;
+    const int64_t rowb = (int64_t)a.in_ld * 4;               // twin bytes per pixel (in_ld = channels per pixel row)
+    const unsigned char* pa[4];                              // twin row of (pixel of the current tap) + this lane's k-slot
+    int l_tap = 0, l_cc = 0;
+    auto set_tap = [&](int tap) {
+        const int r = tap / a.S, s = tap - r * a.S;
+        const int dy = r * a.ody, dx = s * a.odx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = (yx0[j] >> 16) + dy, ix = (int)(short)(yx0[j] & 0xffff) + dx;
+            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            pa[j] = ok ? twin + (int64_t)(pixbase[j] + iy * a.Wi + ix) * rowb + kslot * 32 : nullptr;
+        }
+    };
+    const unsigned char* bimg = a.wgt_img + (int64_t)tile_n * ksteps * (2 * B_PLANE) + (wv * 2 * TN) * 1024 + lane * 16;
+    int l_ks = 0;
+    auto issue = [&](int buf) {          // LDS-DMA loads of the K-step the loader state points at, then advance it
+        unsigned char* stage = smem_b + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned char* src = pa[j] != nullptr ? pa[j] + l_cc * 128 : g_zero16;      // 32 channels = 128 twin bytes
+            const unsigned char* src_lo = pa[j] != nullptr ? src + 16 : g_zero16;
+            unsigned char* dst = stage + (wv * 64 + 16 * j) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lo,
+                                             (__attribute__((address_space(3))) void*)(dst + A_PLANE), 16, 0, 0);
+        }
+        const unsigned char* bsrc = bimg + (int64_t)l_ks * (2 * B_PLANE);
+        unsigned char* bdst = stage + 2 * A_PLANE + (wv * 2 * TN) * 1024;
+#pragma unroll
+        for (int c = 0; c < 2 * TN; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + c * 1024),
+                                             (__attribute__((address_space(3))) void*)(bdst + c * 1024), 16, 0, 0);
+        ++l_ks;
+        if (++l_cc == cchunks) {
+            l_cc = 0;
+            if (++l_tap < RS) set_tap(l_tap);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
+    const int aoff = wm * 128 * 64 + foff;
+    const int boff = 2 * A_PLANE + wn * 32 * TN * 64 + foff;
+
+    // Three-stage ring: the loads of K-step ks + 2 are issued at the top of step ks, so an LDS-DMA load has two steps
+    // (~5 k cycles) to land -- one step does not cover an HBM miss.  A wave waits only for its own loads of the NEXT
+    // stage (counted vmcnt: the newest stage's loads stay in flight), then the raw barrier makes every wave's visible.
+    constexpr int kLoadsPerStage = 8 + 2 * TN;
+    auto wait_next = [&](bool newest_in_flight) {
+        if (newest_in_flight) {
+            if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    static_assert(kLoadsPerStage == (TN == 2 ? 12 : 10), "vmcnt literals above");
+    if (loader) {
+        set_tap(0);
+        issue(0);
+        if (ksteps > 1) issue(1);
+        wait_next(ksteps > 1);
+        int nx = 2;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bool ahead = ks + 2 < ksteps;
+            if (ahead) issue(nx);                          // that stage was last read in step ks - 1 (barrier since)
+            wait_next(ahead);
+            nx = nx == 2 ? 0 : nx + 1;
+        }
+        return;                                            // the epilogue's barriers count the surviving waves
+    }
+    __builtin_amdgcn_s_barrier();                          // stage 0 has landed
+    int cur = 0;                                           // stage of step ks
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const unsigned char* Ah = smem_b + cur * STAGE + aoff;
+        const unsigned char* Al = Ah + A_PLANE;
+        const unsigned char* Bh = smem_b + cur * STAGE + boff;
+        const unsigned char* Bl = Bh + B_PLANE;
+        bf16x8_t bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
+            bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
+        }
+        // one wave per SIMD: fragment reads run TWO 16-row tiles ahead of their MFMAs (nobody else hides LDS latency)
+        bf16x8_t fa[MT][2];
+        fa[0][0] = *reinterpret_cast<const bf16x8_t*>(Ah);
+        fa[0][1] = *reinterpret_cast<const bf16x8_t*>(Al);
+        fa[1][0] = *reinterpret_cast<const bf16x8_t*>(Ah + 1024);
+        fa[1][1] = *reinterpret_cast<const bf16x8_t*>(Al + 1024);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 4, 0);
+#pragma unroll
+        for (int i = 0; i < MT; i += 2) {
+            if (i + 2 < MT) {
+                fa[i + 2][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 2) * 1024);
+                fa[i + 2][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 2) * 1024);
+                fa[i + 3][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 3) * 1024);
+                fa[i + 3][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 3) * 1024);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+            // two row tiles at a time: 2 NT independent accumulators between the three MFMAs of one accumulator
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][1], bh[j], acc[i + u][j], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][0], bl[j], acc[i + u][j], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][0], bh[j], acc[i + u][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this step's fragment reads are done before the stage is released
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();                                       // (4 surviving waves) all MFMA waves are out of the ring
+
+    float* stage = reinterpret_cast<float*>(smem_b);
+    constexpr int LDS_LD = BN + 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (m0 + h * 128 >= a.M) break;              // uniform over the block
+        if (h) __syncthreads();
+        if (wm == h) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        stage[(i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 32 * TN + j * 16 + (lane & 15)] = acc[i][j][e];
+        }
+        __syncthreads();
+        drain_stage<2, TN>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward-weight
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -1600,7 +1843,7 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
     DIGA_REQUIRE(((uintptr_t)wgt_hi & 7u) == 0 && ((uintptr_t)wgt_lo & 7u) == 0, DIGA_EALIGN, "conv2d_bf16x3: weight alignment");
     DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d_bf16x3: too many pixels");
     ConvArgs a;
-    a.in = in; a.wgt = nullptr; a.wgt_hi = wgt_hi; a.wgt_lo = wgt_lo; a.bias = bias; a.out = out; a.stats = stats_partial;
+    a.in = in; a.wgt = nullptr; a.wgt_hi = wgt_hi; a.wgt_lo = wgt_lo; a.wgt_img = nullptr; a.bias = bias; a.out = out; a.stats = stats_partial;
     a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.in_ld = (int)in_ld;
     a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.out_ld = (int)out_ld;
     a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
@@ -1661,6 +1904,72 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
         hipLaunchKernelGGL((conv_fwd_x3p_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
     }
     return launch_status("diga_conv2d_nhwc_bf16x3");
+}
+
+// ---- "twin" path: activations and weights pre-split, staged by LDS-DMA (conv_fwd_x3t_kernel)
+static int64_t image_bn(int64_t K) { return K > 64 ? 128 : 64; }
+
+extern "C" int diga_make_twin(const float* x, int64_t ld, void* twin, int64_t M, int64_t C, void* stream) {
+    DIGA_REQUIRE(x && twin && M > 0 && C > 0 && C % 8 == 0 && ld >= C && ld % 4 == 0, DIGA_EINVAL, "make_twin: C must be a multiple of 8");
+    DIGA_REQUIRE(aligned16(x) && aligned16(twin), DIGA_EALIGN, "make_twin: pointers must be 16-byte aligned");
+    int64_t blocks = ceil_div(M * (C / 8), 256);
+    if (blocks > 16384) blocks = 16384;
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, (hipStream_t)stream);
+    hipLaunchKernelGGL(make_twin_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (unsigned char*)twin, M,
+                       (int)(C / 8));
+    return launch_status("diga_make_twin");
+}
+
+extern "C" size_t diga_split_bf16_image_bytes(int64_t K, int64_t RS, int64_t C) {
+    if (K <= 0 || RS <= 0 || C <= 0 || C % 32 != 0) return 0;
+    const int64_t bn = image_bn(K);
+    return (size_t)(ceil_div(K, bn) * RS * (C / 32) * 2 * bn * 64);
+}
+
+extern "C" int diga_split_bf16_image(const float* w, void* img, int64_t K, int64_t RS, int64_t C, void* stream) {
+    DIGA_REQUIRE(w && img && K > 0 && RS > 0 && C > 0 && C % 32 == 0, DIGA_EINVAL, "split_bf16_image: C must be a multiple of 32");
+    DIGA_REQUIRE(aligned16(w) && aligned16(img), DIGA_EALIGN, "split_bf16_image: pointers must be 16-byte aligned");
+    const int64_t bn = image_bn(K);
+    const int64_t total = ceil_div(K, bn) * RS * (C / 32) * bn * 4;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, (int)K,
+                       (int)RS, (int)C, (int)bn, total);
+    return launch_status("diga_split_bf16_image");
+}
+
+extern "C" int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, const float* bias, float* out, int64_t N,
+                                     int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld,
+                                     int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
+                                     int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream) {
+    DIGA_REQUIRE(in_twin && wgt_img && out, DIGA_EINVAL, "conv2d_twin: null pointer");
+    DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_twin: bad shape");
+    DIGA_REQUIRE(Cin > 0 && Cin % 32 == 0 && out_ld >= Cout, DIGA_EINVAL, "conv2d_twin: Cin must be a multiple of 32");
+    DIGA_REQUIRE(aligned16(in_twin) && aligned16(wgt_img) && ((uintptr_t)out & 3u) == 0, DIGA_EALIGN, "conv2d_twin: alignment");
+    DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d_twin: too many pixels");
+    ConvArgs a;
+    a.in = reinterpret_cast<const float*>(in_twin); a.wgt = nullptr; a.wgt_hi = nullptr; a.wgt_lo = nullptr;
+    a.wgt_img = reinterpret_cast<const unsigned char*>(wgt_img); a.bias = bias; a.out = out; a.stats = stats_partial;
+    a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.in_ld = (int)Cin;
+    a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.out_ld = (int)out_ld;
+    a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
+    a.oy0 = (int)off_y0; a.ox0 = (int)off_x0; a.ody = (int)off_dy; a.odx = (int)off_dx;
+    a.M = (int)(N * Ho * Wo);
+    a.tiles_m = (int)ceil_div(a.M, 256);
+    a.all_inside = 0;
+    const int tn = Cout > 64 ? 2 : 1;
+    a.tiles_n = (int)ceil_div(Cout, 64 * tn);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
+    const size_t sh = (size_t)3 * (2 * 256 * 64 + 2 * 64 * tn * 64);
+    if (tn == 2) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_x3t_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((conv_fwd_x3t_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), sh, st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_x3t_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((conv_fwd_x3t_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), sh, st, a);
+    }
+    return launch_status("diga_conv2d_nhwc_twin");
 }
 
 extern "C" size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout) {

@@ -35,12 +35,39 @@ def _pad_last(t, c_to):
     return out
 
 
-def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None):
+def _use_twin(cin, k, taps, shared):
+    """The staging-free kernel (both operands pre-split, LDS-DMA) needs one extra pass over the activations to build
+    their split twin (read 4 B + write 4 B per element).  That pays when the tensor is read by many tiles: convs with
+    more than one tap, or several convs on one input (`shared`, the ASPP branches).  DIGA_CONV_TWIN=0 switches the
+    path off, =1 forces it for every eligible conv."""
+    mode = os.environ.get("DIGA_CONV_TWIN", "3")
+    if mode == "0" or cin % 32 != 0 or k <= 64:
+        return False
+    return mode == "1" or taps > 1 or shared
+
+
+def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
-    out [N,Ho,Wo,K] (same rule)."""
+    out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x."""
     n, hi, wi, cin = x.shape
     _, ho, wo, k = out.shape
     _, r, s, _ = w_krsc.shape
+    if (_lib.lib.diga_get_conv_math() == 1 and _use_twin(cin, k, r * s, twin_box is not None)
+            and n * hi * wi * cin * 4 < (1 << 40)):
+        # split-bf16 arithmetic without register staging: both operands pre-split, copied global -> LDS by LDS-DMA
+        twin = twin_box[0] if twin_box is not None else None
+        if twin is None:
+            xc = x if x.is_contiguous() else x.contiguous()
+            twin = torch.empty(n * hi * wi * cin * 4, dtype=torch.uint8, device=x.device)
+            _lib.call("diga_make_twin", _lib.ptr(xc), cin, _lib.ptr(twin), n * hi * wi, cin, _lib.stream())
+            if twin_box is not None:
+                twin_box[0] = twin
+        img = torch.empty(_lib.lib.diga_split_bf16_image_bytes(k, r * s, cin), dtype=torch.uint8, device=x.device)
+        _lib.call("diga_split_bf16_image", _lib.ptr(w_krsc), _lib.ptr(img), k, r * s, cin, _lib.stream())
+        _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin, ho, wo, k,
+                  out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], _lib.ptr(stats), tag,
+                  _lib.stream())
+        return
     if _lib.lib.diga_get_conv_math() == 1:
         # split-bf16 arithmetic: the weights are split once here (two bf16 arrays), the activations inside the kernel
         nel = w_krsc.numel()
@@ -61,7 +88,7 @@ class _StemConvFn(torch.autograd.Function):
     floats, then a 1x1 conv on the GEMM kernels.  No gradient wrt the input (it is the image)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None):
         _lib.require_gpu(x, weight)
         xc = x.detach().float().contiguous()                      # NCHW
         n, c, h, w_ = xc.shape
@@ -104,12 +131,12 @@ class _StemConvFn(torch.autograd.Function):
             dw.copy_(dwp[:k, 0, 0, :kk].reshape(k, r, s, c).permute(0, 3, 1, 2))
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return None, dw, db, None, None, None, None, None
+        return None, dw, db, None, None, None, None, None, None
 
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         xn = x.detach().permute(0, 2, 3, 1)
@@ -127,7 +154,7 @@ class _Conv2dFn(torch.autograd.Function):
         wo = (wi + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
-        _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats)
+        _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box)
         ctx.save_for_backward(xn, w)
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         ctx.uses = uses
@@ -201,7 +228,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -213,6 +240,7 @@ class DigaConv2d(nn.Conv2d):
             raise NotImplementedError("DigaConv2d: groups=1 and zero padding only")
         self.emit_bn_stats = False      # set by the model on convs that feed a train-mode BatchNorm
         self._bw_seen = [0]
+        self.share_twin = False         # set by the model on convs that share their input with other convs (ASPP branches)
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def _apply(self, fn, *a, **k):
@@ -238,7 +266,13 @@ class DigaConv2d(nn.Conv2d):
             if self._bw_seen[0] > 0:          # a backward pass has consumed the previous graph(s)
                 self._bw_seen[0] = 0
             uses = self._bw_seen              # [weight-gradient calls of the current backward pass]
-        y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses)
+        twin_box = None
+        if self.share_twin:                   # several convs read this very tensor: the first one builds its split twin
+            twin_box = getattr(x, "_diga_twin_box", None)
+            if twin_box is None:
+                twin_box = x._diga_twin_box = [None]
+        y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
+                     twin_box)
         if stats is not None:
             y._diga_bn_partials = (stats, 128)       # picked up by the DigaBatchNorm2d that consumes y
         return y

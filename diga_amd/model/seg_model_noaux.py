@@ -101,6 +101,8 @@ class Classifier_Module2(nn.Module):
 
         self.conv2d_list = nn.ModuleList([branch(1, 1, 0)] +
                                          [branch(3, d, p) for d, p in zip(dilation_series, padding_series)])
+        for seq in self.conv2d_list:
+            seq[0].share_twin = True               # the five branches read the same tensor: one split twin serves all
         cat = width * (len(dilation_series) + 1)
         tail = [DigaConv2d(cat, width, 3, stride=1, padding=1, bias=True), dn.DigaGroupNorm(groups, width)]
         self.bottleneck = nn.Sequential(*([SEBlock(cat, se_reduction)] if use_se else []), *tail)

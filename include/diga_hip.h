@@ -245,6 +245,22 @@ int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, const uint1
                             int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
                             int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream);
 
+/* The same convolution with BOTH operands pre-split and staged global -> LDS by LDS-DMA loads (no registers, no split
+ * arithmetic, no ds_write in the kernel; two-stage LDS ring, one barrier per K-step):
+ *   in_twin  = diga_make_twin of the [N,Hi,Wi,Cin] fp32 activations: per pixel and group of 8 channels 16 B of bf16 hi
+ *              + 16 B of bf16 lo (4*Cin bytes per pixel, dense);
+ *   wgt_img  = diga_split_bf16_image of the [Cout][R][S][Cin] weights (diga_split_bf16_image_bytes bytes): the hi / lo
+ *              LDS images of every (output-channel tile, K-step).
+ * Cin % 32 == 0.  Pays when the activation tensor is read by many tiles (3x3 taps, wide Cout, several convs on one
+ * input): the twin costs one extra pass (read 4 B + write 4 B per element). */
+int diga_make_twin(const float* x, int64_t ld, void* twin, int64_t M, int64_t C, void* stream);
+size_t diga_split_bf16_image_bytes(int64_t Cout, int64_t RS, int64_t Cin);
+int diga_split_bf16_image(const float* w, void* img, int64_t Cout, int64_t RS, int64_t Cin, void* stream);
+int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, const float* bias, float* out, int64_t N, int64_t Hi,
+                          int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                          int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
+                          float* stats_partial, int prof_tag, void* stream);
+
 /* dw[k][r][s][c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride_y + off_y0 + r*off_dy, wo*stride_x + off_x0 + s*off_dx, c]
  * Split over pixel ranges into fp32 slabs in `workspace`, summed in fixed order (deterministic).
  * Cin % 4 == 0, Cout % 4 == 0. */
