@@ -246,14 +246,18 @@ def rooflines(a, precision, families, steps, counts, geom):
         flops_step = imgs_fwd * fwd_gflop * 1e9
         n_launch = fam["launches"] / steps
         ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
-        kname = "conv_fwd_kernel" if precision == "f32" else "conv_fwd_x3w_kernel"
+        kname = "conv_fwd_kernel" if precision == "f32" else "conv_fwd_x3w_kernel + conv_fwd_x3t_kernel"
         traffic = None
         if pmc and (B, H, W) == (8, 768, 768):
-            # the 128-column instantiation carries > 95 % of the family's time
-            ent = [v for k, v in pmc.items() if k.startswith(f"diga::{kname}<2")]
-            traffic = ent[0]["hbm_bytes_per_launch_corrected"] if ent else None
+            # launch-weighted mean over the family's kernels (the 128-column instantiations carry > 95 % of its time;
+            # the same kernels also serve backward-data, whose launches are in the PMC averages)
+            names = ("diga::conv_fwd_kernel<2",) if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t_kernel<2")
+            ent = [v for k, v in pmc.items() if k.startswith(names)]
+            nl = sum(v["launches"] for v in ent)
+            traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ent) / nl if nl else None
         roof = {"kernel": f"{kname} (implicit-GEMM convolution on the "
-                          f"{'fp32' if precision == 'f32' else 'bf16'} matrix cores; all forward-conv launches of a step)",
+                          f"{'fp32' if precision == 'f32' else 'bf16'} matrix cores; all forward-conv launches of a step"
+                          f"{'' if precision == 'f32' else ', split-twin conversions of their inputs counted in elementwise'})",
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "algorithmic_flops_per_launch": flops_step / n_launch, "avg_launch_ms": fam["avg_ms"],
                 "launches_per_step": n_launch}

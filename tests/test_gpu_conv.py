@@ -200,3 +200,31 @@ def test_conv_epilogue_bn_statistics(case, math):
     cnt = yd.numel() // cout
     assert_close(bn_a.running_mean.cpu(), 0.1 * mean, rtol=1e-5, atol=1e-6, what="running_mean")
     assert_close(bn_a.running_var.cpu(), 0.9 + 0.1 * var * cnt / (cnt - 1), rtol=1e-5, atol=1e-6, what="running_var")
+
+
+def test_twin_path_matches_register_staged_path_and_is_shared(bf16x3, monkeypatch):
+    """The staging-free kernel (pre-split twin + LDS-DMA) computes bit-for-bit what the register-staged kernel does
+    (same split, same MFMA order), and convs flagged `share_twin` build the twin of a common input once."""
+    from diga_amd import _lib
+    from diga_amd.model.conv import DigaConv2d
+    g = synth.gen(77)
+    x = torch.randn((2, 256, 33, 35), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    convs = [DigaConv2d(256, 160, 3, padding=d, dilation=d, bias=True).to(DEV) for d in (1, 6)] + \
+            [DigaConv2d(256, 128, 1, bias=False).to(DEV)]
+    with torch.no_grad():
+        monkeypatch.setenv("DIGA_CONV_TWIN", "0")
+        ref = [c(x) for c in convs]
+        monkeypatch.setenv("DIGA_CONV_TWIN", "3")
+        calls = []
+        orig = _lib.call
+
+        def counting(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+        monkeypatch.setattr(_lib, "call", counting)
+        for c in convs:
+            c.share_twin = True
+        got = [c(x) for c in convs]
+    assert calls.count("diga_make_twin") == 1 and calls.count("diga_conv2d_nhwc_twin") == 3
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
