@@ -228,3 +228,23 @@ def test_twin_path_matches_register_staged_path_and_is_shared(bf16x3, monkeypatc
     assert calls.count("diga_make_twin") == 1 and calls.count("diga_conv2d_nhwc_twin") == 3
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+def test_split_formats_byte_exact():
+    """The pre-split operand formats (activation twin, weight LDS images) against their numpy restatement: byte exact,
+    including values that round up across a bf16 exponent boundary, denormal-sized residuals and negative zero."""
+    import numpy as np
+    from diga_amd import _lib
+    from oracle import split as osp
+    g = synth.gen(123)
+    x = torch.randn((37, 64), generator=g) * torch.logspace(-6, 4, 64)[None, :]
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.00390625, 0.99609375, 3.3895314e38, 1e-30])
+    xd = x.to(DEV)
+    tw = torch.empty(x.numel() * 4, dtype=torch.uint8, device=DEV)
+    _lib.call("diga_make_twin", _lib.ptr(xd), 64, _lib.ptr(tw), 37, 64, _lib.stream())
+    assert np.array_equal(tw.cpu().numpy(), osp.twin(x.numpy()))
+    for k in (19 * 4, 160):                                   # one 128-row tile with padding rows / two tiles
+        w = torch.randn((k, 9, 64), generator=g) * 0.05
+        img = torch.empty(_lib.lib.diga_split_bf16_image_bytes(k, 9, 64), dtype=torch.uint8, device=DEV)
+        _lib.call("diga_split_bf16_image", _lib.ptr(w.to(DEV)), _lib.ptr(img), k, 9, 64, _lib.stream())
+        assert np.array_equal(img.cpu().numpy(), osp.weight_image(w.numpy()))

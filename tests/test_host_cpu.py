@@ -238,3 +238,20 @@ def test_ddp_single_process_is_noop():
     s, c = torch.ones(1, 19, 4), torch.ones(1, 19, dtype=torch.int32)
     assert ddp.gather_class_sums(s, c)[0] is s
     assert ddp.world_size() == 1 and ddp.rank() == 0
+
+
+def test_split_format_restatement_against_torch_bf16():
+    """oracle/split.py (the byte formats of the split-bf16 conv operands): its round-to-nearest-even equals torch's
+    bfloat16 cast, hi + lo reproduces x to 2^-16 relative, and the layouts have the documented sizes."""
+    from oracle import split as osp
+    g = synth.gen(31)
+    x = torch.randn((9, 32), generator=g) * torch.logspace(-5, 5, 32)[None, :]
+    hi, lo = osp.split(x.numpy())
+    assert np.array_equal(hi, x.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16))
+    rec = osp.bf16_to_f32(hi) + osp.bf16_to_f32(lo)
+    assert float(np.abs(rec - x.numpy()).max() / np.abs(x.numpy()).max()) < 2.0 ** -16
+    assert np.all(np.abs(rec - x.numpy()) <= np.abs(x.numpy()) * 2.0 ** -16 + 1e-38)
+    assert osp.twin(x.numpy()).size == x.numel() * 4
+    w = torch.randn((70, 3, 64), generator=g).numpy()
+    assert osp.weight_image(w).size == 1 * 3 * 2 * 2 * 128 * 64          # 1 tile (128 rows), 3 taps x 2 chunks, 2 planes
+    assert [osp.lds_swz(r) for r in range(16)] == [0, 0, 2, 2, 2, 2, 0, 0, 3, 3, 1, 1, 1, 1, 3, 3]
