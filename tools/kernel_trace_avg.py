@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Per-kernel launch count / average / minimum duration of a rocprofv3 --kernel-trace CSV:  python tools/kernel_trace_avg.py <dir>"""
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
 agg = collections.defaultdict(list)

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Per-kernel mean of every counter in the *counter_collection.csv files of a rocprofv3 --pmc run:  python tools/pmc_sum.py <dir>"""
 import csv, glob, sys, collections
 d = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
