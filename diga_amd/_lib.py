@@ -62,6 +62,8 @@ SIGNATURES = {
     "diga_get_conv_math": (INT, []),
     "diga_conv2d_wgrad_workspace_bytes": (SZ, [I64] * 7),
     "diga_conv2d_wgrad_nhwc_f32": (INT, [P, P, P, P, SZ] + [I64] * 17 + [P]),
+    "diga_conv2d_wgrad_twin_workspace_bytes": (SZ, [I64] * 7),
+    "diga_conv2d_wgrad_twin": (INT, [P, P, P, P, SZ] + [I64] * 15 + [P]),
     "diga_weight_transpose": (INT, [P, P, I64, I64, I64, P]),
     "diga_im2col_nchw": (INT, [P, P] + [I64] * 11 + [P]),
     "diga_norm_workspace_bytes": (SZ, [I64, I64, I64]),

@@ -1713,6 +1713,181 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3w_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward-weight on the split twins (multi-tap layers): both operands pre-split ([pixel][8-channel group][hi8 | lo8]
+// twins of dy and of x), staged global -> LDS by LDS-DMA loads into a three-stage ring by four loader waves while four
+// MFMA waves compute -- the structure of conv_fwd_x3t_kernel.  The contraction index is the pixel and the twins are
+// pixel-major, so the LDS image is [32 pixels][channels] per plane and the MFMA fragments (8 consecutive pixels of one
+// channel per lane) are read with the transposing ds_read_b64_tr_b16: per 16-lane group a block of 4 pixel rows x 16
+// channels, lane i receiving channel i of the 4 rows (tools/experiments/tr_read_probe.hip), two reads per fragment.
+// 16-byte chunks (8 channels) of pixel row r are stored at chunk ^ (key(r) << 1), key = (r & 3) | ((r >> 3) & 1) << 2,
+// so that the 8 rows a 32-lane half touches fall on 8 different 32-byte positions of the 256-byte bank row; with
+// LDS-DMA the permutation is applied to the source address.  256 (Cout) x 128 (Cin) tile per (tap, pixel range).
+// ---------------------------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int tr_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(512, 1) void conv_wgrad_x3t_kernel(WgradArgs a) {
+    constexpr int BM = 256, BN = 128, MT = 8, NT = 4;
+    constexpr int A_ROW = BM * 2, B_ROW = BN * 2;                       // bytes per pixel row and plane
+    constexpr int A_PLANE = kBK * A_ROW, B_PLANE = kBK * B_ROW, STAGE = 2 * A_PLANE + 2 * B_PLANE;   // 48 KB
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int t = threadIdx.x & 255, lane = t & 63, wv = t >> 6;
+    const bool loader = threadIdx.x >= 256;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int RS = a.R * a.S;
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n;
+    wg /= a.tiles_n;
+    const int tile_m = wg % a.tiles_m;
+    wg /= a.tiles_m;
+    const int tap = wg % RS;
+    const int split = wg / RS;
+    const int k0 = tile_m * BM, c0 = tile_n * BN;
+    const int p_begin = split * a.steps_per_split * kBK;
+    int p_end = p_begin + a.steps_per_split * kBK;
+    if (p_end > a.M) p_end = a.M;
+    const int ksteps = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
+
+    if (loader) {
+        const unsigned char* dyt = reinterpret_cast<const unsigned char*>(a.dy);
+        const unsigned char* xt = reinterpret_cast<const unsigned char*>(a.x);
+        const int64_t dy_rowb = (int64_t)a.Cout * 4, x_rowb = (int64_t)a.Cin * 4;
+        const int* tab = a.ptab + (int64_t)tap * a.M_pad;
+        // A (dy): 32 rows x 32 chunks per plane = 16 LDS-DMA instructions, 4 per wave: instruction j of wave wv covers
+        //         rows 8 wv + 2 j + (lane >> 5), destination chunk lane & 31.   B (x): 32 rows x 16 chunks = 8
+        //         instructions per plane, 2 per wave: rows 8 wv + 4 j + (lane >> 4), destination chunk lane & 15.
+        const int a_chunk_dst = lane & 31, b_chunk_dst = lane & 15;
+        const int kgrp = k0 / 8, cgrp = c0 / 8, kmax = a.Cout / 8 - 1, cmax = a.Cin / 8 - 1;
+        int bidx[2];                       // x-pixel indices of this lane's two B rows for the step being issued
+        auto load_idx = [&](int ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = p_begin + ks * kBK + 8 * wv + 4 * j + (lane >> 4);
+                bidx[j] = p < p_end ? tab[p] : -1;
+            }
+        };
+        auto issue = [&](int ks, int stg) {
+            unsigned char* stage = smem_b + stg * STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 8 * wv + 2 * j + (lane >> 5);
+                const int p = min(p_begin + ks * kBK + row, a.M - 1);
+                const int chunk = min(kgrp + (a_chunk_dst ^ (tr_key(row) << 1)), kmax);
+                const unsigned char* src = dyt + p * dy_rowb + (int64_t)chunk * 32;
+                unsigned char* dst = stage + (8 * wv + 2 * j) * A_ROW;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + A_PLANE), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 8 * wv + 4 * j + (lane >> 4);
+                const int chunk = min(cgrp + (b_chunk_dst ^ (tr_key(row) << 1)), cmax);
+                const unsigned char* src = bidx[j] >= 0 ? xt + bidx[j] * x_rowb + (int64_t)chunk * 32 : g_zero16;
+                const unsigned char* src_lo = bidx[j] >= 0 ? src + 16 : g_zero16;
+                unsigned char* dst = stage + 2 * A_PLANE + (8 * wv + 4 * j) * B_ROW;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lo,
+                                                 (__attribute__((address_space(3))) void*)(dst + B_PLANE), 16, 0, 0);
+            }
+        };
+        auto wait_next = [&](bool newest_in_flight) {      // 12 LDS-DMA loads per stage and wave
+            if (newest_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        if (ksteps > 0) {
+            load_idx(0);
+            issue(0, 0);
+            if (ksteps > 1) {
+                load_idx(1);
+                issue(1, 1);
+            }
+        }
+        wait_next(ksteps > 1);
+        int nx = 2;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bool ahead = ks + 2 < ksteps;
+            if (ahead) {
+                load_idx(ks + 2);
+                issue(ks + 2, nx);
+            }
+            wait_next(ahead);
+            nx = nx == 2 ? 0 : nx + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- MFMA waves
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // transposing read of this lane: group g = lane >> 4 takes pixel rows 8 g + q (+ 4 for the second read), q = (lane & 15) >> 2,
+    // channels 16 tile + 4 p, p = lane & 3: chunk = 2 tile + (p >> 1) (swizzled), byte (p & 1) * 8 inside the chunk
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int row0 = 8 * g + q, row1 = row0 + 4;
+    const int key0 = tr_key(row0) << 1, key1 = tr_key(row1) << 1;
+    auto a_off = [&](int tile, int row, int key) { return row * A_ROW + (((2 * (wm * 8 + tile) + (pp >> 1)) ^ key) << 4) + ((pp & 1) << 3); };
+    auto b_off = [&](int tile, int row, int key) { return row * B_ROW + (((2 * (wn * 4 + tile) + (pp >> 1)) ^ key) << 4) + ((pp & 1) << 3); };
+
+    __builtin_amdgcn_s_barrier();                          // stage 0 has landed
+    int cur = 0;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const unsigned char* Ah = smem_b + cur * STAGE;
+        const unsigned char* Al = Ah + A_PLANE;
+        const unsigned char* Bh = Ah + 2 * A_PLANE;
+        const unsigned char* Bl = Bh + B_PLANE;
+        bf16x8_t bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = tr_frag(Bh + b_off(j, row0, key0), Bh + b_off(j, row1, key1));
+            bl[j] = tr_frag(Bl + b_off(j, row0, key0), Bl + b_off(j, row1, key1));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const bf16x8_t ah = tr_frag(Ah + a_off(i, row0, key0), Ah + a_off(i, row1, key1));
+            const bf16x8_t al = tr_frag(Al + a_off(i, row0, key0), Al + a_off(i, row1, key1));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+
+    float* out = a.slab + (int64_t)split * a.Cout * RS * a.Cin;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int c = c0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = k0 + wm * 128 + i * 16 + (lane >> 4) * 4 + e;
+                if (kk < a.Cout && c < a.Cin) out[((int64_t)kk * RS + tap) * a.Cin + c] = acc[i][j][e];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                           int64_t n4, int splits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -2105,6 +2280,84 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
                            n4, p.splits);
     }
     return launch_status("diga_conv2d_wgrad_nhwc_f32");
+}
+
+// ---- backward-weight on the split twins (conv_wgrad_x3t_kernel)
+namespace {
+WgradPlan plan_wgrad_twin(int64_t M, int64_t Cout, int64_t Cin, int64_t RS) {
+    WgradPlan p;
+    p.tm = 4;
+    p.tn = 2;
+    p.tiles_m = (int)ceil_div(Cout, 256);
+    p.tiles_n = (int)ceil_div(Cin, 128);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * RS, ksteps = ceil_div(M, kBK);
+    // one block per CU: pick the split count whose grid fills whole rounds of 256 blocks best (>= 16 K-steps per block)
+    int64_t best = 1;
+    double best_eff = 0.0;
+    for (int64_t rounds = 1; rounds <= 4; ++rounds) {
+        int64_t sp = 256 * rounds / tiles;
+        if (sp < 1) sp = 1;
+        if (ksteps / sp < 16) continue;
+        const int64_t blocks = tiles * sp;
+        const double eff = (double)blocks / (256.0 * (double)ceil_div(blocks, 256));
+        if (eff > best_eff + 0.02) {
+            best_eff = eff;
+            best = sp;
+        }
+    }
+    p.steps_per_split = (int)ceil_div(ksteps, best);
+    p.splits = (int)ceil_div(ksteps, p.steps_per_split);
+    return p;
+}
+}  // namespace
+
+extern "C" size_t diga_conv2d_wgrad_twin_workspace_bytes(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout, int64_t Cin,
+                                                         int64_t R, int64_t S) {
+    const int64_t M = N * Ho * Wo, RS = R * S;
+    return wgrad_slab_bytes(plan_wgrad_twin(M, Cout, Cin, RS), Cout, Cin, RS) + (size_t)RS * wgrad_mpad(M) * sizeof(int) + 64;
+}
+
+extern "C" int diga_conv2d_wgrad_twin(const void* dy_twin, const void* x_twin, float* dw, void* workspace,
+                                      size_t workspace_bytes, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho,
+                                      int64_t Wo, int64_t Cout, int64_t R, int64_t S, int64_t stride_y, int64_t stride_x,
+                                      int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx, void* stream) {
+    DIGA_REQUIRE(dy_twin && x_twin && dw && workspace, DIGA_EINVAL, "conv2d_wgrad_twin: null pointer");
+    DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_wgrad_twin: bad shape");
+    DIGA_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0, DIGA_EINVAL, "conv2d_wgrad_twin: channel counts must be multiples of 8");
+    DIGA_REQUIRE(aligned16(dy_twin) && aligned16(x_twin) && aligned16(dw) && aligned16(workspace), DIGA_EALIGN, "conv2d_wgrad_twin: alignment");
+    DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d_wgrad_twin: too many pixels");
+    const int64_t RS = R * S, M = N * Ho * Wo, M_pad = wgrad_mpad(M);
+    const WgradPlan p = plan_wgrad_twin(M, Cout, Cin, RS);
+    const size_t slab_bytes = wgrad_slab_bytes(p, Cout, Cin, RS);
+    DIGA_REQUIRE(workspace_bytes >= slab_bytes + (size_t)RS * M_pad * sizeof(int) + 64, DIGA_EWORKSPACE, "conv2d_wgrad_twin: workspace too small");
+    WgradArgs a;
+    a.dy = reinterpret_cast<const float*>(dy_twin); a.x = reinterpret_cast<const float*>(x_twin);
+    a.slab = p.splits > 1 ? (float*)workspace : dw;
+    a.N = (int)N; a.Hi = (int)Hi; a.Wi = (int)Wi; a.Cin = (int)Cin; a.x_ld = (int)Cin;
+    a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cout = (int)Cout; a.dy_ld = (int)Cout;
+    a.R = (int)R; a.S = (int)S; a.sy = (int)stride_y; a.sx = (int)stride_x;
+    a.oy0 = (int)off_y0; a.ox0 = (int)off_x0; a.ody = (int)off_dy; a.odx = (int)off_dx;
+    a.M = (int)M; a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.splits = p.splits; a.steps_per_split = p.steps_per_split;
+    a.M_pad = (int)M_pad;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st);
+    int* tab = reinterpret_cast<int*>(static_cast<char*>(workspace) + slab_bytes);
+    float* zeros = reinterpret_cast<float*>(tab + RS * M_pad);
+    hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3((unsigned)ceil_div(M_pad, 256), (unsigned)RS), dim3(256), 0, st, tab, zeros, (int)M,
+                       (int)M_pad, (int)Ho, (int)Wo, (int)Hi, (int)Wi, (int)S, (int)stride_y, (int)stride_x, (int)off_y0, (int)off_x0,
+                       (int)off_dy, (int)off_dx);
+    a.ptab = tab;
+    a.zeros = zeros;
+    const unsigned grid = (unsigned)((int64_t)p.tiles_m * p.tiles_n * RS * p.splits);
+    const size_t sh = (size_t)3 * (2 * kBK * 512 + 2 * kBK * 256);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_x3t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(conv_wgrad_x3t_kernel, dim3(grid), dim3(512), sh, st, a);
+    if (p.splits > 1) {
+        const int64_t n4 = Cout * RS * Cin / 4;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw, n4,
+                           p.splits);
+    }
+    return launch_status("diga_conv2d_wgrad_twin");
 }
 
 extern "C" int diga_weight_transpose(const float* w, float* wt, int64_t K, int64_t RS, int64_t C, void* stream) {

@@ -67,7 +67,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin, ho, wo, k,
                   out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], _lib.ptr(stats), tag,
                   _lib.stream())
-        return
+        return twin
     if _lib.lib.diga_get_conv_math() == 1:
         # split-bf16 arithmetic: the weights are split once here (two bf16 arrays), the activations inside the kernel
         nel = w_krsc.numel()
@@ -77,7 +77,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         _lib.call("diga_conv2d_nhwc_bf16x3", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(bias), _lib.ptr(out),
                   n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                   doff[0], doff[1], _lib.ptr(stats), tag, _lib.stream())
-        return
+        return None
     _lib.call("diga_conv2d_nhwc_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin,
               x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
               _lib.ptr(stats), tag, _lib.stream())
@@ -154,8 +154,10 @@ class _Conv2dFn(torch.autograd.Function):
         wo = (wi + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
-        _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box)
+        x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box)
         ctx.save_for_backward(xn, w)
+        # the split twin of the input serves the weight gradient too (multi-tap / shared-input layers, Cout >= 256)
+        ctx.x_twin = x_twin if (ctx.needs_input_grad[1] and k >= 256 and k % 8 == 0 and cp == c) else None
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         ctx.uses = uses
         return out.permute(0, 3, 1, 2)
@@ -174,6 +176,9 @@ class _Conv2dFn(torch.autograd.Function):
         gyp = _pad_last(gy, kp)
         dx = dw = db = None
         st = _lib.stream()
+        x_twin = getattr(ctx, "x_twin", None)
+        use_tw = x_twin is not None and ctx.needs_input_grad[1] and _lib.lib.diga_get_conv_math() == 1 and kp == k
+        dy_box = [None] if use_tw else None            # the twin of dy: built once, read by backward-data and -weight
         if ctx.needs_input_grad[0]:
             # backward-data = stride-1 correlation of dy with the [C][R][S][K] transpose, tap offsets negated
             if kp == k:
@@ -185,7 +190,7 @@ class _Conv2dFn(torch.autograd.Function):
             if stride == (1, 1):
                 dxn = torch.empty((n, hi, wi, cp), dtype=torch.float32, device=w.device)
                 _conv_launch(gyp, wt, None, dxn, (1, 1), (padding[0], padding[1]), (-dilation[0], -dilation[1]),
-                             _TAG_BWD_DATA)
+                             _TAG_BWD_DATA, None, dy_box if (use_tw and cp > 64) else None)
             else:
                 if (r, s) != (1, 1) or padding != (0, 0):
                     raise NotImplementedError("backward-data of strided convs is only needed (and built) for 1x1")
@@ -198,7 +203,24 @@ class _Conv2dFn(torch.autograd.Function):
             dwp = torch.empty((kp, r, s, cp), dtype=torch.float32, device=w.device)
             dw = torch.empty_strided((k, c_true, r, s), w_strides, dtype=torch.float32, device=w.device)
 
+            dy_twin = None
+            if use_tw:
+                dy_twin = dy_box[0]
+                if dy_twin is None:                 # backward-data did not build it (no input gradient, strided, narrow)
+                    dy_twin = torch.empty(n * ho * wo * kp * 4, dtype=torch.uint8, device=w.device)
+                    _lib.call("diga_make_twin", _lib.ptr(gyp), kp, _lib.ptr(dy_twin), n * ho * wo, kp, st)
+
+            def run_twin():
+                nbytes = _lib.lib.diga_conv2d_wgrad_twin_workspace_bytes(n, ho, wo, kp, cp, r, s)
+                ws = _lib.workspace(nbytes, w.device, "wgrad")
+                _lib.call("diga_conv2d_wgrad_twin", _lib.ptr(dy_twin), _lib.ptr(x_twin), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
+                          n, hi, wi, cp, ho, wo, kp, r, s, stride[0], stride[1], -padding[0], -padding[1], dilation[0],
+                          dilation[1], _lib.stream())
+                dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
+
             def run():
+                if use_tw:
+                    return run_twin()
                 nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, cp, r, s)
                 ws = _lib.workspace(nbytes, w.device, "wgrad")
                 _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
@@ -224,7 +246,7 @@ class _Conv2dFn(torch.autograd.Function):
                 side.wait_stream(torch.cuda.current_stream(w.device))
                 with torch.cuda.stream(side):
                     run()
-                for tns in (gyp, xn, dwp, dw):
+                for tns in (gyp, xn, dwp, dw) + ((dy_twin, x_twin) if use_tw else ()):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))

@@ -272,6 +272,15 @@ int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float* dw, void*
                                int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
                                int64_t off_dy, int64_t off_dx, void* stream);
 
+/* Backward-weight of the same convolution on the split twins (diga_make_twin of dy [N,Ho,Wo,Cout] and of x
+ * [N,Hi,Wi,Cin], both dense): operands staged by LDS-DMA, fragments read with transposing LDS reads.  dw [Cout][R][S][Cin].
+ * Pays where the twins exist anyway (multi-tap layers: x twin from the forward pass, dy twin from backward-data). */
+size_t diga_conv2d_wgrad_twin_workspace_bytes(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout, int64_t Cin, int64_t R, int64_t S);
+int diga_conv2d_wgrad_twin(const void* dy_twin, const void* x_twin, float* dw, void* workspace, size_t workspace_bytes,
+                           int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t R,
+                           int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
+                           int64_t off_dx, void* stream);
+
 /* Stem (7x7/2 on the 3-channel NCHW image, G5/model/seg_model_noaux.py:221): out[n,ho,wo][(r*S+s)*C + c] =
  * x[n,c,ho*stride-pad+r,wo*stride-pad+s] (zero outside / beyond R*S*C up to Kpad), after which the conv is a
  * 1x1 conv with Cin = Kpad on the kernels above. */

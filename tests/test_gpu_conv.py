@@ -248,3 +248,32 @@ def test_split_formats_byte_exact():
         img = torch.empty(_lib.lib.diga_split_bf16_image_bytes(k, 9, 64), dtype=torch.uint8, device=DEV)
         _lib.call("diga_split_bf16_image", _lib.ptr(w.to(DEV)), _lib.ptr(img), k, 9, 64, _lib.stream())
         assert np.array_equal(img.cpu().numpy(), osp.weight_image(w.numpy()))
+
+
+@pytest.mark.parametrize("geom", [(2, 64, 96, 33, 35, 3, 2), (1, 256, 320, 19, 23, 3, 1), (3, 128, 256, 40, 40, 1, 1),
+                                  (2, 96, 264, 17, 17, 3, 6)], ids=["3x3d2", "ragged_cout", "1x1", "dil6_outside"])
+def test_wgrad_on_twins_vs_float64(geom, bf16x3):
+    """Backward-weight from the split twins (LDS-DMA staging, transposing LDS reads) against a float64 reference."""
+    from diga_amd import _lib
+    n, cin, cout, h, w, k, dil = geom
+    g = synth.gen(sum(geom))
+    pad = dil * (k // 2)
+    x = torch.randn((n, h, w, cin), generator=g)
+    dy = torch.randn((n, h, w, cout), generator=g)
+    xr = x.permute(0, 3, 1, 2).double()
+    wr = torch.zeros((cout, cin, k, k), dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xr, wr, None, 1, pad, dil) * dy.permute(0, 3, 1, 2).double()).sum().backward()
+    want = wr.grad.permute(0, 2, 3, 1).contiguous()                      # [K][R][S][C]
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    m = n * h * w
+    xt = torch.empty(m * cin * 4, dtype=torch.uint8, device=DEV)
+    dyt = torch.empty(m * cout * 4, dtype=torch.uint8, device=DEV)
+    _lib.call("diga_make_twin", _lib.ptr(xd), cin, _lib.ptr(xt), m, cin, _lib.stream())
+    _lib.call("diga_make_twin", _lib.ptr(dyd), cout, _lib.ptr(dyt), m, cout, _lib.stream())
+    dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=DEV)
+    ws = torch.empty(_lib.lib.diga_conv2d_wgrad_twin_workspace_bytes(n, h, w, cout, cin, k, k), dtype=torch.uint8, device=DEV)
+    for _ in range(2):
+        _lib.call("diga_conv2d_wgrad_twin", _lib.ptr(dyt), _lib.ptr(xt), _lib.ptr(dw), _lib.ptr(ws), ws.numel(), n, h, w, cin, h, w,
+                  cout, k, k, 1, 1, -pad, -pad, dil, dil, _lib.stream())
+    scale = float(want.abs().max())
+    assert_close(dw.cpu(), want, rtol=0.0, atol=5e-5 * scale, what="dw from twins")
