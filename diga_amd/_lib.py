@@ -67,9 +67,9 @@ SIGNATURES = {
     "diga_weight_transpose": (INT, [P, P, I64, I64, I64, P]),
     "diga_im2col_nchw": (INT, [P, P] + [I64] * 11 + [P]),
     "diga_norm_workspace_bytes": (SZ, [I64, I64, I64]),
-    "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, F32, F32, P, SZ, P]),
-    "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, F32, F32, P, I64, P, SZ, P]),
-    "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, P, SZ, P]),
+    "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, INT, F32, F32, P, SZ, P]),
+    "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, F32, F32, P, I64, P, SZ, P]),
+    "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
     "diga_gn_fwd": (INT, [P, I64, P, I64, P, P, P, P, P, I64, I64, I64, I64, INT, F32, P, SZ, P]),
     "diga_gn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, P, SZ, P]),
     "diga_avgpool_nhwc": (INT, [P, I64, P, I64, I64, I64, P, SZ, P]),

@@ -175,11 +175,25 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, ColGeom g,
 }
 
 // y = [relu](x*a + b [+ res]); a,b indexed [seg*ab_seg_stride + c] (stride 0 = shared by all segments)
+// 4 fp32 -> 4 bf16 hi + 4 bf16 lo (the split of csrc/conv.hip: hi = bf16(x) round-to-nearest-even, lo = bf16(x - hi))
+__device__ __forceinline__ void norm_split4(const float4 v, uint2& hi, uint2& lo) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    hi.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){v.x, v.y}, bf2));
+    hi.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){v.z, v.w}, bf2));
+    const float h0 = __uint_as_float(hi.x << 16), h1 = __uint_as_float(hi.x & 0xffff0000u);
+    const float h2 = __uint_as_float(hi.y << 16), h3 = __uint_as_float(hi.y & 0xffff0000u);
+    lo.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){v.x - h0, v.y - h1}, bf2));
+    lo.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){v.z - h2, v.w - h3}, bf2));
+}
+
+// twin_out: y receives the split twin of the result ([row][C/8][hi8 | lo8], dense rows of 4*C bytes) instead of fp32 --
+// for a tensor whose only readers are convolutions on the twin kernels
 __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, int64_t ld_x, float* __restrict__ y,
                                                            int64_t ld_y, const float* __restrict__ res, int64_t ld_r,
                                                            const float* __restrict__ a, const float* __restrict__ b,
                                                            int64_t ab_seg_stride, int64_t rows_per_seg, int64_t rows,
-                                                           int C, int relu) {
+                                                           int C, int relu, int twin_out) {
     // a thread keeps its channel quad(s) and walks rows: no per-element division, coefficients in registers
     const int tq = C >> 2;
     const int tpr = tq < 256 ? tq : 256;          // threads per row
@@ -215,7 +229,15 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
             if (relu) {
                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
-            *reinterpret_cast<float4*>(y + (int64_t)r * ld_y + c) = o;
+            if (twin_out) {
+                uint2 hi, lo;
+                norm_split4(o, hi, lo);
+                unsigned char* tw = reinterpret_cast<unsigned char*>(y) + ((int64_t)r * (C >> 3) + (c >> 3)) * 32 + ((c >> 2) & 1) * 8;
+                *reinterpret_cast<uint2*>(tw) = hi;
+                *reinterpret_cast<uint2*>(tw + 16) = lo;
+            } else {
+                *reinterpret_cast<float4*>(y + (int64_t)r * ld_y + c) = o;
+            }
         }
     }
 }
@@ -318,7 +340,8 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
                                                         int64_t kk_seg_stride, int64_t kk_plane, float* __restrict__ dx,
                                                         int64_t ld_dx, float* __restrict__ dres, int64_t ld_dr,
                                                         int64_t rows_per_seg, int64_t rows, int C,
-                                                        const float* __restrict__ relu_ab) {
+                                                        const float* __restrict__ relu_ab, int twin_out) {
+    // twin_out: dx receives the split twin ([row][C/8][hi8 | lo8]) instead of fp32 (its only readers are twin kernels)
     const int tq = C >> 2;
     const int tpr = tq < 256 ? tq : 256;
     const int rpb = 256 / tpr;
@@ -382,7 +405,15 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
                 const float xh = (xx[e] - mu[e]) * is[e];
                 o[e] = k1a[e] * gg[e] - k2a[e] - xh * k3a[e];
             }
-            *reinterpret_cast<float4*>(dx + (int64_t)r * ld_dx + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (twin_out) {
+                uint2 hi, lo;
+                norm_split4(make_float4(o[0], o[1], o[2], o[3]), hi, lo);
+                unsigned char* tw = reinterpret_cast<unsigned char*>(dx) + ((int64_t)r * (C >> 3) + (c >> 3)) * 32 + ((c >> 2) & 1) * 8;
+                *reinterpret_cast<uint2*>(tw) = hi;
+                *reinterpret_cast<uint2*>(tw + 16) = lo;
+            } else {
+                *reinterpret_cast<float4*>(dx + (int64_t)r * ld_dx + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
             if (dres != nullptr)
                 *reinterpret_cast<float4*>(dres + (int64_t)r * ld_dr + c) = make_float4(gg[0], gg[1], gg[2], gg[3]);
         }
@@ -780,7 +811,9 @@ extern "C" size_t diga_norm_workspace_bytes(int64_t rows_per_seg, int64_t nseg, 
 extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                            float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int training,
-                           int relu, float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+                           int relu, int y_twin, float momentum, float eps, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    DIGA_REQUIRE(!y_twin || (C % 8 == 0 && ld_y == C), DIGA_EINVAL, "bn_fwd: twin output needs C % 8 == 0 and a dense y");
     DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && workspace && M > 0, DIGA_EINVAL, "bn_fwd: bad argument");
     DIGA_REQUIRE(training || (running_mean && running_var), DIGA_EINVAL, "bn_fwd: eval mode needs running statistics");
     int rc = check_norm("bn_fwd", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
@@ -800,14 +833,15 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
                            running_var, save_mean, save_invstd, ab, (int)C, eps);
     }
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
-                       ab + C, (int64_t)0, M, M, (int)C, relu);
+                       ab + C, (int64_t)0, M, M, (int)C, relu, y_twin);
     return launch_status("diga_bn_fwd");
 }
 
 extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
                                     int64_t ld_r, const float* gamma, const float* beta, float* running_mean,
                                     float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
-                                    int64_t C, int relu, float momentum, float eps, const float* partial, int64_t chunk_rows,
+                                    int64_t C, int relu, int y_twin, float momentum, float eps, const float* partial,
+                                    int64_t chunk_rows,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0 && chunk_rows > 0,
                  DIGA_EINVAL, "bn_fwd_partials: bad argument");
@@ -839,15 +873,16 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
     hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
                        running_mean, running_var, save_mean, save_invstd, ab, momentum, eps);
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
-                       ab + C, (int64_t)0, M, M, (int)C, relu);
+                       ab + C, (int64_t)0, M, M, (int)C, relu, y_twin);
     return launch_status("diga_bn_fwd_partials");
 }
 
 extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
                            const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd,
                            float* dx, int64_t ld_dx,
-                           float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, void* workspace,
+                           float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, int dx_twin, void* workspace,
                            size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(!dx_twin || (C % 8 == 0 && ld_dx == C), DIGA_EINVAL, "bn_bwd: twin output needs C % 8 == 0 and a dense dx");
     DIGA_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && workspace && M > 0, DIGA_EINVAL, "bn_bwd: bad argument");
     int rc = check_norm("bn_bwd", C, {ld_dy, ld_x, y ? ld_y : C, ld_dx, dres ? ld_dr : C}, {dy, x, y, dx, dres});
     if (rc) return rc;
@@ -864,7 +899,7 @@ extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma,
                        save_invstd, kk, training);
     hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y, save_mean,
-                       save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, dres, ld_dr, M, M, (int)C, relu_ab);
+                       save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, dres, ld_dr, M, M, (int)C, relu_ab, dx_twin);
     return launch_status("diga_bn_bwd");
 }
 
@@ -890,7 +925,7 @@ extern "C" int diga_gn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ceil_div(N * G, 64)), dim3(64), 0, st, partial, g, (int)G, gamma,
                            beta, chan_scale, save_mean, save_invstd, ab, eps);
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y,
-                       (const float*)nullptr, (int64_t)0, ab, ab + N * C, C, HW, N * HW, (int)C, relu);
+                       (const float*)nullptr, (int64_t)0, ab, ab + N * C, C, HW, N * HW, (int)C, relu, 0);
     return launch_status("diga_gn_fwd");
 }
 
@@ -923,7 +958,7 @@ extern "C" int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
                        dgamma, dbeta);
     hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
                        save_mean, save_invstd, (int)G, cpg, kk, C, N * C, dx, ld_dx, (float*)nullptr, (int64_t)0, HW, N * HW,
-                       (int)C, (const float*)nullptr);
+                       (int)C, (const float*)nullptr, 0);
     return launch_status("diga_gn_bwd");
 }
 
@@ -950,7 +985,7 @@ extern "C" int diga_channel_affine(const float* x, int64_t ld_x, float* y, int64
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y,
-                       (const float*)nullptr, (int64_t)0, a, b, C, HW, N * HW, (int)C, 0);
+                       (const float*)nullptr, (int64_t)0, a, b, C, HW, N * HW, (int)C, 0, 0);
     return launch_status("diga_channel_affine");
 }
 

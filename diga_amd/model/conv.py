@@ -46,6 +46,16 @@ def _use_twin(cin, k, taps, shared):
     return mode == "1" or taps > 1 or shared
 
 
+def takes_twin_only_input(conv):
+    """True when `conv` (a DigaConv2d) reads its input exclusively through split twins -- forward on the twin kernel and
+    backward-weight on the twin kernel -- so that its producer may write the twin instead of the fp32 tensor."""
+    taps = conv.kernel_size[0] * conv.kernel_size[1]
+    return (_lib.lib.diga_get_conv_math() == 1 and os.environ.get("DIGA_CONV_TWIN", "3") != "0"
+            and os.environ.get("DIGA_TWIN_ONLY", "1") != "0"
+            and taps > 1 and conv.in_channels % 32 == 0 and conv.out_channels >= 256 and conv.out_channels % 8 == 0
+            and tuple(conv.stride) == (1, 1) and conv.groups == 1)
+
+
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x."""
@@ -136,9 +146,15 @@ class _StemConvFn(torch.autograd.Function):
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None, x_is_twin=False,
+                dy_is_twin=False):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
+        if x_is_twin:          # the producer wrote the split twin instead of fp32 (same bytes per element): hand it on
+            xt = x.detach().permute(0, 2, 3, 1)
+            if not (xt.is_contiguous() and xt.dtype == torch.float32):
+                raise RuntimeError("DigaConv2d: a twin-only input must be a dense NHWC float32-shaped buffer")
+            twin_box = [xt.reshape(-1).view(torch.uint8)]
         xn = x.detach().permute(0, 2, 3, 1)
         if not xn.is_contiguous() or xn.dtype != torch.float32:
             xn = xn.contiguous().float()
@@ -158,6 +174,12 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(xn, w)
         # the split twin of the input serves the weight gradient too (multi-tap / shared-input layers, Cout >= 256)
         ctx.x_twin = x_twin if (ctx.needs_input_grad[1] and k >= 256 and k % 8 == 0 and cp == c) else None
+        ctx.dy_is_twin = bool(dy_is_twin)
+        if dy_is_twin and ctx.x_twin is None and ctx.needs_input_grad[1]:
+            raise RuntimeError("DigaConv2d: twin_grad=True on a layer whose weight gradient is not on the twin kernel")
+        if x_is_twin and (x_twin is None or (ctx.needs_input_grad[1] and ctx.x_twin is None)):
+            raise RuntimeError("DigaConv2d: got a twin-only input but this layer is not on the twin kernels "
+                               "(check takes_twin_only_input before asking the producer for a twin)")
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         ctx.uses = uses
         return out.permute(0, 3, 1, 2)
@@ -179,6 +201,10 @@ class _Conv2dFn(torch.autograd.Function):
         x_twin = getattr(ctx, "x_twin", None)
         use_tw = x_twin is not None and ctx.needs_input_grad[1] and _lib.lib.diga_get_conv_math() == 1 and kp == k
         dy_box = [None] if use_tw else None            # the twin of dy: built once, read by backward-data and -weight
+        if ctx.dy_is_twin:          # the BatchNorm after this conv wrote its dx as a twin (same bytes per element)
+            if not (kp == k and _lib.lib.diga_get_conv_math() == 1 and cp > 64 and (use_tw or not ctx.needs_input_grad[1])):
+                raise RuntimeError("DigaConv2d: twin gradient on a layer that is not on the twin kernels")
+            dy_box = [gyp.reshape(-1).view(torch.uint8)]
         if ctx.needs_input_grad[0]:
             # backward-data = stride-1 correlation of dy with the [C][R][S][K] transpose, tap offsets negated
             if kp == k:
@@ -190,7 +216,7 @@ class _Conv2dFn(torch.autograd.Function):
             if stride == (1, 1):
                 dxn = torch.empty((n, hi, wi, cp), dtype=torch.float32, device=w.device)
                 _conv_launch(gyp, wt, None, dxn, (1, 1), (padding[0], padding[1]), (-dilation[0], -dilation[1]),
-                             _TAG_BWD_DATA, None, dy_box if (use_tw and cp > 64) else None)
+                             _TAG_BWD_DATA, None, dy_box if ((use_tw or ctx.dy_is_twin) and cp > 64) else None)
             else:
                 if (r, s) != (1, 1) or padding != (0, 0):
                     raise NotImplementedError("backward-data of strided convs is only needed (and built) for 1x1")
@@ -250,7 +276,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -271,7 +297,9 @@ class DigaConv2d(nn.Conv2d):
             self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
         return self
 
-    def forward(self, x):
+    def forward(self, x, twin_grad=False):
+        """twin_grad: the gradient of this conv's output will arrive as a split twin (the BatchNorm that consumes the
+        output was called with dx_twin=True)."""
         fn = _Conv2dFn
         if (self.in_channels < 8 and not x.requires_grad and tuple(self.dilation) == (1, 1)
                 and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]):
@@ -293,8 +321,17 @@ class DigaConv2d(nn.Conv2d):
             twin_box = getattr(x, "_diga_twin_box", None)
             if twin_box is None:
                 twin_box = x._diga_twin_box = [None]
-        y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
-                     twin_box)
+        x_is_twin = bool(getattr(x, "_diga_is_twin", False))
+        if x_is_twin and fn is not _Conv2dFn:
+            raise RuntimeError("DigaConv2d: twin-only input on the stem path")
+        if x_is_twin or twin_grad:
+            if fn is not _Conv2dFn or (self.bias is not None and twin_grad):
+                raise RuntimeError("DigaConv2d: twin gradient needs a bias-free conv on the implicit-GEMM path")
+            y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
+                         twin_box, x_is_twin, bool(twin_grad))
+        else:
+            y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
+                         twin_box)
         if stats is not None:
             y._diga_bn_partials = (stats, 128)       # picked up by the DigaBatchNorm2d that consumes y
         return y

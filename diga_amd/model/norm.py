@@ -55,7 +55,7 @@ def _ws(rows_per_seg, nseg, c, device):
 class _BnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, relu, momentum, eps,
-                partials=None):
+                partials=None, twin_out=False, dx_twin=False):
         _lib.require_gpu(x)
         xn = nhwc(x.detach())
         n, h, w, c = xn.shape
@@ -71,15 +71,17 @@ class _BnFn(torch.autograd.Function):
             # the producing conv already reduced its output tile by tile: finalise + apply only
             _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
-                      _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, float(momentum), float(eps),
-                      _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(), _lib.stream())
+                      _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
+                      float(momentum), float(eps), _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(),
+                      _lib.stream())
         else:
             _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
                       _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd),
-                      _lib.ptr(save_ab), m, c, 1 if training else 0, 1 if relu else 0, float(momentum), float(eps),
-                      _lib.ptr(ws), ws.numel(), _lib.stream())
+                      _lib.ptr(save_ab), m, c, 1 if training else 0, 1 if relu else 0, 1 if twin_out else 0,
+                      float(momentum), float(eps), _lib.ptr(ws), ws.numel(), _lib.stream())
         ctx.save_for_backward(xn, y if (relu and save_ab is None) else None, weight, save_mean, save_invstd, save_ab)
         ctx.flags = (training, residual is not None)
+        ctx.dx_twin = bool(dx_twin and c % 8 == 0)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -94,9 +96,9 @@ class _BnFn(torch.autograd.Function):
         ws = _ws(m, 1, c, xn.device)
         _lib.call("diga_bn_bwd", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(save_ab), _lib.ptr(weight),
                   _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dres), c, m, c,
-                  1 if training else 0, _lib.ptr(ws), ws.numel(), _lib.stream())
+                  1 if training else 0, 1 if ctx.dx_twin else 0, _lib.ptr(ws), ws.numel(), _lib.stream())
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 class DigaBatchNorm2d(nn.BatchNorm2d):
@@ -104,15 +106,22 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
     G5/model/seg_model_noaux.py:64-76) -- gradients flow to the input only.  forward(x, residual, relu)
     computes relu(bn(x) + residual) in one pass."""
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, twin_out=False, dx_twin=False):
+        """twin_out (ReLU, no residual, C % 8 == 0): the result is written as the split twin the staging-free conv
+        kernels read (same 4 bytes per element, diga_make_twin's format) INSTEAD of fp32; the returned tensor has the
+        usual shape and dtype but holds twin bytes (`_diga_is_twin`) -- only a DigaConv2d on the twin path may read it."""
         if self.weight.requires_grad or self.bias.requires_grad:
             raise RuntimeError("DigaBatchNorm2d implements the frozen-affine BN of the DiGA path; "
                                "set requires_grad=False on weight and bias")
         training = self.training or self.running_mean is None
         if self.training and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
-        return _BnFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, training, relu,
-                           self.momentum, self.eps, getattr(x, "_diga_bn_partials", None))
+        twin_out = bool(twin_out and relu and residual is None and x.shape[1] % 8 == 0)
+        y = _BnFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, training, relu,
+                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin))
+        if twin_out:
+            y._diga_is_twin = True
+        return y
 
 
 # --------------------------------------------------------------------------------------------- GroupNorm

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from diga_amd.model import norm as dn
-from diga_amd.model.conv import DigaConv2d
+from diga_amd.model.conv import DigaConv2d, takes_twin_only_input
 
 
 @dataclass(frozen=True)
@@ -69,8 +69,12 @@ class Bottleneck(nn.Module):
             conv.emit_bn_stats = True              # BN statistics come out of the conv epilogue
 
     def forward(self, x):
-        y = self.bn1(self.conv1(x), relu=True)
-        y = self.bn2(self.conv2(y), relu=True)
+        # bn1's output is read only by conv2 (and conv2's weight gradient): when those run on the split-twin kernels
+        # the BN writes the twin instead of the fp32 tensor (no separate conversion pass)
+        # ... and the dx of bn2's backward is read only by conv2's backward-data and backward-weight: a twin as well
+        tw = takes_twin_only_input(self.conv2)
+        y = self.bn1(self.conv1(x), relu=True, twin_out=tw)
+        y = self.bn2(self.conv2(y, twin_grad=tw and torch.is_grad_enabled()), relu=True, dx_twin=tw and torch.is_grad_enabled())
         skip = x if self.downsample is None else self.downsample(x)
         return self.bn3(self.conv3(y), residual=skip, relu=True)
 

@@ -301,26 +301,28 @@ size_t diga_norm_workspace_bytes(int64_t rows_per_segment, int64_t n_segments, i
  * M rows (biased variance), running_mean/var updated with `momentum` (unbiased variance), statistics saved for the
  * backward pass; eval: running statistics.  residual nullable.  save_ab (nullable, [2][C]) receives a and b: passed
  * back to diga_bn_bwd as `relu_ab` it lets the backward of a residual-free BN+ReLU re-derive the ReLU mask from x
- * instead of reading y. */
+ * instead of reading y.  y_twin != 0: y (dense, ld_y == C, C % 8 == 0) receives the split twin of the result (the
+ * format of diga_make_twin, 4 bytes per element) instead of fp32 -- for a tensor read only by the twin conv kernels. */
 int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                 float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int training, int relu,
-                float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+                int y_twin, float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Train-mode diga_bn_fwd whose statistics pass is replaced by partials the producing conv already wrote
  * (`partial` = stats_partial of diga_conv2d_nhwc_*, `chunk_rows` = 128). */
 int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
-                         float momentum, float eps, const float* partial, int64_t chunk_rows, void* workspace,
+                         int y_twin, float momentum, float eps, const float* partial, int64_t chunk_rows, void* workspace,
                          size_t workspace_bytes, void* stream);
 
 /* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*mask, mask = [y>0] when y is given,
  * [fma(x, a, b) > 0] when relu_ab = save_ab of the forward is given instead (BN without residual), 1 when both are
- * null (no ReLU); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (nullable) = g. */
+ * null (no ReLU); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (nullable) = g.  dx_twin != 0: dx (dense,
+ * C % 8 == 0) receives the split twin instead of fp32 (the conv before this BN runs backward on the twin kernels). */
 int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
                 const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
-                int64_t ld_dx, float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, void* workspace,
+                int64_t ld_dx, float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, int dx_twin, void* workspace,
                 size_t workspace_bytes, void* stream);
 
 /* GroupNorm over (HW x C/G) per image and group, then y = [relu](chan_scale[n,c] * (xhat*gamma + beta));
