@@ -46,13 +46,15 @@ def _use_twin(cin, k, taps, shared):
     return mode == "1" or taps > 1 or shared
 
 
-def takes_twin_only_input(conv):
+def takes_twin_only_input(conv, pointwise_ok=False):
     """True when `conv` (a DigaConv2d) reads its input exclusively through split twins -- forward on the twin kernel and
-    backward-weight on the twin kernel -- so that its producer may write the twin instead of the fp32 tensor."""
+    backward-weight on the twin kernel -- so that its producer may write the twin instead of the fp32 tensor.
+    pointwise_ok: also for 1x1 layers (worth it only when both of its twins are free, i.e. under autograd where the
+    weight gradient gains 35-39 %; the forward kernel alone gains nothing on 8-step tiles)."""
     taps = conv.kernel_size[0] * conv.kernel_size[1]
     return (_lib.lib.diga_get_conv_math() == 1 and os.environ.get("DIGA_CONV_TWIN", "3") != "0"
             and os.environ.get("DIGA_TWIN_ONLY", "1") != "0"
-            and taps > 1 and conv.in_channels % 32 == 0 and conv.out_channels >= 256 and conv.out_channels % 8 == 0
+            and (taps > 1 or pointwise_ok) and conv.in_channels % 32 == 0 and conv.in_channels > 64 and conv.out_channels >= 256 and conv.out_channels % 8 == 0
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
 
 
