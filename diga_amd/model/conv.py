@@ -58,7 +58,7 @@ def takes_twin_only_input(conv, pointwise_ok=False):
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
 
 
-def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None):
+def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x."""
     n, hi, wi, cin = x.shape
@@ -80,6 +80,9 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                   out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], _lib.ptr(stats), tag,
                   _lib.stream())
         return twin
+    if must_twin:
+        raise RuntimeError("DigaConv2d: the input holds split-twin bytes but the twin kernel is not selected "
+                           "(conv math or DIGA_CONV_TWIN changed since the producer ran)")
     if _lib.lib.diga_get_conv_math() == 1:
         # split-bf16 arithmetic: the weights are split once here (two bf16 arrays), the activations inside the kernel
         nel = w_krsc.numel()
@@ -172,7 +175,8 @@ class _Conv2dFn(torch.autograd.Function):
         wo = (wi + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
-        x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box)
+        x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box,
+                              must_twin=bool(x_is_twin))
         ctx.save_for_backward(xn, w)
         # the split twin of the input serves the weight gradient too (multi-tap / shared-input layers, Cout >= 256)
         ctx.x_twin = x_twin if (ctx.needs_input_grad[1] and k >= 256 and k % 8 == 0 and cp == c) else None
@@ -184,12 +188,20 @@ class _Conv2dFn(torch.autograd.Function):
                                "(check takes_twin_only_input before asking the producer for a twin)")
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         ctx.uses = uses
+        # the arithmetic / twin decisions of this forward bind its backward: saved tensors may hold twin bytes
+        ctx.math = _lib.lib.diga_get_conv_math()
+        ctx.x_is_twin = bool(x_is_twin)
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, grad_out):
         xn, w = ctx.saved_tensors
         stride, padding, dilation, c_true, has_bias, w_strides = ctx.geom
+        if (ctx.x_is_twin or ctx.dy_is_twin or ctx.x_twin is not None) and _lib.lib.diga_get_conv_math() != ctx.math:
+            raise RuntimeError("DigaConv2d: diga_set_conv_math() changed between forward and backward of a graph that "
+                               "holds split-twin tensors (their bytes are only readable by the twin kernels)")
+        if ctx.x_is_twin and ctx.needs_input_grad[1] and ctx.x_twin is None:
+            raise RuntimeError("DigaConv2d: twin-only input saved for backward but the weight gradient is off the twin kernel")
         n, hi, wi, cp = xn.shape
         k, r, s, _ = w.shape
         gy = grad_out.permute(0, 2, 3, 1)
@@ -218,7 +230,8 @@ class _Conv2dFn(torch.autograd.Function):
             if stride == (1, 1):
                 dxn = torch.empty((n, hi, wi, cp), dtype=torch.float32, device=w.device)
                 _conv_launch(gyp, wt, None, dxn, (1, 1), (padding[0], padding[1]), (-dilation[0], -dilation[1]),
-                             _TAG_BWD_DATA, None, dy_box if ((use_tw or ctx.dy_is_twin) and cp > 64) else None)
+                             _TAG_BWD_DATA, None, dy_box if ((use_tw or ctx.dy_is_twin) and cp > 64) else None,
+                             must_twin=ctx.dy_is_twin)
             else:
                 if (r, s) != (1, 1) or padding != (0, 0):
                     raise NotImplementedError("backward-data of strided convs is only needed (and built) for 1x1")

@@ -65,6 +65,28 @@ def _bottleneck(sd, pfx, x, stride, dilation, has_down, training, update_stats):
     return F.relu(out + res)
 
 
+def bottleneck_fixed_masks(sd, pfx, x, stride, dilation, has_down, masks):
+    """_bottleneck in train mode with its three ReLUs replaced by multiplications with given 0/1 masks
+    (masks = activation patterns observed on the device under test).  The block's gradients are discontinuous
+    where a pre-activation crosses zero; with the switches pinned the function is smooth around the operating
+    point, so gradients can be compared elementwise with a tight bound.  Where a mask disagrees with the sign of
+    this function's own pre-activation that value is within rounding of zero, so the forward value is unchanged
+    to the same precision.  Same reference lines as _bottleneck (seg_model_noaux.py:81-101)."""
+    m1, m2, m3 = masks
+    out = F.conv2d(x, sd[pfx + ".conv1.weight"], stride=stride)
+    out = _bn(sd, pfx + ".bn1", out, True) * m1
+    out = F.conv2d(out, sd[pfx + ".conv2.weight"], padding=dilation, dilation=dilation)
+    out = _bn(sd, pfx + ".bn2", out, True) * m2
+    out = F.conv2d(out, sd[pfx + ".conv3.weight"])
+    out = _bn(sd, pfx + ".bn3", out, True)
+    if has_down:
+        res = F.conv2d(x, sd[pfx + ".downsample.0.weight"], stride=stride)
+        res = _bn(sd, pfx + ".downsample.1", res, True)
+    else:
+        res = x
+    return (out + res) * m3
+
+
 def trunk(sd, x, arch=RESNET101, training=False, update_stats=False):
     """layer0..layer4; returns (layer2 output, layer4 output)."""
     x = F.conv2d(x, sd["layer0.0.weight"], stride=2, padding=3)

@@ -43,6 +43,17 @@ def golden():
     return load
 
 
+@pytest.fixture(params=[0, 1], ids=["f32", "bf16x3"])
+def conv_math(request):
+    """Runs a GPU test under both convolution arithmetics: exact fp32 (library default) and the split-bf16 mode that
+    bench.py times (twin kernels, twin-only tensors and DIGA_TWIN_CONV3 at their defaults = on)."""
+    from diga_amd import _lib
+    prev = _lib.lib.diga_get_conv_math()
+    _lib.call("diga_set_conv_math", request.param)
+    yield request.param
+    _lib.call("diga_set_conv_math", prev)
+
+
 def assert_close(a, b, rtol=1e-5, atol=1e-6, what=""):
     a = torch.as_tensor(a).detach().cpu().to(torch.float64)
     b = torch.as_tensor(b).detach().cpu().to(torch.float64)
@@ -56,3 +67,18 @@ def assert_close(a, b, rtol=1e-5, atol=1e-6, what=""):
             f"{what}: {int(bad.sum())}/{bad.numel()} out of tol; worst idx {i}: "
             f"got {a.reshape(-1)[i].item():.9g} want {b.reshape(-1)[i].item():.9g} "
             f"(err {err.reshape(-1)[i].item():.3g}, rtol {rtol}, atol {atol})")
+
+
+def assert_mostly_close(a, b, rtol, atol, frac, l2, what=""):
+    """For gradients of networks with ReLUs compared against a FIXED capture: a 1e-5-level arithmetic difference (the
+    split-bf16 conv mode) flips the few ReLUs whose pre-activation is that close to zero, which moves the gradients in
+    their receptive field by O(1) -- a property of the function, present between any two fp32 implementations at a
+    smaller rate.  At most `frac` of the elements may exceed the elementwise bound and the whole tensor must agree to
+    `l2` in relative L2 norm."""
+    a = torch.as_tensor(a).detach().cpu().to(torch.float64)
+    b = torch.as_tensor(b).detach().cpu().to(torch.float64)
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    bad = float(((a - b).abs() > atol + rtol * b.abs()).double().mean())
+    err = float((a - b).norm() / b.norm().clamp_min(1e-300))
+    frac = max(frac, 8.0 / a.numel())            # small tensors (bias gradients): up to 8 elements
+    assert bad <= frac and err <= l2, f"{what}: {bad:.2e} of the elements out of tol (allowed {frac}), L2 error {err:.2e} (allowed {l2})"

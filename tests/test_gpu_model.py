@@ -50,13 +50,31 @@ def test_forward_eval_golden(golden):
     assert synth.checksum(dp.cpu()) == pytest.approx(float(g["deep_sum"]), rel=1e-3, abs=5e-2)
 
 
-def test_forward_backward_train_golden(golden):
+@pytest.mark.parametrize("side", [False, True], ids=["inline", "wgrad_side_stream"])
+def test_forward_backward_train_golden(golden, conv_math, side):
+    """Train-mode forward + backward of the ResNet-101 build against the capture of the reference, in both conv
+    arithmetics; in bf16x3 the bottlenecks run on twin-only tensors (bn1/bn2 twin_out, bn2/bn3 dx_twin, conv2/conv3
+    twin_grad) exactly as in bench.py, with the weight gradients in line or on the side stream."""
+    from diga_amd import _lib
     g = golden("model")
     m = _model().train()
     m.final.head[0].p = 0.0                                     # dropout off, as in the capture
+    if conv_math == 1:
+        from diga_amd.model.conv import takes_twin_only_input
+        blk = m.layer3[1]
+        assert takes_twin_only_input(blk.conv2) and takes_twin_only_input(blk.conv3, pointwise_ok=True)
     _, _, out, feat = m(g.t("x").to(DEV))
-    assert_close(out, g.t("out_train"), 1e-3, 2e-4, "train logits")
-    (out * g.t("probe").to(DEV)).sum().backward()
+    scale = float(g.t("out_train").abs().max())
+    # north_star: logits within 1e-3 relative; fp32 mode is held to the tighter elementwise bound of round 1
+    assert float((out.detach().cpu() - g.t("out_train")).abs().max()) < 1e-3 * scale
+    if conv_math == 0:
+        assert_close(out, g.t("out_train"), 1e-3, 2e-4, "train logits")
+    _lib.side_overlap = side
+    try:
+        (out * g.t("probe").to(DEV)).sum().backward()
+    finally:
+        _lib.side_overlap = False
+        _lib.join_side()
     named = dict(m.named_parameters())
     ref = g.t("g_head")
     assert_close(named["final.head.1.weight"].grad, ref, 5e-3, 1e-3 * float(ref.abs().max()), "head grad")
@@ -72,7 +90,7 @@ def test_forward_backward_train_golden(golden):
     assert_close(sd["layer4.2.bn3.running_var"], g.t("rv_after"), 1e-3, 1e-6, "running var")
 
 
-def test_warmup_three_steps_golden(golden):
+def test_warmup_three_steps_golden(golden, conv_math):
     from diga_amd.train_step import DigaTrainer
     g = golden("step")
     student, teacher = _model(), _model()

@@ -35,7 +35,7 @@ def test_oracle_selftrain_step(golden):
 
 
 @pytest.mark.gpu
-def test_gpu_selftrain_step(golden):
+def test_gpu_selftrain_step(golden, conv_math):
     from diga_amd.calc_centroids import Class_Features
     from diga_amd.model.model_noaux import SegModel
     from diga_amd.train_step import DigaTrainer
