@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the DiGA training hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+    python bench.py --gpus N --steps K --warmup W
 
-A step is one full DiGA warm-up iteration (EMA teacher update, ClassMix, student forward on 2B images,
-teacher forward on 2B images, fused upsample+CE+distillation, backward, gradient all-reduce, fused SGD)
-on BASELINE.json configs[1]: ResNet-101 DeepLabV2, B=8 source crops of 768x768 per GPU, synthetic inputs
-already resident in HBM.  Rank 0 prints ONE JSON line; `value` is source crops/s over all ranks.
+N = 1 runs in this process.  N > 1: when the process was not started by torch.distributed.run (no WORLD_SIZE in
+the environment) it starts N worker processes itself -- before anything touches the GPU, as children, never by
+exec -- one per GPU, rendezvous on 127.0.0.1, backend "nccl" (= RCCL over xGMI); under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one of the ranks.
 
-Arithmetic (`--precision`): the convolutions run either in exact fp32 on the fp32 matrix cores ("f32") or
-with fp32 operands split into bf16 hi+lo and three bf16 MFMAs per product, fp32 accumulate ("bf16x3",
-default: ~1e-5 relative per product, the whole network stays within the path's 1e-3 logit tolerance --
-tests/test_gpu_conv.py).  Everything else is fp32.  The other mode is timed too (2 steps) and reported
-under "other_precision".
+A step is one full DiGA warm-up iteration (EMA teacher update, ClassMix, student forward on 2B images, teacher
+forward on 2B images, fused upsample+CE+distillation, backward, gradient all-reduce, fused SGD) on BASELINE.json
+configs[1]: ResNet-101 DeepLabV2, B=8 source crops of 768x768 per GPU, synthetic inputs already resident in HBM.
+Rank 0 prints ONE JSON line; `value` is source crops/s over all ranks.
+
+Arithmetic (`--precision`): the convolutions run either in exact fp32 on the fp32 matrix cores ("f32") or with fp32
+operands split into bf16 hi+lo and three bf16 MFMAs per product, fp32 accumulate ("bf16x3", default: ~1e-5 relative
+per product; gradients of the twin-only bottlenecks within 1e-5 of scale of a float64 oracle, a full-size C2 step
+within 2e-4 of the fp32 logits -- tests/test_gpu_bf16x3_parity.py).  Everything else is fp32.  The other mode is timed
+too (`--other-steps`, default 10 after 3 warm-ups) and reported under "other_precision".
+
+Also in the line: `roofline` (dominant kernel family: forward convolution), `roofline_other_kernels` (every other
+family of the step, from the algorithmic work each library call declares), `bandwidth_kernels` (the API-boundary loss
+kernels and the centroid pseudo-labeler at full size, timed on their own), `other_configs` (self-training step c4,
+small-backbone c1), `cpu_baseline` (the oracle on this box's host cores).
 """
 import argparse
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,28 +38,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # only the two SE linears reach a vendor library
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak
 SERIAL_STEPS = 2          # steps of the serialised-stream pass that times kernels for the roofline
 FWD_GFLOP_768 = 1232.9           # model forward, one 768x768 image
 FWD_GFLOP_256 = 142.6
+PROFILE_TAG = "r02"              # profiles/<tag>_<precision>_serial_pmc_summary.json feeds roofline.traffic
 
 CONFIGS = {
-    # name: (arch, batch per GPU, H, W, label block, description)
-    "c2": ("RESNET101", 8, 768, 768, 32,
-           "configs[1]: ResNet-101 DeepLabV2 DiGA warm-up (student + EMA teacher, KL distill), synthetic "
-           "GTA5-shape 768x768, batch 8 per GPU"),
-    "c1": ("TINY", 2, 256, 256, 16, "configs[0] stand-in: small-backbone DeepLab, 2x256x256 warm-up step"),
-    "c4": ("RESNET101", 8, 512, 1024, 32,
-           "configs[3]: self-training step (centroid pseudo-labeler + two ClassMix blocks + centroid EMA), synthetic "
-           "Cityscapes-shape 512x1024, 8 source + 8 target crops per GPU"),
+    # name: (arch, batch per GPU, H, W, label block, BASELINE.json entry, description)
+    "c2": ("RESNET101", 8, 768, 768, 32, "configs[1]",
+           "ResNet-101 DeepLabV2 DiGA warm-up (student + EMA teacher, KL distill), synthetic GTA5-shape"),
+    "c1": ("TINY", 2, 256, 256, 16, "configs[0] stand-in",
+           "small-backbone (Bottleneck 1-1-2-1, 16..128 planes) DeepLab warm-up step; the reference cannot build a "
+           "ResNet-18 (seg_model_noaux.py:253 raises for BasicBlock)"),
+    "c4": ("RESNET101", 8, 512, 1024, 32, "configs[3]",
+           "self-training step (centroid pseudo-labeler + two ClassMix blocks + centroid EMA), synthetic "
+           "Cityscapes-shape, B source + B target crops per GPU"),
 }
 DTYPE = {"f32": "f32",
-         "bf16x3": "bf16x3 (conv operands = f32 split into bf16 hi+lo, 3 bf16 MFMAs per product, f32 accumulate; "
-                   "all other kernels f32)"}
+         "bf16x3": "bf16x3 (conv operands = f32 split into bf16 hi+lo = 16 significand bits per operand, hi*hi + hi*lo + "
+                   "lo*hi on the bf16 matrix cores, f32 accumulate; all other kernels f32)"}
 
 
 def parse():
@@ -60,20 +71,34 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="override crops per GPU (debug only)")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override crop H W (debug only)")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
-    ap.add_argument("--no-other-precision", action="store_true", help="skip the short run of the other arithmetic")
+    ap.add_argument("--no-other-precision", action="store_true", help="skip the run of the other arithmetic")
+    ap.add_argument("--other-steps", type=int, default=10)
+    ap.add_argument("--other-warmup", type=int, default=3)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the c4 / c1 legs")
+    ap.add_argument("--c4-steps", type=int, default=3)
+    ap.add_argument("--no-bandwidth-kernels", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the CPU leg and print its JSON")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel families with HIP events")
+    ap.add_argument("--lean", action="store_true",
+                    help="only the timed steps (= --no-other-precision --no-other-configs --no-bandwidth-kernels "
+                         "--no-cpu-baseline): the form rocprofv3 runs use")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the whole step on one stream (no teacher / weight-gradient side stream): the mode the "
                          "per-kernel roofline durations are measured in; profiles/*_serial_* are rocprofv3 runs of it")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.lean:
+        a.no_other_precision = a.no_other_configs = a.no_bandwidth_kernels = a.no_cpu_baseline = True
+    return a
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline():
-    """The oracle's warm-up step (PyTorch-CPU restatement of the reference, pinned by tests/golden) timed on
-    this box's host cores: ResNet-101, B=2 crops of 256x256, second of two steps.  Reported in 768x768-crop
-    units by the forward-FLOP ratio."""
+    """The oracle's warm-up step (PyTorch-CPU restatement of the reference, pinned by tests/golden) timed on this box's
+    host cores: ResNet-101, B=2 crops of 256x256, second of two steps, reported in 768x768-crop units by the forward-FLOP
+    ratio; plus BASELINE configs[0] exactly as the build can state it (small backbone, 2x256x256)."""
+    import torch
+    from oracle import deeplab as od
     from oracle import detweights, synth
     from oracle import step as ost
     try:
@@ -82,25 +107,34 @@ def cpu_baseline():
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 32))            # beyond ~32 threads torch's CPU convs stop scaling at this size
     torch.set_num_threads(cores)
-    tr = ost.Trainer(detweights.state_dict(), detweights.state_dict())
-    rng = random.Random(5)
-    dt = None
-    for it in range(2):
-        batch = synth.warmup_batch(300 + it, 2, 256, 256, block=16)
-        t0 = time.perf_counter()
-        tr.warmup_step(it, *batch, rng)
-        dt = time.perf_counter() - t0
+
+    def timed(arch, seed):
+        tr = ost.Trainer(detweights.state_dict(arch), detweights.state_dict(arch), arch=arch)
+        rng = random.Random(5)
+        dt = None
+        for it in range(2):
+            batch = synth.warmup_batch(seed + it, 2, 256, 256, block=16)
+            t0 = time.perf_counter()
+            tr.warmup_step(it, *batch, rng)
+            dt = time.perf_counter() - t0
+        return dt
+
+    dt = timed(od.RESNET101, 300)
+    dt1 = timed(od.TINY, 310)
     crops256 = 2.0 / dt
     return {"value": crops256 * FWD_GFLOP_256 / FWD_GFLOP_768, "unit": "crops/s", "cores": cores, "kind": "port",
+            "host_cores_total": os.cpu_count(), "host_cores_available": avail,
             "sample": f"oracle warm-up step, ResNet-101, B=2 crops of 256x256 fp32, 2nd of 2 steps: {dt:.2f} s/step "
                       f"= {crops256:.3f} 256x256-crops/s; scaled to 768x768 crops by forward FLOPs "
-                      f"({FWD_GFLOP_256}/{FWD_GFLOP_768} GFLOP)"}
+                      f"({FWD_GFLOP_256}/{FWD_GFLOP_768} GFLOP); {cores} threads of {os.cpu_count()} host cores",
+            "c1": {"value": 2.0 / dt1, "unit": "256x256 crops/s", "cores": cores,
+                   "sample": f"oracle warm-up step, configs[0] stand-in (small backbone), B=2 crops of 256x256, 2nd of 2 "
+                             f"steps: {dt1:.3f} s/step (exact size, no scaling)"}}
 
 
-def cpu_baseline_subprocess(limit_s=240):
+def cpu_baseline_subprocess(limit_s=300):
     """Run the CPU leg in a child process (started before this process touches the GPU) so that a slow or
     memory-hungry host cannot take the GPU measurement down with it."""
-    import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
                            text=True, timeout=limit_s)
@@ -111,22 +145,64 @@ def cpu_baseline_subprocess(limit_s=240):
                 "sample": f"CPU leg failed (rc={r.returncode}): {r.stderr[-300:]}"}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "crops/s", "cores": None, "kind": "port",
-                "sample": f"CPU leg did not finish two B=2 256x256 oracle steps within {limit_s} s"}
+                "sample": f"CPU leg did not finish its oracle steps within {limit_s} s"}
 
 
-def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
-    """Build student/teacher, run `warmup` + `steps` warm-up iterations; returns (seconds for `steps` = max over
-    ranks, kernel families, last losses, parameter counts)."""
+# ------------------------------------------------------------------------------------------------ N > 1 launcher
+def spawn_workers(a):
+    """--gpus N > 1 without a torchrun environment: start N fresh worker processes (this process has not touched the
+    GPU and never will), one rank per GPU; rank 0 inherits stdout and prints the JSON line."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:          # a dead rank leaves the others hanging in a collective
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ timed steps
+def geometry(a, config):
+    arch_name, B, H, W, block, _, _ = CONFIGS[config]
+    if config == a.config:
+        B = a.batch or B
+        if a.size:
+            H, W = a.size
+    return arch_name, B, H, W, block
+
+
+def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof):
+    """Build student/teacher, run `warmup` + `steps` iterations of `config`; returns (seconds for `steps` = max over
+    ranks, kernel families, last losses, parameter counts, geometry)."""
+    import torch
     from diga_amd import _lib, ddp, synthetic
     from diga_amd.model import seg_model_noaux as sm
     from diga_amd.model.model_noaux import SegModel
     from diga_amd.train_step import DigaTrainer
 
     _lib.call("diga_set_conv_math", 1 if precision == "bf16x3" else 0)
-    arch_name, B, H, W, block, _ = CONFIGS[a.config]
-    B = a.batch or B
-    if a.size:
-        H, W = a.size
+    arch_name, B, H, W, block = geometry(a, config)
     arch = getattr(sm, arch_name)
     torch.manual_seed(0)                       # identical random-init weights on every rank
     student, teacher = SegModel(arch=arch).to(dev), SegModel(arch=arch).to(dev)
@@ -134,7 +210,7 @@ def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
     teacher.train()
     rng = random.Random(1234 + rank)           # ClassMix class choice differs per rank, reproducibly
     tr = DigaTrainer(student, teacher, rng=rng)
-    if a.config == "c4":
+    if config == "c4":
         from diga_amd.calc_centroids import Class_Features
         batch = synthetic.selftrain_batch(1234 + rank, B, H, W, block=block, device=dev)
         cf = Class_Features(numbers=19)
@@ -181,12 +257,14 @@ def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
     losses = {k: float(v) for k, v in out.items()}
     if not all(v == v and abs(v) < 1e6 for v in losses.values()):
         raise SystemExit(f"non-finite loss in the timed region: {losses}")
+
     def query(nsteps):
         fam = {}
         for tag in _lib.PROF_TAGS:
             n, ms = _lib.prof_query(tag)
             if n:
-                fam[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / nsteps}
+                fam[tag] = {"launches": n, "avg_ms": ms / n, "ms_per_step": ms / nsteps,
+                            "work_per_step": _lib.prof_work(tag) / nsteps}
         return fam
 
     families_overlapped = query(steps) if prof else {}
@@ -216,15 +294,23 @@ def run_steps(a, precision, steps, warmup, rank, world, dev, prof):
                 else:
                     os.environ[k] = v
         barrier()
+    if prof:
+        _lib.call("diga_prof_reset")
     del tr, student, teacher, batch, one_step
     torch.cuda.empty_cache()
     return float(t), (families, families_overlapped), losses, counts, (B, H, W, arch_name)
 
 
-def rooflines(a, precision, families, steps, counts, geom):
+def images_per_step(config, B):
+    """Images through the student (forward + backward) and through the teacher (forward) per step and GPU."""
+    return (3 * B, 3 * B) if config == "c4" else (2 * B, 2 * B)
+
+
+def rooflines(config, precision, families, counts, geom):
     """Dominant kernel: the forward implicit-GEMM convolution (MFMA-bound).  Algorithmic work of its launches in
-    one step = model forward FLOPs (1232.9 GFLOP per 768x768 image, scaled by area) x 2B
-    student + 2B teacher images; achieved = that / the summed HIP-event durations of those launches."""
+    one step = model forward FLOPs (1232.9 GFLOP per 768x768 image, scaled by area) x the images
+    of the student's and the teacher's forward passes; achieved = that / the summed HIP-event durations of those
+    launches.  The other families: the algorithmic bytes (or FLOPs) each library call declared / its duration."""
     B, H, W, arch_name = geom
     n_trainable, n_params = counts
     roof, other = None, {}
@@ -235,20 +321,19 @@ def rooflines(a, precision, families, steps, counts, geom):
     # as MI355X_MICROARCH.md prescribes), condensed by tools/summarize_prof.py into profiles/
     pmc = None
     try:
-        tag = "r01_f32" if precision == "f32" else "r01_bf16x3_serial"      # rocprofv3 --pmc runs of bench.py --serial-streams
-        with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{precision}_serial_pmc_summary.json")) as fh:
             pmc = json.load(fh)["kernels"]
     except (OSError, ValueError, KeyError):
         pass
+    n_stu, n_tea = images_per_step(config, B)
     if "conv_fwd" in families and arch_name == "RESNET101":
         fam = families["conv_fwd"]
-        imgs_fwd = (2 * (2 * B)) if a.config != "c4" else (2 * (3 * B))      # student + teacher forward images
-        flops_step = imgs_fwd * fwd_gflop * 1e9
-        n_launch = fam["launches"] / steps
+        flops_step = (n_stu + n_tea) * fwd_gflop * 1e9
+        n_launch = fam["ms_per_step"] / fam["avg_ms"]                     # launches per step
         ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
         kname = "conv_fwd_kernel" if precision == "f32" else "conv_fwd_x3w_kernel + conv_fwd_x3t_kernel"
         traffic = None
-        if pmc and (B, H, W) == (8, 768, 768):
+        if pmc and (B, H, W) == (8, 768, 768) and config == "c2":
             # launch-weighted mean over the family's kernels (the 128-column instantiations carry > 95 % of its time;
             # the same kernels also serve backward-data, whose launches are in the PMC averages)
             names = ("diga::conv_fwd_kernel<2",) if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t_kernel<2")
@@ -260,79 +345,173 @@ def rooflines(a, precision, families, steps, counts, geom):
                           f"{'' if precision == 'f32' else ', split-twin conversions of their inputs counted in elementwise'})",
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "algorithmic_flops_per_launch": flops_step / n_launch, "avg_launch_ms": fam["avg_ms"],
-                "launches_per_step": n_launch}
+                "launches_per_step": n_launch, "declared_flops_per_step": fam["work_per_step"]}
         for tag in ("conv_bwd_data", "conv_bwd_weight"):
-            if tag in families:        # backward: one pass each over the student's 2B images
-                f = ((2 * B) if a.config != "c4" else (3 * B)) * fwd_gflop * 1e9
+            if tag in families:        # backward: one pass each over the student's images
+                f = n_stu * fwd_gflop * 1e9
                 v = f / (families[tag]["ms_per_step"] * 1e-3) / 1e12
-                other[tag] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": v, "frac": v / peak}
-    for tag, nbytes in (("sgd", 20.0 * n_trainable), ("ema", 12.0 * n_params),
-                        ("classmix_paste", 44.0 * B * H * W), ("classmix_hist", 8.0 * B * H * W)):
-        if tag in families:
-            v = nbytes / (families[tag]["avg_ms"] * 1e-3) / 1e9
-            other[tag] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": v, "frac": v / HBM_PEAK_GBS,
-                          "algorithmic_bytes_per_launch": nbytes}
+                other[tag] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": v, "frac": v / peak,
+                              "ms_per_step": families[tag]["ms_per_step"]}
+    # per-launch byte counts the host knows (the multi-tensor kernels get device-side size tables)
+    known = {"sgd": 20.0 * n_trainable, "ema": 12.0 * n_params}
+    for tag, fam in families.items():
+        if tag.startswith("conv_"):
+            continue
+        nbytes = known.get(tag, fam["work_per_step"] / max(fam["ms_per_step"] / fam["avg_ms"], 1e-9))
+        if not nbytes:
+            continue
+        v = nbytes / (fam["avg_ms"] * 1e-3) / 1e9
+        other[tag] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": v, "frac": v / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": fam["avg_ms"], "ms_per_step": fam["ms_per_step"]}
     return roof, other
+
+
+def bandwidth_kernels(dev):
+    """The HBM-bound kernels north_star names, timed on their own at full size (HIP events on the launch stream, 10
+    launches after 2 warm-ups each): the loss kernels at the reference's API boundary (full-resolution logits, the path
+    an unmodified train_DiGA_*.py takes) at C2 size, the centroid pseudo-labeler and the class-mean pass at C4 size."""
+    import torch
+    from diga_amd import _lib
+    from diga_amd.calc_centroids import Class_Features
+    from diga_amd.util import loss as L
+    out = {}
+    g = torch.Generator(device="cpu")
+    g.manual_seed(99)
+
+    def timed(tags, fn, note):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        _lib.call("diga_prof_reset")
+        _lib.call("diga_prof_enable", 1)
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        _lib.call("diga_prof_enable", 0)
+        for tag in tags:
+            n, ms = _lib.prof_query(tag)
+            if not n:
+                continue
+            nbytes = _lib.prof_work(tag) / n
+            gbs = nbytes / (ms / n * 1e-3) / 1e9
+            out[tag] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms / n, "launches": n, "shape": note}
+        _lib.call("diga_prof_reset")
+
+    # C2: B = 8 crops of 768x768, 19 classes; CE on the first B images, distillation on 2B
+    B, C, H, W = 8, 19, 768, 768
+    stu = torch.randn((2 * B, C, H, W), device=dev).requires_grad_()
+    tea = torch.randn((2 * B, C, H, W), device=dev)
+    lab = torch.randint(0, 19, (B, H, W), device=dev, dtype=torch.int64)
+    lab[:, ::17, ::13] = 255
+    timed(["ce2d"], lambda: L.cross_entropy2d(stu[:B], lab), f"cross_entropy2d fwd+bwd, logits [{B},{C},{H},{W}] fp32 + int64 labels")
+    timed(["distill"], lambda: L.distillation_loss(tea, stu, 0.5), f"distillation_loss fwd+bwd, teacher/student [{2 * B},{C},{H},{W}] fp32")
+    del stu, tea, lab
+    # C4: B = 8 target crops of 512x1024 -> low-res 65x129, 256-channel features
+    B, D, h, w, H, W = 8, 256, 65, 129, 512, 1024
+    cf = Class_Features(numbers=19)
+    cf.objective_vectors = torch.randn((19, D), generator=g).to(dev)
+    feat = torch.randn((B, D, h, w), device=dev)
+    logit = torch.randn((B, 19, h, w), device=dev)
+    pseudo = torch.randint(0, 19, (B, H, W), device=dev, dtype=torch.int64)
+    timed(["centroid_weights", "consensus"], lambda: cf.consensus_pseudo_labels(feat, pseudo),
+          f"feat [{B},{D},{h},{w}] -> softmax(-dist) weights -> upsample + argmax + consensus on [{B},{H},{W}] int64")
+    timed(["class_means", "centroid_apply"], lambda: cf.update_from_batch(feat, logit, labels_full=pseudo),
+          f"class sums of feat [{B},{D},{h},{w}] under argmax(out) & nearest-downsampled labels + sequential centroid EMA")
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     a = parse()
     if a.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
-        return
+        return 0
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return spawn_workers(a)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     cpu_line = None
     if world_env == 1 and not a.no_cpu_baseline:
         cpu_line = cpu_baseline_subprocess()
+    import torch
     from diga_amd import ddp
     rank, world, local = ddp.init_from_env()
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = torch.distributed.get_backend() if world > 1 else None
+    prof = not a.no_prof
 
     if a.serial_streams:
         os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
-    dt, (families, families_ov), losses, counts, geom = run_steps(a, a.precision, a.steps, a.warmup, rank, world, dev,
-                                                                  not a.no_prof)
-    fam_steps = a.steps if (a.serial_streams or a.no_prof) else SERIAL_STEPS
+    dt, (families, families_ov), losses, counts, geom = run_steps(a, a.config, a.precision, a.steps, a.warmup, rank, world,
+                                                                  dev, prof)
     B, H, W, _ = geom
     other_line = None
     if not a.no_other_precision and world == 1:
         oprec = "f32" if a.precision == "bf16x3" else "bf16x3"
-        odt, (ofam, _), olosses, _, _ = run_steps(a, oprec, 2, 1, rank, world, dev, not a.no_prof)
-        oroof, _ = rooflines(a, oprec, ofam, 2 if (a.serial_streams or a.no_prof) else SERIAL_STEPS, counts, geom)
-        other_line = {"dtype": DTYPE[oprec], "value": world * B * 2 / odt, "unit": "crops/s", "steps": 2, "warmup": 1,
-                      "ms_per_step": 1e3 * odt / 2, "roofline": oroof, "losses_last_step": olosses}
+        odt, (ofam, _), olosses, _, _ = run_steps(a, a.config, oprec, a.other_steps, a.other_warmup, rank, world, dev, prof)
+        oroof, oother = rooflines(a.config, oprec, ofam, counts, geom)
+        other_line = {"dtype": DTYPE[oprec], "value": world * B * a.other_steps / odt, "unit": "crops/s",
+                      "steps": a.other_steps, "warmup": a.other_warmup, "ms_per_step": 1e3 * odt / a.other_steps,
+                      "roofline": oroof, "roofline_other_kernels": {k: oother[k] for k in ("conv_bwd_data", "conv_bwd_weight") if k in oother},
+                      "losses_last_step": olosses}
+    other_cfg = {}
+    if not a.no_other_configs:
+        for cfg, (st, wu) in (("c4", (a.c4_steps, 1)), ("c1", (5, 2))):
+            if cfg == a.config or (cfg == "c1" and world > 1):
+                continue
+            cdt, (cfam, _), closs, ccounts, cgeom = run_steps(a, cfg, a.precision, st, wu, rank, world, dev, prof)
+            cB, cH, cW, carch = cgeom
+            croof, _ = rooflines(cfg, a.precision, cfam, ccounts, cgeom)
+            n_stu, n_tea = images_per_step(cfg, cB)
+            other_cfg[cfg] = {
+                "workload": f"{CONFIGS[cfg][5]}: {CONFIGS[cfg][6]}, {cH}x{cW}, batch {cB} per GPU",
+                "metric": (f"{cH}x{cW} 19-class (source,target) crop pairs/sec (DiGA self-training step)" if cfg == "c4"
+                           else f"{cH}x{cW} 19-class crops/sec (DiGA warm-up step)"),
+                "value": world * cB * st / cdt, "unit": "pairs/s" if cfg == "c4" else "crops/s", "steps": st, "warmup": wu,
+                "ms_per_step": 1e3 * cdt / st, "n_gpus": world, "dtype": a.precision,
+                "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea},
+                "roofline_conv_fwd": None if croof is None else {k: croof[k] for k in ("achieved", "peak", "unit", "frac")},
+                "losses_last_step": closs}
+    bw = None
+    if rank == 0 and not a.no_bandwidth_kernels:
+        bw = bandwidth_kernels(dev)
 
     if rank == 0:
-        roof, other = rooflines(a, a.precision, families, fam_steps, counts, geom)
+        roof, other = rooflines(a.config, a.precision, families, counts, geom)
         if roof is not None:
             roof["measured"] = ("HIP events around every launch, on the launch stream; "
                                 + ("timed region (single stream)" if a.serial_streams else
                                    f"{SERIAL_STEPS} extra steps with the teacher / weight-gradient side streams serialised "
                                    "(in the timed region they overlap other kernels; see kernel_families_overlapped)"))
+        n_stu, n_tea = images_per_step(a.config, B)
+        fwd_tflop = FWD_GFLOP_768 * (H * W) / (768.0 * 768.0) / 1e3
         line = {
-            "metric": ("768x768 19-class crops/sec (DiGA warm-up step)" if a.config != "c4" else
-                       "512x1024 19-class (source,target) crop pairs/sec (DiGA self-training step)"),
-            "value": world * B * a.steps / dt, "unit": "crops/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE[a.precision], "data": "synthetic",
-            "config": {"workload": CONFIGS[a.config][5], "global_batch": world * B, "crop": [H, W],
-                       "parallelism": f"dp{world}",
-                       "images_per_step_per_gpu": {"student_fwd_bwd": 2 * B, "teacher_fwd": 2 * B}},
-            "roofline": roof, "roofline_other_kernels": other, "cpu_baseline": cpu_line,
-            "other_precision": other_line, "kernel_families": families,
+            "metric": (f"{H}x{W} 19-class crops/sec (DiGA warm-up step)" if a.config != "c4" else
+                       f"{H}x{W} 19-class (source,target) crop pairs/sec (DiGA self-training step)"),
+            "value": world * B * a.steps / dt, "unit": "crops/s" if a.config != "c4" else "pairs/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[a.precision], "data": "synthetic",
+            "config": {"workload": f"{CONFIGS[a.config][5]}: {CONFIGS[a.config][6]} {H}x{W}, batch {B} per GPU",
+                       "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
+                       "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea}},
+            "rccl_ranks": world, "backend": backend if world > 1 else "none (single process)",
+            "roofline": roof, "roofline_other_kernels": other, "bandwidth_kernels": bw, "cpu_baseline": cpu_line,
+            "other_precision": other_line, "other_configs": other_cfg or None, "kernel_families": families,
             "kernel_families_overlapped": None if a.serial_streams else families_ov, "losses_last_step": losses,
-            "model_tflop_per_step_per_gpu": (2 * B) * 4 * (FWD_GFLOP_768 * (H * W) / (768.0 * 768.0)) / 1e3,
+            # student: forward + backward-data + backward-weight (3 passes) ; teacher: forward
+            "model_tflop_per_step_per_gpu": (3 * n_stu + n_tea) * fwd_tflop,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

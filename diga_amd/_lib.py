@@ -80,6 +80,7 @@ SIGNATURES = {
     "diga_prof_enable": (INT, [INT]),
     "diga_prof_reset": (INT, []),
     "diga_prof_query": (INT, [INT, P, P]),
+    "diga_prof_query_work": (INT, [INT, P]),
 }
 
 # enum order of include/diga_hip.h
@@ -93,6 +94,13 @@ def prof_query(tag):
     n, ms = C.c_int64(0), C.c_double(0.0)
     call("diga_prof_query", PROF_TAGS.index(tag), C.byref(n), C.byref(ms))
     return n.value, ms.value
+
+def prof_work(tag):
+    """Algorithmic work (bytes or FLOPs) the calls of one kernel family declared since the last prof_reset."""
+    w = C.c_double(0.0)
+    call("diga_prof_query_work", PROF_TAGS.index(tag), C.byref(w))
+    return w.value
+
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync
@@ -154,6 +162,12 @@ def side_stream(device):
         st = _side_streams[idx] = torch.cuda.Stream(device=idx)
     _side_dirty.add(idx)
     return st
+
+
+def active_side_stream(device):
+    """The side stream of `device` if work has been put on it since the last join, else None."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _side_streams.get(idx) if idx in _side_dirty else None
 
 
 def join_side():

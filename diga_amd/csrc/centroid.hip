@@ -241,7 +241,8 @@ extern "C" int diga_centroid_softmax_weights(const float* feat, const float* cen
                  "centroid_softmax_weights: bad shape N=%lld D=%lld K=%lld HW=%lld", (long long)N, (long long)D,
                  (long long)K, (long long)HW);
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_CENTROID_WEIGHTS, st);
+    // D*4 B of features per low-res pixel in, K*4 B of weights out (+ K*4 with distances)
+    ProfScope prof(DIGA_PROF_CENTROID_WEIGHTS, st, (double)N * HW * (D * 4.0 + K * 4.0 * (neg_dist ? 2.0 : 1.0)));
     dim3 grid((unsigned)ceil_div(HW, 64), (unsigned)N);
     if (K <= 19 && K > 16) {
         const size_t sh = ((size_t)D * 20 + 4 * 19 * 64) * sizeof(float);
@@ -267,7 +268,9 @@ extern "C" int diga_upsample_argmax_consensus(const float* weights, const int64_
     DIGA_REQUIRE(weights && pseudo_in && pseudo_out, DIGA_EINVAL, "upsample_argmax_consensus: null pointer");
     DIGA_REQUIRE(N > 0 && K >= 1 && h > 0 && w > 0 && H > 0 && W > 0, DIGA_EINVAL, "upsample_argmax_consensus: bad shape");
     dim3 grid((unsigned)ceil_div(W, 64), (unsigned)ceil_div(H, 4), (unsigned)N);
-    ProfScope prof(DIGA_PROF_CONSENSUS, (hipStream_t)stream);
+    // low-res weights in, int64 label map read and written [, second map written]
+    ProfScope prof(DIGA_PROF_CONSENSUS, (hipStream_t)stream,
+                   (double)N * (h * w * K * 4.0 + (double)H * W * (feat_pseudo ? 24.0 : 16.0)));
     hipLaunchKernelGGL(argmax_consensus_kernel, grid, dim3(256), 0, (hipStream_t)stream, weights,
                        (const long long*)pseudo_in, (long long*)pseudo_out, (long long*)feat_pseudo, (int)K, (int)h,
                        (int)w, (int)H, (int)W, ac_scale(h, H), ac_scale(w, W));
@@ -291,7 +294,8 @@ extern "C" int diga_class_mean_vectors(const float* feat, const float* out, cons
                  "class_mean_vectors: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     uint8_t* ids = (uint8_t*)workspace;
-    ProfScope prof(DIGA_PROF_CLASS_MEANS, st);
+    // features D*4 + logits K*4 per low-res pixel + the labels the ids are drawn from
+    ProfScope prof(DIGA_PROF_CLASS_MEANS, st, (double)N * hw * (D * 4.0 + K * 4.0 + (labels_full ? 8.0 : 4.0)));
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)N * K * sizeof(int32_t), st);
     DIGA_REQUIRE(e == hipSuccess, (int)e, "class_mean_vectors: memset failed: %s", hipGetErrorString(e));
     const float ry = labels_full ? (float)H / (float)h : 0.f, rx = labels_full ? (float)W / (float)w : 0.f;
@@ -309,7 +313,7 @@ extern "C" int diga_centroid_ema_apply(float* centroids, float* nums, const floa
     DIGA_REQUIRE(N > 0 && K >= 1 && D >= 1 && D <= 1024 && hw > 0 && (mode == 0 || mode == 1), DIGA_EINVAL,
                  "centroid_ema_apply: bad argument (D <= 1024, mode in {0,1})");
     const int threads = (int)(ceil_div(D, 64) * 64);
-    ProfScope prof(DIGA_PROF_CENTROID_APPLY, (hipStream_t)stream);
+    ProfScope prof(DIGA_PROF_CENTROID_APPLY, (hipStream_t)stream, (double)K * D * (N * 4.0 + 8.0));
     hipLaunchKernelGGL(centroid_apply_kernel, dim3((unsigned)K), dim3(threads), 0, (hipStream_t)stream, centroids, nums,
                        sums, counts, (int)N, (int)K, (int)D, (float)hw, momentum, min_pixels, mode);
     return launch_status("diga_centroid_ema_apply");

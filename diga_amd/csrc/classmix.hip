@@ -93,7 +93,7 @@ extern "C" int diga_label_hist256(const int64_t* labels, uint32_t* hist, int64_t
     int64_t bx = ceil_div(HW, 256 * 8);  // ~8 grid-stride rounds per block
     if (bx < 1) bx = 1;
     if (bx > 1024) bx = 1024;
-    ProfScope prof(DIGA_PROF_CLASSMIX_HIST, (hipStream_t)stream);
+    ProfScope prof(DIGA_PROF_CLASSMIX_HIST, (hipStream_t)stream, (double)B * HW * 8.0);
     hipLaunchKernelGGL(label_hist256_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)labels, hist, HW);
     return launch_status("diga_label_hist256");
@@ -108,7 +108,8 @@ extern "C" int diga_classmix_paste(const float* bg, const float* fg, const int64
                  "classmix_paste: labels_out needs bg_labels");
     const bool vec4 = (HW % 4 == 0) && aligned16(bg) && aligned16(fg) && aligned16(out);
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_CLASSMIX_PASTE, st);
+    // per pixel: int64 label + CH floats of each image in, CH floats out [+ background label in, label out]
+    ProfScope prof(DIGA_PROF_CLASSMIX_PASTE, st, (double)B * HW * (8.0 + CH * 12.0 + (labels_out ? 16.0 : 0.0)));
     if (vec4) {
         dim3 grid((unsigned)ceil_div(HW / 4, 256), (unsigned)B);
         hipLaunchKernelGGL((classmix_paste_kernel<4>), grid, dim3(256), 0, st, bg, fg, (const long long*)labels, lut, out,

@@ -19,9 +19,10 @@ int launch_status(const char* what);  // hipGetLastError() -> 0 or hipError_t, r
         }                                 \
     } while (0)
 
-// Brackets the launches of one entry point with HIP events when diga_prof_enable(1) is on.
+// Brackets the launches of one entry point with HIP events when diga_prof_enable(1) is on.  `work` = the ALGORITHMIC
+// work of the call (bytes for the HBM-bound families, FLOPs for the convolutions: what the roofline divides by).
 struct ProfScope {
-    ProfScope(int tag, hipStream_t st);
+    ProfScope(int tag, hipStream_t st, double work = 0.0);
     ~ProfScope();
     hipEvent_t stop_ = nullptr;
     hipStream_t st_;

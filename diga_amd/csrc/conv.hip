@@ -1963,7 +1963,8 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
     a.all_inside = 0;
     a.tiles_m = (int)ceil_div(a.M, 128);
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
+    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
+                   2.0 * (double)a.M * (double)Cout * (double)(R * S) * (double)Cin);
     static const int bk_env = [] { const char* e = getenv("DIGA_CONV_BK"); return e ? atoi(e) : 32; }();
     const int bk = (bk_env == 16 && stats_partial == nullptr) ? 16 : 32;
 #define DIGA_FWD_LAUNCH(TN_, BK_)                                                                                      \
@@ -2031,7 +2032,8 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
         a.all_inside = y_lo >= 0 && y_hi < Hi && x_lo >= 0 && x_hi < Wi;
     }
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
+    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
+                   2.0 * (double)a.M * (double)Cout * (double)(R * S) * (double)Cin);
     static const bool narrow = [] {
         const char* e = getenv("DIGA_CONV_X3_TILE");          // "128": the 128-row kernel (A/B runs)
         return e != nullptr && atoi(e) == 128;
@@ -2089,7 +2091,7 @@ extern "C" int diga_make_twin(const float* x, int64_t ld, void* twin, int64_t M,
     DIGA_REQUIRE(aligned16(x) && aligned16(twin), DIGA_EALIGN, "make_twin: pointers must be 16-byte aligned");
     int64_t blocks = ceil_div(M * (C / 8), 256);
     if (blocks > 16384) blocks = 16384;
-    ProfScope prof(DIGA_PROF_ELEMENTWISE, (hipStream_t)stream);
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, (hipStream_t)stream, (double)M * C * 8.0);
     hipLaunchKernelGGL(make_twin_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (unsigned char*)twin, M,
                        (int)(C / 8));
     return launch_status("diga_make_twin");
@@ -2135,7 +2137,8 @@ extern "C" int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, c
     const int tn = Cout > 64 ? 2 : 1;
     a.tiles_n = (int)ceil_div(Cout, 64 * tn);
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st);
+    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
+                   2.0 * (double)a.M * (double)Cout * (double)(R * S) * (double)Cin);
     const size_t sh = (size_t)3 * (2 * 256 * 64 + 2 * 64 * tn * 64);
     if (tn == 2) {
         (void)hipFuncSetAttribute((const void*)conv_fwd_x3t_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -2228,7 +2231,7 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
     a.M = (int)M; a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.splits = p.splits; a.steps_per_split = p.steps_per_split;
     a.ptab = nullptr; a.zeros = nullptr; a.M_pad = (int)M_pad;
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st);
+    ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st, 2.0 * (double)M * (double)Cout * (double)RS * (double)Cin);
     const unsigned grid = (unsigned)((int64_t)p.tiles_m * p.tiles_n * RS * p.splits);
     if (wide) {
         int* tab = reinterpret_cast<int*>(static_cast<char*>(workspace) + slab_bytes);
@@ -2340,7 +2343,7 @@ extern "C" int diga_conv2d_wgrad_twin(const void* dy_twin, const void* x_twin, f
     a.M = (int)M; a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.splits = p.splits; a.steps_per_split = p.steps_per_split;
     a.M_pad = (int)M_pad;
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st);
+    ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st, 2.0 * (double)M * (double)Cout * (double)RS * (double)Cin);
     int* tab = reinterpret_cast<int*>(static_cast<char*>(workspace) + slab_bytes);
     float* zeros = reinterpret_cast<float*>(tab + RS * M_pad);
     hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3((unsigned)ceil_div(M_pad, 256), (unsigned)RS), dim3(256), 0, st, tab, zeros, (int)M,
@@ -2416,7 +2419,7 @@ extern "C" int diga_im2col_nchw(const float* x, float* out, int64_t N, int64_t C
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 16384) blocks = 16384;
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st, (double)N * (C * H * W + Ho * Wo * Kpad) * 4.0);
     hipLaunchKernelGGL(im2col_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, out, (int)N, (int)C, (int)H, (int)W,
                        (int)R, (int)S, (int)stride, (int)pad, (int)Ho, (int)Wo, (int)Kpad);
     return launch_status("diga_im2col_nchw");

@@ -516,7 +516,8 @@ extern "C" int diga_ce2d_fwd_bwd(const float* logits, const int64_t* target, flo
     const int64_t HW = H * W, total = N * HW;
     DIGA_REQUIRE(workspace_bytes >= diga_loss_workspace_bytes(total), DIGA_EWORKSPACE, "ce2d: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_CE2D, st);
+    // read C*4 + 8 (int64 label) per pixel, write the C*4-byte gradient
+    ProfScope prof(DIGA_PROF_CE2D, st, (double)total * (C * 4.0 + 8.0 + (grad ? C * 4.0 : 0.0)));
     float* partials = (float*)workspace;
     const float gs = grad_scale / (float)total;
     const bool vec4 = (HW % 4 == 0) && aligned16(logits) && (!grad || aligned16(grad));
@@ -554,7 +555,8 @@ extern "C" int diga_distill_fwd_bwd(const float* teacher, const float* student, 
     const int64_t HW = H * W, total = B2 * HW, B = B2 / 2;
     DIGA_REQUIRE(workspace_bytes >= diga_loss_workspace_bytes(total), DIGA_EWORKSPACE, "distill: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_DISTILL, st);
+    // per student-image pixel: read teacher and student logits, write the gradient
+    ProfScope prof(DIGA_PROF_DISTILL, st, (double)total * (C * 8.0 + (grad ? C * 4.0 : 0.0)));
     float* partials = (float*)workspace;
     const float gs = grad_scale / (float)(B * HW);
     const bool vec2 = (HW % 2 == 0) && aligned16(teacher) && aligned16(student) && (!grad || aligned16(grad));
@@ -617,7 +619,8 @@ int run_upsample_loss(const float* stu_lr, const float* tea_lr, const int64_t* l
                       float* losses_out, void* workspace, int64_t N, int64_t B, int64_t n_ce, int64_t h, int64_t w,
                       int64_t H, int64_t W, float k_ce, float k_di, float scale, double ce_norm, double di_norm,
                       bool distill, hipStream_t st) {
-    ProfScope prof(DIGA_PROF_UPSAMPLE_LOSS, st);
+    // low-res logits of both nets + full-res int64 labels in, low-res gradient out
+    ProfScope prof(DIGA_PROF_UPSAMPLE_LOSS, st, (double)N * h * w * C * 4.0 * (distill ? 3.0 : 2.0) + (double)n_ce * H * W * 8.0);
     CellWs cw = carve(workspace, N, C, h, w);
     const float sy = ac_scale(h, H), sx = ac_scale(w, W);
     const int tmax = (int)(h > w ? h : w);

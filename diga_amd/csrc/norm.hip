@@ -820,7 +820,8 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     if (rc) return rc;
     DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(M, 1, C), DIGA_EWORKSPACE, "bn_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_NORM, st);
+    // algorithmic bytes per element: statistics pass reads x (4), apply reads x (4) [+ residual (4)], writes y (4)
+    ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * (8.0 + (training ? 4.0 : 0.0) + (residual ? 4.0 : 0.0)));
     const ColGeom g = make_geom(M, 1, C);
     float* partial = (float*)workspace;
     float* ab = save_ab != nullptr ? save_ab : partial + (size_t)g.nchunk * 3 * C;     // [2][C] y = fma(x, a, b)
@@ -848,7 +849,7 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
     int rc = check_norm("bn_fwd_partials", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_NORM, st);
+    ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * (8.0 + (residual ? 4.0 : 0.0)));   // read x [+ residual], write y
     ColGeom g;
     g.rows_per_seg = M;
     g.nseg = 1;
@@ -888,7 +889,9 @@ extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     if (rc) return rc;
     DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(M, 1, C), DIGA_EWORKSPACE, "bn_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_NORM, st);
+    // reduce pass reads dy, x [, y] (training only); apply pass reads dy, x [, y], writes dx [, dres]
+    ProfScope prof(DIGA_PROF_NORM, st,
+                   (double)M * C * ((training ? 8.0 + (y ? 4.0 : 0.0) : 0.0) + 12.0 + (y ? 4.0 : 0.0) + (dres ? 4.0 : 0.0)));
     const ColGeom g = make_geom(M, 1, C);
     float* partial = (float*)workspace;
     float* kk = partial + (size_t)g.nchunk * 3 * C;
@@ -912,7 +915,7 @@ extern "C" int diga_gn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     if (rc) return rc;
     DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(HW, N, C), DIGA_EWORKSPACE, "gn_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_NORM, st);
+    ProfScope prof(DIGA_PROF_NORM, st, (double)N * HW * C * 12.0);      // statistics read, apply read + write
     const ColGeom g = make_geom(HW, N, C);
     float* partial = (float*)workspace;
     float* ab = partial + (size_t)N * g.nchunk * 3 * C;
@@ -940,7 +943,7 @@ extern "C" int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     if (rc) return rc;
     DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(HW, N, C), DIGA_EWORKSPACE, "gn_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_NORM, st);
+    ProfScope prof(DIGA_PROF_NORM, st, (double)N * HW * C * (20.0 + (y ? 8.0 : 0.0)));   // reduce: dy, x [, y]; apply: dy, x [, y], dx
     const ColGeom g = make_geom(HW, N, C);
     const int cpg = (int)(C / G);
     float* partial = (float*)workspace;
@@ -969,7 +972,7 @@ extern "C" int diga_avgpool_nhwc(const float* x, int64_t ld_x, float* out, int64
     if (rc) return rc;
     DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(HW, N, C), DIGA_EWORKSPACE, "avgpool: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_NORM, st);
+    ProfScope prof(DIGA_PROF_NORM, st, (double)N * HW * C * 4.0);
     const ColGeom g = make_geom(HW, N, C);
     float* partial = (float*)workspace;
     hipLaunchKernelGGL(colstats_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, x, ld_x, g, partial);
@@ -983,7 +986,7 @@ extern "C" int diga_channel_affine(const float* x, int64_t ld_x, float* y, int64
     int rc = check_norm("channel_affine", C, {ld_x, ld_y}, {x, y, a, b});
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st, (double)N * HW * C * 8.0);
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y,
                        (const float*)nullptr, (int64_t)0, a, b, C, HW, N * HW, (int)C, 0, 0);
     return launch_status("diga_channel_affine");
@@ -996,7 +999,7 @@ extern "C" int diga_channel_dot(const float* dy, int64_t ld_dy, const float* x, 
     if (rc) return rc;
     DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(HW, N, C), DIGA_EWORKSPACE, "channel_dot: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_NORM, st);
+    ProfScope prof(DIGA_PROF_NORM, st, (double)N * HW * C * 8.0);
     const ColGeom g = make_geom(HW, N, C);
     float* partial = (float*)workspace;
     float* unit = partial + (size_t)N * g.nchunk * 3 * C;     // [0] = mean 0, [1] = invstd 1
@@ -1016,7 +1019,7 @@ extern "C" int diga_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int
     if (rc) return rc;
     DIGA_REQUIRE((Ho - 1) * 2 - 1 < H && (Wo - 1) * 2 - 1 < W, DIGA_EINVAL, "maxpool_fwd: last window starts outside the input");
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st, (double)N * C * (H * W * 4.0 + Ho * Wo * 5.0));
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(N * Ho * Wo * C / 4)), dim3(256), 0, st, x, y, idx, (int)N, (int)H,
                        (int)W, (int)C, (int)Ho, (int)Wo);
     return launch_status("diga_maxpool3x3s2_fwd");
@@ -1028,7 +1031,7 @@ extern "C" int diga_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float*
     int rc = check_norm("maxpool_bwd", C, {}, {dy, dx});
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_ELEMENTWISE, st);
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st, (double)N * C * (H * W * 4.0 + Ho * Wo * 5.0));
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(N * H * W * C / 4)), dim3(256), 0, st, dy, idx, dx, (int)N, (int)H,
                        (int)W, (int)C, (int)Ho, (int)Wo);
     return launch_status("diga_maxpool3x3s2_bwd");

@@ -29,6 +29,7 @@ int launch_status(const char* what) {
 struct ProfRec {
     int tag;
     hipEvent_t start, stop;
+    double work;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -46,13 +47,13 @@ static hipEvent_t prof_event() {
     return e;
 }
 
-ProfScope::ProfScope(int tag, hipStream_t st) : st_(st) {
+ProfScope::ProfScope(int tag, hipStream_t st, double work) : st_(st) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     hipEvent_t a = prof_event(), b = prof_event();
     if (!a || !b) return;
     (void)hipEventRecord(a, st);
-    g_prof_recs.push_back({tag, a, b});
+    g_prof_recs.push_back({tag, a, b, work});
     stop_ = b;
 }
 
@@ -96,6 +97,16 @@ extern "C" int diga_prof_query(int tag, int64_t* h_count, double* h_total_ms) {
     }
     *h_count = n;
     *h_total_ms = ms;
+    return DIGA_OK;
+}
+
+extern "C" int diga_prof_query_work(int tag, double* h_work) {
+    DIGA_REQUIRE(h_work && tag >= 0 && tag < DIGA_PROF_NTAGS, DIGA_EINVAL, "prof_query_work: bad argument");
+    std::lock_guard<std::mutex> lk(diga::g_prof_mu);
+    double w = 0.0;
+    for (auto& r : diga::g_prof_recs)
+        if (r.tag == tag) w += r.work;
+    *h_work = w;
     return DIGA_OK;
 }
 

@@ -91,6 +91,12 @@ class GradReducer:
     def _make_hook(self, i):
         def hook(_param):
             self._ready[i] += 1
+            if self._ready[i] > len(self.buckets[i]):
+                # a second backward() accumulated into p.grad after the bucket was packed and sent: its contribution
+                # would be overwritten by reduce().  Gradient accumulation needs the hooks off (overlap=False).
+                raise RuntimeError("GradReducer: a parameter's gradient was accumulated again after its bucket had been "
+                                   "launched (two backward passes before reduce()); build the reducer with "
+                                   "overlap=False for gradient accumulation")
             if self._ready[i] == len(self.buckets[i]) and self._work[i] is None:
                 self._launch(i)
         return hook
@@ -110,11 +116,24 @@ class GradReducer:
         flat = self._flat[i]
         if flat is None or flat.numel() != n or flat.device != grads[0].device:
             self._flat[i] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        side = None
         if grads[0].is_cuda:
             from diga_amd import _lib
-            _lib.join_side()              # weight gradients may still be in flight on the side stream
-        torch._foreach_copy_(self._views(i), [g.detach() for g in grads])
-        self._work[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            side = _lib.active_side_stream(grads[0].device)
+        if side is not None:
+            # Weight gradients of this bucket may still be running on the side stream.  Pack and launch FROM the side
+            # stream (it first waits for the main stream's work so far: bias / GroupNorm gradients live there): RCCL's
+            # stream then orders itself behind the side stream only, and the main stream -- the backward-data /
+            # BatchNorm chain -- is never made to wait for a weight gradient inside backward.
+            side.wait_stream(torch.cuda.current_stream(grads[0].device))
+            with torch.cuda.stream(side):
+                torch._foreach_copy_(self._views(i), [g.detach() for g in grads])
+                self._work[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            for g in grads:
+                g.record_stream(side)
+        else:
+            torch._foreach_copy_(self._views(i), [g.detach() for g in grads])
+            self._work[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def reduce(self):
         """Sum gradients over all ranks in place.  No-op for world size 1."""

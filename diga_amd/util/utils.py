@@ -261,7 +261,12 @@ class DigaSGD(torch.optim.Optimizer):
     reference builds, where a tensor may occur k times in a group (k sequential micro-steps sharing one
     momentum buffer; on the very first step every occurrence starts from a fresh buffer, as torch 2.x does).
     One launch per step for the whole model; `param_groups[i]['lr']` stays the knob that
-    adjust_learning_rate() turns."""
+    adjust_learning_rate() turns.  Duplicate entries follow torch's single-tensor path (foreach=False; torch 2.x's
+    foreach path on GPU would treat them differently: shared buffer multiplied k times, all d = g + wd*p formed before
+    any update) -- the reference pins torch 1.7.1, which has only the single-tensor path.  momentum and weight_decay
+    are one scalar each for the launch: every group must carry the same values (the reference's two groups do).
+    Momentum buffers live in `self.state[p]['momentum_buffer']`, so state_dict()/load_state_dict() round-trip them
+    (the 'first step' flag travels as state['first'] of the first parameter's entry)."""
 
     def __init__(self, params, lr=2.5e-4, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
         groups = []
@@ -292,7 +297,25 @@ class DigaSGD(torch.optim.Optimizer):
                     self._group_of.append(gi)
         dev = self._params[0].device
         _lib.require_gpu(*self._params)
-        self._bufs = [torch.zeros_like(p.data) for p in self._params]
+        for key in ("momentum", "weight_decay"):
+            vals = {float(g[key]) for g in self.param_groups}
+            if len(vals) != 1:
+                raise ValueError(f"DigaSGD: all param groups must share one {key} (got {sorted(vals)}); "
+                                 "per-group values are not supported by the fused kernel")
+        self._bufs = []
+        for p in self._params:
+            st = self.state[p]
+            buf = st.get("momentum_buffer")
+            if buf is None or buf.shape != p.shape or buf.device != p.device or not same_dense_layout(buf, p.data):
+                loaded = buf
+                buf = torch.zeros_like(p.data)
+                if loaded is not None:                 # restored by load_state_dict: bring to the parameter's layout
+                    buf.copy_(loaded.to(p.device))
+                    self._first = False
+                st["momentum_buffer"] = buf
+            else:
+                self._first = False
+            self._bufs.append(buf)
         self._tab = TensorTables([p.numel() for p in self._params], dev)
         self._mult_dev = torch.tensor(self._mult, dtype=torch.int32, device=dev)
         self._lr_host = None
@@ -325,6 +348,10 @@ class DigaSGD(torch.optim.Optimizer):
                   float(g0["weight_decay"]), 1 if self._first else 0, self.grad_scale, _lib.stream())
         self._first = False
         return None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tab = None                   # rebuild the pointer tables (and adopt the restored buffers) on the next step
 
     def momentum_buffers(self):
         return {id(p): b for p, b in zip(self._params, self._bufs)} if self._tab else {}

@@ -377,6 +377,10 @@ int diga_prof_enable(int on);
 int diga_prof_reset(void);
 /* Waits for the recorded events of `tag`; h_count = launches seen, h_total_ms = summed duration. */
 int diga_prof_query(int tag, int64_t* h_count, double* h_total_ms);
+/* Summed ALGORITHMIC work the recorded calls of `tag` declared: bytes (HBM-bound families: what the call must move
+ * given its arguments, e.g. 8 B per element for a BatchNorm apply, +4 with a residual) or FLOPs (convolutions:
+ * 2*M*Cout*R*S*Cin). */
+int diga_prof_query_work(int tag, double* h_work);
 
 #ifdef __cplusplus
 }

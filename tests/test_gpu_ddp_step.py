@@ -1,0 +1,122 @@
+"""Two data-parallel ranks (one process each, gloo, both on the one GPU of the test box) run a DiGA warm-up step and a
+self-training step on their own shards; the result must equal a single-process emulation:
+  * student after the step == one optimizer step on the AVERAGE of the two shards' gradients (each shard's forward /
+    backward with its own BatchNorm batch statistics and its own ClassMix draw, as every rank of the reference would);
+    the all-reduce sums two addends, the 1/world lives in the SGD kernel's grad_scale -- bit for bit;
+  * every rank holds the same parameters afterwards;
+  * the centroid bank == the order-dependent EMA (G5/calc_centroids.py:147-156) applied to the class sums of rank 0's
+    images then rank 1's (rank-major, image-major, class-minor), target pass before source pass -- checked against
+    the CPU oracle on the per-rank sums the workers sent into the all-gather."""
+import os
+import random
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import centroids as oc
+from oracle import deeplab as od
+from oracle import detweights, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+
+def _run_workers(tmp, math):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DIGA_TEST_MATH=str(math))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_step_worker.py"), str(tmp)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    return [torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(2)]
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_steps_equal_single_process_emulation(tmp_path, conv_math):
+    from diga_amd.calc_centroids import Class_Features
+    from diga_amd.model import seg_model_noaux as sm
+    from diga_amd.model.model_noaux import SegModel
+    from diga_amd.train_step import DigaTrainer
+    from diga_amd.util import loss as L
+    from diga_amd.util import utils as U
+    r0, r1 = _run_workers(tmp_path, conv_math)
+    # every rank ends with the same student
+    for tag in ("after1", "after2"):
+        for k in r0[tag]:
+            assert torch.equal(r0[tag][k], r1[tag][k]), f"{tag}: ranks disagree on {k}"
+
+    # ---- single-process emulation of the warm-up step: per-shard gradients, summed, grad_scale = 1/2
+    def make():
+        m = SegModel(arch=sm.TINY)
+        m.load_state_dict(detweights.state_dict(od.TINY))
+        m.final.head[0].p = 0.0
+        return m.to(DEV)
+
+    student, teacher = make(), make()
+    teacher.train()
+    tr = DigaTrainer(student, teacher, rng=random)
+    tr.opt.grad_scale = 0.5
+    tr._begin(0)
+    tr.opt.zero_grad(set_to_none=True)
+    bn_state = {k: v.clone() for k, v in student.state_dict().items() if "running" in k or "num_batches" in k}
+    t_state = {k: v.clone() for k, v in teacher.state_dict().items() if "running" in k or "num_batches" in k}
+    ces = []
+    for rank in range(2):
+        student.load_state_dict(bn_state, strict=False)          # each rank starts from the same buffers
+        teacher.load_state_dict(t_state, strict=False)
+        x, x_aug, rec, lab = (t.to(DEV) for t in synth.warmup_batch(900 + rank, 2, 96, 128, block=16))
+        with torch.no_grad():
+            mix, _ = U.classmix(rec, x_aug, lab, random.Random(500 + rank))
+            cat = torch.cat([x, mix])
+            t_lr = teacher(cat)[2]
+        s_lr = student(cat)[2]
+        total, ce, di = L.upsample_ce_distill(s_lr, t_lr, lab, 1.0, 0.5, 0.5)
+        total.backward()                                         # accumulates: p.grad = g(shard 0) + g(shard 1)
+        ces.append(float(ce))
+    tr.opt.step()
+    torch.cuda.synchronize()
+    assert ces[0] == pytest.approx(r0["log1"]["ce"], rel=1e-6) and ces[1] == pytest.approx(r1["log1"]["ce"], rel=1e-6)
+    for k, v in student.named_parameters():
+        assert torch.equal(v.detach().cpu(), r0["after1"][k]), f"warm-up step: 2-rank result differs from the emulation at {k}"
+
+    # ---- centroid bank: oracle's sequential EMA over the rank-major concatenation of what the ranks sent
+    assert len(r0["sent"]) == 2 and len(r1["sent"]) == 2            # target pass, then source pass
+    cents = torch.randn((19, 256), generator=torch.Generator().manual_seed(7))
+    nums = torch.zeros(19)
+    hw = 13 * 17                                                    # low-res map of a 96x128 crop
+    for ps in range(2):
+        sums = torch.cat([r0["sent"][ps][0], r1["sent"][ps][0]])    # [2 ranks x 2 images, 19, 256], rank-major
+        counts = torch.cat([r0["sent"][ps][1], r1["sent"][ps][1]])
+        vectors, ids = [], []
+        for n in range(sums.shape[0]):
+            for t in range(19):
+                c = int(counts[n, t])
+                if c == 0 or c < 5:
+                    continue
+                vectors.append((sums[n, t] / float(hw)) / (float(c) / float(hw)))
+                ids.append(t)
+        oc.centroid_ema_apply(cents, nums, vectors, ids)
+    for r in (r0, r1):
+        assert torch.allclose(r["cents"], cents, rtol=1e-6, atol=1e-7)
+        assert torch.equal(r["nums"], nums)
+    assert float(nums.sum()) > 0                                    # the update did something
+    cf = Class_Features(numbers=19)                                 # and hw above is the map size the library used
+    f = torch.zeros((1, 256, 13, 17), device=DEV)
+    assert cf._class_sums(f, torch.zeros((1, 19, 13, 17), device=DEV), labels_full=torch.zeros((1, 96, 128), dtype=torch.int64, device=DEV))[2] == hw
