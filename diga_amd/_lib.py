@@ -70,6 +70,10 @@ SIGNATURES = {
     "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, INT, F32, F32, P, SZ, P]),
     "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, F32, F32, P, I64, P, SZ, P]),
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
+    "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
+    "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
+    "diga_conv2d_nhwc_bf16x3_epi": (INT, [P, P, P, P] + [I64] * 17 + [P, INT, P]),
+    "diga_conv2d_nhwc_twin_epi": (INT, [P, P, P] + [I64] * 16 + [P, INT, P]),
     "diga_gn_fwd": (INT, [P, I64, P, I64, P, P, P, P, P, I64, I64, I64, I64, INT, F32, P, SZ, P]),
     "diga_gn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, P, SZ, P]),
     "diga_avgpool_nhwc": (INT, [P, I64, P, I64, I64, I64, P, SZ, P]),
@@ -82,6 +86,12 @@ SIGNATURES = {
     "diga_prof_query": (INT, [INT, P, P]),
     "diga_prof_query_work": (INT, [INT, P]),
 }
+
+class BwdEpilogue(C.Structure):
+    """diga_bwd_epilogue_t of include/diga_hip.h."""
+    _fields_ = [("addend", P), ("addend_ld", I64), ("mask_y", P), ("mask_ld", I64), ("x", P), ("x_ld", I64),
+                ("relu_ab", P), ("mean", P), ("invstd", P), ("partials", P)]
+
 
 # enum order of include/diga_hip.h
 PROF_TAGS = ["ce2d", "distill", "upsample_loss", "ema", "sgd", "classmix_hist", "classmix_paste",

@@ -52,6 +52,16 @@ struct ConvArgs {
     int oy0, ox0, ody, odx;
     int M, tiles_m, tiles_n;
     int all_inside;              // every tap of every output pixel reads inside the image (no zero padding needed)
+    // backward-data epilogue fusion (diga_bwd_epilogue_t): out = [mask](acc + addend), + the BatchNorm-backward column
+    // sums of the result -- all null for a plain convolution
+    const float* e_add;          // [M][e_add_ld]
+    const float* e_masky;        // [M][e_masky_ld]: keep where > 0
+    const float* e_x;            // [M][e_x_ld]: input of the BatchNorm whose backward consumes `out`
+    const float* e_relu_ab;      // [2][Cout]: keep where fma(x, a, b) > 0
+    const float* e_mean;         // [Cout]
+    const float* e_invstd;       // [Cout]
+    float* e_partials;           // [ceil(M/128)][2][Cout]: sum g, sum g*xhat per 128-row chunk
+    int e_add_ld, e_masky_ld, e_x_ld;
 };
 
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
@@ -67,10 +77,11 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // what the BatchNorm after the conv needs -- per channel sum(y - s), sum((y - s)^2) and s = the tile's first row,
 // over the tile's valid rows -- in exactly the layout colstats_partial_kernel produces with 128-row chunks, so the
 // BN forward skips its own statistics pass over the conv output.
-template <int TM, int TN>
-__device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArgs& a, int m0, int n0, int t, int tile_m);
+template <int TM, int TN, bool EPI = false>
+__device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArgs& a, int m0, int n0, int t, int tile_m,
+                                            bool active = true);
 
-template <int TM, int TN>
+template <int TM, int TN, bool EPI = false>
 __device__ __forceinline__ void epilogue_tile(f32x16 (&acc)[TM][TN], float* __restrict__ stage, const ConvArgs& a,
                                               int m0, int n0, int wm, int wn, int lane, int t, int tile_m) {
     constexpr int BN = 64 * TN, LDS_LD = BN + 4;
@@ -84,13 +95,17 @@ __device__ __forceinline__ void epilogue_tile(f32x16 (&acc)[TM][TN], float* __re
                 stage[(wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDS_LD + wn * 32 * TN + j * 32 + li] =
                     acc[i][j][e];
     __syncthreads();
-    drain_stage<TM, TN>(stage, a, m0, n0, t, tile_m);
+    drain_stage<TM, TN, EPI>(stage, a, m0, n0, t, tile_m);
 }
 
 // Second half of the epilogue: 128 staged rows x 64*TN columns (row stride 64*TN + 4 floats) -> global memory
 // (+ bias, + BatchNorm partials for 128-row chunk `tile_m`).  Entered after a barrier that follows the stage writes.
-template <int TM, int TN>
-__device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArgs& a, int m0, int n0, int t, int tile_m) {
+// active = false: a thread group whose 128-row half lies beyond M still walks the barriers (nothing is stored).
+// EPI: the backward-data epilogue of diga_bwd_epilogue_t (its own instantiation of every kernel, so that the plain
+// kernels keep their register budget: inlined into the 256-register kernels the extra row buffers spilled).
+template <int TM, int TN, bool EPI>
+__device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArgs& a, int m0, int n0, int t, int tile_m,
+                                            bool active) {
     float* stage = const_cast<float*>(stage_in);
     constexpr int BN = 64 * TN, LDS_LD = BN + 4;
     constexpr int CQ = BN / 4;            // column quads per row
@@ -109,6 +124,88 @@ __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArg
     const float4 s0 = *reinterpret_cast<const float4*>(stage + cq * 4);       // tile row 0 (always a valid row)
     const float4 sh = make_float4(s0.x + bv.x, s0.y + bv.y, s0.z + bv.z, s0.w + bv.w);
     float sd[4] = {0.f, 0.f, 0.f, 0.f}, sd2[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI) {
+        // Backward-data of a convolution whose input came out of a BatchNorm(+ReLU)(+residual): the gradient this tile
+        // produces is, on its way out, (1) summed with the gradient that reaches the same tensor through the residual
+        // branch, (2) masked by that BatchNorm's ReLU, (3) reduced into the column sums its backward needs
+        // (sum g, sum g*xhat per 128-row chunk) -- instead of an add pass, a mask inside two later passes and a reduce
+        // pass over the tensor.  Entry points guarantee Cout % 4 == 0, 16-byte aligned pointers, lds % 4 == 0.
+        float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool col_ok = n + 3 < a.Cout;
+        if (col_ok && a.e_relu_ab != nullptr) {
+            const float4 t0 = *reinterpret_cast<const float4*>(a.e_relu_ab + n), t1 = *reinterpret_cast<const float4*>(a.e_relu_ab + a.Cout + n);
+            ra[0] = t0.x; ra[1] = t0.y; ra[2] = t0.z; ra[3] = t0.w;
+            rb[0] = t1.x; rb[1] = t1.y; rb[2] = t1.z; rb[3] = t1.w;
+        }
+        if (col_ok && a.e_partials != nullptr) {
+            const float4 t0 = *reinterpret_cast<const float4*>(a.e_mean + n), t1 = *reinterpret_cast<const float4*>(a.e_invstd + n);
+            mu[0] = t0.x; mu[1] = t0.y; mu[2] = t0.z; mu[3] = t0.w;
+            is[0] = t1.x; is[1] = t1.y; is[2] = t1.z; is[3] = t1.w;
+        }
+        // The epilogue moves 3-4x the bytes of the tile itself: rows are taken four at a time with all their loads
+        // (up to 12 x 16 B per thread, ~48 KB per block) in flight before the first use.
+        constexpr int RB = RPT >= 4 ? 4 : RPT;      // (acc registers are dead here: 48 row-buffer registers fit)
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k0 = 0; k0 < RPT; k0 += RB) {
+            float4 va[RB], vx[RB], vy[RB];
+            bool ok[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int m = m0 + rg + RG * (k0 + u);
+                ok[u] = m < a.M && col_ok;
+                const int64_t mm = ok[u] ? m : 0;
+                const int nn = col_ok ? n : 0;
+                va[u] = a.e_add != nullptr ? *reinterpret_cast<const float4*>(a.e_add + mm * a.e_add_ld + nn) : z4;
+                vx[u] = a.e_x != nullptr ? *reinterpret_cast<const float4*>(a.e_x + mm * a.e_x_ld + nn) : z4;
+                vy[u] = a.e_masky != nullptr ? *reinterpret_cast<const float4*>(a.e_masky + mm * a.e_masky_ld + nn) : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = rg + RG * (k0 + u);
+                const int m = m0 + r;
+                const float4 v4 = *reinterpret_cast<const float4*>(stage + r * LDS_LD + cq * 4);
+                float v[4] = {v4.x + va[u].x, v4.y + va[u].y, v4.z + va[u].z, v4.w + va[u].w};
+                const float xx[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
+                if (a.e_masky != nullptr) {
+                    v[0] = vy[u].x > 0.f ? v[0] : 0.f; v[1] = vy[u].y > 0.f ? v[1] : 0.f;
+                    v[2] = vy[u].z > 0.f ? v[2] : 0.f; v[3] = vy[u].w > 0.f ? v[3] : 0.f;
+                } else if (a.e_relu_ab != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xx[e], ra[e], rb[e]) > 0.f ? v[e] : 0.f;
+                }
+                if (ok[u]) {
+                    *reinterpret_cast<float4*>(a.out + (int64_t)m * a.out_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sd[e] += v[e];
+                        sd2[e] += v[e] * ((xx[e] - mu[e]) * is[e]);
+                    }
+                }
+            }
+        }
+        if (a.e_partials == nullptr) return;   // uniform over the grid
+        __syncthreads();
+        float* red = stage;                    // [2][RG][BN]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(0 * RG + rg) * BN + cq * 4 + e] = sd[e];
+            red[(1 * RG + rg) * BN + cq * 4 + e] = sd2[e];
+        }
+        __syncthreads();
+        if (active && t < BN && n0 + t < a.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                t1 += red[(0 * RG + g) * BN + t];
+                t2 += red[(1 * RG + g) * BN + t];
+            }
+            float* sp = a.e_partials + (int64_t)tile_m * 2 * a.Cout + n0 + t;
+            sp[0] = t1;
+            sp[a.Cout] = t2;
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = rg + RG * k;
@@ -140,7 +237,7 @@ __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArg
     }
     if (rg == 0) *reinterpret_cast<float4*>(red + 2 * RG * BN + cq * 4) = sh;      // the shift of these 4 columns
     __syncthreads();
-    if (t < BN && n0 + t < a.Cout) {
+    if (active && t < BN && n0 + t < a.Cout) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
@@ -187,7 +284,7 @@ __device__ __forceinline__ void mma_kstep(const float* __restrict__ As, const fl
 // ---------------------------------------------------------------------------------------------
 // block tile 128 x (64*TN) x BK; wave tile 64 x (32*TN).  BK = 32: 2 blocks per CU (74 KB LDS each);
 // BK = 16: 37 KB LDS, 3 blocks per CU (register-limited) -> a third wave per SIMD to cover barrier stalls.
-template <int TN, int BK>
+template <int TN, int BK, bool EPI = false>
 __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_fwd_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 64 * TN, TM = 2;
     constexpr int LD = BK + 4;
@@ -290,7 +387,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_fwd_kernel(ConvA
 
     // epilogue: accumulator register e of a 32x32 tile is row (e&3) + 8*(e>>2) + 4*(lane>>5), col lane&31
     if constexpr (BK == 32) {
-        epilogue_tile<TM, TN>(acc, smem, a, m0, n0, wm, wn, lane, t, tile_m);
+        epilogue_tile<TM, TN, EPI>(acc, smem, a, m0, n0, wm, wn, lane, t, tile_m);
     } else {
         const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -353,7 +450,7 @@ __device__ __forceinline__ void split4_nomask(const float4 v, uint2& hi, uint2& 
 
 constexpr int kRowB = 80;   // bytes per LDS row: 32 bf16 + 16 B pad
 
-template <int TN>
+template <int TN, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void conv_fwd_x3_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 64 * TN, TM = 2, BK = 32;
     constexpr int CPR = BK / 4, RPP = 256 / CPR, NPA = BM / RPP, NPB = BN / RPP;
@@ -477,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    epilogue_tile<TM, TN>(acc, reinterpret_cast<float*>(smem_b), a, m0, n0, wm, wn, lane, t, tile_m);
+    epilogue_tile<TM, TN, EPI>(acc, reinterpret_cast<float*>(smem_b), a, m0, n0, wm, wn, lane, t, tile_m);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -487,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3_kernel(ConvArgs a) {
 // (one 64-bit add per load instead of a clamp + multiply-add chain).  Rows beyond M / columns beyond Cout
 // read clamped addresses and are simply never stored; only out-of-image taps are zeroed.
 // ---------------------------------------------------------------------------------------------
-template <int TN>
+template <int TN, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void conv_fwd_x3p_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 64 * TN, TM = 2, BK = 32;
     constexpr int CPR = BK / 4, RPP = 256 / CPR, NPA = BM / RPP, NPB = BN / RPP;
@@ -621,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3p_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    epilogue_tile<TM, TN>(acc, reinterpret_cast<float*>(smem_b), a, m0, n0, wm, wn, lane, t, tile_m);
+    epilogue_tile<TM, TN, EPI>(acc, reinterpret_cast<float*>(smem_b), a, m0, n0, wm, wn, lane, t, tile_m);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -660,7 +757,7 @@ __device__ __forceinline__ uint64_t stamp() {
     return v;
 }
 
-template <int TN, bool STAMP = false, int ABL = 0>
+template <int TN, bool STAMP = false, int ABL = 0, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
     constexpr int BM = 256, BN = 64 * TN, NT = 2 * TN, MT = 8;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
@@ -895,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
                         stage[(i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 32 * TN + j * 16 + (lane & 15)] = acc[i][j][e];
         }
         __syncthreads();
-        drain_stage<2, TN>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
+        drain_stage<2, TN, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
     }
 }
 
@@ -969,7 +1066,7 @@ __global__ __launch_bounds__(256) void split_image_kernel(const float* __restric
     }
 }
 
-template <int TN>
+template <int TN, bool EPI = false>
 __global__ __launch_bounds__(512, 1) void conv_fwd_x3t_kernel(ConvArgs a) {
     constexpr int BM = 256, BN = 64 * TN, NT = 2 * TN, MT = 8;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
@@ -1149,8 +1246,233 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_x3t_kernel(ConvArgs a) {
                         stage[(i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 32 * TN + j * 16 + (lane & 15)] = acc[i][j][e];
         }
         __syncthreads();
-        drain_stage<2, TN>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
+        drain_stage<2, TN, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
     }
+}
+
+// Taps of which at least one row of the block's M-tile reads inside the image (bit r*S + s), conservatively: a tile
+// inside one image covers the output rows ho0..ho1 (and every column once it spans a full row); a tap whose input rows
+// all fall outside contributes exact zeros and its K-steps are skipped (dilated ASPP branches near the image border:
+// 15 % of the K-steps at dilation 24 on a 97-row map).  Uniform over the block.  RS <= 64.
+__device__ __forceinline__ uint64_t live_taps(const ConvArgs& a, int m0, int BM) {
+    const int RS = a.R * a.S;
+    const uint64_t all = RS >= 64 ? ~0ull : ((1ull << RS) - 1ull);
+    const int HoWo = a.Ho * a.Wo;
+    const int m_last = min(m0 + BM, a.M) - 1;
+    const int img0 = m0 / HoWo, img1 = m_last / HoWo;
+    if (img0 != img1) return all;
+    const int rem0 = m0 - img0 * HoWo, rem1 = m_last - img0 * HoWo;
+    const int ho0 = rem0 / a.Wo, ho1 = rem1 / a.Wo;
+    int wo0 = 0, wo1 = a.Wo - 1;
+    if (ho0 == ho1) {
+        wo0 = rem0 - ho0 * a.Wo;
+        wo1 = rem1 - ho0 * a.Wo;
+    }
+    uint64_t live = 0;
+    for (int r = 0; r < a.R; ++r) {
+        const int ylo = ho0 * a.sy + a.oy0 + r * a.ody, yhi = ho1 * a.sy + a.oy0 + r * a.ody;
+        if (yhi < 0 || ylo >= a.Hi) continue;
+        for (int q = 0; q < a.S; ++q) {
+            const int xlo = wo0 * a.sx + a.ox0 + q * a.odx, xhi = wo1 * a.sx + a.ox0 + q * a.odx;
+            if (xhi < 0 || xlo >= a.Wi) continue;
+            live |= 1ull << (r * a.S + q);
+        }
+    }
+    return live != 0 ? live : all;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_fwd_x3t_kernel with TWO MFMA waves per SIMD: 12 waves = 8 MFMA waves as 4 (M) x 2 (N), wave tile 64 x (32*TN)
+// (64 accumulator registers, ~150 VGPRs: three waves fit a SIMD), + 4 LDS-DMA loader waves (one per SIMD).  Same
+// 256 x (64*TN) x 32 block tile, same three-stage ring, same split / MFMA order per accumulator (bit-identical results).
+// Why: with one MFMA wave per SIMD nothing covers that wave's barrier wait and the LDS latency of the first fragment
+// reads of every K-step (matrix pipe 66 % busy); a second wave's MFMAs fill those holes.  K-steps of taps that lie
+// outside the image for the whole tile are skipped (live_taps).  Both 128-row halves of the epilogue drain at once
+// (two 256-thread groups, two stage areas).
+// ---------------------------------------------------------------------------------------------
+template <int TN, bool EPI = false>
+__global__ __launch_bounds__(768, 3) void conv_fwd_x3t8_kernel(ConvArgs a) {
+    constexpr int BM = 256, BN = 64 * TN, NT = 2 * TN, MT = 4;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool loader = wv >= 8;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int RS = a.R * a.S;
+    const int cchunks = a.Cin / 32;
+    const uint64_t live = RS <= 64 ? live_taps(a, m0, BM) : ~0ull;
+    const int ntaps = RS <= 64 ? __builtin_popcountll(live) : RS;
+    const int ksteps = ntaps * cchunks;
+
+    if (loader) {
+        const int lw = wv - 8;                                   // 0..3: A rows lw*64 + 16 j + (lane >> 2)
+        const unsigned char* twin = reinterpret_cast<const unsigned char*>(a.in);
+        const int lrow = lane >> 2;
+        const int kslot = (lane & 3) ^ lds_swz(lrow);
+        int pixbase[4], yx0[4];
+        const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = min(m0 + lw * 64 + 16 * j + lrow, a.M - 1);
+            const int img = m / HoWo, rem = m - img * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            pixbase[j] = img * a.Hi * a.Wi;
+            yx0[j] = ((ho * a.sy + a.oy0) << 16) | ((wo * a.sx + a.ox0) & 0xffff);
+        }
+        const int64_t rowb = (int64_t)a.in_ld * 4;
+        const unsigned char* pa[4];
+        uint64_t todo = live;
+        int l_tap = 0, l_cc = 0;
+        auto next_tap = [&]() {                                  // -> l_tap = next live tap
+            if (RS <= 64) {
+                l_tap = __builtin_ctzll(todo);
+                todo &= todo - 1;
+            } else {
+                ++l_tap;
+            }
+        };
+        auto set_tap = [&](int tap) {
+            const int r = tap / a.S, q = tap - r * a.S;
+            const int dy = r * a.ody, dx = q * a.odx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = (yx0[j] >> 16) + dy, ix = (int)(short)(yx0[j] & 0xffff) + dx;
+                const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+                pa[j] = ok ? twin + (int64_t)(pixbase[j] + iy * a.Wi + ix) * rowb + kslot * 32 : nullptr;
+            }
+        };
+        const unsigned char* bimg = a.wgt_img + (int64_t)tile_n * (RS * cchunks) * (2 * B_PLANE) + (lw * 2 * TN) * 1024 + lane * 16;
+        int issued = 0;
+        auto issue = [&](int buf) {
+            unsigned char* stage = smem_b + buf * STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned char* src = pa[j] != nullptr ? pa[j] + l_cc * 128 : g_zero16;
+                const unsigned char* src_lo = pa[j] != nullptr ? src + 16 : g_zero16;
+                unsigned char* dst = stage + (lw * 64 + 16 * j) * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lo,
+                                                 (__attribute__((address_space(3))) void*)(dst + A_PLANE), 16, 0, 0);
+            }
+            const unsigned char* bsrc = bimg + (int64_t)(l_tap * cchunks + l_cc) * (2 * B_PLANE);
+            unsigned char* bdst = stage + 2 * A_PLANE + (lw * 2 * TN) * 1024;
+#pragma unroll
+            for (int c = 0; c < 2 * TN; ++c)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + c * 1024),
+                                                 (__attribute__((address_space(3))) void*)(bdst + c * 1024), 16, 0, 0);
+            ++issued;
+            if (++l_cc == cchunks) {
+                l_cc = 0;
+                if (issued < ksteps) {
+                    next_tap();
+                    set_tap(l_tap);
+                }
+            }
+        };
+        auto wait_next = [&](bool newest_in_flight) {
+            if (newest_in_flight) {
+                if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        };
+        if (RS <= 64) {
+            next_tap();
+        }
+        set_tap(l_tap);
+        issue(0);
+        if (ksteps > 1) issue(1);
+        wait_next(ksteps > 1);
+        int nx = 2;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bool ahead = ks + 2 < ksteps;
+            if (ahead) issue(nx);
+            wait_next(ahead);
+            nx = nx == 2 ? 0 : nx + 1;
+        }
+        return;
+    }
+
+    const int wm = wv >> 1, wn = wv & 1;                          // 4 x 2 MFMA waves
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
+    const int aoff = wm * 64 * 64 + foff;
+    const int boff = 2 * A_PLANE + wn * 32 * TN * 64 + foff;
+
+    __builtin_amdgcn_s_barrier();                                // stage 0 has landed
+    int cur = 0;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const unsigned char* Ah = smem_b + cur * STAGE + aoff;
+        const unsigned char* Al = Ah + A_PLANE;
+        const unsigned char* Bh = smem_b + cur * STAGE + boff;
+        const unsigned char* Bl = Bh + B_PLANE;
+        bf16x8_t bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
+            bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
+        }
+        bf16x8_t fa[MT][2];
+        fa[0][0] = *reinterpret_cast<const bf16x8_t*>(Ah);
+        fa[0][1] = *reinterpret_cast<const bf16x8_t*>(Al);
+        fa[1][0] = *reinterpret_cast<const bf16x8_t*>(Ah + 1024);
+        fa[1][1] = *reinterpret_cast<const bf16x8_t*>(Al + 1024);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 4, 0);
+#pragma unroll
+        for (int i = 0; i < MT; i += 2) {
+            if (i + 2 < MT) {
+                fa[i + 2][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 2) * 1024);
+                fa[i + 2][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 2) * 1024);
+                fa[i + 3][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 3) * 1024);
+                fa[i + 3][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 3) * 1024);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][1], bh[j], acc[i + u][j], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][0], bl[j], acc[i + u][j], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][0], bh[j], acc[i + u][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();                                             // (8 surviving waves) everyone is out of the ring
+
+    // epilogue: thread group h = wv >> 2 (waves 4h .. 4h+3 = rows 128h .. 128h+127) stages and drains its half
+    constexpr int LDS_LD = BN + 4;
+    const int h = wv >> 2, t = threadIdx.x & 255;
+    float* stage = reinterpret_cast<float*>(smem_b) + h * (128 * LDS_LD);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                stage[((wm & 1) * 64 + i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 32 * TN + j * 16 + (lane & 15)] = acc[i][j][e];
+    __syncthreads();
+    drain_stage<2, TN, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h, m0 + h * 128 < a.M);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1939,15 +2261,38 @@ static int check_conv_common(const char* who, int64_t Cin, int64_t in_ld, int64_
     return DIGA_OK;
 }
 
+// fills the backward-epilogue fields of ConvArgs from the public descriptor (nullptr = plain convolution)
+static int set_bwd_epilogue(ConvArgs& a, const diga_bwd_epilogue_t* e, const char* who) {
+    a.e_add = a.e_masky = a.e_x = a.e_relu_ab = a.e_mean = a.e_invstd = nullptr;
+    a.e_partials = nullptr;
+    a.e_add_ld = a.e_masky_ld = a.e_x_ld = 0;
+    if (e == nullptr) return DIGA_OK;
+    DIGA_REQUIRE(e->addend || e->mask_y || e->x, DIGA_EINVAL, "%s: empty epilogue descriptor", who);
+    DIGA_REQUIRE(a.Cout % 4 == 0 && a.out_ld % 4 == 0 && aligned16(a.out) && a.bias == nullptr && a.stats == nullptr, DIGA_EINVAL,
+                 "%s: a backward epilogue needs Cout %% 4 == 0, out_ld %% 4 == 0, a 16-byte aligned output, no bias, no forward statistics", who);
+    DIGA_REQUIRE(!e->addend || (aligned16(e->addend) && e->addend_ld >= a.Cout && e->addend_ld % 4 == 0), DIGA_EINVAL, "%s: bad addend", who);
+    DIGA_REQUIRE(!e->mask_y || (aligned16(e->mask_y) && e->mask_ld >= a.Cout && e->mask_ld % 4 == 0), DIGA_EINVAL, "%s: bad mask_y", who);
+    DIGA_REQUIRE(!e->x || (aligned16(e->x) && e->x_ld >= a.Cout && e->x_ld % 4 == 0), DIGA_EINVAL, "%s: bad x", who);
+    DIGA_REQUIRE(!(e->mask_y && e->relu_ab), DIGA_EINVAL, "%s: give mask_y or relu_ab, not both", who);
+    DIGA_REQUIRE(!e->relu_ab || (e->x && aligned16(e->relu_ab)), DIGA_EINVAL, "%s: relu_ab needs x", who);
+    DIGA_REQUIRE(!e->partials || (e->x && e->mean && e->invstd && aligned16(e->mean) && aligned16(e->invstd)), DIGA_EINVAL,
+                 "%s: partials need x, mean and invstd", who);
+    a.e_add = e->addend; a.e_add_ld = (int)e->addend_ld;
+    a.e_masky = e->mask_y; a.e_masky_ld = (int)e->mask_ld;
+    a.e_x = e->x; a.e_x_ld = (int)e->x_ld;
+    a.e_relu_ab = e->relu_ab; a.e_mean = e->mean; a.e_invstd = e->invstd; a.e_partials = e->partials;
+    return DIGA_OK;
+}
+
 }  // namespace diga
 
 using namespace diga;
 
-extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, float* out, int64_t N,
+static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias, float* out, int64_t N,
                                     int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo,
                                     int64_t Cout, int64_t out_ld, int64_t R, int64_t S, int64_t stride_y,
                                     int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
-                                    float* stats_partial, int prof_tag, void* stream) {
+                                    float* stats_partial, int prof_tag, void* stream, const diga_bwd_epilogue_t* epi) {
     DIGA_REQUIRE(in && wgt && out, DIGA_EINVAL, "conv2d: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d: bad shape");
     int rc = check_conv_common("conv2d", Cin, in_ld, out_ld, Cout, in, wgt, out);
@@ -1962,24 +2307,29 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
     a.M = (int)(N * Ho * Wo);
     a.all_inside = 0;
     a.tiles_m = (int)ceil_div(a.M, 128);
+    rc = set_bwd_epilogue(a, epi, "conv2d");
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
                    2.0 * (double)a.M * (double)Cout * (double)(R * S) * (double)Cin);
     static const int bk_env = [] { const char* e = getenv("DIGA_CONV_BK"); return e ? atoi(e) : 32; }();
-    const int bk = (bk_env == 16 && stats_partial == nullptr) ? 16 : 32;
+    const int bk = (bk_env == 16 && stats_partial == nullptr && epi == nullptr) ? 16 : 32;
+#define DIGA_LAUNCH_K(KERNEL_, THREADS_, SH_)                                                                          \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)KERNEL_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SH_));        \
+        hipLaunchKernelGGL(KERNEL_, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(THREADS_), (SH_), st, a);             \
+    } while (0)
 #define DIGA_FWD_LAUNCH(TN_, BK_)                                                                                      \
     do {                                                                                                               \
         const size_t sh = (size_t)(2 * 128 * (BK_ + 4) + 2 * 64 * TN_ * (BK_ + 4)) * sizeof(float);                     \
-        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<TN_, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                  (int)sh);                                                                            \
-        hipLaunchKernelGGL((conv_fwd_kernel<TN_, BK_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a); \
+        if (epi != nullptr && BK_ == 32) DIGA_LAUNCH_K((conv_fwd_kernel<TN_, 32, true>), 256, sh);                      \
+        else DIGA_LAUNCH_K((conv_fwd_kernel<TN_, BK_, false>), 256, sh);                                                \
     } while (0)
 #define DIGA_X3_LAUNCH(TN_)                                                                                            \
     do {                                                                                                               \
         const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 64 * TN_ * kRowB);                                         \
-        (void)hipFuncSetAttribute((const void*)conv_fwd_x3_kernel<TN_>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                  (int)sh);                                                                            \
-        hipLaunchKernelGGL((conv_fwd_x3_kernel<TN_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);   \
+        if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3_kernel<TN_, true>), 256, sh);                                    \
+        else DIGA_LAUNCH_K((conv_fwd_x3_kernel<TN_, false>), 256, sh);                                                  \
     } while (0)
     const bool x3 = g_conv_math.load(std::memory_order_relaxed) == DIGA_CONV_MATH_BF16X3;
     if (Cout > 64) {
@@ -1998,6 +2348,25 @@ extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const flo
     return launch_status("diga_conv2d_nhwc_f32");
 }
 
+extern "C" int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, float* out, int64_t N,
+                                    int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo,
+                                    int64_t Cout, int64_t out_ld, int64_t R, int64_t S, int64_t stride_y,
+                                    int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
+                                    float* stats_partial, int prof_tag, void* stream) {
+    return conv2d_f32_impl(in, wgt, bias, out, N, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x, off_y0, off_x0,
+                           off_dy, off_dx, stats_partial, prof_tag, stream, nullptr);
+}
+
+extern "C" int diga_conv2d_nhwc_f32_epi(const float* in, const float* wgt, float* out, int64_t N, int64_t Hi, int64_t Wi,
+                                        int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld,
+                                        int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0,
+                                        int64_t off_x0, int64_t off_dy, int64_t off_dx, const diga_bwd_epilogue_t* epi,
+                                        int prof_tag, void* stream) {
+    DIGA_REQUIRE(epi != nullptr, DIGA_EINVAL, "conv2d_epi: null epilogue descriptor");
+    return conv2d_f32_impl(in, wgt, nullptr, out, N, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x, off_y0,
+                           off_x0, off_dy, off_dx, nullptr, prof_tag, stream, epi);
+}
+
 extern "C" int diga_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, void* stream) {
     DIGA_REQUIRE(x && hi && lo && n > 0 && n % 4 == 0, DIGA_EINVAL, "split_bf16: n must be a positive multiple of 4");
     DIGA_REQUIRE(aligned16(x) && ((uintptr_t)hi & 7u) == 0 && ((uintptr_t)lo & 7u) == 0, DIGA_EALIGN, "split_bf16: alignment");
@@ -2007,11 +2376,12 @@ extern "C" int diga_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64
     return launch_status("diga_split_bf16");
 }
 
-extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, const float* bias,
+static int conv2d_bf16x3_impl(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, const float* bias,
                                        float* out, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld,
                                        int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
                                        int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
-                                       int64_t off_dx, float* stats_partial, int prof_tag, void* stream) {
+                                       int64_t off_dx, float* stats_partial, int prof_tag, void* stream,
+                                       const diga_bwd_epilogue_t* epi) {
     DIGA_REQUIRE(in && wgt_hi && wgt_lo && out, DIGA_EINVAL, "conv2d_bf16x3: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_bf16x3: bad shape");
     int rc = check_conv_common("conv2d_bf16x3", Cin, in_ld, out_ld, Cout, in, in, out);
@@ -2031,6 +2401,8 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
         const int64_t x_lo = off_x0 + std::min<int64_t>(0, (S - 1) * off_dx), x_hi = (Wo - 1) * stride_x + off_x0 + std::max<int64_t>(0, (S - 1) * off_dx);
         a.all_inside = y_lo >= 0 && y_hi < Hi && x_lo >= 0 && x_hi < Wi;
     }
+    rc = set_bwd_epilogue(a, epi, "conv2d_bf16x3");
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
                    2.0 * (double)a.M * (double)Cout * (double)(R * S) * (double)Cin);
@@ -2065,22 +2437,41 @@ extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, 
             (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             hipLaunchKernelGGL((conv_fwd_x3w_kernel<2, false, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
         } else if (tn == 2) {
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            hipLaunchKernelGGL((conv_fwd_x3w_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w_kernel<2, false, 0, true>), 256, sh);
+            else DIGA_LAUNCH_K((conv_fwd_x3w_kernel<2, false, 0, false>), 256, sh);
         } else {
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            hipLaunchKernelGGL((conv_fwd_x3w_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w_kernel<1, false, 0, true>), 256, sh);
+            else DIGA_LAUNCH_K((conv_fwd_x3w_kernel<1, false, 0, false>), 256, sh);
         }
     } else if (tn == 2) {
         const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 128 * kRowB);
-        (void)hipFuncSetAttribute((const void*)conv_fwd_x3p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((conv_fwd_x3p_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+        if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3p_kernel<2, true>), 256, sh);
+        else DIGA_LAUNCH_K((conv_fwd_x3p_kernel<2, false>), 256, sh);
     } else {
         const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 64 * kRowB);
-        (void)hipFuncSetAttribute((const void*)conv_fwd_x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((conv_fwd_x3p_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+        if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3p_kernel<1, true>), 256, sh);
+        else DIGA_LAUNCH_K((conv_fwd_x3p_kernel<1, false>), 256, sh);
     }
     return launch_status("diga_conv2d_nhwc_bf16x3");
+}
+
+extern "C" int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, const float* bias,
+                                       float* out, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld,
+                                       int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                                       int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
+                                       int64_t off_dx, float* stats_partial, int prof_tag, void* stream) {
+    return conv2d_bf16x3_impl(in, wgt_hi, wgt_lo, bias, out, N, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x,
+                              off_y0, off_x0, off_dy, off_dx, stats_partial, prof_tag, stream, nullptr);
+}
+
+extern "C" int diga_conv2d_nhwc_bf16x3_epi(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, float* out, int64_t N,
+                                           int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo,
+                                           int64_t Cout, int64_t out_ld, int64_t R, int64_t S, int64_t stride_y,
+                                           int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
+                                           const diga_bwd_epilogue_t* epi, int prof_tag, void* stream) {
+    DIGA_REQUIRE(epi != nullptr, DIGA_EINVAL, "conv2d_bf16x3_epi: null epilogue descriptor");
+    return conv2d_bf16x3_impl(in, wgt_hi, wgt_lo, nullptr, out, N, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x,
+                              off_y0, off_x0, off_dy, off_dx, nullptr, prof_tag, stream, epi);
 }
 
 // ---- "twin" path: activations and weights pre-split, staged by LDS-DMA (conv_fwd_x3t_kernel)
@@ -2115,10 +2506,11 @@ extern "C" int diga_split_bf16_image(const float* w, void* img, int64_t K, int64
     return launch_status("diga_split_bf16_image");
 }
 
-extern "C" int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, const float* bias, float* out, int64_t N,
+static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const float* bias, float* out, int64_t N,
                                      int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld,
                                      int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
-                                     int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream) {
+                                     int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream,
+                                     const diga_bwd_epilogue_t* epi) {
     DIGA_REQUIRE(in_twin && wgt_img && out, DIGA_EINVAL, "conv2d_twin: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_twin: bad shape");
     DIGA_REQUIRE(Cin > 0 && Cin % 32 == 0 && out_ld >= Cout, DIGA_EINVAL, "conv2d_twin: Cin must be a multiple of 32");
@@ -2136,18 +2528,56 @@ extern "C" int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, c
     a.all_inside = 0;
     const int tn = Cout > 64 ? 2 : 1;
     a.tiles_n = (int)ceil_div(Cout, 64 * tn);
+    {
+        const int rc = set_bwd_epilogue(a, epi, "conv2d_twin");
+        if (rc) return rc;
+    }
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
                    2.0 * (double)a.M * (double)Cout * (double)(R * S) * (double)Cin);
     const size_t sh = (size_t)3 * (2 * 256 * 64 + 2 * 64 * tn * 64);
+    // 0: one MFMA wave per SIMD (round-1 kernel); 1: two MFMA waves per SIMD + dead-tap skipping.  Measured on the C2
+    // layer shapes (tools/bench_twin.py, interleaved rounds): multi-tap layers 3-6 % faster with 1 (ASPP dilation 24:
+    // 17 %), 1x1 layers 1-3 % slower -- so 1 for multi-tap layers, 0 for pointwise ones.
+    const char* var_env = getenv("DIGA_X3T_VARIANT");
+    const int variant = var_env ? atoi(var_env) : (R * S > 1 ? 1 : 0);
+    if (variant == 1 && R * S <= 64) {
+        const size_t stg = (size_t)2 * 128 * (64 * tn + 4) * sizeof(float);
+        const size_t sh8 = sh > stg ? sh : stg;
+        if (tn == 2) {
+            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3t8_kernel<2, true>), 768, sh8);
+            else DIGA_LAUNCH_K((conv_fwd_x3t8_kernel<2, false>), 768, sh8);
+        } else {
+            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3t8_kernel<1, true>), 768, sh8);
+            else DIGA_LAUNCH_K((conv_fwd_x3t8_kernel<1, false>), 768, sh8);
+        }
+        return launch_status("diga_conv2d_nhwc_twin");
+    }
     if (tn == 2) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_x3t_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((conv_fwd_x3t_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), sh, st, a);
+        if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3t_kernel<2, true>), 512, sh);
+        else DIGA_LAUNCH_K((conv_fwd_x3t_kernel<2, false>), 512, sh);
     } else {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_x3t_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((conv_fwd_x3t_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), sh, st, a);
+        if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3t_kernel<1, true>), 512, sh);
+        else DIGA_LAUNCH_K((conv_fwd_x3t_kernel<1, false>), 512, sh);
     }
     return launch_status("diga_conv2d_nhwc_twin");
+}
+
+extern "C" int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, const float* bias, float* out, int64_t N,
+                                     int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld,
+                                     int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
+                                     int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream) {
+    return conv2d_twin_impl(in_twin, wgt_img, bias, out, N, Hi, Wi, Cin, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x, off_y0, off_x0,
+                            off_dy, off_dx, stats_partial, prof_tag, stream, nullptr);
+}
+
+extern "C" int diga_conv2d_nhwc_twin_epi(const void* in_twin, const void* wgt_img, float* out, int64_t N, int64_t Hi, int64_t Wi,
+                                         int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                                         int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
+                                         int64_t off_dx, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream) {
+    DIGA_REQUIRE(epi != nullptr, DIGA_EINVAL, "conv2d_twin_epi: null epilogue descriptor");
+    return conv2d_twin_impl(in_twin, wgt_img, nullptr, out, N, Hi, Wi, Cin, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x, off_y0,
+                            off_x0, off_dy, off_dx, nullptr, prof_tag, stream, epi);
 }
 
 extern "C" size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout) {

@@ -906,6 +906,33 @@ extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     return launch_status("diga_bn_bwd");
 }
 
+extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,
+                                    const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx, int64_t M,
+                                    int64_t C, int dx_twin, const float* partial, int64_t chunk_rows, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(!dx_twin || (C % 8 == 0 && ld_dx == C), DIGA_EINVAL, "bn_bwd_partials: twin output needs C % 8 == 0 and a dense dx");
+    DIGA_REQUIRE(g && x && gamma && save_mean && save_invstd && dx && partial && workspace && M > 0 && chunk_rows > 0, DIGA_EINVAL,
+                 "bn_bwd_partials: bad argument");
+    int rc = check_norm("bn_bwd_partials", C, {ld_g, ld_x, ld_dx}, {g, x, dx});
+    if (rc) return rc;
+    DIGA_REQUIRE(workspace_bytes >= (size_t)3 * C * sizeof(float), DIGA_EWORKSPACE, "bn_bwd_partials: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * 12.0);        // apply pass only: g, x in, dx out
+    ColGeom geo;
+    geo.rows_per_seg = M;
+    geo.nseg = 1;
+    geo.C = (int)C;
+    geo.chunk_rows = (int)chunk_rows;
+    geo.nchunk = (int)ceil_div(M, chunk_rows);
+    float* kk = (float*)workspace;
+    hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, geo, gamma,
+                       save_invstd, kk, 1);
+    hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, g, ld_g, x, ld_x, (const float*)nullptr,
+                       (int64_t)0, save_mean, save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, (float*)nullptr,
+                       (int64_t)0, M, M, (int)C, (const float*)nullptr, dx_twin);
+    return launch_status("diga_bn_bwd_partials");
+}
+
 extern "C" int diga_gn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* gamma, const float* beta,
                            const float* chan_scale, float* save_mean, float* save_invstd, int64_t N, int64_t HW, int64_t C,
                            int64_t G, int relu, float eps, void* workspace, size_t workspace_bytes, void* stream) {

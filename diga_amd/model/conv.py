@@ -58,9 +58,11 @@ def takes_twin_only_input(conv, pointwise_ok=False):
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
 
 
-def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False):
+def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
-    out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x."""
+    out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x.
+    epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue."""
+    import ctypes
     n, hi, wi, cin = x.shape
     _, ho, wo, k = out.shape
     _, r, s, _ = w_krsc.shape
@@ -76,6 +78,11 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                 twin_box[0] = twin
         img = torch.empty(_lib.lib.diga_split_bf16_image_bytes(k, r * s, cin), dtype=torch.uint8, device=x.device)
         _lib.call("diga_split_bf16_image", _lib.ptr(w_krsc), _lib.ptr(img), k, r * s, cin, _lib.stream())
+        if epi is not None:
+            _lib.call("diga_conv2d_nhwc_twin_epi", _lib.ptr(twin), _lib.ptr(img), _lib.ptr(out), n, hi, wi, cin, ho, wo, k,
+                      out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], ctypes.byref(epi), tag,
+                      _lib.stream())
+            return twin
         _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin, ho, wo, k,
                   out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], _lib.ptr(stats), tag,
                   _lib.stream())
@@ -89,9 +96,19 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         w_hi = torch.empty(nel, dtype=torch.int16, device=w_krsc.device)
         w_lo = torch.empty(nel, dtype=torch.int16, device=w_krsc.device)
         _lib.call("diga_split_bf16", _lib.ptr(w_krsc), _lib.ptr(w_hi), _lib.ptr(w_lo), nel, _lib.stream())
+        if epi is not None:
+            _lib.call("diga_conv2d_nhwc_bf16x3_epi", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(out),
+                      n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
+                      doff[0], doff[1], ctypes.byref(epi), tag, _lib.stream())
+            return None
         _lib.call("diga_conv2d_nhwc_bf16x3", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(bias), _lib.ptr(out),
                   n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                   doff[0], doff[1], _lib.ptr(stats), tag, _lib.stream())
+        return None
+    if epi is not None:
+        _lib.call("diga_conv2d_nhwc_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), n, hi, wi, cin,
+                  x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
+                  ctypes.byref(epi), tag, _lib.stream())
         return None
     _lib.call("diga_conv2d_nhwc_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin,
               x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
@@ -152,7 +169,7 @@ class _StemConvFn(torch.autograd.Function):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None, x_is_twin=False,
-                dy_is_twin=False):
+                dy_is_twin=False, bn_box=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         if x_is_twin:          # the producer wrote the split twin instead of fp32 (same bytes per element): hand it on
@@ -191,6 +208,14 @@ class _Conv2dFn(torch.autograd.Function):
         # the arithmetic / twin decisions of this forward bind its backward: saved tensors may hold twin bytes
         ctx.math = _lib.lib.diga_get_conv_math()
         ctx.x_is_twin = bool(x_is_twin)
+        # the BatchNorm that produced x lets this conv's backward-data epilogue finish its incoming gradient (norm._BnFn)
+        ctx.bn_box = None
+        if (bn_box is not None and ctx.needs_input_grad[0] and stride == (1, 1) and cp == c and c % 4 == 0
+                and "claimed" not in bn_box and bn_box.get("rows") == n * hi * wi and bn_box.get("C") == c
+                and (not bn_box["has_res"] or not x_is_twin)):
+            bn_box["claimed"] = True
+            bn_box["consumer_ready"] = True
+            ctx.bn_box = bn_box
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -229,9 +254,23 @@ class _Conv2dFn(torch.autograd.Function):
                 wt[..., :k] = w.permute(3, 1, 2, 0)
             if stride == (1, 1):
                 dxn = torch.empty((n, hi, wi, cp), dtype=torch.float32, device=w.device)
+                epi, box = None, ctx.bn_box
+                if box is not None:
+                    # finish the gradient of the BatchNorm in front of this conv in the epilogue: + residual-branch
+                    # gradient, ReLU mask, sum g / sum g*xhat per 128-row chunk (include/diga_hip.h, diga_bwd_epilogue_t)
+                    m_rows = n * hi * wi
+                    part = torch.empty(((m_rows + 127) // 128) * 2 * cp, dtype=torch.float32, device=w.device)
+                    add = box.pop("dres", None) if box["has_res"] else None
+                    epi = _lib.BwdEpilogue()
+                    epi.addend, epi.addend_ld = _lib.ptr(add), cp
+                    epi.mask_y, epi.mask_ld = (_lib.ptr(xn), cp) if box["has_res"] else (None, 0)
+                    epi.x, epi.x_ld = _lib.ptr(box["x"]), cp
+                    epi.relu_ab = _lib.ptr(box["relu_ab"]) if not box["has_res"] else None
+                    epi.mean, epi.invstd, epi.partials = _lib.ptr(box["mean"]), _lib.ptr(box["invstd"]), _lib.ptr(part)
+                    box["premasked"] = (dxn.data_ptr(), part, dxn, add)
                 _conv_launch(gyp, wt, None, dxn, (1, 1), (padding[0], padding[1]), (-dilation[0], -dilation[1]),
                              _TAG_BWD_DATA, None, dy_box if ((use_tw or ctx.dy_is_twin) and cp > 64) else None,
-                             must_twin=ctx.dy_is_twin)
+                             must_twin=ctx.dy_is_twin, epi=epi)
             else:
                 if (r, s) != (1, 1) or padding != (0, 0):
                     raise NotImplementedError("backward-data of strided convs is only needed (and built) for 1x1")
@@ -291,7 +330,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -339,11 +378,14 @@ class DigaConv2d(nn.Conv2d):
         x_is_twin = bool(getattr(x, "_diga_is_twin", False))
         if x_is_twin and fn is not _Conv2dFn:
             raise RuntimeError("DigaConv2d: twin-only input on the stem path")
-        if x_is_twin or twin_grad:
+        bn_box = getattr(x, "_diga_bn_box", None)
+        if bn_box is not None and (self.share_twin or fn is not _Conv2dFn or not torch.is_grad_enabled()):
+            bn_box = None                     # several convs read this tensor / no backward: autograd keeps the plain path
+        if x_is_twin or twin_grad or bn_box is not None:
             if fn is not _Conv2dFn or (self.bias is not None and twin_grad):
                 raise RuntimeError("DigaConv2d: twin gradient needs a bias-free conv on the implicit-GEMM path")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
-                         twin_box, x_is_twin, bool(twin_grad))
+                         twin_box, x_is_twin, bool(twin_grad), bn_box)
         else:
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
                          twin_box)

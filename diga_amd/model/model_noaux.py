@@ -12,7 +12,8 @@ import torch.nn as nn
 _pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.path.dirname(_pkg) not in sys.path:
     sys.path.append(os.path.dirname(_pkg))
-from diga_amd import _lib  # noqa: E402,F401  (fails loudly when the HIP library is missing)
+from diga_amd import _lib
+from diga_amd.model import norm as dn  # noqa: E402,F401  (fails loudly when the HIP library is missing)
 from diga_amd.model.seg_model_noaux import RESNET101, DeeplabMulti  # noqa: E402
 from diga_amd.model.translator import ImgDecoder, ImgEncoder  # noqa: E402,F401  (same import surface as the reference)
 
@@ -36,6 +37,8 @@ class SegModel(nn.Module):
 
     def forward(self, x):
         _lib.require_gpu(x)
+        if self.training:
+            dn.bump_batches_tracked(self)                     # one launch for the 104 BatchNorm step counters
         conv1, bn1, _relu, maxpool = self.layer0              # ReLU is fused into the BN kernel
         shallow = self.layer2(self.layer1(maxpool(bn1(conv1(x), relu=True))))
         deep = self.layer4(self.layer3(shallow))

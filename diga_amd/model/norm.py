@@ -53,9 +53,15 @@ def _ws(rows_per_seg, nseg, c, device):
 
 # --------------------------------------------------------------------------------------------- BatchNorm
 class _BnFn(torch.autograd.Function):
+    """Train-mode BatchNorm (+ReLU, +residual).  `box` (a dict, or None) ties this BN to the convolution that consumes its
+    output: that conv's backward-data kernel finishes this BN's incoming gradient in its epilogue -- adds the
+    residual-branch gradient (`box['dres']`, put there by the backward of the BN that took this BN's output as residual),
+    applies this BN's ReLU mask and reduces sum g / sum g*xhat -- and leaves (pointer, partials) in `box['premasked']`;
+    backward() then only finalises and applies.  `res_box`: the box of the BN that produced `residual`."""
+
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, relu, momentum, eps,
-                partials=None, twin_out=False, dx_twin=False):
+                partials=None, twin_out=False, dx_twin=False, box=None, res_box=None):
         _lib.require_gpu(x)
         xn = nhwc(x.detach())
         n, h, w, c = xn.shape
@@ -82,6 +88,9 @@ class _BnFn(torch.autograd.Function):
         ctx.save_for_backward(xn, y if (relu and save_ab is None) else None, weight, save_mean, save_invstd, save_ab)
         ctx.flags = (training, residual is not None)
         ctx.dx_twin = bool(dx_twin and c % 8 == 0)
+        ctx.box, ctx.res_box = box, res_box
+        if box is not None:
+            box.update(x=xn, mean=save_mean, invstd=save_invstd, relu_ab=save_ab, has_res=residual is not None, rows=m, C=c)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -92,13 +101,28 @@ class _BnFn(torch.autograd.Function):
         m = n * h * w
         g, ld_g = as_rows(gy.permute(0, 2, 3, 1))
         dx = torch.empty_like(xn)
-        dres = torch.empty_like(xn) if has_res else None
-        ws = _ws(m, 1, c, xn.device)
-        _lib.call("diga_bn_bwd", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(save_ab), _lib.ptr(weight),
-                  _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dres), c, m, c,
-                  1 if training else 0, 1 if ctx.dx_twin else 0, _lib.ptr(ws), ws.numel(), _lib.stream())
+        pre = ctx.box.pop("premasked", None) if ctx.box is not None else None
+        if pre is not None and pre[0] == g.data_ptr() and ld_g == c and training:
+            # the consumer conv's backward-data epilogue delivered g = mask * (its gradient + residual-branch gradient) and
+            # its column sums: finalise + apply only; the residual gradient of this BN IS g
+            ws = _lib.workspace(3 * c * 4, xn.device, "norm_kk")
+            _lib.call("diga_bn_bwd_partials", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(weight), _lib.ptr(save_mean),
+                      _lib.ptr(save_invstd), _lib.ptr(dx), c, m, c, 1 if ctx.dx_twin else 0, _lib.ptr(pre[1]), 128,
+                      _lib.ptr(ws), ws.numel(), _lib.stream())
+            dres = g if has_res else None
+        else:
+            dres = torch.empty_like(xn) if has_res else None
+            ws = _ws(m, 1, c, xn.device)
+            _lib.call("diga_bn_bwd", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(save_ab), _lib.ptr(weight),
+                      _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dres), c, m, c,
+                      1 if training else 0, 1 if ctx.dx_twin else 0, _lib.ptr(ws), ws.numel(), _lib.stream())
+        if dres is not None and ctx.res_box is not None:
+            # hand the residual-branch gradient to the conv that reads the same tensor: its backward-data epilogue adds it
+            # (autograd gets None here and therefore launches no add kernel)
+            ctx.res_box["dres"] = dres
+            dres = None
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class DigaBatchNorm2d(nn.BatchNorm2d):
@@ -114,14 +138,51 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
             raise RuntimeError("DigaBatchNorm2d implements the frozen-affine BN of the DiGA path; "
                                "set requires_grad=False on weight and bias")
         training = self.training or self.running_mean is None
-        if self.training and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+        if self.training and self.num_batches_tracked is not None and not getattr(self, "_nbt_external", False):
+            self.num_batches_tracked.add_(1)          # (a model may bump all its counters with one launch instead)
         twin_out = bool(twin_out and relu and residual is None and x.shape[1] % 8 == 0)
+        box = res_box = None
+        if training and relu and torch.is_grad_enabled() and x.requires_grad and fuse_backward_enabled():
+            box = {}
+            if residual is not None:
+                rb = getattr(residual, "_diga_bn_box", None)
+                if rb is not None and rb.get("consumer_ready") and "res_claimed" not in rb:
+                    rb["res_claimed"] = True
+                    res_box = rb
         y = _BnFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, training, relu,
-                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin))
+                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin), box, res_box)
         if twin_out:
             y._diga_is_twin = True
+        if box is not None:
+            y._diga_bn_box = box
         return y
+
+
+def bump_batches_tracked(model):
+    """num_batches_tracked += 1 for every DigaBatchNorm2d of `model` with ONE launch instead of one per layer (every BN
+    of the DeepLab trunk runs exactly once per forward; the reference's nn.BatchNorm2d bumps its own counter,
+    seg_model_noaux.py:64-76 / torch).  The counters become views of one flat int64 buffer (state-dict keys and values
+    unchanged); the views are rebuilt whenever .to() / load_state_dict() replaced the buffers."""
+    bns = [m for m in model.modules() if isinstance(m, DigaBatchNorm2d) and m.num_batches_tracked is not None]
+    if not bns:
+        return
+    flat = getattr(model, "_nbt_flat", None)
+    ok = (flat is not None and len(bns) == flat.numel() and flat.device == bns[0].num_batches_tracked.device
+          and all(b.num_batches_tracked.data_ptr() == flat.data_ptr() + 8 * i for i, b in enumerate(bns)))
+    if not ok:
+        flat = torch.stack([b.num_batches_tracked.detach().reshape(()) for b in bns]).contiguous()
+        for i, b in enumerate(bns):
+            b.num_batches_tracked = flat[i]
+            b._nbt_external = True
+        object.__setattr__(model, "_nbt_flat", flat)
+    flat.add_(1)
+
+
+def fuse_backward_enabled():
+    """DIGA_FUSE_BWD=0 switches the backward-epilogue fusion (residual add + ReLU mask + BN-backward sums inside the
+    backward-data convolution) off: the A/B switch of the parity tests."""
+    import os
+    return os.environ.get("DIGA_FUSE_BWD", "1") != "0"
 
 
 # --------------------------------------------------------------------------------------------- GroupNorm

@@ -75,6 +75,10 @@ class Bottleneck(nn.Module):
         # ... and the dx of bn2's backward is read only by conv2's backward-data and backward-weight: a twin as well
         # Under autograd the same holds for conv3 (bn2's output / bn3's dx): its weight gradient is 35-39 % faster on twins.
         grad = torch.is_grad_enabled()
+        if self.downsample is not None and getattr(x, "_diga_bn_box", None) is not None:
+            # two convolutions read x here (conv1 and the downsample conv): their gradients meet in an autograd add, so
+            # the BatchNorm that produced x keeps its own mask / reduce passes (no backward-epilogue fusion)
+            x._diga_bn_box = None
         tw2 = takes_twin_only_input(self.conv2)
         tw3 = grad and os.environ.get("DIGA_TWIN_CONV3", "1") != "0" and takes_twin_only_input(self.conv3, pointwise_ok=True)
         y = self.bn1(self.conv1(x), relu=True, twin_out=tw2)
@@ -186,6 +190,8 @@ class ResNetMulti(nn.Module):
         return self.maxpool(self.bn1(self.conv1(x), relu=True))
 
     def forward(self, x):
+        if self.training:
+            dn.bump_batches_tracked(self)
         x = self.layer4(self.layer3(self.layer2(self.layer1(self.stem(x)))))
         if self.bn_clr:
             x = self.bn_pretrain(x)

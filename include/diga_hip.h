@@ -226,6 +226,47 @@ int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, f
  * conv (diga_bn_fwd_partials), which then needs no statistics pass of its own over y. */
 size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout);
 
+/* ------------------------------------------------------------------------------------
+ * Backward-data with a fused epilogue.  The gradient a backward-data convolution produces is the input gradient of the
+ * layer in front of it -- in the DeepLab trunk always a train-mode BatchNorm (+ReLU, + the residual junction of
+ * G5/model/seg_model_noaux.py:81-101).  The `_epi` forms of the three convolution entry points finish that tensor on its
+ * way out of the matrix cores instead of in separate passes over HBM:
+ *     out = acc                               the convolution (bias-free, no forward statistics)
+ *     out += addend                           the gradient reaching the same tensor through the residual branch
+ *     out  = out where (mask_y > 0)           ReLU of a BatchNorm with residual (mask_y = its output)          -- or --
+ *     out  = out where fma(x, a, b) > 0       ReLU of a BatchNorm without residual (relu_ab = its forward coefficients)
+ *     partials[chunk] = { sum out, sum out*xhat } per 128-row chunk and channel, xhat = (x - mean) * invstd
+ * `out` is then the MASKED gradient g of that BatchNorm and `partials` what diga_bn_bwd_partials finalises -- its
+ * reduce pass over (g, x), the separate add and the residual-gradient copy are gone.  All tensors [M][ld] fp32 with
+ * M = N*Ho*Wo rows, ld % 4 == 0, 16-byte aligned; Cout % 4 == 0; partials holds ceil(M/128)*2*Cout floats.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    const float* addend;   /* nullable */
+    int64_t addend_ld;
+    const float* mask_y;   /* nullable */
+    int64_t mask_ld;
+    const float* x;        /* nullable (needed by relu_ab and partials) */
+    int64_t x_ld;
+    const float* relu_ab;  /* nullable [2][Cout] */
+    const float* mean;     /* [Cout] (with partials) */
+    const float* invstd;   /* [Cout] (with partials) */
+    float* partials;       /* nullable */
+} diga_bwd_epilogue_t;
+
+int diga_conv2d_nhwc_f32_epi(const float* in, const float* wgt, float* out, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin,
+                             int64_t in_ld, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                             int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
+                             int64_t off_dx, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
+int diga_conv2d_nhwc_bf16x3_epi(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, float* out, int64_t N,
+                                int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo, int64_t Cout,
+                                int64_t out_ld, int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0,
+                                int64_t off_x0, int64_t off_dy, int64_t off_dx, const diga_bwd_epilogue_t* epi, int prof_tag,
+                                void* stream);
+int diga_conv2d_nhwc_twin_epi(const void* in_twin, const void* wgt_img, float* out, int64_t N, int64_t Hi, int64_t Wi,
+                              int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                              int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
+                              int64_t off_dx, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
+
 /* Arithmetic of diga_conv2d_nhwc_f32 (process-wide; default from the environment variable DIGA_CONV_MATH):
  *   DIGA_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, exact fp32 (k-ordered fmaf chain)            [default]
  *   DIGA_CONV_MATH_BF16X3 operands split into bf16 hi+lo while staged, hi*hi + hi*lo + lo*hi on
@@ -324,6 +365,15 @@ int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, co
                 const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
                 int64_t ld_dx, float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, int dx_twin, void* workspace,
                 size_t workspace_bytes, void* stream);
+
+/* diga_bn_bwd for a gradient that arrives already masked and reduced: `g` and `partial` ([ceil(M/chunk_rows)][2][C]:
+ * sum g, sum g*xhat per chunk) come out of the epilogue of the backward-data convolution that produced g
+ * (diga_conv2d_nhwc_*_epi, chunk_rows = 128): one finalise launch + the apply pass (read g, x; write dx).
+ * workspace >= 3*C floats. */
+int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,
+                         const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx, int64_t M, int64_t C,
+                         int dx_twin, const float* partial, int64_t chunk_rows, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* GroupNorm over (HW x C/G) per image and group, then y = [relu](chan_scale[n,c] * (xhat*gamma + beta));
  * chan_scale (nullable, [N][C]) carries the Dropout2d keep/(1-p) pattern.  save_mean/invstd [N][G]. */

@@ -269,3 +269,91 @@ def test_c2_fullsize_step_bf16x3_vs_f32():
     for k in h0:
         upd = float((h1[k] - h0[k]).abs().max())
         assert upd <= 1e-3 * float(h0[k].abs().max()), k
+
+
+@pytest.mark.parametrize("planes,inpl,dil,n,h,w", [(256, 1024, 2, 2, 33, 33), (64, 256, 1, 2, 31, 29), (512, 2048, 4, 1, 18, 19)],
+                         ids=["layer3", "layer1", "layer4"])
+def test_residual_junction_fused_backward_vs_float64(planes, inpl, dil, n, h, w, conv_math, monkeypatch):
+    """Three bottlenecks in a row (identity residuals), forward + backward.  The backward-data convolutions finish the
+    gradient of the BatchNorm in front of them in their epilogue (diga_bwd_epilogue_t): conv1 of block j adds the
+    residual-branch gradient of block j, applies the ReLU mask of block j-1's bn3 and reduces its BatchNorm-backward
+    sums; conv2 / conv3 do the same for bn1 / bn2 (mask from the forward coefficients).  DIGA_FUSE_BWD=1 against =0
+    (separate add / mask / reduce passes) and both against the float64 oracle with the device's ReLU patterns pinned."""
+    from diga_amd import _lib
+    from diga_amd.model import norm as dn
+    names = [f"junction{planes}.b{i}" for i in range(3)]
+    sds = [_block_state(nm, inpl, planes, False) for nm in names]
+    blocks = [_make_block(sd, nm, inpl, planes, 1, dil, False) for sd, nm in zip(sds, names)]
+    g = synth.gen(planes + 5)
+    x = torch.randn((n, inpl, h, w), generator=g).relu_() + 0.1 * torch.randn((n, inpl, h, w), generator=g)
+    probe = torch.randn((n, inpl, h, w), generator=g)
+
+    def run(masks_out=None):
+        for b in blocks:
+            for p in b.parameters():
+                p.grad = None
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+        hooks, seen = [], {}
+        if masks_out is not None:
+            for i, b in enumerate(blocks):
+                hooks.append(b.bn1.register_forward_hook(lambda m, a, o, i=i: seen.__setitem__((i, 1), (o.detach() > 0).cpu().double())))
+                hooks.append(b.bn2.register_forward_hook(lambda m, a, o, i=i: seen.__setitem__((i, 2), (o.detach() > 0).cpu().double())))
+                hooks.append(b.register_forward_hook(lambda m, a, o, i=i: seen.__setitem__((i, 3), (o.detach() > 0).cpu().double())))
+        y = xd
+        for b in blocks:
+            y = b(y)
+        for hk in hooks:
+            hk.remove()
+        (y * probe.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        if masks_out is not None:
+            masks_out.update(seen)
+        return y.detach().clone(), xd.grad.clone(), {f"{i}.{k}": p.grad.clone() for i, b in enumerate(blocks)
+                                                     for k, p in b.named_parameters() if p.grad is not None}
+
+    calls = []
+    orig = _lib.call
+
+    def counting(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    monkeypatch.setattr(_lib, "call", counting)
+    monkeypatch.setenv("DIGA_TWIN_ONLY", "0")                      # readable BN outputs for the mask hooks
+    monkeypatch.setenv("DIGA_FUSE_BWD", "0")
+    masks = {}
+    y0, dx0, gr0 = run(masks)
+    assert not any(c.endswith("_epi") for c in calls) and "diga_bn_bwd_partials" not in calls
+    monkeypatch.delenv("DIGA_TWIN_ONLY")
+    monkeypatch.setenv("DIGA_FUSE_BWD", "1")
+    assert dn.fuse_backward_enabled()
+    calls.clear()
+    y1, dx1, gr1 = run()
+    # 3 blocks: conv3 and conv2 of every block (6 epilogues without residual) + conv1 of blocks 1 and 2 (junctions)
+    assert sum(c.endswith("_epi") for c in calls) == 8, calls
+    assert calls.count("diga_bn_bwd_partials") == 8 and calls.count("diga_bn_bwd") == 1     # bn3 of the last block stays plain
+    assert torch.equal(y0, y1)
+
+    sd64 = {}
+    for sd in sds:
+        sd64.update({k: v.double().requires_grad_(v.dim() == 4) for k, v in sd.items()})
+    xr = x.double().requires_grad_()
+    yr = xr
+    for i, nm in enumerate(names):
+        yr = od.bottleneck_fixed_masks(sd64, nm, yr, 1, dil, False, (masks[(i, 1)], masks[(i, 2)], masks[(i, 3)]))
+    (yr * probe.double()).sum().backward()
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach()).abs().max()) / float(b.detach().abs().max())
+
+    tol = 2e-4 if conv_math == 1 else 2e-5
+    errs = {"y": rel(y1, yr), "dx fused": rel(dx1, xr.grad), "dx plain": rel(dx0, xr.grad)}
+    for k in gr1:
+        i, nm = k.split(".", 1)
+        errs["fused " + k] = rel(gr1[k], sd64[f"{names[int(i)]}.{nm}"].grad)
+    print(f"\n{planes}: worst error / scale vs float64: {max(errs.values()):.1e} ({max(errs, key=errs.get)})")
+    for k, v in errs.items():
+        assert v < tol, f"{k}: {v:.2e} of scale"
+    # fused against unfused: same arithmetic up to the order of the column sums
+    assert rel(dx1, dx0.double().cpu()) < 2e-5
+    for k in gr1:
+        assert rel(gr1[k], gr0[k].double().cpu()) < 3e-5, k
