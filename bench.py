@@ -22,7 +22,8 @@ too (`--other-steps`, default 10 after 3 warm-ups) and reported under "other_pre
 Also in the line: `roofline` (dominant kernel family: forward convolution), `roofline_other_kernels` (every other
 family of the step, from the algorithmic work each library call declares), `bandwidth_kernels` (the API-boundary loss
 kernels and the centroid pseudo-labeler at full size, timed on their own), `other_configs` (self-training step c4,
-small-backbone c1), `cpu_baseline` (the oracle on this box's host cores).
+small-backbone c1), `miou_parity` (fixed-seed validation mIoU against the capture of the reference, both arithmetics),
+`cpu_baseline` (the oracle on this box's host cores).
 """
 import argparse
 import json
@@ -77,6 +78,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the c4 / c1 legs")
     ap.add_argument("--c4-steps", type=int, default=3)
     ap.add_argument("--no-bandwidth-kernels", action="store_true")
+    ap.add_argument("--no-miou", action="store_true", help="skip the fixed-seed validation-mIoU parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the CPU leg and print its JSON")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel families with HIP events")
@@ -88,7 +90,7 @@ def parse():
                          "per-kernel roofline durations are measured in; profiles/*_serial_* are rocprofv3 runs of it")
     a = ap.parse_args()
     if a.lean:
-        a.no_other_precision = a.no_other_configs = a.no_bandwidth_kernels = a.no_cpu_baseline = True
+        a.no_other_precision = a.no_other_configs = a.no_bandwidth_kernels = a.no_cpu_baseline = a.no_miou = True
     return a
 
 
@@ -146,6 +148,21 @@ def cpu_baseline_subprocess(limit_s=300):
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "crops/s", "cores": None, "kind": "port",
                 "sample": f"CPU leg did not finish its oracle steps within {limit_s} s"}
+
+
+def miou_parity_subprocess(limit_s=300):
+    """Fixed-seed validation mIoU of the build (both conv arithmetics) against the capture of the reference
+    (tests/golden/valmiou.npz): the checker lives with the tests (it needs the oracle's deterministic weights), so it
+    runs as a child process, after the timed regions."""
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "miou_parity.py")], capture_output=True, text=True,
+                           timeout=limit_s)
+        for ln in reversed(r.stdout.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": f"rc={r.returncode}: {r.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {limit_s} s"}
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 launcher
@@ -481,6 +498,11 @@ def main():
     if rank == 0 and not a.no_bandwidth_kernels:
         bw = bandwidth_kernels(dev)
 
+    miou = None
+    if rank == 0 and world == 1 and not a.no_miou:
+        torch.cuda.synchronize()
+        miou = miou_parity_subprocess()
+
     if rank == 0:
         roof, other = rooflines(a.config, a.precision, families, counts, geom)
         if roof is not None:
@@ -501,7 +523,7 @@ def main():
                        "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea}},
             "rccl_ranks": world, "backend": backend if world > 1 else "none (single process)",
             "roofline": roof, "roofline_other_kernels": other, "bandwidth_kernels": bw, "cpu_baseline": cpu_line,
-            "other_precision": other_line, "other_configs": other_cfg or None, "kernel_families": families,
+            "other_precision": other_line, "other_configs": other_cfg or None, "miou_parity": miou, "kernel_families": families,
             "kernel_families_overlapped": None if a.serial_streams else families_ov, "losses_last_step": losses,
             # student: forward + backward-data + backward-weight (3 passes) ; teacher: forward
             "model_tflop_per_step_per_gpu": (3 * n_stu + n_tea) * fwd_tflop,

@@ -636,6 +636,23 @@ __global__ __launch_bounds__(256) void merge_partials_kernel(const float* __rest
     o[2 * g.C + c] = base;
 }
 
+// Folds K rows of a [K][W] matrix of partial sums into `parts` rows (part p sums rows p, p + parts, ...): block = 4 row
+// lanes x 64 columns, coalesced 256-byte row pieces, sums in double.  Used in front of bn_bwd_finalize2_kernel when the
+// backward-data epilogue delivered one partial per 128-row chunk (> 1000 chunks at C2 sizes: walking them with the
+// finaliser's 16 lanes per channel took 44 us per layer).
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ in, int K, int W, int parts,
+                                                          float* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, part = blockIdx.y;
+    double acc = 0.0;
+    if (c < W)
+        for (int k = part + lane * parts; k < K; k += 4 * parts) acc += (double)in[(int64_t)k * W + c];
+    red[lane][cl] = acc;
+    __syncthreads();
+    if (lane == 0 && c < W) out[(int64_t)part * W + c] = (float)(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ invstd, float* __restrict__ kk,
@@ -915,7 +932,7 @@ extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x
                  "bn_bwd_partials: bad argument");
     int rc = check_norm("bn_bwd_partials", C, {ld_g, ld_x, ld_dx}, {g, x, dx});
     if (rc) return rc;
-    DIGA_REQUIRE(workspace_bytes >= (size_t)3 * C * sizeof(float), DIGA_EWORKSPACE, "bn_bwd_partials: workspace too small");
+    DIGA_REQUIRE(workspace_bytes >= (size_t)(3 + 64) * C * sizeof(float), DIGA_EWORKSPACE, "bn_bwd_partials: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * 12.0);        // apply pass only: g, x in, dx out
     ColGeom geo;
@@ -925,6 +942,16 @@ extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x
     geo.chunk_rows = (int)chunk_rows;
     geo.nchunk = (int)ceil_div(M, chunk_rows);
     float* kk = (float*)workspace;
+    if (geo.nchunk > 64) {
+        // many 128-row chunks: fold them to 32 rows first (the finaliser only needs sum g, sum g*xhat over all rows)
+        constexpr int kParts = 32;
+        float* folded = kk + 3 * C;
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)ceil_div(2 * C, 64), kParts), dim3(256), 0, st, partial, geo.nchunk,
+                           (int)(2 * C), kParts, folded);
+        partial = folded;
+        geo.nchunk = kParts;
+        geo.chunk_rows = (int)ceil_div(M, kParts);       // (only nseg * nchunk and rows_per_seg enter the finaliser)
+    }
     hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, geo, gamma,
                        save_invstd, kk, 1);
     hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, g, ld_g, x, ld_x, (const float*)nullptr,

@@ -369,7 +369,7 @@ int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, co
 /* diga_bn_bwd for a gradient that arrives already masked and reduced: `g` and `partial` ([ceil(M/chunk_rows)][2][C]:
  * sum g, sum g*xhat per chunk) come out of the epilogue of the backward-data convolution that produced g
  * (diga_conv2d_nhwc_*_epi, chunk_rows = 128): one finalise launch + the apply pass (read g, x; write dx).
- * workspace >= 3*C floats. */
+ * workspace >= 67*C floats. */
 int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,
                          const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx, int64_t M, int64_t C,
                          int dx_twin, const float* partial, int64_t chunk_rows, void* workspace, size_t workspace_bytes,

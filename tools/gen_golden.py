@@ -616,6 +616,46 @@ def gen_miou():
          fwavacc=np.array(sc["FreqW Acc : \t"]), iu=np.array([cls_iu[i] for i in range(19)]))
 
 
+# ------------------------------------------------------------------ G-valmiou (two-scale validation mIoU)
+def gen_valmiou():
+    """The reference's validation pass (G5/evaluate_val.py:73-93 = warm_up.py:346-359) re-enacted on a seeded synthetic
+    val set with the deterministic ResNet-101 weights: eval() model on the image and on its half-size bilinear
+    (align_corners) downscale, both logit maps upsampled to label size, element-wise max, argmax, runningScore.
+    Ground truth = the reference's own prediction with 30 % of 16x16 blocks re-drawn (so the score is neither 0 nor 1
+    and every pixel whose argmax flips moves it).  Inputs are regenerated from the seed by the test; stored: labels,
+    prediction, confusion matrix, scores."""
+    import contextlib
+    import io
+    m = _ref_model().eval()
+    n_img, H, W = 3, 256, 512
+    up = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+    rs = runningScore(19)
+    preds, gts, margins = [], [], []
+    for i in range(n_img):
+        g = synth.gen(7000 + i)
+        img = torch.rand((1, 3, H, W), generator=g) * 2.0 - 1.0 + 0.5 * torch.randn((1, 3, 1, 1), generator=g)
+        img_ds = F.interpolate(img, (H // 2, W // 2), mode="bilinear", align_corners=True)
+        with torch.no_grad():
+            pred = up(m(img)[2])
+            pred_ds = up(m(img_ds)[2])
+        fused = torch.max(pred, pred_ds)
+        top2 = fused.topk(2, dim=1).values
+        margins.append((top2[:, 0] - top2[:, 1])[0])
+        p = fused.max(1)[1]
+        noisy = synth.block_labels(g, 1, H, W, 16)
+        flip = (torch.rand((1, H // 16, W // 16), generator=g) < 0.3).repeat_interleave(16, 1).repeat_interleave(16, 2)
+        gt = torch.where(flip, noisy, p)
+        rs.update(gt.numpy(), p.numpy())
+        preds.append(p[0])
+        gts.append(gt[0])
+    with contextlib.redirect_stdout(io.StringIO()):
+        sc, cls_iu = rs.get_scores()
+    save("valmiou", gt=torch.stack(gts).to(torch.uint8), pred=torch.stack(preds).to(torch.uint8),
+         near_ties=np.array([int((torch.stack(margins) < t).sum()) for t in (1e-4, 1e-3, 1e-2)]), hist=rs.confusion_matrix, miou=np.array(sc["Mean IoU : \t"]),
+         acc=np.array(sc["Overall Acc: \t"]), iu=np.array([cls_iu[i] for i in range(19)]),
+         geometry=np.array([n_img, H, W]), seed0=np.array(7000))
+
+
 # ------------------------------------------------------------------ G-ohem ("next" row 4)
 def gen_ohem():
     """OhemCrossEntropy (G5/util/loss.py:65-122) in its three regimes: threshold = thresh (many uncertain
@@ -653,7 +693,7 @@ def gen_ohem():
 
 ALL = dict(ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
-           model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou)
+           model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
