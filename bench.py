@@ -395,7 +395,7 @@ def bandwidth_kernels(dev):
     g = torch.Generator(device="cpu")
     g.manual_seed(99)
 
-    def timed(tags, fn, note):
+    def timed(tags, fn, note, rename=None):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -411,7 +411,7 @@ def bandwidth_kernels(dev):
                 continue
             nbytes = _lib.prof_work(tag) / n
             gbs = nbytes / (ms / n * 1e-3) / 1e9
-            out[tag] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+            out[(rename or {}).get(tag, tag)] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms / n, "launches": n, "shape": note}
         _lib.call("diga_prof_reset")
 
@@ -424,6 +424,12 @@ def bandwidth_kernels(dev):
     timed(["ce2d"], lambda: L.cross_entropy2d(stu[:B], lab), f"cross_entropy2d fwd+bwd, logits [{B},{C},{H},{W}] fp32 + int64 labels")
     timed(["distill"], lambda: L.distillation_loss(tea, stu, 0.5), f"distillation_loss fwd+bwd, teacher/student [{2 * B},{C},{H},{W}] fp32")
     del stu, tea, lab
+    from diga_amd.util import augment as A
+    aug = A.ExtraAug(seed=1)
+    xa = torch.randn((8, 3, 768, 768), device=dev)
+    timed(["elementwise"], lambda: aug.view(xa, 0.4, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)),
+          "colour-augmentation view beta*norm(extra_aug(x)) + (1-beta)*x, x [8,3,768,768] fp32, one pass", {"elementwise": "color_aug_view"})
+    del xa
     # C4: B = 8 target crops of 512x1024 -> low-res 65x129, 256-channel features
     B, D, h, w, H, W = 8, 256, 65, 129, 512, 1024
     cf = Class_Features(numbers=19)

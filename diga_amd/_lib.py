@@ -81,6 +81,7 @@ SIGNATURES = {
     "diga_channel_dot": (INT, [P, I64, P, I64, P, I64, I64, I64, P, SZ, P]),
     "diga_maxpool3x3s2_fwd": (INT, [P, P, P, I64, I64, I64, I64, I64, I64, P]),
     "diga_maxpool3x3s2_bwd": (INT, [P, P, P, I64, I64, I64, I64, I64, I64, P]),
+    "diga_color_aug_view": (INT, [P, P, P, P, I64, I64, I64, F32, P, P, P]),
     "diga_prof_enable": (INT, [INT]),
     "diga_prof_reset": (INT, []),
     "diga_prof_query": (INT, [INT, P, P]),

@@ -401,6 +401,19 @@ int diga_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int64_
                           int64_t Ho, int64_t Wo, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Colour-augmentation view: out = beta*Normalize(extra_aug(x)) + (1-beta)*x in one pass,
+ * G5/train_DiGA_gta2city_warm_up.py:105-111,233 with extra_aug = kornia 0.5.8 ColorJitter -> RandomGrayscale ->
+ * RandomGaussianBlur(3x3, sigma 2, reflect) -> RandomSharpness and Normalize = G5/util/utils.py:141-156.  kornia is not
+ * part of the reference tree: PARITY UNPINNED against kornia, pinned against oracle/coloraug.py's restatement.
+ * x, out [B,3,H,W] fp32 NCHW (device).  params [B][12] fp32 (device): {apply jitter, apply grayscale, apply blur,
+ * apply sharpness} as 0/1, then brightness, contrast, saturation, hue factors, sharpness factor.  order (HOST int32[4]):
+ * the permutation of {0 brightness, 1 contrast, 2 saturation, 3 hue} applied to every jittered sample.  mean, std:
+ * HOST float[3].
+ * ---------------------------------------------------------------------------------- */
+int diga_color_aug_view(const float* x, float* out, const float* params, const int32_t* order_host, int64_t B, int64_t H,
+                        int64_t W, float beta, const float* mean_host, const float* std_host, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Kernel-family timing (bench.py's roofline leg): when enabled, every entry point brackets its
  * launches with HIP events recorded on the launch stream.  Not for production steps.
  * ---------------------------------------------------------------------------------- */
