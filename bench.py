@@ -383,6 +383,38 @@ def rooflines(config, precision, families, counts, geom):
     return roof, other
 
 
+def translator_leg(dev, precision):
+    """the frozen source->target translator dec_s2t(enc_s(x)) that runs every step right before the
+    scoped path (warm_up.py:235-237), B = 8 crops of 768x768, no_grad: reflection pads, nearest upsampling and tanh inside
+    the conv kernels, InstanceNorm on the HIP kernels -- next to the same modules with explicit pad / upsample / tanh ops."""
+    import torch
+    from diga_amd import _lib
+    from diga_amd.model.model_noaux import ImgDecoder, ImgEncoder
+    _lib.call("diga_set_conv_math", 1 if precision == "bf16x3" else 0)
+    torch.manual_seed(3)
+    enc, dec = ImgEncoder().to(dev).eval(), ImgDecoder().to(dev).eval()
+    for m in (enc, dec):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    x = torch.rand((8, 3, 768, 768), device=dev) * 2 - 1
+    res = {}
+    for name, ctx in (("folded", torch.no_grad), ("explicit_ops", torch.enable_grad)):
+        with ctx():
+            y = dec(enc(x))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                y = dec(enc(x))
+            torch.cuda.synchronize()
+            res[name + "_ms"] = 1e3 * (time.perf_counter() - t0) / 3
+        del y
+    res.update(images_per_s=8.0 / (res["folded_ms"] * 1e-3), dtype=precision,
+               workload="dec_s2t(enc_s(x)), x [8,3,768,768], random-init weights, inference")
+    del enc, dec, x
+    torch.cuda.empty_cache()
+    return res
+
+
 def bandwidth_kernels(dev):
     """The HBM-bound kernels north_star names, timed on their own at full size (HIP events on the launch stream, 10
     launches after 2 warm-ups each): the loss kernels at the reference's API boundary (full-resolution logits, the path
@@ -503,6 +535,8 @@ def main():
     bw = None
     if rank == 0 and not a.no_bandwidth_kernels:
         bw = bandwidth_kernels(dev)
+    if rank == 0 and world == 1 and not a.no_other_configs:
+        other_cfg["translator"] = translator_leg(dev, a.precision)
 
     miou = None
     if rank == 0 and world == 1 and not a.no_miou:

@@ -58,6 +58,7 @@ SIGNATURES = {
     "diga_split_bf16_image_bytes": (SZ, [I64, I64, I64]),
     "diga_split_bf16_image": (INT, [P, P, I64, I64, I64, P]),
     "diga_conv2d_nhwc_twin": (INT, [P, P, P, P] + [I64] * 16 + [P, INT, P]),
+    "diga_conv2d_next_options": (INT, [INT, INT, INT]),
     "diga_set_conv_math": (INT, [INT]),
     "diga_get_conv_math": (INT, []),
     "diga_conv2d_wgrad_workspace_bytes": (SZ, [I64] * 7),

@@ -62,7 +62,26 @@ struct ConvArgs {
     const float* e_invstd;       // [Cout]
     float* e_partials;           // [ceil(M/128)][2][Cout]: sum g, sum g*xhat per 128-row chunk
     int e_add_ld, e_masky_ld, e_x_ld;
+    // input map / output activation (diga_conv2d_next_options; 0 = plain zero-padded convolution)
+    int pad_reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d in front of the conv)
+    int up_shift;                // the conv reads the 2^up_shift nearest-neighbour upsampling of `in` (nn.Upsample in front)
+    int act;                     // 1: tanh on the output
 };
+
+// Logical input coordinate (in the optionally upsampled image, before padding) -> source pixel of `in`.
+// Returns false for a tap that reads zero padding (then (py, px) is a clamped, valid pixel).
+__device__ __forceinline__ bool map_tap(const ConvArgs& a, int iy, int ix, int& py, int& px) {
+    const int Hl = a.Hi << a.up_shift, Wl = a.Wi << a.up_shift;
+    bool ok = (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+    if (a.pad_reflect) {
+        iy = iy < 0 ? -iy : (iy >= Hl ? 2 * (Hl - 1) - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= Wl ? 2 * (Wl - 1) - ix : ix);
+        ok = true;
+    }
+    py = min(max(iy, 0), Hl - 1) >> a.up_shift;
+    px = min(max(ix, 0), Wl - 1) >> a.up_shift;
+    return ok;
+}
 
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     // blocks b and b+8 share an XCD (observed round-robin dispatch): give every XCD a contiguous range
@@ -213,6 +232,9 @@ __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArg
         if (m < a.M) {
             float4 v = *reinterpret_cast<const float4*>(stage + r * LDS_LD + cq * 4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (a.act == 1) {
+                v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+            }
             float* o = a.out + (int64_t)m * a.out_ld + n;
             if (vec_ok) {
                 *reinterpret_cast<float4*>(o) = v;
@@ -340,8 +362,8 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void conv_fwd_kernel(ConvA
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            const bool ok = mok[i] && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-            const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+            int cy, cx;
+            const bool ok = map_tap(a, iy, ix, cy, cx) && mok[i];
             const float* p = a.in + (int64_t)(pixbase[i] + cy * a.Wi + cx) * a.in_ld + c0 + c4;
             ra[i] = *reinterpret_cast<const float4*>(p);
             fa[i] = ok ? 1.f : 0.f;               // applied at LDS-store time (a multiply: hipcc turns a select
@@ -799,8 +821,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int iy = (yx0[p] >> 16) + dy, ix = (int)(short)(yx0[p] & 0xffff) + dx;
-            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-            const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+            int cy, cx;
+            const bool ok = map_tap(a, iy, ix, cy, cx);
             po[p] = (pixbase[p] + cy * a.Wi + cx) * a.in_ld + 4 * q;
             tapmask |= ok ? (1u << p) : 0u;
         }
@@ -1107,8 +1129,9 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_x3t_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int iy = (yx0[j] >> 16) + dy, ix = (int)(short)(yx0[j] & 0xffff) + dx;
-            const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-            pa[j] = ok ? twin + (int64_t)(pixbase[j] + iy * a.Wi + ix) * rowb + kslot * 32 : nullptr;
+            int cy, cx;
+            const bool ok = map_tap(a, iy, ix, cy, cx);
+            pa[j] = ok ? twin + (int64_t)(pixbase[j] + cy * a.Wi + cx) * rowb + kslot * 32 : nullptr;
         }
     };
     const unsigned char* bimg = a.wgt_img + (int64_t)tile_n * ksteps * (2 * B_PLANE) + (wv * 2 * TN) * 1024 + lane * 16;
@@ -1257,6 +1280,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_x3t_kernel(ConvArgs a) {
 __device__ __forceinline__ uint64_t live_taps(const ConvArgs& a, int m0, int BM) {
     const int RS = a.R * a.S;
     const uint64_t all = RS >= 64 ? ~0ull : ((1ull << RS) - 1ull);
+    if (a.pad_reflect) return all;                       // mirrored taps are never zero
     const int HoWo = a.Ho * a.Wo;
     const int m_last = min(m0 + BM, a.M) - 1;
     const int img0 = m0 / HoWo, img1 = m_last / HoWo;
@@ -1271,10 +1295,10 @@ __device__ __forceinline__ uint64_t live_taps(const ConvArgs& a, int m0, int BM)
     uint64_t live = 0;
     for (int r = 0; r < a.R; ++r) {
         const int ylo = ho0 * a.sy + a.oy0 + r * a.ody, yhi = ho1 * a.sy + a.oy0 + r * a.ody;
-        if (yhi < 0 || ylo >= a.Hi) continue;
+        if (yhi < 0 || ylo >= (a.Hi << a.up_shift)) continue;
         for (int q = 0; q < a.S; ++q) {
             const int xlo = wo0 * a.sx + a.ox0 + q * a.odx, xhi = wo1 * a.sx + a.ox0 + q * a.odx;
-            if (xhi < 0 || xlo >= a.Wi) continue;
+            if (xhi < 0 || xlo >= (a.Wi << a.up_shift)) continue;
             live |= 1ull << (r * a.S + q);
         }
     }
@@ -1339,8 +1363,9 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_x3t8_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int iy = (yx0[j] >> 16) + dy, ix = (int)(short)(yx0[j] & 0xffff) + dx;
-                const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-                pa[j] = ok ? twin + (int64_t)(pixbase[j] + iy * a.Wi + ix) * rowb + kslot * 32 : nullptr;
+                int cy, cx;
+                const bool ok = map_tap(a, iy, ix, cy, cx);
+                pa[j] = ok ? twin + (int64_t)(pixbase[j] + cy * a.Wi + cx) * rowb + kslot * 32 : nullptr;
             }
         };
         const unsigned char* bimg = a.wgt_img + (int64_t)tile_n * (RS * cchunks) * (2 * B_PLANE) + (lw * 2 * TN) * 1024 + lane * 16;
@@ -2261,6 +2286,19 @@ static int check_conv_common(const char* who, int64_t Cin, int64_t in_ld, int64_
     return DIGA_OK;
 }
 
+// diga_conv2d_next_options: consumed by the next forward-convolution call of this thread
+struct NextOpts {
+    int reflect = 0, up_shift = 0, act = 0;
+};
+static thread_local NextOpts g_next_opts;
+
+static void take_next_options(ConvArgs& a) {
+    a.pad_reflect = g_next_opts.reflect;
+    a.up_shift = g_next_opts.up_shift;
+    a.act = g_next_opts.act;
+    g_next_opts = NextOpts();
+}
+
 // fills the backward-epilogue fields of ConvArgs from the public descriptor (nullptr = plain convolution)
 static int set_bwd_epilogue(ConvArgs& a, const diga_bwd_epilogue_t* e, const char* who) {
     a.e_add = a.e_masky = a.e_x = a.e_relu_ab = a.e_mean = a.e_invstd = nullptr;
@@ -2307,6 +2345,7 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
     a.M = (int)(N * Ho * Wo);
     a.all_inside = 0;
     a.tiles_m = (int)ceil_div(a.M, 128);
+    take_next_options(a);
     rc = set_bwd_epilogue(a, epi, "conv2d");
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -2332,6 +2371,7 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
         else DIGA_LAUNCH_K((conv_fwd_x3_kernel<TN_, false>), 256, sh);                                                  \
     } while (0)
     const bool x3 = g_conv_math.load(std::memory_order_relaxed) == DIGA_CONV_MATH_BF16X3;
+    DIGA_REQUIRE(!x3 || !(a.pad_reflect || a.up_shift), DIGA_EINVAL, "conv2d: input map options need the f32 kernel here");
     if (Cout > 64) {
         a.tiles_n = (int)ceil_div(Cout, 128);
         if (x3) DIGA_X3_LAUNCH(2);
@@ -2401,6 +2441,8 @@ static int conv2d_bf16x3_impl(const float* in, const uint16_t* wgt_hi, const uin
         const int64_t x_lo = off_x0 + std::min<int64_t>(0, (S - 1) * off_dx), x_hi = (Wo - 1) * stride_x + off_x0 + std::max<int64_t>(0, (S - 1) * off_dx);
         a.all_inside = y_lo >= 0 && y_hi < Hi && x_lo >= 0 && x_hi < Wi;
     }
+    take_next_options(a);
+    if (a.pad_reflect || a.up_shift) a.all_inside = 0;
     rc = set_bwd_epilogue(a, epi, "conv2d_bf16x3");
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -2414,6 +2456,8 @@ static int conv2d_bf16x3_impl(const float* in, const uint16_t* wgt_hi, const uin
     a.tiles_n = (int)ceil_div(Cout, 64 * tn);
     // the wide kernel addresses the input and the weights with 32-bit element offsets
     const bool fits32 = N * Hi * Wi * in_ld < (1ll << 31) && Cout * R * S * Cin < (1ll << 31);
+    DIGA_REQUIRE((!narrow && fits32) || !(a.pad_reflect || a.up_shift), DIGA_EINVAL,
+                 "conv2d_bf16x3: reflect padding / fused upsampling are implemented by the 256-row kernel only");
     if (!narrow && fits32) {
         a.tiles_m = (int)ceil_div(a.M, 256);
         const size_t loop = (size_t)2 * 256 * 64 + (size_t)2 * 64 * tn * 64, stage = (size_t)128 * (64 * tn + 4) * sizeof(float);
@@ -2528,6 +2572,7 @@ static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const floa
     a.all_inside = 0;
     const int tn = Cout > 64 ? 2 : 1;
     a.tiles_n = (int)ceil_div(Cout, 64 * tn);
+    take_next_options(a);
     {
         const int rc = set_bwd_epilogue(a, epi, "conv2d_twin");
         if (rc) return rc;
@@ -2578,6 +2623,16 @@ extern "C" int diga_conv2d_nhwc_twin_epi(const void* in_twin, const void* wgt_im
     DIGA_REQUIRE(epi != nullptr, DIGA_EINVAL, "conv2d_twin_epi: null epilogue descriptor");
     return conv2d_twin_impl(in_twin, wgt_img, nullptr, out, N, Hi, Wi, Cin, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x, off_y0,
                             off_x0, off_dy, off_dx, nullptr, prof_tag, stream, epi);
+}
+
+extern "C" int diga_conv2d_next_options(int reflect_pad, int upsample_shift, int activation) {
+    DIGA_REQUIRE((reflect_pad == 0 || reflect_pad == 1) && upsample_shift >= 0 && upsample_shift <= 2 &&
+                     (activation == 0 || activation == 1),
+                 DIGA_EINVAL, "conv2d_next_options: reflect_pad in {0,1}, upsample_shift in 0..2, activation in {0 none, 1 tanh}");
+    g_next_opts.reflect = reflect_pad;
+    g_next_opts.up_shift = upsample_shift;
+    g_next_opts.act = activation;
+    return DIGA_OK;
 }
 
 extern "C" size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout) {

@@ -58,11 +58,18 @@ def takes_twin_only_input(conv, pointwise_ok=False):
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
 
 
-def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None):
+def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
+                 opts=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x.
-    epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue."""
+    epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue.
+    opts: (reflect_pad, upsample_shift, activation) of diga_conv2d_next_options -- x is then the SOURCE tensor of the
+    (virtually) upsampled / mirrored input."""
     import ctypes
+
+    def arm():
+        if opts is not None and any(opts):
+            _lib.call("diga_conv2d_next_options", int(opts[0]), int(opts[1]), int(opts[2]))
     n, hi, wi, cin = x.shape
     _, ho, wo, k = out.shape
     _, r, s, _ = w_krsc.shape
@@ -83,6 +90,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                       out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], ctypes.byref(epi), tag,
                       _lib.stream())
             return twin
+        arm()
         _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin, ho, wo, k,
                   out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], _lib.ptr(stats), tag,
                   _lib.stream())
@@ -101,6 +109,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                       n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                       doff[0], doff[1], ctypes.byref(epi), tag, _lib.stream())
             return None
+        arm()
         _lib.call("diga_conv2d_nhwc_bf16x3", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(bias), _lib.ptr(out),
                   n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                   doff[0], doff[1], _lib.ptr(stats), tag, _lib.stream())
@@ -110,6 +119,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                   x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
                   ctypes.byref(epi), tag, _lib.stream())
         return None
+    arm()
     _lib.call("diga_conv2d_nhwc_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin,
               x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
               _lib.ptr(stats), tag, _lib.stream())
@@ -169,7 +179,7 @@ class _StemConvFn(torch.autograd.Function):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None, x_is_twin=False,
-                dy_is_twin=False, bn_box=None):
+                dy_is_twin=False, bn_box=None, opts=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         if x_is_twin:          # the producer wrote the split twin instead of fp32 (same bytes per element): hand it on
@@ -188,12 +198,15 @@ class _Conv2dFn(torch.autograd.Function):
             w = w.contiguous()
         w = _pad_last(w, cp)
         n, hi, wi, _ = xn.shape
-        ho = (hi + 2 * padding[0] - dilation[0] * (r - 1) - 1) // stride[0] + 1
-        wo = (wi + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
+        up = int(opts[1]) if opts is not None else 0
+        if opts is not None and any(opts) and (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)):
+            raise RuntimeError("DigaConv2d: folded reflect padding / upsampling / tanh are inference-only (no backward)")
+        ho = ((hi << up) + 2 * padding[0] - dilation[0] * (r - 1) - 1) // stride[0] + 1
+        wo = ((wi << up) + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
         x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box,
-                              must_twin=bool(x_is_twin))
+                              must_twin=bool(x_is_twin), opts=opts)
         ctx.save_for_backward(xn, w)
         # the split twin of the input serves the weight gradient too (multi-tap / shared-input layers, Cout >= 256)
         ctx.x_twin = x_twin if (ctx.needs_input_grad[1] and k >= 256 and k % 8 == 0 and cp == c) else None
@@ -330,7 +343,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -351,9 +364,10 @@ class DigaConv2d(nn.Conv2d):
             self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
         return self
 
-    def forward(self, x, twin_grad=False):
+    def forward(self, x, twin_grad=False, opts=None):
         """twin_grad: the gradient of this conv's output will arrive as a split twin (the BatchNorm that consumes the
-        output was called with dx_twin=True)."""
+        output was called with dx_twin=True).  opts = (reflect_pad, upsample_shift, activation): inference-only input
+        map / output activation folded into the kernel (diga_conv2d_next_options)."""
         fn = _Conv2dFn
         if (self.in_channels < 8 and not x.requires_grad and tuple(self.dilation) == (1, 1)
                 and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]):
@@ -381,7 +395,12 @@ class DigaConv2d(nn.Conv2d):
         bn_box = getattr(x, "_diga_bn_box", None)
         if bn_box is not None and (self.share_twin or fn is not _Conv2dFn or not torch.is_grad_enabled()):
             bn_box = None                     # several convs read this tensor / no backward: autograd keeps the plain path
-        if x_is_twin or twin_grad or bn_box is not None:
+        if opts is not None and any(opts):
+            if fn is not _Conv2dFn or stats is not None:
+                raise RuntimeError("DigaConv2d: folded padding / upsampling / activation need the implicit-GEMM path without BN statistics")
+            y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), None, uses,
+                         twin_box, False, False, None, tuple(int(v) for v in opts))
+        elif x_is_twin or twin_grad or bn_box is not None:
             if fn is not _Conv2dFn or (self.bias is not None and twin_grad):
                 raise RuntimeError("DigaConv2d: twin gradient needs a bias-free conv on the implicit-GEMM path")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,

@@ -267,6 +267,17 @@ int diga_conv2d_nhwc_twin_epi(const void* in_twin, const void* wgt_img, float* o
                               int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
                               int64_t off_dx, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
 
+/* Options of the NEXT forward convolution call of the calling thread (diga_conv2d_nhwc_f32 / _bf16x3 / _twin; consumed
+ * and reset by it) -- the non-conv ops around the translator's convolutions (G5/model/model_util.py:21-61: ReflectionPad2d
+ * -> Conv2d -> [norm] -> [activation]; G5/model/model_noaux.py:100-117: nn.Upsample(scale_factor=2) in front of a block)
+ * folded into the kernel's addressing instead of separate passes over HBM:
+ *   reflect_pad     1: taps outside the image read the mirrored pixel (index -i -> i, H-1+i -> H-1-i) instead of zero
+ *   upsample_shift  s: the conv reads the 2^s nearest-neighbour upsampling of `in` ([N,Hi,Wi,Cin] stays the SOURCE tensor;
+ *                      Ho/Wo and the tap offsets are those of the upsampled image)
+ *   activation      1: tanh on the (biased) output
+ * Not combinable with BatchNorm statistics output or a backward epilogue. */
+int diga_conv2d_next_options(int reflect_pad, int upsample_shift, int activation);
+
 /* Arithmetic of diga_conv2d_nhwc_f32 (process-wide; default from the environment variable DIGA_CONV_MATH):
  *   DIGA_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, exact fp32 (k-ordered fmaf chain)            [default]
  *   DIGA_CONV_MATH_BF16X3 operands split into bf16 hi+lo while staged, hi*hi + hi*lo + lo*hi on

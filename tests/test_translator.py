@@ -22,13 +22,28 @@ def test_translator_state_dict_keys(golden):
 
 
 @pytest.mark.gpu
-def test_translator_output(golden):
+@pytest.mark.parametrize("folded", [True, False], ids=["folded_no_grad", "explicit_ops"])
+def test_translator_output(golden, conv_math, folded, monkeypatch):
+    """dec_s2t(enc_s(x)) against the capture of the reference: with the reflection pads / nearest upsampling / tanh
+    folded into the conv kernels and InstanceNorm on the HIP kernels (no_grad, how the DiGA scripts call it), and with
+    explicit pad / upsample / tanh ops around the convs (autograd enabled)."""
+    from diga_amd import _lib
     from diga_amd.model.model_noaux import ImgDecoder, ImgEncoder
     g = golden("translator")
     enc, dec = _filled(ImgEncoder, "enc").cuda(), _filled(ImgDecoder, "dec").cuda()
-    with torch.no_grad():
+    calls = []
+    orig = _lib.call
+
+    def counting(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    monkeypatch.setattr(_lib, "call", counting)
+    with (torch.no_grad() if folded else torch.enable_grad()):
         feat = enc(g.t("x").cuda())
         rec = dec(feat)
+    # folded: every conv but the 3-channel stem arms the input map (reflect; + upsample for the two decoder blocks; + tanh)
+    assert (calls.count("diga_conv2d_next_options") == 21) == folded, calls.count("diga_conv2d_next_options")
+    assert calls.count("diga_gn_fwd") == 21                      # every InstanceNorm on the HIP kernels
     assert list(feat.shape) == g["feat_shape"].tolist()
-    assert synth.checksum(feat.cpu()) == pytest.approx(float(g["feat_sum"]), rel=1e-3, abs=1e-2)
+    assert synth.checksum(feat.detach().cpu()) == pytest.approx(float(g["feat_sum"]), rel=1e-3, abs=1e-2)
     assert_close(rec, g.t("rec"), 1e-3, 1e-4, "translated image")
