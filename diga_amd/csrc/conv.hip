@@ -96,7 +96,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // what the BatchNorm after the conv needs -- per channel sum(y - s), sum((y - s)^2) and s = the tile's first row,
 // over the tile's valid rows -- in exactly the layout colstats_partial_kernel produces with 128-row chunks, so the
 // BN forward skips its own statistics pass over the conv output.
-template <int TM, int TN, bool EPI = false>
+template <int TM, int TN, bool EPI = false, int NTHR = 256>
 __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArgs& a, int m0, int n0, int t, int tile_m,
                                             bool active = true);
 
@@ -122,13 +122,13 @@ __device__ __forceinline__ void epilogue_tile(f32x16 (&acc)[TM][TN], float* __re
 // active = false: a thread group whose 128-row half lies beyond M still walks the barriers (nothing is stored).
 // EPI: the backward-data epilogue of diga_bwd_epilogue_t (its own instantiation of every kernel, so that the plain
 // kernels keep their register budget: inlined into the 256-register kernels the extra row buffers spilled).
-template <int TM, int TN, bool EPI>
+template <int TM, int TN, bool EPI, int NTHR>
 __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArgs& a, int m0, int n0, int t, int tile_m,
                                             bool active) {
     float* stage = const_cast<float*>(stage_in);
     constexpr int BN = 64 * TN, LDS_LD = BN + 4;
     constexpr int CQ = BN / 4;            // column quads per row
-    constexpr int RG = 256 / CQ;          // row groups (threads sharing a column quad)
+    constexpr int RG = NTHR / CQ;         // row groups (threads sharing a column quad)
     constexpr int RPT = 128 / RG;         // rows per thread
     const int cq = t % CQ, rg = t / CQ;
     const int n = n0 + cq * 4;
@@ -1015,6 +1015,191 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
         }
         __syncthreads();
         drain_stage<2, TN, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_fwd_x3w_kernel with a 256 x 256 block tile: 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 -- the MFMA loop of a
+// wave is the one of conv_fwd_x3w_kernel<2>, but the block's 256 activation rows now feed 256 output channels instead
+// of 128: every activation value is loaded, split (the VALU work that bounds the register-staged kernel) and written
+// to LDS once per 256 columns, i.e. half the split arithmetic, half the activation traffic through L2 and 3/4 of the
+// global-load instructions per MFMA.  For layers with Cout >= 256 (the 1x1 convs of layer3 / layer4: K = 256..2048).
+// One block (two waves per SIMD) per CU; 64 KB of LDS in the loop, 130 KB for the staged 128 x 256 epilogue half.
+// ---------------------------------------------------------------------------------------------
+template <bool EPI = false>
+__global__ __launch_bounds__(512, 2) void conv_fwd_x3w8_kernel(ConvArgs a) {
+    constexpr int BM = 256, BN = 256, TN = 4, NT = 4, MT = 8;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 2, wn = wv & 3;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // loader: thread = (rows lr and lr + 128, float4 chunks q and q + 4 of the 32-deep K slice)
+    const int q = t & 3, lr = t >> 2;
+    int pixbase[2], yx0[2];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int m = min(m0 + lr + 128 * p, a.M - 1);
+        const int img = m / HoWo, rem = m - img * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        pixbase[p] = img * a.Hi * a.Wi;
+        yx0[p] = ((ho * a.sy + a.oy0) << 16) | ((wo * a.sx + a.ox0) & 0xffff);
+    }
+    const int RS = a.R * a.S;
+    const int cchunks = a.Cin / 32;
+    const int ksteps = RS * cchunks;
+    const int wrow = RS * a.Cin;
+    int wbase[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) wbase[p] = min(n0 + lr + 128 * p, a.Cout - 1) * wrow + 4 * q;
+
+    int po[2];
+    unsigned tapmask = 0, ldmask = 0;
+    int l_tap = 0, l_cc = 0;
+    auto set_tap = [&](int tap) {
+        const int r = tap / a.S, s = tap - r * a.S;
+        const int dy = r * a.ody, dx = s * a.odx;
+        tapmask = 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int iy = (yx0[p] >> 16) + dy, ix = (int)(short)(yx0[p] & 0xffff) + dx;
+            int cy, cx;
+            const bool ok = map_tap(a, iy, ix, cy, cx);
+            po[p] = (pixbase[p] + cy * a.Wi + cx) * a.in_ld + 4 * q;
+            tapmask |= ok ? (1u << p) : 0u;
+        }
+    };
+    float4 ra[2][2];
+    uint2 rbh[2][2], rbl[2][2];
+    auto gload = [&](bool real) {
+        const int koff = real ? l_tap * a.Cin + l_cc * 32 : 0;
+        const int aoff = real ? l_cc * 32 : 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* src = a.in + po[p] + aoff;
+            ra[p][0] = *reinterpret_cast<const float4*>(src);
+            ra[p][1] = *reinterpret_cast<const float4*>(src + 16);
+        }
+        ldmask = tapmask;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            rbh[p][0] = *reinterpret_cast<const uint2*>(a.wgt_hi + wbase[p] + koff);
+            rbh[p][1] = *reinterpret_cast<const uint2*>(a.wgt_hi + wbase[p] + koff + 16);
+            rbl[p][0] = *reinterpret_cast<const uint2*>(a.wgt_lo + wbase[p] + koff);
+            rbl[p][1] = *reinterpret_cast<const uint2*>(a.wgt_lo + wbase[p] + koff + 16);
+        }
+    };
+    auto advance = [&]() {
+        if (++l_cc == cchunks) {
+            l_cc = 0;
+            if (++l_tap < RS) set_tap(l_tap);
+        }
+    };
+    const int wsw = lds_swz(lr);                      // row lr + 128 p keeps lr's swizzle
+    const int woff0 = lr * 64 + ((((q >> 1)) ^ wsw) << 4) + ((q & 1) << 3);
+    const int woff1 = lr * 64 + ((((q >> 1) | 2) ^ wsw) << 4) + ((q & 1) << 3);
+    auto lstore = [&]() {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            uint2 hi, lo;
+            const float f = (ldmask >> p) & 1u ? 1.f : 0.f;
+            if (a.all_inside) split4_nomask(ra[p][0], hi, lo);
+            else split4(ra[p][0], f, hi, lo);
+            *reinterpret_cast<uint2*>(smem_b + p * 8192 + woff0) = hi;
+            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 8192 + woff0) = lo;
+            if (a.all_inside) split4_nomask(ra[p][1], hi, lo);
+            else split4(ra[p][1], f, hi, lo);
+            *reinterpret_cast<uint2*>(smem_b + p * 8192 + woff1) = hi;
+            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 8192 + woff1) = lo;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + p * 8192 + woff0) = rbh[p][0];
+            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + p * 8192 + woff1) = rbh[p][1];
+            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + B_PLANE + p * 8192 + woff0) = rbl[p][0];
+            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + B_PLANE + p * 8192 + woff1) = rbl[p][1];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
+    const unsigned char* Ah = smem_b + wm * 128 * 64 + foff;
+    const unsigned char* Al = Ah + A_PLANE;
+    const unsigned char* Bh = smem_b + 2 * A_PLANE + wn * 64 * 64 + foff;
+    const unsigned char* Bl = Bh + B_PLANE;
+
+    set_tap(0);
+    gload(true);
+    advance();
+    lstore();
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const bool more = ks + 1 < ksteps;
+        gload(more);
+        bf16x8_t bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
+            bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
+        }
+        bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(Ah);
+        bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(Al);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 2, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            bf16x8_t ahn = ah, aln = al;
+            if (i + 1 < MT) {
+                ahn = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 1) * 1024);
+                aln = *reinterpret_cast<const bf16x8_t*>(Al + (i + 1) * 1024);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            if (i * 2 < 12) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // 12 global loads, two per MFMA group
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
+            ah = ahn;
+            al = aln;
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            advance();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: the two 128-row halves go through one 128 x (256 + 4) float stage, drained by all 512 threads
+    float* stage = reinterpret_cast<float*>(smem_b);
+    constexpr int LDS_LD = BN + 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (m0 + h * 128 >= a.M) break;              // uniform over the block
+        if (h) __syncthreads();
+        if (wm == h) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        stage[(i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][e];
+        }
+        __syncthreads();
+        drain_stage<2, TN, EPI, 512>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
     }
 }
 
@@ -2463,6 +2648,12 @@ static int conv2d_bf16x3_impl(const float* in, const uint16_t* wgt_hi, const uin
         const size_t loop = (size_t)2 * 256 * 64 + (size_t)2 * 64 * tn * 64, stage = (size_t)128 * (64 * tn + 4) * sizeof(float);
         const size_t sh = loop > stage ? loop : stage;
         static const bool stamped = getenv("DIGA_CONV_STAMP") != nullptr;      // diagnostic: see the kernel
+        // DIGA_X3W8=1 selects the 256 x 256 tile kernel for Cout >= 256.  Measured (tools/bench_conv.py, C2 1x1 layer
+        // shapes): layer4 3-5 % faster, layer3 0-8 % slower -- halving the activation-split work per MFMA does not help
+        // the 8..32-K-step tiles, whose time goes to the two barriers per K-step and the prologue / epilogue, not to the
+        // vector port.  Off by default; kept as the experiment it is.
+        const char* w8 = getenv("DIGA_X3W8");
+        const bool wide8 = w8 != nullptr && atoi(w8) != 0;
         if (stamped && tn == 2 && a.stats != nullptr) {
             const int abl = atoi(getenv("DIGA_CONV_STAMP"));                     // 10 + n: ablation n (wrong results)
 #define DIGA_STAMP_LAUNCH(ABL_)                                                                                         \
@@ -2480,6 +2671,12 @@ static int conv2d_bf16x3_impl(const float* in, const uint16_t* wgt_hi, const uin
         } else if (tn == 2 && getenv("DIGA_CONV_ABL1") != nullptr) {     // timing experiment only (wrong results)
             (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             hipLaunchKernelGGL((conv_fwd_x3w_kernel<2, false, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
+        } else if (tn == 2 && Cout >= 256 && wide8) {
+            // 256 x 256 tile, 8 waves: half the activation split / staging work per MFMA (see the kernel)
+            a.tiles_n = (int)ceil_div(Cout, 256);
+            const size_t sh8 = (size_t)128 * (256 + 4) * sizeof(float);
+            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w8_kernel<true>), 512, sh8);
+            else DIGA_LAUNCH_K((conv_fwd_x3w8_kernel<false>), 512, sh8);
         } else if (tn == 2) {
             if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w_kernel<2, false, 0, true>), 256, sh);
             else DIGA_LAUNCH_K((conv_fwd_x3w_kernel<2, false, 0, false>), 256, sh);

@@ -31,6 +31,8 @@ CASES = [
     ("wide_ragged_cout", 1, 96, 19, 23, 320, 3, 1, 1, 1, False),    # 256-channel wgrad tile with a partial second tile
     ("wide_stride2", 2, 128, 33, 31, 512, 1, 2, 0, 1, False),         # pixel-index table with a stride
     ("wide_many_splits", 3, 64, 97, 97, 256, 1, 1, 0, 1, False),      # split-K over a ragged pixel range
+    ("1x1_ragged_320", 2, 96, 19, 23, 320, 1, 1, 0, 1, False),        # 256 x 256 tile kernel with a partial second column tile
+    ("1x1_1024_bias", 1, 256, 33, 31, 1024, 1, 1, 0, 1, True),
 ]
 
 
