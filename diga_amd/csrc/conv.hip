@@ -66,6 +66,7 @@ struct ConvArgs {
     int pad_reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d in front of the conv)
     int up_shift;                // the conv reads the 2^up_shift nearest-neighbour upsampling of `in` (nn.Upsample in front)
     int act;                     // 1: tanh on the output
+    int tap_inner;               // conv_fwd_x3t8_kernel: K order = channel chunk outer, tap inner (see the dispatcher)
 };
 
 // Logical input coordinate (in the optionally upsampled image, before padding) -> source pixel of `in`.
@@ -1574,7 +1575,18 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_x3t8_kernel(ConvArgs a) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + c * 1024),
                                                  (__attribute__((address_space(3))) void*)(bdst + c * 1024), 16, 0, 0);
             ++issued;
-            if (++l_cc == cchunks) {
+            if (a.tap_inner) {
+                // channel chunk outer, tap inner: tiles that run together walk the same channel chunk at the same time, so
+                // the input rows two tiles share through different taps are still in L2 when the second one asks
+                if (issued < ksteps) {
+                    if (todo == 0) {
+                        todo = live;
+                        ++l_cc;
+                    }
+                    next_tap();
+                    set_tap(l_tap);
+                }
+            } else if (++l_cc == cchunks) {
                 l_cc = 0;
                 if (issued < ksteps) {
                     next_tap();
@@ -2783,7 +2795,15 @@ static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const floa
     // 17 %), 1x1 layers 1-3 % slower -- so 1 for multi-tap layers, 0 for pointwise ones.
     const char* var_env = getenv("DIGA_X3T_VARIANT");
     const int variant = var_env ? atoi(var_env) : (R * S > 1 ? 1 : 0);
+    a.tap_inner = 0;
     if (variant == 1 && R * S <= 64) {
+        // K order: tap-major (the weight layout's order, bit-identical to the register-staged kernel).  DIGA_TAP_INNER=1
+        // walks channel chunks outer / taps inner instead, to line up in time the re-reads of an input row that tiles
+        // running together make through different vertical taps (the 2048-channel ASPP inputs span 9-37 MB per tap window,
+        // far beyond an XCD's 4 MB L2).  Measured (tools/bench_twin.py --variants 10 11): 8-14 % SLOWER on every shape,
+        // ASPP included -- the loader's per-step tap switch costs more than the locality returns.  Off; kept as a switch.
+        const char* ti = getenv("DIGA_TAP_INNER");
+        a.tap_inner = ti ? atoi(ti) : 0;
         const size_t stg = (size_t)2 * 128 * (64 * tn + 4) * sizeof(float);
         const size_t sh8 = sh > stg ? sh : stg;
         if (tn == 2) {
