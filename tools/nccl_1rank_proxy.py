@@ -30,3 +30,29 @@ for it in range(2, 6):
 torch.cuda.synchronize()
 print(f"nccl-1rank proxy: {1e3 * (time.perf_counter() - t0) / 4:.1f} ms/step  hooks={len(tr.reducer._hooks)} buckets={len(tr.reducer.buckets)} loss={float(out['total']):.4f}", flush=True)
 dist.destroy_process_group()
+
+# ---- correctness of the hook-driven RCCL path (buckets packed and launched from the weight-gradient side stream): with
+# one real rank the all-reduce is an identity, so 3 steps through it must leave the student bit-identical to 3 steps
+# without a reducer whose optimizer carries the same grad_scale = 1/2.
+def run(with_reducer):
+    dist_ws = (lambda: 2) if with_reducer else (lambda: 1)
+    ddp.world_size = dist_ws
+    torch.manual_seed(1)
+    s, t = SegModel(arch=sm.RESNET101).to(dev), SegModel(arch=sm.RESNET101).to(dev)
+    t.train()
+    trn = DigaTrainer(s, t, rng=random.Random(2))
+    trn.opt.grad_scale = 0.5
+    assert (len(trn.reducer._hooks) > 0) == with_reducer
+    b = synthetic.warmup_batch(77, 2, 256, 256, block=32, device=dev)
+    for it in range(3):
+        trn.warmup_step(it, *b)
+    torch.cuda.synchronize()
+    return {k: v.detach().clone() for k, v in s.named_parameters()}
+
+
+dist.init_process_group("nccl", rank=0, world_size=1)
+a_, b_ = run(True), run(False)
+bad = [k for k in a_ if not torch.equal(a_[k], b_[k])]
+print("nccl-1rank proxy check: student after 3 steps through hook-driven RCCL buckets", "== plain run (bit for bit)" if not bad else f"DIFFERS in {len(bad)} tensors, e.g. {bad[:3]}", flush=True)
+dist.destroy_process_group()
+sys.exit(1 if bad else 0)
