@@ -16,55 +16,74 @@ namespace diga {
 constexpr int kKMax = 32;
 
 // ------------------------------------------------------------------------------------------
-template <int K>
+// PX pixels per lane (block = 64 * PX pixels): the 20 KB centroid image is staged once per 128 pixels, every centroid
+// value read from LDS serves PX pixels, and PX * 4 plane loads are in flight per lane.  Per pixel the arithmetic (channel
+// order inside a wave's quarter of D, then the four partials in wave order) does not depend on PX.
+template <int K, int PX>
 __global__ __launch_bounds__(256) void centroid_weights_kernel(const float* __restrict__ feat,
                                                                const float* __restrict__ cent,
                                                                float* __restrict__ weights,
                                                                float* __restrict__ neg_dist, int D, int Krt,
                                                                int64_t HW) {
     constexpr int KP = (K + 3) & ~3;
+    constexpr int BP = 64 * PX;       // pixels per block
     extern __shared__ __align__(16) float smem[];
     float* cT = smem;                 // [D][KP]  transposed centroids
-    float* part = smem + (size_t)D * KP;  // [4][K][64] per-wave partial squared distances
+    float* part = smem + (size_t)D * KP;  // [4][K][BP] per-wave partial squared distances
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < D * KP; i += 256) {
-        const int d = i / KP, k = i - d * KP;
-        cT[i] = (k < Krt) ? cent[(int64_t)k * D + d] : 0.f;
+    // coalesced read of the [K][D] centroids (consecutive threads = consecutive d), transposed on the LDS write
+    for (int i = threadIdx.x; i < KP * D; i += 256) {
+        const int k = i / D, d = i - k * D;
+        cT[d * KP + k] = (k < Krt) ? cent[(int64_t)k * D + d] : 0.f;
     }
     __syncthreads();
-    const int64_t p = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = p < HW;
+    const int64_t p0 = (int64_t)blockIdx.x * BP + lane;
     const int dper = (D + 3) / 4;
     const int d0 = wv * dper, d1 = (d0 + dper < D) ? d0 + dper : D;
-    float acc[K];
+    float acc[PX][K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.f;
-    const float* f = feat + ((int64_t)n * D) * HW + (live ? p : 0);
+    for (int u = 0; u < PX; ++u)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[u][k] = 0.f;
+    const float* f[PX];
+#pragma unroll
+    for (int u = 0; u < PX; ++u) f[u] = feat + ((int64_t)n * D) * HW + (p0 + 64 * u < HW ? p0 + 64 * u : 0);
 #pragma unroll 4
     for (int d = d0; d < d1; ++d) {
-        const float x = f[(int64_t)d * HW];
+        float x[PX];
+#pragma unroll
+        for (int u = 0; u < PX; ++u) x[u] = f[u][(int64_t)d * HW];
         const float4* c4 = reinterpret_cast<const float4*>(cT + (size_t)d * KP);
 #pragma unroll
         for (int q = 0; q < KP / 4; ++q) {
             const float4 c = c4[q];
-            const float e0 = c.x - x, e1 = c.y - x, e2 = c.z - x, e3 = c.w - x;
-            if (q * 4 + 0 < K) acc[q * 4 + 0] += e0 * e0;
-            if (q * 4 + 1 < K) acc[q * 4 + 1] += e1 * e1;
-            if (q * 4 + 2 < K) acc[q * 4 + 2] += e2 * e2;
-            if (q * 4 + 3 < K) acc[q * 4 + 3] += e3 * e3;
+#pragma unroll
+            for (int u = 0; u < PX; ++u) {
+                const float e0 = c.x - x[u], e1 = c.y - x[u], e2 = c.z - x[u], e3 = c.w - x[u];
+                if (q * 4 + 0 < K) acc[u][q * 4 + 0] += e0 * e0;
+                if (q * 4 + 1 < K) acc[u][q * 4 + 1] += e1 * e1;
+                if (q * 4 + 2 < K) acc[u][q * 4 + 2] += e2 * e2;
+                if (q * 4 + 3 < K) acc[u][q * 4 + 3] += e3 * e3;
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) part[(wv * K + k) * 64 + lane] = acc[k];
+    for (int u = 0; u < PX; ++u)
+#pragma unroll
+        for (int k = 0; k < K; ++k) part[(wv * K + k) * BP + 64 * u + lane] = acc[u][k];
     __syncthreads();
-    if (wv != 0 || !live) return;
+    // softmax over classes: wave w finishes the pixels lane + 64 * u with u % 4 == w (PX <= 4: one group per wave)
+    if (wv >= PX) return;
+    const int64_t p = p0 + 64 * wv;
+    if (p >= HW) return;
+    const int col = 64 * wv + lane;
     float dist[K];
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float s = part[(0 * K + k) * 64 + lane] + part[(1 * K + k) * 64 + lane] +
-                        part[(2 * K + k) * 64 + lane] + part[(3 * K + k) * 64 + lane];
+        const float s = part[(0 * K + k) * BP + col] + part[(1 * K + k) * BP + col] +
+                        part[(2 * K + k) * BP + col] + part[(3 * K + k) * BP + col];
         dist[k] = -sqrtf(s);
         if (k < Krt) m = fmaxf(m, dist[k]);
     }
@@ -84,29 +103,67 @@ __global__ __launch_bounds__(256) void centroid_weights_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// Block = 64 x 4 output pixels.  The low-res weights its bilinear taps touch (<= 3 rows x <= 66 columns x K classes for
+// any upsampling factor >= 1) are staged in LDS once -- the 4 x K taps of a pixel were 76 gathers through L1 before.
+// Falls back to direct reads when the footprint does not fit (downsampling geometries).
+constexpr int kConsRows = 6, kConsCols = 68;
 __global__ __launch_bounds__(256) void argmax_consensus_kernel(const float* __restrict__ wts,
                                                                const long long* __restrict__ pseudo_in,
                                                                long long* __restrict__ pseudo_out,
                                                                long long* __restrict__ feat_pseudo, int K, int h, int w,
                                                                int H, int W, float sy, float sx) {
-    const int X = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    extern __shared__ float tile[];        // [K][rows][cols]
+    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 4;
+    const int X = X0 + (threadIdx.x & 63);
+    const int Y = Y0 + (threadIdx.x >> 6);
     const int n = blockIdx.z;
+    // footprint of the block (uniform): taps of the first and last pixel row / column
+    int ia, ib, ja, jb;
+    float t_;
+    bilinear_cell(Y0, sy, h, ia, t_);
+    bilinear_cell(min(Y0 + 3, H - 1), sy, h, ib, t_);
+    bilinear_cell(X0, sx, w, ja, t_);
+    bilinear_cell(min(X0 + 63, W - 1), sx, w, jb, t_);
+    const int rows = min(ib + 1, h - 1) - ia + 1, cols = min(jb + 1, w - 1) - ja + 1;
+    const bool staged = rows <= kConsRows && cols <= kConsCols;
+    const float* base_n = wts + ((int64_t)n * K) * h * w;
+    if (staged) {
+        const int per = rows * cols;
+        for (int i = threadIdx.x; i < K * per; i += 256) {
+            const int k = i / per, r = (i - k * per) / cols, c = i - k * per - r * cols;
+            tile[i] = base_n[(int64_t)k * h * w + (int64_t)(ia + r) * w + ja + c];
+        }
+        __syncthreads();
+    }
     if (X >= W || Y >= H) return;
     int i0, j0;
     float wy, wx;
     bilinear_cell(Y, sy, h, i0, wy);
     bilinear_cell(X, sx, w, j0, wx);
-    const int dj = (w > 1) ? 1 : 0, di = (h > 1) ? w : 0;
-    const float* base = wts + ((int64_t)n * K) * h * w + (int64_t)i0 * w + j0;
     float best = -INFINITY;
     int arg = 0;
-    for (int k = 0; k < K; ++k) {
-        const float* p = base + (int64_t)k * h * w;
-        const float v = (1.f - wy) * ((1.f - wx) * p[0] + wx * p[dj]) + wy * ((1.f - wx) * p[di] + wx * p[di + dj]);
-        if (v > best) {  // strict: first maximum wins, as torch.max
-            best = v;
-            arg = k;
+    if (staged) {
+        const int dj = (w > 1) ? 1 : 0, di = (h > 1) ? cols : 0;
+        const float* t0 = tile + (i0 - ia) * cols + (j0 - ja);
+        const int per = rows * cols;
+        for (int k = 0; k < K; ++k) {
+            const float* p = t0 + k * per;
+            const float v = (1.f - wy) * ((1.f - wx) * p[0] + wx * p[dj]) + wy * ((1.f - wx) * p[di] + wx * p[di + dj]);
+            if (v > best) {  // strict: first maximum wins, as torch.max
+                best = v;
+                arg = k;
+            }
+        }
+    } else {
+        const int dj = (w > 1) ? 1 : 0, di = (h > 1) ? w : 0;
+        const float* base = base_n + (int64_t)i0 * w + j0;
+        for (int k = 0; k < K; ++k) {
+            const float* p = base + (int64_t)k * h * w;
+            const float v = (1.f - wy) * ((1.f - wx) * p[0] + wx * p[dj]) + wy * ((1.f - wx) * p[di] + wx * p[di + dj]);
+            if (v > best) {
+                best = v;
+                arg = k;
+            }
         }
     }
     const int64_t o = ((int64_t)n * H + Y) * W + X;
@@ -243,20 +300,24 @@ extern "C" int diga_centroid_softmax_weights(const float* feat, const float* cen
     hipStream_t st = (hipStream_t)stream;
     // D*4 B of features per low-res pixel in, K*4 B of weights out (+ K*4 with distances)
     ProfScope prof(DIGA_PROF_CENTROID_WEIGHTS, st, (double)N * HW * (D * 4.0 + K * 4.0 * (neg_dist ? 2.0 : 1.0)));
-    dim3 grid((unsigned)ceil_div(HW, 64), (unsigned)N);
     if (K <= 19 && K > 16) {
-        const size_t sh = ((size_t)D * 20 + 4 * 19 * 64) * sizeof(float);
-        hipLaunchKernelGGL((centroid_weights_kernel<19>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
+        constexpr int PX = 2;
+        dim3 grid((unsigned)ceil_div(HW, 64 * PX), (unsigned)N);
+        const size_t sh = ((size_t)D * 20 + 4 * 19 * 64 * PX) * sizeof(float);
+        hipLaunchKernelGGL((centroid_weights_kernel<19, PX>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
                            (int)D, (int)K, HW);
     } else if (K <= 16) {
-        const size_t sh = ((size_t)D * 16 + 4 * 16 * 64) * sizeof(float);
-        hipLaunchKernelGGL((centroid_weights_kernel<16>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
+        constexpr int PX = 2;
+        dim3 grid((unsigned)ceil_div(HW, 64 * PX), (unsigned)N);
+        const size_t sh = ((size_t)D * 16 + 4 * 16 * 64 * PX) * sizeof(float);
+        hipLaunchKernelGGL((centroid_weights_kernel<16, PX>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
                            (int)D, (int)K, HW);
     } else {
+        dim3 grid((unsigned)ceil_div(HW, 64), (unsigned)N);
         const size_t sh = ((size_t)D * 32 + 4 * 32 * 64) * sizeof(float);
         DIGA_REQUIRE(sh <= 160 * 1024, DIGA_EINVAL, "centroid_softmax_weights: D*K too large for LDS");
-        (void)hipFuncSetAttribute((const void*)centroid_weights_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((centroid_weights_kernel<32>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
+        (void)hipFuncSetAttribute((const void*)centroid_weights_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((centroid_weights_kernel<32, 1>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
                            (int)D, (int)K, HW);
     }
     return launch_status("diga_centroid_softmax_weights");
@@ -271,7 +332,7 @@ extern "C" int diga_upsample_argmax_consensus(const float* weights, const int64_
     // low-res weights in, int64 label map read and written [, second map written]
     ProfScope prof(DIGA_PROF_CONSENSUS, (hipStream_t)stream,
                    (double)N * (h * w * K * 4.0 + (double)H * W * (feat_pseudo ? 24.0 : 16.0)));
-    hipLaunchKernelGGL(argmax_consensus_kernel, grid, dim3(256), 0, (hipStream_t)stream, weights,
+    hipLaunchKernelGGL(argmax_consensus_kernel, grid, dim3(256), (size_t)K * kConsRows * kConsCols * sizeof(float), (hipStream_t)stream, weights,
                        (const long long*)pseudo_in, (long long*)pseudo_out, (long long*)feat_pseudo, (int)K, (int)h,
                        (int)w, (int)H, (int)W, ac_scale(h, H), ac_scale(w, W));
     return launch_status("diga_upsample_argmax_consensus");
