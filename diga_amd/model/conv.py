@@ -179,7 +179,7 @@ class _StemConvFn(torch.autograd.Function):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None, x_is_twin=False,
-                dy_is_twin=False, bn_box=None, opts=None):
+                dy_is_twin=False, bn_box=None, opts=None, chain=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         if x_is_twin:          # the producer wrote the split twin instead of fp32 (same bytes per element): hand it on
@@ -229,6 +229,18 @@ class _Conv2dFn(torch.autograd.Function):
             bn_box["claimed"] = True
             bn_box["consumer_ready"] = True
             ctx.bn_box = bn_box
+        # several convs on one tensor (the ASPP branches): their input gradients are summed by chaining the running sum
+        # through the backward-data epilogues (`addend`) instead of autograd adds; the last one to run also finishes the
+        # gradient of the BatchNorm that produced the tensor.  All members must be eligible, else the chain is off.
+        ctx.chain = chain
+        if chain is not None:
+            if not (ctx.needs_input_grad[0] and stride == (1, 1) and cp == c and c % 4 == 0 and not x_is_twin):
+                chain["disabled"] = True
+            box = chain.get("box")
+            if box is not None and ("claimed" in box or box.get("rows") != n * hi * wi or box.get("C") != c):
+                chain["box"] = None
+            elif box is not None:
+                chain["box_ok"] = True
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -268,7 +280,27 @@ class _Conv2dFn(torch.autograd.Function):
             if stride == (1, 1):
                 dxn = torch.empty((n, hi, wi, cp), dtype=torch.float32, device=w.device)
                 epi, box = None, ctx.bn_box
-                if box is not None:
+                chain = ctx.chain if (ctx.chain is not None and not ctx.chain.get("disabled")) else None
+                last_of_chain = False
+                if chain is not None:
+                    chain["remaining"] -= 1
+                    last_of_chain = chain["remaining"] == 0
+                    prev = chain.get("acc")
+                    cbox = chain.get("box") if (last_of_chain and chain.get("box_ok")) else None
+                    if prev is not None or cbox is not None:
+                        epi = _lib.BwdEpilogue()
+                        epi.addend, epi.addend_ld = _lib.ptr(prev), cp
+                        if cbox is not None:
+                            m_rows = n * hi * wi
+                            part = torch.empty(((m_rows + 127) // 128) * 2 * cp, dtype=torch.float32, device=w.device)
+                            epi.mask_y, epi.mask_ld = (_lib.ptr(xn), cp) if cbox["has_res"] else (None, 0)
+                            epi.x, epi.x_ld = _lib.ptr(cbox["x"]), cp
+                            epi.relu_ab = _lib.ptr(cbox["relu_ab"]) if not cbox["has_res"] else None
+                            epi.mean, epi.invstd, epi.partials = _lib.ptr(cbox["mean"]), _lib.ptr(cbox["invstd"]), _lib.ptr(part)
+                            cbox["claimed"] = True
+                            cbox["premasked"] = (dxn.data_ptr(), part, dxn, prev)
+                    chain["acc"] = dxn
+                elif box is not None:
                     # finish the gradient of the BatchNorm in front of this conv in the epilogue: + residual-branch
                     # gradient, ReLU mask, sum g / sum g*xhat per 128-row chunk (include/diga_hip.h, diga_bwd_epilogue_t)
                     m_rows = n * hi * wi
@@ -292,6 +324,8 @@ class _Conv2dFn(torch.autograd.Function):
                 dxn = torch.zeros((n, hi, wi, cp), dtype=torch.float32, device=w.device)
                 dxn[:, ::stride[0], ::stride[1]] = dense
             dx = dxn[..., :c_true].permute(0, 3, 1, 2)
+            if ctx.chain is not None and not ctx.chain.get("disabled") and ctx.chain["remaining"] > 0:
+                dx = None                           # the running sum travels on through the chain; the last member returns it
         if ctx.needs_input_grad[1]:
             dwp = torch.empty((kp, r, s, cp), dtype=torch.float32, device=w.device)
             dw = torch.empty_strided((k, c_true, r, s), w_strides, dtype=torch.float32, device=w.device)
@@ -343,7 +377,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -364,7 +398,7 @@ class DigaConv2d(nn.Conv2d):
             self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
         return self
 
-    def forward(self, x, twin_grad=False, opts=None):
+    def forward(self, x, twin_grad=False, opts=None, chain=None):
         """twin_grad: the gradient of this conv's output will arrive as a split twin (the BatchNorm that consumes the
         output was called with dx_twin=True).  opts = (reflect_pad, upsample_shift, activation): inference-only input
         map / output activation folded into the kernel (diga_conv2d_next_options)."""
@@ -400,11 +434,15 @@ class DigaConv2d(nn.Conv2d):
                 raise RuntimeError("DigaConv2d: folded padding / upsampling / activation need the implicit-GEMM path without BN statistics")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), None, uses,
                          twin_box, False, False, None, tuple(int(v) for v in opts))
-        elif x_is_twin or twin_grad or bn_box is not None:
+        elif x_is_twin or twin_grad or bn_box is not None or chain is not None:
             if fn is not _Conv2dFn or (self.bias is not None and twin_grad):
-                raise RuntimeError("DigaConv2d: twin gradient needs a bias-free conv on the implicit-GEMM path")
+                if chain is not None:
+                    chain["disabled"] = True
+                else:
+                    raise RuntimeError("DigaConv2d: twin gradient needs a bias-free conv on the implicit-GEMM path")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
-                         twin_box, x_is_twin, bool(twin_grad), bn_box)
+                         twin_box, x_is_twin, bool(twin_grad), bn_box, None, chain) if fn is _Conv2dFn else \
+                fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses, twin_box)
         else:
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
                          twin_box)

@@ -136,9 +136,13 @@ class Classifier_Module2(nn.Module):
         nb = len(self.conv2d_list)
         buf = torch.empty((n, h, w, self.width * nb), dtype=torch.float32, device=x.device)
         slices = []
+        chain = None
+        if torch.is_grad_enabled() and x.requires_grad and dn.fuse_backward_enabled():
+            # the branches' input gradients are summed through their backward-data epilogues (model/conv.py)
+            chain = {"remaining": nb, "acc": None, "box": getattr(x, "_diga_bn_box", None)}
         for b, (conv, gn, _) in enumerate(self.conv2d_list):
             dst = dn.alias_slice(buf, b * self.width, (b + 1) * self.width)
-            slices.append(gn(conv(x), relu=True, out=dst))
+            slices.append(gn(conv(x, chain=chain), relu=True, out=dst))
         y = dn.assemble(buf, self.width, slices)
         mods = list(self.bottleneck)
         if len(mods) == 3:
