@@ -298,7 +298,7 @@ class _Conv2dFn(torch.autograd.Function):
                             epi.relu_ab = _lib.ptr(cbox["relu_ab"]) if not cbox["has_res"] else None
                             epi.mean, epi.invstd, epi.partials = _lib.ptr(cbox["mean"]), _lib.ptr(cbox["invstd"]), _lib.ptr(part)
                             cbox["claimed"] = True
-                            cbox["premasked"] = (dxn.data_ptr(), part, dxn, prev)
+                            cbox["premasked"] = (dxn.data_ptr(), part, dxn, prev, dxn._version)
                     chain["acc"] = dxn
                 elif box is not None:
                     # finish the gradient of the BatchNorm in front of this conv in the epilogue: + residual-branch
@@ -312,7 +312,7 @@ class _Conv2dFn(torch.autograd.Function):
                     epi.x, epi.x_ld = _lib.ptr(box["x"]), cp
                     epi.relu_ab = _lib.ptr(box["relu_ab"]) if not box["has_res"] else None
                     epi.mean, epi.invstd, epi.partials = _lib.ptr(box["mean"]), _lib.ptr(box["invstd"]), _lib.ptr(part)
-                    box["premasked"] = (dxn.data_ptr(), part, dxn, add)
+                    box["premasked"] = (dxn.data_ptr(), part, dxn, add, dxn._version)
                 _conv_launch(gyp, wt, None, dxn, (1, 1), (padding[0], padding[1]), (-dilation[0], -dilation[1]),
                              _TAG_BWD_DATA, None, dy_box if ((use_tw or ctx.dy_is_twin) and cp > 64) else None,
                              must_twin=ctx.dy_is_twin, epi=epi)

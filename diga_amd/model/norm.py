@@ -102,7 +102,9 @@ class _BnFn(torch.autograd.Function):
         g, ld_g = as_rows(gy.permute(0, 2, 3, 1))
         dx = torch.empty_like(xn)
         pre = ctx.box.pop("premasked", None) if ctx.box is not None else None
-        if pre is not None and pre[0] == g.data_ptr() and ld_g == c and training:
+        # (same buffer AND untouched since the conv wrote it: autograd sums a second gradient into a NEW tensor while the
+        #  box holds a reference to this one; the version check also catches an in-place accumulation)
+        if pre is not None and pre[0] == g.data_ptr() and pre[2]._version == pre[4] and ld_g == c and training:
             # the consumer conv's backward-data epilogue delivered g = mask * (its gradient + residual-branch gradient) and
             # its column sums: finalise + apply only; the residual gradient of this BN IS g
             ws = _lib.workspace(67 * c * 4, xn.device, "norm_kk")

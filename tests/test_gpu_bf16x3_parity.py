@@ -357,3 +357,37 @@ def test_residual_junction_fused_backward_vs_float64(planes, inpl, dil, n, h, w,
     assert rel(dx1, dx0.double().cpu()) < 2e-5
     for k in gr1:
         assert rel(gr1[k], gr0[k].double().cpu()) < 3e-5, k
+
+
+def test_fused_gradient_with_a_second_consumer_falls_back(bf16x3):
+    """A tensor whose gradient the backward-data epilogue finished gets a SECOND gradient from another consumer (autograd
+    adds it): the BatchNorm must notice that what arrives is not the buffer the conv wrote and re-mask / re-reduce.
+    Checked against the same graph with the fusion switched off."""
+    import os
+    name = "junction2nd"
+    sds = [_block_state(f"{name}.b{i}", 1024, 256, False) for i in range(2)]
+    blocks = [_make_block(sd, f"{name}.b{i}", 1024, 256, 1, 2, False) for i, sd in enumerate(sds)]
+    g = synth.gen(321)
+    x = torch.randn((1, 1024, 19, 17), generator=g).relu_()
+    probe = torch.randn((1, 1024, 19, 17), generator=g).to(DEV)
+    side = torch.randn((1, 1024, 19, 17), generator=g).to(DEV)
+    res = {}
+    for fuse in ("1", "0"):
+        os.environ["DIGA_FUSE_BWD"] = fuse
+        try:
+            for b in blocks:
+                for p in b.parameters():
+                    p.grad = None
+            xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+            mid = blocks[0](xd)
+            out = blocks[1](mid)
+            ((out * probe).sum() + (mid * side).sum()).backward()        # `mid` has a consumer outside the block chain
+            torch.cuda.synchronize()
+            res[fuse] = (xd.grad.clone(), {k: p.grad.clone() for k, p in blocks[0].named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("DIGA_FUSE_BWD", None)
+    dx1, g1 = res["1"]
+    dx0, g0 = res["0"]
+    assert float((dx1 - dx0).abs().max()) <= 3e-5 * float(dx0.abs().max())
+    for k in g0:
+        assert float((g1[k] - g0[k]).abs().max()) <= 3e-5 * float(g0[k].abs().max()), k
