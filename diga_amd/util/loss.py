@@ -16,7 +16,8 @@ if os.path.dirname(_pkg) not in sys.path:          # drop-in use: only .../diga_
     sys.path.append(os.path.dirname(_pkg))
 from diga_amd import _lib  # noqa: E402
 
-__all__ = ["cross_entropy2d", "distillation_loss", "upsample_ce_distill", "upsample_ce", "OhemCrossEntropy"]
+__all__ = ["cross_entropy2d", "distillation_loss", "upsample_ce_distill", "upsample_ce", "upsample_ce_distill_aux",
+           "OhemCrossEntropy"]
 
 
 def _f32c(t):
@@ -214,3 +215,21 @@ class _UpsampleCe(torch.autograd.Function):
 def upsample_ce(logits_lr, labels, lambda_seg=1.0):
     """lambda_seg * cross_entropy2d(up(logits_lr), labels), upsampling fused (self_training.py:343-351)."""
     return _UpsampleCe.apply(logits_lr, labels, lambda_seg)
+
+
+def upsample_ce_distill_aux(stu_main, stu_aux, tea_main, tea_aux, labels, lambda_seg=1.0, lambda_distil=0.5,
+                            lambda_aux=0.1, scale=0.5):
+    """Loss block of the two-headed (HRNet-OCR) student of the semi-supervised tree
+    (semi-supervised_segmentation/train_DiGA_semiseg_warm_up.py:239-263,282):
+
+        loss_semseg = CE(up(main)[:B], y) + lambda_aux * CE(up(aux)[:B], y)
+        loss_distil = distill(up(tea_main), up(stu_main)) + lambda_aux * distill(up(tea_aux), up(stu_aux))
+        total       = lambda_seg * loss_semseg + lambda_distil * loss_distil
+
+    taken at the low-res logit boundary with the upsampling fused: two launches of the fused loss block, one per head
+    (the network itself is outside the scoped path; its four logit maps are the inputs here).  Returns
+    (total, loss_semseg, loss_distil); differentiable wrt both student maps."""
+    t_m, ce_m, di_m = upsample_ce_distill(stu_main, tea_main, labels, lambda_seg, lambda_distil, scale)
+    t_a, ce_a, di_a = upsample_ce_distill(stu_aux, tea_aux, labels, lambda_seg, lambda_distil, scale)
+    la = float(lambda_aux)
+    return t_m + la * t_a, ce_m + la * ce_a, di_m + la * di_a

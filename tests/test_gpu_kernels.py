@@ -188,6 +188,29 @@ def test_fused_loss_block_vs_oracle(mods, B, hw, HW):
     assert torch.equal(sd.grad, sd2.grad) and torch.equal(t2, t3)
 
 
+def test_aux_head_loss_block_vs_oracle(mods):
+    """Two-headed (HRNet-OCR) warm-up loss of the semi-supervised tree, train_DiGA_semiseg_warm_up.py:259-263,282:
+    CE + 0.1 CE_aux and distill + 0.1 distill_aux on full-resolution upsampled logits, against the oracle composition."""
+    g = synth.gen(4100)
+    B, hw, HW = 2, (17, 33), (129, 257)
+    maps = [2.0 * torch.randn((2 * B, 19, *hw), generator=g) for _ in range(4)]     # stu main, stu aux, tea main, tea aux
+    lab = torch.randint(0, 19, (B, *HW), generator=g)
+    lab[torch.rand((B, *HW), generator=g) < 0.1] = 255
+    sm, sa = maps[0].clone().requires_grad_(), maps[1].clone().requires_grad_()
+    up = lambda t: ol.upsample_bilinear_ac(t, HW)  # noqa: E731
+    semseg = ol.cross_entropy2d(up(sm)[:B], lab) + 0.1 * ol.cross_entropy2d(up(sa)[:B], lab)
+    distil = ol.distillation_loss(up(maps[2]), up(sm)) + 0.1 * ol.distillation_loss(up(maps[3]), up(sa))
+    (1.0 * semseg + 0.5 * distil).backward()
+    dm, da = maps[0].to(DEV).requires_grad_(), maps[1].to(DEV).requires_grad_()
+    total, ce, di = mods["loss"].upsample_ce_distill_aux(dm, da, maps[2].to(DEV), maps[3].to(DEV), lab.to(DEV), 1.0, 0.5, 0.1)
+    total.backward()
+    assert_close(ce, semseg.detach(), 2e-5, 1e-7, "loss_semseg")
+    assert_close(di, distil.detach(), 2e-5, 1e-7, "loss_distil")
+    assert_close(total, (semseg + 0.5 * distil).detach(), 2e-5, 1e-7, "total")
+    assert_close(dm.grad, sm.grad, 3e-4, 5e-8, "grad main head")
+    assert_close(da.grad, sa.grad, 3e-4, 5e-8, "grad aux head")
+
+
 def test_fused_ce_only_vs_oracle(mods):
     g = synth.gen(77)
     lr = 2.0 * torch.randn((3, 19, 9, 17), generator=g)
