@@ -298,7 +298,8 @@ int diga_conv2d_nhwc_bf16x3(const float* in, const uint16_t* wgt_hi, const uint1
                             int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream);
 
 /* The same convolution with BOTH operands pre-split and staged global -> LDS by LDS-DMA loads (no registers, no split
- * arithmetic, no ds_write in the kernel; two-stage LDS ring, one barrier per K-step):
+ * arithmetic, no ds_write in the kernel; three-stage LDS ring, one barrier per K-step; multi-tap layers run with two
+ * MFMA waves per SIMD and skip the K-steps of taps that lie outside the image for a whole tile):
  *   in_twin  = diga_make_twin of the [N,Hi,Wi,Cin] fp32 activations: per pixel and group of 8 channels 16 B of bf16 hi
  *              + 16 B of bf16 lo (4*Cin bytes per pixel, dense);
  *   wgt_img  = diga_split_bf16_image of the [Cout][R][S][Cin] weights (diga_split_bf16_image_bytes bytes): the hi / lo
