@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from diga_amd import _lib  # noqa: E402
 from diga_amd.model.conv import DigaConv2d  # noqa: E402
 
-PEAK = 157.3
+PEAK = 157.3          # fp32 MFMA peak; the split-bf16 mode is priced against 2500 / 3 = 833.3 (see --math)
 # name, count per forward, Cin, Cout, k, stride, dil, spatial (H=W)
 SHAPES = [
     ("stem7x7", 1, 3, 64, 7, 2, 1, 768),
@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"])
     a = ap.parse_args()
     _lib.call("diga_set_conv_math", 1 if a.math == "bf16x3" else 0)
+    global PEAK
+    PEAK = 2500.0 / 3.0 if a.math == "bf16x3" else 157.3
     dev = "cuda"
     rows, tot = [], {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     for name, count, cin, cout, k, stride, dil, hw in SHAPES:
