@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiga_hip.so")
+LIB_PATH = os.environ.get("DIGA_LIB") or os.path.join(_HERE, "libdiga_hip.so")      # DIGA_LIB: A/B builds of the library
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -21,6 +21,14 @@ namespace diga {
 
 constexpr int kNormThreads = 256;
 
+// streaming (non-temporal) 16 / 8-byte stores and 16-byte loads for the apply passes: every tensor here is 150-600 MB and
+// is touched once per pass
+using nf4 = __attribute__((ext_vector_type(4))) float;
+using nu2 = __attribute__((ext_vector_type(2))) unsigned int;
+__device__ __forceinline__ void st4s(float* p, float4 v) { __builtin_nontemporal_store((nf4){v.x, v.y, v.z, v.w}, reinterpret_cast<nf4*>(p)); }
+__device__ __forceinline__ void st2s(unsigned char* p, uint2 v) { __builtin_nontemporal_store((nu2){v.x, v.y}, reinterpret_cast<nu2*>(p)); }
+__device__ __forceinline__ float4 ld4s(const float* p) { const nf4 v = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+
 struct ColGeom {
     int64_t rows_per_seg;   // rows of one segment
     int nseg, C, chunk_rows, nchunk;
@@ -216,14 +224,14 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
                     if (b != nullptr) bv = *reinterpret_cast<const float4*>(b + (int64_t)seg * ab_seg_stride + c);
                 }
             }
-            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * ld_x + c);
+            const float4 xv = ld4s(x + (int64_t)r * ld_x + c);
             float4 o;
             // explicit fma: the backward kernels re-derive the ReLU mask of a residual-free BatchNorm from x with the
             // same expression instead of re-reading y
             o.x = __builtin_fmaf(xv.x, av.x, bv.x); o.y = __builtin_fmaf(xv.y, av.y, bv.y);
             o.z = __builtin_fmaf(xv.z, av.z, bv.z); o.w = __builtin_fmaf(xv.w, av.w, bv.w);
             if (res != nullptr) {
-                const float4 rv = *reinterpret_cast<const float4*>(res + (int64_t)r * ld_r + c);
+                const float4 rv = ld4s(res + (int64_t)r * ld_r + c);
                 o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
             }
             if (relu) {
@@ -233,10 +241,10 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
                 uint2 hi, lo;
                 norm_split4(o, hi, lo);
                 unsigned char* tw = reinterpret_cast<unsigned char*>(y) + ((int64_t)r * (C >> 3) + (c >> 3)) * 32 + ((c >> 2) & 1) * 8;
-                *reinterpret_cast<uint2*>(tw) = hi;
-                *reinterpret_cast<uint2*>(tw + 16) = lo;
+                st2s(tw, hi);
+                st2s(tw + 16, lo);
             } else {
-                *reinterpret_cast<float4*>(y + (int64_t)r * ld_y + c) = o;
+                st4s(y + (int64_t)r * ld_y + c, o);
             }
         }
     }
@@ -386,12 +394,12 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
                     load_coeff(seg);
                 }
             }
-            const float4 gv = *reinterpret_cast<const float4*>(dy + (int64_t)r * ld_dy + c);
-            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)r * ld_x + c);
+            const float4 gv = ld4s(dy + (int64_t)r * ld_dy + c);
+            const float4 xv = ld4s(x + (int64_t)r * ld_x + c);
             float gg[4] = {gv.x, gv.y, gv.z, gv.w};
             const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
             if (y != nullptr) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + (int64_t)r * ld_y + c);
+                const float4 yv = ld4s(y + (int64_t)r * ld_y + c);
                 const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
@@ -409,13 +417,13 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
                 uint2 hi, lo;
                 norm_split4(make_float4(o[0], o[1], o[2], o[3]), hi, lo);
                 unsigned char* tw = reinterpret_cast<unsigned char*>(dx) + ((int64_t)r * (C >> 3) + (c >> 3)) * 32 + ((c >> 2) & 1) * 8;
-                *reinterpret_cast<uint2*>(tw) = hi;
-                *reinterpret_cast<uint2*>(tw + 16) = lo;
+                st2s(tw, hi);
+                st2s(tw + 16, lo);
             } else {
-                *reinterpret_cast<float4*>(dx + (int64_t)r * ld_dx + c) = make_float4(o[0], o[1], o[2], o[3]);
+                st4s(dx + (int64_t)r * ld_dx + c, make_float4(o[0], o[1], o[2], o[3]));
             }
             if (dres != nullptr)
-                *reinterpret_cast<float4*>(dres + (int64_t)r * ld_dr + c) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+                st4s(dres + (int64_t)r * ld_dr + c, make_float4(gg[0], gg[1], gg[2], gg[3]));
         }
     }
 }

@@ -80,7 +80,10 @@ class Bottleneck(nn.Module):
             # the BatchNorm that produced x keeps its own mask / reduce passes (no backward-epilogue fusion)
             x._diga_bn_box = None
         tw2 = takes_twin_only_input(self.conv2)
-        tw3 = grad and os.environ.get("DIGA_TWIN_CONV3", "1") != "0" and takes_twin_only_input(self.conv3, pointwise_ok=True)
+        # (round 2: pointwise layers on twins run on the persistent kernel, which also pays without a weight gradient --
+        #  the no-grad teacher takes it too; DIGA_TWIN_CONV3=2 restricts it to autograd passes as in round 1)
+        c3 = os.environ.get("DIGA_TWIN_CONV3", "1")
+        tw3 = (grad or c3 != "2") and c3 != "0" and takes_twin_only_input(self.conv3, pointwise_ok=True)
         y = self.bn1(self.conv1(x), relu=True, twin_out=tw2)
         y = self.bn2(self.conv2(y, twin_grad=tw2 and grad), relu=True, twin_out=tw3, dx_twin=tw2 and grad)
         skip = x if self.downsample is None else self.downsample(x)

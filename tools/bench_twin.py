@@ -20,6 +20,8 @@ SHAPES = [
     ("aspp.d24", 2048, 256, 3, 24, 97), ("aspp.bottleneck", 1280, 256, 3, 1, 97), ("l3.conv1 1x1", 1024, 256, 1, 1, 97),
     ("l3.conv3 1x1", 256, 1024, 1, 1, 97), ("l4.conv1 1x1", 2048, 512, 1, 1, 97), ("l4.conv3 1x1", 512, 2048, 1, 1, 97),
     ("l2.conv2 3x3", 128, 128, 3, 1, 97), ("l1.conv2 3x3", 64, 64, 3, 1, 193),
+    ("l2.conv1 1x1", 512, 128, 1, 1, 97), ("l2.conv3 1x1", 128, 512, 1, 1, 97), ("l1.conv3 1x1", 64, 256, 1, 1, 193),
+    ("l3.conv1.dgrad 1x1", 256, 1024, 1, 1, 97), ("l4.conv1.dgrad 1x1", 512, 2048, 1, 1, 97),
 ]
 
 
@@ -51,12 +53,21 @@ def main():
         outs = {v: torch.empty((n, hw, hw, cout), device=dev) for v in a.variants}
 
         def run(v):
-            os.environ["DIGA_X3T_VARIANT"] = str(1 if v >= 10 else v)
-            if v >= 10:
+            for key in ("DIGA_X3T_VARIANT", "DIGA_TAP_INNER", "DIGA_X3TP", "DIGA_X3S"):
+                os.environ.pop(key, None)
+            vsel = v
+            if v == 31:                       # the self-loading two-blocks-per-CU kernel
+                os.environ["DIGA_X3S"] = "1"
+                v = 21
+            if v >= 20:                       # 20 / 21: pointwise layers on the one-tile / persistent kernel (defaults otherwise)
+                os.environ["DIGA_X3TP"] = str(v - 20)
+            elif v >= 10:
+                os.environ["DIGA_X3T_VARIANT"] = "1"
                 os.environ["DIGA_TAP_INNER"] = str(v - 10)
             else:
-                os.environ.pop("DIGA_TAP_INNER", None)
-            _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), None, _lib.ptr(outs[v]), n, hw, hw, cin, hw, hw, cout,
+                os.environ["DIGA_X3T_VARIANT"] = str(v)
+                os.environ["DIGA_X3TP"] = "0"
+            _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), None, _lib.ptr(outs[vsel]), n, hw, hw, cin, hw, hw, cout,
                       cout, k, k, 1, 1, -pad, -pad, dil, dil, _lib.ptr(stats), 11, _lib.stream())
 
         for v in a.variants:
