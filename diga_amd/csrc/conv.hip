@@ -36,7 +36,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4nt = __attribute__((ext_vector_type(4))) float;
 
 // 16-byte streaming store: conv outputs (150-600 MB per layer) are never re-read before they have left the caches, and a
-// default-policy store keeps its line in L2.  Measured on the persistent pointwise kernel (in-kernel stamps, 256 -> 1024
+// default-policy store keeps its line in L2.  Measured with in-kernel stamps on a pointwise layer (persistent-kernel experiment, 256 -> 1024
 // channels): epilogue 17.7 k -> 10.7 k cycles per 128 KB tile and the loaders' waits 3.9 k -> 1.0 k (their L2-resident
 // weight panels are no longer evicted by the output stream).
 __device__ __forceinline__ void store4_stream(float* p, float x, float y, float z, float w) {
@@ -44,7 +44,6 @@ __device__ __forceinline__ void store4_stream(float* p, float x, float y, float 
 }
 
 constexpr int kBK = 32;
-constexpr int kLD = kBK + 4;   // padded LDS row (floats)
 
 struct ConvArgs {
     const float* in;
@@ -76,7 +75,6 @@ struct ConvArgs {
     int up_shift;                // the conv reads the 2^up_shift nearest-neighbour upsampling of `in` (nn.Upsample in front)
     int act;                     // 1: tanh on the output
     int tap_inner;               // conv_fwd_x3t8_kernel: K order = channel chunk outer, tap inner (see the dispatcher)
-    float* dbg;                  // diagnostic builds only (DIGA_X3TP_STAMP): per-block cycle stamps, else null
 };
 
 // Logical input coordinate (in the optionally upsampled image, before padding) -> source pixel of `in`.
@@ -1469,358 +1467,11 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_x3t_kernel(ConvArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Pointwise (1x1) layers on twins, PERSISTENT: conv_fwd_x3t_kernel's block (4 MFMA waves + 4 LDS-DMA loader waves, 256 x 128
-// tile, three-stage ring) walks a list of output tiles.  A pointwise layer has 8..64 K-steps per tile, so in the
-// one-tile-per-block kernel the matrix pipe is 29-34 % busy: every tile pays the first stage's HBM latency, an epilogue
-// that needs the ring's LDS (so nothing can be prefetched under it) and a block launch.  Here
-//   * the loader waves run on into the next tile while the MFMA waves are still in the epilogue of the current one: the
-//     ring stays primed (the loaders stop at their per-step barrier two stages ahead);
-//   * the epilogue therefore does NOT go through LDS: each MFMA wave stores its 128 x 64 accumulator tile straight from
-//     registers (16 consecutive channels = 64 B per quarter-wave and row) and reduces the BatchNorm column statistics of
-//     its 128-row chunk with two cross-lane steps (the fp32 summation ORDER of those partial sums differs from
-//     drain_stage's: BatchNorm outputs downstream agree to ~1e-7 relative, not bit for bit; the conv output itself is
-//     bit-identical);
-//   * tiles are dealt so that the eight 128-column tiles of one 256-row panel run on one XCD at the same time (the panel
-//     is fetched from HBM once, seven times from that XCD's L2).
-// EPI: the backward-epilogue of diga_bwd_epilogue_t from registers (4-byte loads with the store's coalescing).
-// ---------------------------------------------------------------------------------------------
-// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15): four v_add_f32 with row_shr modifiers (prefix sums; the
-// total ends up in lane 16 r + 15).  __shfl_xor over 4 / 8 lanes compiles to ds_bpermute (an LDS-crossbar instruction):
-// 128 of them per tile made the statistics cost 6.6 k cycles per tile.
-template <int CTRL>
-__device__ __forceinline__ float dpp_row_shr(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_total_in_lane15(float v) {
-    v += dpp_row_shr<0x111>(v);     // row_shr:1
-    v += dpp_row_shr<0x112>(v);     // row_shr:2
-    v += dpp_row_shr<0x114>(v);     // row_shr:4
-    v += dpp_row_shr<0x118>(v);     // row_shr:8
-    return v;
-}
-
-// acc[i][j] holds the TRANSPOSED 16 x 16 tile (the kernel feeds the weight fragment as the MFMA's row operand and the
-// pixel fragment as its column operand): lane (lc = lane & 15, lg = lane >> 4), register e = output channel
-// ncol0 + 16 j + 4 lg + e of pixel mrow0 + 16 i + lc -- four consecutive channels of one pixel per lane, i.e. one
-// 16-byte store (load) per accumulator tile and lane instead of four 4-byte ones (a 128-scalar-store epilogue was
-// store-issue bound: ~30 k cycles per tile).
-template <bool EPI, int NTW = 4>
-__device__ __forceinline__ void reg_epilogue(f32x4 (&acc)[8][NTW], const ConvArgs& a, int mrow0, int ncol0, int lane, int chunk) {
-    if (mrow0 >= a.M) return;                                   // uniform over the wave
-    const int lc = lane & 15, lg = lane >> 4;
-    const bool vec = (a.out_ld & 3) == 0 && ((uintptr_t)a.out & 15u) == 0;
-    if constexpr (!EPI) {
-        // row-major walk: the four 64-byte pieces of a pixel's 64 channels leave in four consecutive store instructions
-        float bv[NTW][4], sh[NTW][4], s1[NTW][4], s2[NTW][4];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = ncol0 + j * 16 + lg * 4 + e;
-                bv[j][e] = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
-                s1[j][e] = s2[j][e] = 0.f;
-                sh[j][e] = 0.f;
-            }
-        if (a.stats != nullptr) {
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sh[j][e] = __shfl(acc[0][j][e] + bv[j][e], lane & 48, 64);   // the chunk's first row
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = mrow0 + i * 16 + lc;
-            if (m < a.M) {
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const int n = ncol0 + j * 16 + lg * 4;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[j][e];
-                    float* o = a.out + (int64_t)m * a.out_ld + n;
-                    if (vec && n + 3 < a.Cout) {
-                        store4_stream(o, v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < a.Cout) o[e] = v[e];
-                    }
-                    if (a.stats != nullptr) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = v[e] - sh[j][e];
-                            s1[j][e] += d;
-                            s2[j][e] += d * d;
-                        }
-                    }
-                }
-            }
-        }
-        if (a.stats != nullptr) {
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s1[j][e] = row16_total_in_lane15(s1[j][e]);
-                    s2[j][e] = row16_total_in_lane15(s2[j][e]);
-                    const int n = ncol0 + j * 16 + lg * 4 + e;
-                    if (lc == 15 && n < a.Cout) {
-                        float* sp = a.stats + (int64_t)chunk * 3 * a.Cout + n;
-                        sp[0] = s1[j][e];
-                        sp[a.Cout] = s2[j][e];
-                        sp[2 * a.Cout] = sh[j][e];
-                    }
-                }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const int n = ncol0 + j * 16 + lg * 4;                   // first of this lane's 4 channels
-        const bool nok4 = n + 3 < a.Cout;
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI) {
-            // entry points guarantee Cout % 4 == 0, 16-byte aligned operands with lds % 4 == 0 for the epilogue tensors
-            const int nn = nok4 ? n : 0;
-            float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, mu = ra, is = ra;
-            if (a.e_relu_ab != nullptr) {
-                ra = *reinterpret_cast<const float4*>(a.e_relu_ab + nn);
-                rb = *reinterpret_cast<const float4*>(a.e_relu_ab + a.Cout + nn);
-            }
-            if (a.e_partials != nullptr) {
-                mu = *reinterpret_cast<const float4*>(a.e_mean + nn);
-                is = *reinterpret_cast<const float4*>(a.e_invstd + nn);
-            }
-            const float raa[4] = {ra.x, ra.y, ra.z, ra.w}, rba[4] = {rb.x, rb.y, rb.z, rb.w};
-            const float mua[4] = {mu.x, mu.y, mu.z, mu.w}, isa[4] = {is.x, is.y, is.z, is.w};
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = make_float4(1.f, 1.f, 1.f, 1.f);
-#pragma unroll
-            for (int i0 = 0; i0 < 8; i0 += 4) {                   // four pixel rows' operands in flight (up to 12 x 16 B)
-                float4 va[4], vx[4], vy[4];
-                bool ok[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int m = mrow0 + (i0 + u) * 16 + lc;
-                    ok[u] = m < a.M && nok4;
-                    const int64_t mm = ok[u] ? m : 0;
-                    va[u] = a.e_add != nullptr ? *reinterpret_cast<const float4*>(a.e_add + mm * a.e_add_ld + nn) : z4;
-                    vx[u] = a.e_x != nullptr ? *reinterpret_cast<const float4*>(a.e_x + mm * a.e_x_ld + nn) : z4;
-                    vy[u] = a.e_masky != nullptr ? *reinterpret_cast<const float4*>(a.e_masky + mm * a.e_masky_ld + nn) : o4;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int m = mrow0 + (i0 + u) * 16 + lc;
-                    const float aa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, xx[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
-                    const float yy[4] = {vy[u].x, vy[u].y, vy[u].z, vy[u].w};
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[i0 + u][j][e] + aa[e];
-                        bool keep = yy[e] > 0.f;
-                        if (a.e_masky == nullptr && a.e_relu_ab != nullptr) keep = __builtin_fmaf(xx[e], raa[e], rba[e]) > 0.f;
-                        v[e] = keep ? v[e] : 0.f;
-                    }
-                    if (ok[u]) {
-                        store4_stream(a.out + (int64_t)m * a.out_ld + n, v[0], v[1], v[2], v[3]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            s1[e] += v[e];
-                            s2[e] += v[e] * ((xx[e] - mua[e]) * isa[e]);
-                        }
-                    }
-                }
-            }
-            if (a.e_partials != nullptr) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s1[e] = row16_total_in_lane15(s1[e]);
-                    s2[e] = row16_total_in_lane15(s2[e]);
-                }
-                if (lc == 15 && nok4) {
-                    float* sp = a.e_partials + (int64_t)chunk * 2 * a.Cout + n;
-                    *reinterpret_cast<float4*>(sp) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-                    *reinterpret_cast<float4*>(sp + a.Cout) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-                }
-            }
-        }
-    }
-}
-
-template <bool EPI>
-__global__ __launch_bounds__(512, 1) void conv_fwd_x3tp_kernel(ConvArgs a) {
-    constexpr int TN = 2, BM = 256, BN = 128, NT = 4, MT = 8;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
-    extern __shared__ __align__(16) unsigned char smem_b[];
-    const int t = threadIdx.x & 255, lane = t & 63, wv = t >> 6;
-    const bool loader = threadIdx.x >= 256;
-    // tile schedule: blocks b, b + 8, ... share an XCD (observed round-robin placement; speed only): XCD x takes the
-    // contiguous tile range [x * per_xcd, (x + 1) * per_xcd), its blocks take consecutive tiles of it, stride nslots
-    const int total = a.tiles_m * a.tiles_n;
-    const int nslots = gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per_xcd = (total + 7) >> 3;
-    const int t_begin = xcd * per_xcd + slot;
-    const int t_end = min(total, (xcd + 1) * per_xcd);
-    const int ntiles = t_begin < t_end ? (t_end - t_begin + nslots - 1) / nslots : 0;
-    if (ntiles == 0) return;
-    const int cchunks = a.Cin / 32;                              // K-steps per tile (one tap)
-    const int total_steps = ntiles * cchunks;
-
-    if (loader) {
-        const unsigned char* twin = reinterpret_cast<const unsigned char*>(a.in);
-        const int lrow = lane >> 2;
-        const int kslot = (lane & 3) ^ lds_swz(lrow);
-        const int64_t rowb = (int64_t)a.in_ld * 4;
-        const int HoWo = a.Ho * a.Wo;
-        const bool identity = a.Hi == a.Ho && a.Wi == a.Wo && a.sy == 1 && a.sx == 1 && a.oy0 == 0 && a.ox0 == 0 &&
-                              !a.pad_reflect && !a.up_shift;     // output pixel m reads input pixel m
-        const unsigned char* pa[4];
-        const unsigned char* bimg = nullptr;
-        int tile = t_begin, cc = 0;
-        auto setup = [&](int tl) {
-            const int tile_n = tl % a.tiles_n, tile_m = tl / a.tiles_n;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = min(tile_m * BM + wv * 64 + 16 * j + lrow, a.M - 1);
-                if (identity) {
-                    pa[j] = twin + (int64_t)m * rowb + kslot * 32;
-                } else {
-                    const int img = m / HoWo, rem = m - img * HoWo;
-                    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-                    int cy, cx;
-                    const bool ok = map_tap(a, ho * a.sy + a.oy0, wo * a.sx + a.ox0, cy, cx);
-                    pa[j] = ok ? twin + ((int64_t)img * a.Hi * a.Wi + (int64_t)cy * a.Wi + cx) * rowb + kslot * 32 : nullptr;
-                }
-            }
-            bimg = a.wgt_img + (int64_t)tile_n * cchunks * (2 * B_PLANE) + (wv * 2 * TN) * 1024 + lane * 16;
-        };
-        auto issue = [&](int buf) {
-            unsigned char* stage = smem_b + buf * STAGE;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned char* src = pa[j] != nullptr ? pa[j] + cc * 128 : g_zero16;
-                const unsigned char* src_lo = pa[j] != nullptr ? src + 16 : g_zero16;
-                unsigned char* dst = stage + (wv * 64 + 16 * j) * 64;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lo,
-                                                 (__attribute__((address_space(3))) void*)(dst + A_PLANE), 16, 0, 0);
-            }
-            const unsigned char* bsrc = bimg + (int64_t)cc * (2 * B_PLANE);
-            unsigned char* bdst = stage + 2 * A_PLANE + (wv * 2 * TN) * 1024;
-#pragma unroll
-            for (int c = 0; c < 2 * TN; ++c)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + c * 1024),
-                                                 (__attribute__((address_space(3))) void*)(bdst + c * 1024), 16, 0, 0);
-            if (++cc == cchunks) {                               // on into the next tile of this block
-                cc = 0;
-                tile += nslots;
-                if (tile < t_end) setup(tile);
-            }
-        };
-        auto wait_next = [&](bool newest_in_flight) {            // 12 LDS-DMA loads per stage and wave
-            if (newest_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        };
-        setup(tile);
-        issue(0);
-        if (total_steps > 1) issue(1);
-        wait_next(total_steps > 1);
-        int nx = 2;
-        for (int g = 0; g < total_steps; ++g) {
-            const bool ahead = g + 2 < total_steps;
-            if (ahead) issue(nx);
-            wait_next(ahead);
-            nx = nx == 2 ? 0 : nx + 1;
-        }
-        return;
-    }
-
-    const int wm = wv >> 1, wn = wv & 1;
-    const int frow = lane & 15;
-    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
-    const int aoff = wm * 128 * 64 + foff;
-    const int boff = 2 * A_PLANE + wn * 32 * TN * 64 + foff;
-    __builtin_amdgcn_s_barrier();                                // stage 0 has landed
-    int cur = 0;
-    uint64_t st_mma = 0, st_bar = 0, st_epi = 0, st_t0 = 0, st_t1 = 0;      // DIGA_X3TP_STAMP diagnostics (a.dbg != null)
-    const uint64_t st_begin = a.dbg != nullptr ? stamp() : 0;
-    for (int it = 0, tile = t_begin; it < ntiles; ++it, tile += nslots) {
-        f32x4 acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < cchunks; ++ks) {
-            const unsigned char* Ah = smem_b + cur * STAGE + aoff;
-            const unsigned char* Al = Ah + A_PLANE;
-            const unsigned char* Bh = smem_b + cur * STAGE + boff;
-            const unsigned char* Bl = Bh + B_PLANE;
-            bf16x8_t bh[NT], bl[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
-                bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
-            }
-            bf16x8_t fa[MT][2];
-            fa[0][0] = *reinterpret_cast<const bf16x8_t*>(Ah);
-            fa[0][1] = *reinterpret_cast<const bf16x8_t*>(Al);
-            fa[1][0] = *reinterpret_cast<const bf16x8_t*>(Ah + 1024);
-            fa[1][1] = *reinterpret_cast<const bf16x8_t*>(Al + 1024);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 4, 0);
-#pragma unroll
-            for (int i = 0; i < MT; i += 2) {
-                if (i + 2 < MT) {
-                    fa[i + 2][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 2) * 1024);
-                    fa[i + 2][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 2) * 1024);
-                    fa[i + 3][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 3) * 1024);
-                    fa[i + 3][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 3) * 1024);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], fa[i + u][1], acc[i + u][j], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], fa[i + u][0], acc[i + u][j], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], fa[i + u][0], acc[i + u][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (a.dbg != nullptr) st_t1 = stamp();
-            __builtin_amdgcn_s_barrier();
-            if (a.dbg != nullptr) {
-                const uint64_t now = stamp();
-                st_mma += st_t1 - (st_t0 != 0 ? st_t0 : st_begin);
-                st_bar += now - st_t1;
-                st_t0 = now;
-            }
-            cur = cur == 2 ? 0 : cur + 1;
-        }
-        const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
-        reg_epilogue<EPI>(acc, a, tile_m * BM + wm * 128, tile_n * BN + wn * 64, lane, tile_m * 2 + wm);
-        if (a.dbg != nullptr) {
-            const uint64_t now = stamp();
-            st_epi += now - st_t0;
-            st_t0 = now;
-        }
-    }
-    if (a.dbg != nullptr && threadIdx.x == 0) {
-        float* d = a.dbg + (int64_t)blockIdx.x * 8;
-        d[0] = (float)st_mma; d[1] = (float)st_bar; d[2] = (float)st_epi; d[3] = (float)(stamp() - st_begin);
-        d[4] = (float)ntiles; d[5] = (float)cchunks;
-    }
-}
+// Two pointwise-layer experiments were measured against the 12-wave kernel below and removed again (commit 78ff4b5 has
+// them): a persistent 8-wave kernel whose MFMA waves store from registers while the loader waves prefetch the next
+// tile (1-6 % faster on K <= 512 into >= 1024 channels without statistics, 2-9 % slower elsewhere; +-0 on the step), and a
+// self-loading 4-wave 128 x 128 kernel at two blocks per CU (6-12 % slower).  In-kernel stamps from the first one gave the
+// number that mattered: a CU stores ~7.4 B/cycle with plain stores, ~12 B/cycle with non-temporal ones (store4_stream).
 
 // Taps of which at least one row of the block's M-tile reads inside the image (bit r*S + s), conservatively: a tile
 // inside one image covers the output rows ho0..ho1 (and every column once it spans a full row); a tap whose input rows
@@ -1852,165 +1503,6 @@ __device__ __forceinline__ uint64_t live_taps(const ConvArgs& a, int m0, int BM)
         }
     }
     return live != 0 ? live : all;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Staging-free split-bf16 convolution, SELF-LOADING waves, two blocks per CU ("x3s").
-//
-// In-kernel stamps of the persistent pointwise kernel showed what the one-block-per-CU twin kernels cannot hide: a CU
-// stores at ~7.4 B/cycle, so the 128 KB epilogue of a 256 x 128 tile takes ~17.5 k cycles during which that CU's matrix
-// pipe idles (12-49 k cycles of MFMA work per tile on the pointwise layers, 120 k on the 3x3 ones).  Only a second
-// resident block can compute meanwhile, and the ring + loader-wave structure leaves neither LDS nor registers for one.
-// Here: 128 x 128 x 32 tile, 4 waves (1 x 4: wave tile 128 x 32, 64 accumulator registers), every wave issues its share of
-// the LDS-DMA loads itself (8 per K-step, between its MFMA groups; the partner block's MFMAs fill the issue bubbles) --
-// no loader waves, no staging registers -- two-stage ring (64 KB), epilogue straight from registers (transposed
-// accumulators: one 16-byte store per tile and lane; BatchNorm / backward sums by DPP row reductions), so two blocks
-// fit a CU and one block's stores run under the other's K loop.  Dead taps are skipped per tile.
-// Same operand formats (twin, weight LDS images of 128 channels), same split and per-accumulator MFMA order as the other
-// twin kernels: the convolution result is bit-identical; the statistics' fp32 summation order is its own.
-// ---------------------------------------------------------------------------------------------
-template <bool EPI>
-__global__ __launch_bounds__(256, 2) void conv_fwd_x3s_kernel(ConvArgs a) {
-    constexpr int BM = 128, BN = 128, MT = 8, NT = 2;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;      // 32 KB
-    extern __shared__ __align__(16) unsigned char smem_b[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int RS = a.R * a.S;
-    const int cchunks = a.Cin / 32;
-    const uint64_t live = RS <= 64 ? live_taps(a, m0, BM) : ~0ull;
-    const int ntaps = RS <= 64 ? __builtin_popcountll(live) : RS;
-    const int ksteps = ntaps * cchunks;
-
-    // this wave's share of a stage: A rows 32 wv + 16 j + (lane >> 2), j = 0, 1 (hi and lo plane), B chunks 4 wv .. 4 wv + 3
-    const unsigned char* twin = reinterpret_cast<const unsigned char*>(a.in);
-    const int lrow = lane >> 2;
-    const int kslot = (lane & 3) ^ lds_swz(lrow);
-    int pixbase[2], yx0[2];
-    const int HoWo = a.Ho * a.Wo;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = min(m0 + wv * 32 + 16 * j + lrow, a.M - 1);
-        const int img = m / HoWo, rem = m - img * HoWo;
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        pixbase[j] = img * a.Hi * a.Wi;
-        yx0[j] = ((ho * a.sy + a.oy0) << 16) | ((wo * a.sx + a.ox0) & 0xffff);
-    }
-    const int64_t rowb = (int64_t)a.in_ld * 4;
-    const unsigned char* pa[2];
-    uint64_t todo = live;
-    int l_tap = 0, l_cc = 0, issued = 0;
-    auto next_tap = [&]() {
-        if (RS <= 64) {
-            l_tap = __builtin_ctzll(todo);
-            todo &= todo - 1;
-        } else {
-            ++l_tap;
-        }
-    };
-    auto set_tap = [&](int tap) {
-        const int r = tap / a.S, q = tap - r * a.S;
-        const int dy = r * a.ody, dx = q * a.odx;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int iy = (yx0[j] >> 16) + dy, ix = (int)(short)(yx0[j] & 0xffff) + dx;
-            int cy, cx;
-            const bool ok = map_tap(a, iy, ix, cy, cx);
-            pa[j] = ok ? twin + (int64_t)(pixbase[j] + cy * a.Wi + cx) * rowb + kslot * 32 : nullptr;
-        }
-    };
-    const unsigned char* bimg = a.wgt_img + (int64_t)tile_n * (RS * cchunks) * (2 * B_PLANE) + (wv * 4) * 1024 + lane * 16;
-    auto issue = [&](int buf) {
-        unsigned char* stage = smem_b + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned char* src = pa[j] != nullptr ? pa[j] + l_cc * 128 : g_zero16;
-            const unsigned char* src_lo = pa[j] != nullptr ? src + 16 : g_zero16;
-            unsigned char* dst = stage + (wv * 32 + 16 * j) * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lo,
-                                             (__attribute__((address_space(3))) void*)(dst + A_PLANE), 16, 0, 0);
-        }
-        const unsigned char* bsrc = bimg + (int64_t)(l_tap * cchunks + l_cc) * (2 * B_PLANE);
-        unsigned char* bdst = stage + 2 * A_PLANE + (wv * 4) * 1024;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + c * 1024),
-                                             (__attribute__((address_space(3))) void*)(bdst + c * 1024), 16, 0, 0);
-        ++issued;
-        if (++l_cc == cchunks) {
-            l_cc = 0;
-            if (issued < ksteps) {
-                next_tap();
-                set_tap(l_tap);
-            }
-        }
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15;
-    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
-    const int boff = 2 * A_PLANE + wv * 32 * 64 + foff;
-
-    if (RS <= 64) next_tap();
-    set_tap(l_tap);
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < ksteps) issue(cur ^ 1);                     // that stage was last read in step ks - 1 (barrier since)
-        const unsigned char* Ah = smem_b + cur * STAGE + foff;
-        const unsigned char* Al = Ah + A_PLANE;
-        const unsigned char* Bh = smem_b + cur * STAGE + boff;
-        const unsigned char* Bl = Bh + B_PLANE;
-        bf16x8_t bh[NT], bl[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
-            bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
-        }
-        bf16x8_t fa[MT][2];
-        fa[0][0] = *reinterpret_cast<const bf16x8_t*>(Ah);
-        fa[0][1] = *reinterpret_cast<const bf16x8_t*>(Al);
-        fa[1][0] = *reinterpret_cast<const bf16x8_t*>(Ah + 1024);
-        fa[1][1] = *reinterpret_cast<const bf16x8_t*>(Al + 1024);
-#pragma unroll
-        for (int i = 0; i < MT; i += 2) {
-            if (i + 2 < MT) {
-                fa[i + 2][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 2) * 1024);
-                fa[i + 2][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 2) * 1024);
-                fa[i + 3][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 3) * 1024);
-                fa[i + 3][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 3) * 1024);
-            }
-            // transposed tiles: the weight fragment is the MFMA's row operand (see reg_epilogue)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], fa[i + u][1], acc[i + u][j], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], fa[i + u][0], acc[i + u][j], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], fa[i + u][0], acc[i + u][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's loads of the next stage have landed, its reads are done
-        __builtin_amdgcn_s_barrier();
-    }
-    reg_epilogue<EPI, NT>(acc, a, m0, n0 + wv * 32, lane, tile_m);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3012,7 +2504,6 @@ struct NextOpts {
 static thread_local NextOpts g_next_opts;
 
 static void take_next_options(ConvArgs& a) {
-    a.dbg = nullptr;
     a.pad_reflect = g_next_opts.reflect;
     a.up_shift = g_next_opts.up_shift;
     a.act = g_next_opts.act;
@@ -3315,53 +2806,10 @@ static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const floa
     const size_t sh = (size_t)3 * (2 * 256 * 64 + 2 * 64 * tn * 64);
     // 0: one MFMA wave per SIMD (round-1 kernel); 1: two MFMA waves per SIMD + dead-tap skipping.  Measured on the C2
     // layer shapes (tools/bench_twin.py, interleaved rounds): multi-tap layers 3-6 % faster with 1 (ASPP dilation 24:
-    // 17 %), 1x1 layers 1-3 % slower -- so 1 for multi-tap layers, 0 for pointwise ones.
+    // 17 %); pointwise layers 3-12 % faster with 1 once the epilogue stores stream (before that: 1-3 % slower).
     const char* var_env = getenv("DIGA_X3T_VARIANT");
     const int variant = var_env ? atoi(var_env) : 1;
     a.tap_inner = 0;
-    {
-        // DIGA_X3S=1: the self-loading two-blocks-per-CU kernel for every twin convolution with Cout > 64
-        const char* xs = getenv("DIGA_X3S");
-        if (xs != nullptr && atoi(xs) != 0 && tn == 2 && R * S <= 64 && a.act == 0) {
-            a.tiles_m = (int)ceil_div(a.M, 128);
-            const size_t shs = (size_t)2 * (2 * 128 * 64 + 2 * 128 * 64);
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs);
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs);
-            const unsigned grid = (unsigned)(a.tiles_m * a.tiles_n);
-            if (epi != nullptr) hipLaunchKernelGGL((conv_fwd_x3s_kernel<true>), dim3(grid), dim3(256), shs, st, a);
-            else hipLaunchKernelGGL((conv_fwd_x3s_kernel<false>), dim3(grid), dim3(256), shs, st, a);
-            return launch_status("diga_conv2d_nhwc_twin");
-        }
-    }
-    {
-        // pointwise layers: persistent blocks, epilogue from registers (DIGA_X3TP=0: the one-tile-per-block kernel)
-        const char* tp = getenv("DIGA_X3TP");
-        const int tp_mode = tp ? atoi(tp) : 2;
-        // mode 2: only where it beats the 12-wave kernel (tools/bench_twin.py --variants 20 1 21): short K into wide outputs
-        // with nothing but the store in the epilogue; mode 3: the same shapes with the backward epilogue as well; 1: all
-        const bool shape_ok = a.Cin <= 512 && a.Cout >= 2 * a.Cin;
-        const bool persistent = tp_mode == 1 || (tp_mode == 2 && shape_ok && a.stats == nullptr && epi == nullptr) ||
-                                (tp_mode == 3 && shape_ok && a.stats == nullptr);
-        const int64_t total = (int64_t)a.tiles_m * a.tiles_n;
-        if (persistent && R * S == 1 && tn == 2 && a.act == 0 && total >= 64) {
-            static const int n_cu = [] {
-                int dev = 0, v = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
-                return v > 8 ? v : 256;
-            }();
-            int64_t nb = total < n_cu ? total : n_cu;
-            nb -= nb % 8;
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3tp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3tp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            if (getenv("DIGA_X3TP_STAMP") != nullptr && a.stats != nullptr) {     // tools/stamp_x3tp.py: stamps instead of statistics
-                a.dbg = a.stats;
-                a.stats = nullptr;
-            }
-            if (epi != nullptr) hipLaunchKernelGGL((conv_fwd_x3tp_kernel<true>), dim3((unsigned)nb), dim3(512), sh, st, a);
-            else hipLaunchKernelGGL((conv_fwd_x3tp_kernel<false>), dim3((unsigned)nb), dim3(512), sh, st, a);
-            return launch_status("diga_conv2d_nhwc_twin");
-        }
-    }
     if (variant == 1 && R * S <= 64) {
         // K order: tap-major (the weight layout's order, bit-identical to the register-staged kernel).  DIGA_TAP_INNER=1
         // walks channel chunks outer / taps inner instead, to line up in time the re-reads of an input row that tiles

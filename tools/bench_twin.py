@@ -53,20 +53,14 @@ def main():
         outs = {v: torch.empty((n, hw, hw, cout), device=dev) for v in a.variants}
 
         def run(v):
-            for key in ("DIGA_X3T_VARIANT", "DIGA_TAP_INNER", "DIGA_X3TP", "DIGA_X3S"):
+            for key in ("DIGA_X3T_VARIANT", "DIGA_TAP_INNER"):
                 os.environ.pop(key, None)
             vsel = v
-            if v == 31:                       # the self-loading two-blocks-per-CU kernel
-                os.environ["DIGA_X3S"] = "1"
-                v = 21
-            if v >= 20:                       # 20 / 21: pointwise layers on the one-tile / persistent kernel (defaults otherwise)
-                os.environ["DIGA_X3TP"] = str(v - 20)
-            elif v >= 10:
+            if v >= 10:
                 os.environ["DIGA_X3T_VARIANT"] = "1"
                 os.environ["DIGA_TAP_INNER"] = str(v - 10)
             else:
                 os.environ["DIGA_X3T_VARIANT"] = str(v)
-                os.environ["DIGA_X3TP"] = "0"
             _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), None, _lib.ptr(outs[vsel]), n, hw, hw, cin, hw, hw, cout,
                       cout, k, k, 1, 1, -pad, -pad, dil, dil, _lib.ptr(stats), 11, _lib.stream())
 
