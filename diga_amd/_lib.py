@@ -68,8 +68,8 @@ SIGNATURES = {
     "diga_weight_transpose": (INT, [P, P, I64, I64, I64, P]),
     "diga_im2col_nchw": (INT, [P, P] + [I64] * 11 + [P]),
     "diga_norm_workspace_bytes": (SZ, [I64, I64, I64]),
-    "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, INT, F32, F32, P, SZ, P]),
-    "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, F32, F32, P, I64, P, SZ, P]),
+    "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, INT, P, F32, F32, P, SZ, P]),
+    "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, I64, P, SZ, P]),
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
     "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
     "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
@@ -92,7 +92,7 @@ SIGNATURES = {
 class BwdEpilogue(C.Structure):
     """diga_bwd_epilogue_t of include/diga_hip.h."""
     _fields_ = [("addend", P), ("addend_ld", I64), ("mask_y", P), ("mask_ld", I64), ("x", P), ("x_ld", I64),
-                ("relu_ab", P), ("mean", P), ("invstd", P), ("partials", P)]
+                ("relu_ab", P), ("mean", P), ("invstd", P), ("partials", P), ("mask_bits", P), ("mask_bits_ld", I64)]
 
 
 # enum order of include/diga_hip.h

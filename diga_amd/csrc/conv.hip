@@ -64,12 +64,13 @@ struct ConvArgs {
     // sums of the result -- all null for a plain convolution
     const float* e_add;          // [M][e_add_ld]
     const float* e_masky;        // [M][e_masky_ld]: keep where > 0
+    const unsigned char* e_maskbits;   // [M][e_maskbits_ld bytes]: the same mask as one bit per channel (bit c & 7 of byte c >> 3)
     const float* e_x;            // [M][e_x_ld]: input of the BatchNorm whose backward consumes `out`
     const float* e_relu_ab;      // [2][Cout]: keep where fma(x, a, b) > 0
     const float* e_mean;         // [Cout]
     const float* e_invstd;       // [Cout]
     float* e_partials;           // [ceil(M/128)][2][Cout]: sum g, sum g*xhat per 128-row chunk
-    int e_add_ld, e_masky_ld, e_x_ld;
+    int e_add_ld, e_masky_ld, e_x_ld, e_maskbits_ld;
     // input map / output activation (diga_conv2d_next_options; 0 = plain zero-padded convolution)
     int pad_reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d in front of the conv)
     int up_shift;                // the conv reads the 2^up_shift nearest-neighbour upsampling of `in` (nn.Upsample in front)
@@ -177,6 +178,7 @@ __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArg
 #pragma unroll
         for (int k0 = 0; k0 < RPT; k0 += RB) {
             float4 va[RB], vx[RB], vy[RB];
+            unsigned vb[RB];
             bool ok[RB];
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
@@ -187,6 +189,7 @@ __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArg
                 va[u] = a.e_add != nullptr ? *reinterpret_cast<const float4*>(a.e_add + mm * a.e_add_ld + nn) : z4;
                 vx[u] = a.e_x != nullptr ? *reinterpret_cast<const float4*>(a.e_x + mm * a.e_x_ld + nn) : z4;
                 vy[u] = a.e_masky != nullptr ? *reinterpret_cast<const float4*>(a.e_masky + mm * a.e_masky_ld + nn) : z4;
+                vb[u] = a.e_maskbits != nullptr ? a.e_maskbits[mm * a.e_maskbits_ld + (nn >> 3)] >> (nn & 4) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
@@ -198,6 +201,9 @@ __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArg
                 if (a.e_masky != nullptr) {
                     v[0] = vy[u].x > 0.f ? v[0] : 0.f; v[1] = vy[u].y > 0.f ? v[1] : 0.f;
                     v[2] = vy[u].z > 0.f ? v[2] : 0.f; v[3] = vy[u].w > 0.f ? v[3] : 0.f;
+                } else if (a.e_maskbits != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((vb[u] >> e) & 1u) ? v[e] : 0.f;
                 } else if (a.e_relu_ab != nullptr) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xx[e], ra[e], rb[e]) > 0.f ? v[e] : 0.f;
@@ -2514,20 +2520,24 @@ static void take_next_options(ConvArgs& a) {
 static int set_bwd_epilogue(ConvArgs& a, const diga_bwd_epilogue_t* e, const char* who) {
     a.e_add = a.e_masky = a.e_x = a.e_relu_ab = a.e_mean = a.e_invstd = nullptr;
     a.e_partials = nullptr;
-    a.e_add_ld = a.e_masky_ld = a.e_x_ld = 0;
+    a.e_maskbits = nullptr;
+    a.e_add_ld = a.e_masky_ld = a.e_x_ld = a.e_maskbits_ld = 0;
     if (e == nullptr) return DIGA_OK;
-    DIGA_REQUIRE(e->addend || e->mask_y || e->x, DIGA_EINVAL, "%s: empty epilogue descriptor", who);
+    DIGA_REQUIRE(e->addend || e->mask_y || e->mask_bits || e->x, DIGA_EINVAL, "%s: empty epilogue descriptor", who);
     DIGA_REQUIRE(a.Cout % 4 == 0 && a.out_ld % 4 == 0 && aligned16(a.out) && a.bias == nullptr && a.stats == nullptr, DIGA_EINVAL,
                  "%s: a backward epilogue needs Cout %% 4 == 0, out_ld %% 4 == 0, a 16-byte aligned output, no bias, no forward statistics", who);
     DIGA_REQUIRE(!e->addend || (aligned16(e->addend) && e->addend_ld >= a.Cout && e->addend_ld % 4 == 0), DIGA_EINVAL, "%s: bad addend", who);
     DIGA_REQUIRE(!e->mask_y || (aligned16(e->mask_y) && e->mask_ld >= a.Cout && e->mask_ld % 4 == 0), DIGA_EINVAL, "%s: bad mask_y", who);
     DIGA_REQUIRE(!e->x || (aligned16(e->x) && e->x_ld >= a.Cout && e->x_ld % 4 == 0), DIGA_EINVAL, "%s: bad x", who);
-    DIGA_REQUIRE(!(e->mask_y && e->relu_ab), DIGA_EINVAL, "%s: give mask_y or relu_ab, not both", who);
+    DIGA_REQUIRE((e->mask_y != nullptr) + (e->relu_ab != nullptr) + (e->mask_bits != nullptr) <= 1, DIGA_EINVAL,
+                 "%s: give one of mask_y, mask_bits, relu_ab", who);
+    DIGA_REQUIRE(!e->mask_bits || e->mask_bits_ld * 8 >= a.Cout, DIGA_EINVAL, "%s: bad mask_bits", who);
     DIGA_REQUIRE(!e->relu_ab || (e->x && aligned16(e->relu_ab)), DIGA_EINVAL, "%s: relu_ab needs x", who);
     DIGA_REQUIRE(!e->partials || (e->x && e->mean && e->invstd && aligned16(e->mean) && aligned16(e->invstd)), DIGA_EINVAL,
                  "%s: partials need x, mean and invstd", who);
     a.e_add = e->addend; a.e_add_ld = (int)e->addend_ld;
     a.e_masky = e->mask_y; a.e_masky_ld = (int)e->mask_ld;
+    a.e_maskbits = e->mask_bits; a.e_maskbits_ld = (int)e->mask_bits_ld;
     a.e_x = e->x; a.e_x_ld = (int)e->x_ld;
     a.e_relu_ab = e->relu_ab; a.e_mean = e->mean; a.e_invstd = e->invstd; a.e_partials = e->partials;
     return DIGA_OK;

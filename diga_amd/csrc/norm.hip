@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
                                                            int64_t ld_y, const float* __restrict__ res, int64_t ld_r,
                                                            const float* __restrict__ a, const float* __restrict__ b,
                                                            int64_t ab_seg_stride, int64_t rows_per_seg, int64_t rows,
-                                                           int C, int relu, int twin_out) {
+                                                           int C, int relu, int twin_out,
+                                                           unsigned char* __restrict__ relu_bits = nullptr) {
     // a thread keeps its channel quad(s) and walks rows: no per-element division, coefficients in registers
     const int tq = C >> 2;
     const int tpr = tq < 256 ? tq : 256;          // threads per row
@@ -235,6 +236,17 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
                 o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
             }
             if (relu) {
+                if (relu_bits != nullptr) {
+                    // the ReLU mask as one bit per channel (C % 32 == 0): 8 lanes = 32 consecutive channels of one row OR
+                    // their nibbles together (two quad permutes + a half-row mirror) and the first lane stores the word
+                    unsigned v = ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u))
+                                 << (4 * (threadIdx.x & 7));
+                    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+                    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+                    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);     // row_half_mirror
+                    if ((threadIdx.x & 7) == 0)
+                        *reinterpret_cast<unsigned*>(relu_bits + (int64_t)r * (C >> 3) + (c >> 3)) = v;
+                }
                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
             if (twin_out) {
@@ -836,8 +848,9 @@ extern "C" size_t diga_norm_workspace_bytes(int64_t rows_per_seg, int64_t nseg, 
 extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                            float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int training,
-                           int relu, int y_twin, float momentum, float eps, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+                           int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "bn_fwd: relu_bits needs relu and C % 32 == 0");
     DIGA_REQUIRE(!y_twin || (C % 8 == 0 && ld_y == C), DIGA_EINVAL, "bn_fwd: twin output needs C % 8 == 0 and a dense y");
     DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && workspace && M > 0, DIGA_EINVAL, "bn_fwd: bad argument");
     DIGA_REQUIRE(training || (running_mean && running_var), DIGA_EINVAL, "bn_fwd: eval mode needs running statistics");
@@ -859,16 +872,17 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
                            running_var, save_mean, save_invstd, ab, (int)C, eps);
     }
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
-                       ab + C, (int64_t)0, M, M, (int)C, relu, y_twin);
+                       ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
     return launch_status("diga_bn_fwd");
 }
 
 extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
                                     int64_t ld_r, const float* gamma, const float* beta, float* running_mean,
                                     float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
-                                    int64_t C, int relu, int y_twin, float momentum, float eps, const float* partial,
-                                    int64_t chunk_rows,
+                                    int64_t C, int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps,
+                                    const float* partial, int64_t chunk_rows,
                                     void* workspace, size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "bn_fwd_partials: relu_bits needs relu and C % 32 == 0");
     DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0 && chunk_rows > 0,
                  DIGA_EINVAL, "bn_fwd_partials: bad argument");
     int rc = check_norm("bn_fwd_partials", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
@@ -901,7 +915,7 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
     hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
                        running_mean, running_var, save_mean, save_invstd, ab, momentum, eps);
     hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
-                       ab + C, (int64_t)0, M, M, (int)C, relu, y_twin);
+                       ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
     return launch_status("diga_bn_fwd_partials");
 }
 

@@ -176,6 +176,18 @@ class _StemConvFn(torch.autograd.Function):
         return None, dw, db, None, None, None, None, None, None
 
 
+def _set_mask(epi, box, xn, cp):
+    """ReLU mask of a BatchNorm with residual for the backward epilogue: its bit mask when the forward wrote one
+    (norm._BnFn, `mask_bits`), else its output (= this conv's input xn)."""
+    if not box["has_res"]:
+        epi.mask_y, epi.mask_ld = None, 0
+    elif box.get("mask_bits") is not None:
+        epi.mask_y, epi.mask_ld = None, 0
+        epi.mask_bits, epi.mask_bits_ld = _lib.ptr(box["mask_bits"]), cp // 8
+    else:
+        epi.mask_y, epi.mask_ld = _lib.ptr(xn), cp
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None, x_is_twin=False,
@@ -293,7 +305,7 @@ class _Conv2dFn(torch.autograd.Function):
                         if cbox is not None:
                             m_rows = n * hi * wi
                             part = torch.empty(((m_rows + 127) // 128) * 2 * cp, dtype=torch.float32, device=w.device)
-                            epi.mask_y, epi.mask_ld = (_lib.ptr(xn), cp) if cbox["has_res"] else (None, 0)
+                            _set_mask(epi, cbox, xn, cp)
                             epi.x, epi.x_ld = _lib.ptr(cbox["x"]), cp
                             epi.relu_ab = _lib.ptr(cbox["relu_ab"]) if not cbox["has_res"] else None
                             epi.mean, epi.invstd, epi.partials = _lib.ptr(cbox["mean"]), _lib.ptr(cbox["invstd"]), _lib.ptr(part)
@@ -308,7 +320,7 @@ class _Conv2dFn(torch.autograd.Function):
                     add = box.pop("dres", None) if box["has_res"] else None
                     epi = _lib.BwdEpilogue()
                     epi.addend, epi.addend_ld = _lib.ptr(add), cp
-                    epi.mask_y, epi.mask_ld = (_lib.ptr(xn), cp) if box["has_res"] else (None, 0)
+                    _set_mask(epi, box, xn, cp)
                     epi.x, epi.x_ld = _lib.ptr(box["x"]), cp
                     epi.relu_ab = _lib.ptr(box["relu_ab"]) if not box["has_res"] else None
                     epi.mean, epi.invstd, epi.partials = _lib.ptr(box["mean"]), _lib.ptr(box["invstd"]), _lib.ptr(part)

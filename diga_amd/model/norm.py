@@ -73,24 +73,30 @@ class _BnFn(torch.autograd.Function):
         # ReLU without residual: the backward re-derives the mask from x and the forward coefficients (no y read)
         save_ab = torch.empty(2 * c, dtype=torch.float32, device=xn.device) if (relu and residual is None) else None
         ws = _ws(m, 1, c, xn.device)
+        # a BN with residual keeps its ReLU mask as one bit per element for the backward epilogue of the conv that reads
+        # y (instead of y itself: 1/32 of the bytes); DIGA_RELU_BITS=0 reads y as before
+        bits = None
+        if (box is not None and relu and residual is not None and c % 32 == 0 and _relu_bits_enabled()):
+            bits = torch.empty((m, c // 8), dtype=torch.uint8, device=xn.device)
         if partials is not None and training:
             # the producing conv already reduced its output tile by tile: finalise + apply only
             _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
-                      _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
+                      _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0, _lib.ptr(bits),
                       float(momentum), float(eps), _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(),
                       _lib.stream())
         else:
             _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
                       _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd),
-                      _lib.ptr(save_ab), m, c, 1 if training else 0, 1 if relu else 0, 1 if twin_out else 0,
+                      _lib.ptr(save_ab), m, c, 1 if training else 0, 1 if relu else 0, 1 if twin_out else 0, _lib.ptr(bits),
                       float(momentum), float(eps), _lib.ptr(ws), ws.numel(), _lib.stream())
         ctx.save_for_backward(xn, y if (relu and save_ab is None) else None, weight, save_mean, save_invstd, save_ab)
         ctx.flags = (training, residual is not None)
         ctx.dx_twin = bool(dx_twin and c % 8 == 0)
         ctx.box, ctx.res_box = box, res_box
         if box is not None:
-            box.update(x=xn, mean=save_mean, invstd=save_invstd, relu_ab=save_ab, has_res=residual is not None, rows=m, C=c)
+            box.update(x=xn, mean=save_mean, invstd=save_invstd, relu_ab=save_ab, has_res=residual is not None, rows=m, C=c,
+                       mask_bits=bits)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -178,6 +184,11 @@ def bump_batches_tracked(model):
             b._nbt_external = True
         object.__setattr__(model, "_nbt_flat", flat)
     flat.add_(1)
+
+
+def _relu_bits_enabled():
+    import os
+    return os.environ.get("DIGA_RELU_BITS", "1") != "0"
 
 
 def fuse_backward_enabled():

@@ -234,6 +234,7 @@ size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout)
  *     out = acc                               the convolution (bias-free, no forward statistics)
  *     out += addend                           the gradient reaching the same tensor through the residual branch
  *     out  = out where (mask_y > 0)           ReLU of a BatchNorm with residual (mask_y = its output)          -- or --
+ *     out  = out where bit c of mask_bits     the same mask as one bit per channel (relu_bits of diga_bn_fwd*) -- or --
  *     out  = out where fma(x, a, b) > 0       ReLU of a BatchNorm without residual (relu_ab = its forward coefficients)
  *     partials[chunk] = { sum out, sum out*xhat } per 128-row chunk and channel, xhat = (x - mean) * invstd
  * `out` is then the MASKED gradient g of that BatchNorm and `partials` what diga_bn_bwd_partials finalises -- its
@@ -251,6 +252,8 @@ typedef struct {
     const float* mean;     /* [Cout] (with partials) */
     const float* invstd;   /* [Cout] (with partials) */
     float* partials;       /* nullable */
+    const unsigned char* mask_bits;   /* nullable: [M][mask_bits_ld bytes], bit (c & 7) of byte (c >> 3) = keep channel c */
+    int64_t mask_bits_ld;
 } diga_bwd_epilogue_t;
 
 int diga_conv2d_nhwc_f32_epi(const float* in, const float* wgt, float* out, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin,
@@ -355,19 +358,23 @@ size_t diga_norm_workspace_bytes(int64_t rows_per_segment, int64_t n_segments, i
  * backward pass; eval: running statistics.  residual nullable.  save_ab (nullable, [2][C]) receives a and b: passed
  * back to diga_bn_bwd as `relu_ab` it lets the backward of a residual-free BN+ReLU re-derive the ReLU mask from x
  * instead of reading y.  y_twin != 0: y (dense, ld_y == C, C % 8 == 0) receives the split twin of the result (the
- * format of diga_make_twin, 4 bytes per element) instead of fp32 -- for a tensor read only by the twin conv kernels. */
+ * format of diga_make_twin, 4 bytes per element) instead of fp32 -- for a tensor read only by the twin conv kernels.
+ * relu_bits (nullable; relu, C % 32 == 0): also receives the ReLU mask as [M][C/8] bytes, bit (c & 7) of byte (c >> 3) =
+ * (y[c] > 0) -- `mask_bits` of diga_bwd_epilogue_t: the backward-data epilogue of the conv that consumes y reads 1 bit
+ * per element instead of y itself. */
 int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                 float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int training, int relu,
-                int y_twin, float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+                int y_twin, unsigned char* relu_bits, float momentum, float eps, void* workspace, size_t workspace_bytes,
+                void* stream);
 
 /* Train-mode diga_bn_fwd whose statistics pass is replaced by partials the producing conv already wrote
  * (`partial` = stats_partial of diga_conv2d_nhwc_*, `chunk_rows` = 128). */
 int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
-                         int y_twin, float momentum, float eps, const float* partial, int64_t chunk_rows, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         int y_twin, unsigned char* relu_bits, float momentum, float eps, const float* partial,
+                         int64_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*mask, mask = [y>0] when y is given,
  * [fma(x, a, b) > 0] when relu_ab = save_ab of the forward is given instead (BN without residual), 1 when both are

@@ -332,6 +332,14 @@ def test_residual_junction_fused_backward_vs_float64(planes, inpl, dil, n, h, w,
     assert sum(c.endswith("_epi") for c in calls) == 8, calls
     assert calls.count("diga_bn_bwd_partials") == 8 and calls.count("diga_bn_bwd") == 1     # bn3 of the last block stays plain
     assert torch.equal(y0, y1)
+    # the junction epilogues read the ReLU mask as one bit per element (relu_bits of diga_bn_fwd*); reading the BatchNorm
+    # output instead (DIGA_RELU_BITS=0) is the same mask: bit-identical gradients
+    monkeypatch.setenv("DIGA_RELU_BITS", "0")
+    y2, dx2, gr2 = run()
+    monkeypatch.delenv("DIGA_RELU_BITS")
+    assert torch.equal(y2, y1) and torch.equal(dx2, dx1)
+    for k in gr1:
+        assert torch.equal(gr1[k], gr2[k]), k
 
     sd64 = {}
     for sd in sds:

@@ -76,6 +76,29 @@ def test_batchnorm_large_mean_is_stable():
     assert_close(y, want, 1e-3, 2e-3, "bn with large mean")
 
 
+@pytest.mark.parametrize("m,c", [(300, 64), (77, 1024), (129, 1280), (50, 2048), (9, 32)])
+def test_batchnorm_relu_bits(m, c):
+    """relu_bits of diga_bn_fwd: [M][C/8] bytes, bit (c & 7) of byte (c >> 3) = (y[c] > 0) -- the mask the backward
+    epilogue of the consuming conv reads (diga_bwd_epilogue_t.mask_bits) instead of y."""
+    import numpy as np
+    from diga_amd import _lib
+    g = synth.gen(m + c)
+    x = torch.randn((m, c), generator=g).to(DEV)
+    r = torch.randn((m, c), generator=g).to(DEV)
+    gam, bet = (1 + 0.2 * torch.randn(c, generator=g)).to(DEV), (0.3 * torch.randn(c, generator=g)).to(DEV)
+    y = torch.empty_like(x)
+    bits = torch.full((m, c // 8), 0xAA, dtype=torch.uint8, device=DEV)
+    mean, invstd = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ws = torch.empty(_lib.lib.diga_norm_workspace_bytes(m, 1, c), dtype=torch.uint8, device=DEV)
+    _lib.call("diga_bn_fwd", _lib.ptr(x), c, _lib.ptr(y), c, _lib.ptr(r), c, _lib.ptr(gam), _lib.ptr(bet), None, None,
+              _lib.ptr(mean), _lib.ptr(invstd), None, m, c, 1, 1, 0, _lib.ptr(bits), 0.1, 1e-5, _lib.ptr(ws), ws.numel(),
+              _lib.stream())
+    torch.cuda.synchronize()
+    want = np.packbits((y > 0).cpu().numpy(), axis=1, bitorder="little")
+    assert np.array_equal(bits.cpu().numpy(), want)
+    assert 0.2 < float((y > 0).float().mean()) < 0.8
+
+
 @pytest.mark.parametrize("n,c,h,w,groups", [(2, 256, 17, 19, 32), (3, 64, 9, 9, 32), (1, 256, 33, 33, 32)])
 @pytest.mark.parametrize("relu,scale", [(True, False), (False, True), (False, False)])
 def test_groupnorm(n, c, h, w, groups, relu, scale):
