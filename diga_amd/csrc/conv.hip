@@ -75,7 +75,6 @@ struct ConvArgs {
     int pad_reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d in front of the conv)
     int up_shift;                // the conv reads the 2^up_shift nearest-neighbour upsampling of `in` (nn.Upsample in front)
     int act;                     // 1: tanh on the output
-    int tap_inner;               // conv_fwd_x3t8_kernel: K order = channel chunk outer, tap inner (see the dispatcher)
 };
 
 // Logical input coordinate (in the optionally upsampled image, before padding) -> source pixel of `in`.
@@ -794,7 +793,7 @@ __device__ __forceinline__ uint64_t stamp() {
     return v;
 }
 
-template <int TN, bool STAMP = false, int ABL = 0, bool EPI = false>
+template <int TN, bool STAMP = false, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
     constexpr int BM = 256, BN = 64 * TN, NT = 2 * TN, MT = 8;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
@@ -880,34 +879,20 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
         for (int p = 0; p < 4; ++p) {
             uint2 hi, lo;
             const float f = (ldmask >> p) & 1u ? 1.f : 0.f;
-            if constexpr (ABL == 1) {          // ablation: no split arithmetic (wrong results)
-                hi = make_uint2(__float_as_uint(ra[p][0].x), __float_as_uint(ra[p][0].y));
-                lo = make_uint2(__float_as_uint(ra[p][0].z), __float_as_uint(ra[p][0].w));
-            } else if (a.all_inside) {         // uniform
+            if (a.all_inside) {                // uniform
                 split4_nomask(ra[p][0], hi, lo);
             } else {
                 split4(ra[p][0], f, hi, lo);
             }
-            if constexpr (ABL == 2) {          // ablation: no ds_write of A (wrong results)
-                asm volatile("" ::"v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y));
-            } else {
-                *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff0) = hi;
-                *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff0) = lo;
-            }
-            if constexpr (ABL == 1) {
-                hi = make_uint2(__float_as_uint(ra[p][1].x), __float_as_uint(ra[p][1].y));
-                lo = make_uint2(__float_as_uint(ra[p][1].z), __float_as_uint(ra[p][1].w));
-            } else if (a.all_inside) {
+            *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff0) = hi;
+            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff0) = lo;
+            if (a.all_inside) {
                 split4_nomask(ra[p][1], hi, lo);
             } else {
                 split4(ra[p][1], f, hi, lo);
             }
-            if constexpr (ABL == 2) {
-                asm volatile("" ::"v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y));
-            } else {
-                *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff1) = hi;
-                *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff1) = lo;
-            }
+            *reinterpret_cast<uint2*>(smem_b + p * 4096 + woff1) = hi;
+            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 4096 + woff1) = lo;
         }
 #pragma unroll
         for (int p = 0; p < TN; ++p) {
@@ -941,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
     for (int ks = 0; ks < ksteps; ++ks) {
         const bool more = ks + 1 < ksteps;
         if constexpr (STAMP) t0 = stamp();
-        if constexpr (ABL != 3) gload(more);
+        gload(more);
         // fragment reads run one 16-row tile ahead of the MFMAs that consume them (hipcc otherwise parks every read
         // directly in front of its first use and drains lgkmcnt(0) sixteen times per K-step)
         bf16x8_t bh[NT], bl[NT];
@@ -961,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
                 aln = *reinterpret_cast<const bf16x8_t*>(Al + (i + 1) * 1024);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
-            if (ABL != 3 && i * 2 < 8 + 4 * TN) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // 2 global loads
+            if (i * 2 < 8 + 4 * TN) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // 2 global loads
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
@@ -987,10 +972,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
                 t1 = stamp();
                 tacc[2] += t1 - t0;
             }
-            if constexpr (ABL != 3) {
-                lstore();
-                advance();
-            }
+            lstore();
+            advance();
             if constexpr (STAMP) {
                 t0 = stamp();
                 tacc[3] += t0 - t1;
@@ -1030,191 +1013,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x3w_kernel(ConvArgs a) {
         }
         __syncthreads();
         drain_stage<2, TN, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// conv_fwd_x3w_kernel with a 256 x 256 block tile: 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 -- the MFMA loop of a
-// wave is the one of conv_fwd_x3w_kernel<2>, but the block's 256 activation rows now feed 256 output channels instead
-// of 128: every activation value is loaded, split (the VALU work that bounds the register-staged kernel) and written
-// to LDS once per 256 columns, i.e. half the split arithmetic, half the activation traffic through L2 and 3/4 of the
-// global-load instructions per MFMA.  For layers with Cout >= 256 (the 1x1 convs of layer3 / layer4: K = 256..2048).
-// One block (two waves per SIMD) per CU; 64 KB of LDS in the loop, 130 KB for the staged 128 x 256 epilogue half.
-// ---------------------------------------------------------------------------------------------
-template <bool EPI = false>
-__global__ __launch_bounds__(512, 2) void conv_fwd_x3w8_kernel(ConvArgs a) {
-    constexpr int BM = 256, BN = 256, TN = 4, NT = 4, MT = 8;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
-    extern __shared__ __align__(16) unsigned char smem_b[];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int wm = wv >> 2, wn = wv & 3;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // loader: thread = (rows lr and lr + 128, float4 chunks q and q + 4 of the 32-deep K slice)
-    const int q = t & 3, lr = t >> 2;
-    int pixbase[2], yx0[2];
-    const int HoWo = a.Ho * a.Wo;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int m = min(m0 + lr + 128 * p, a.M - 1);
-        const int img = m / HoWo, rem = m - img * HoWo;
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        pixbase[p] = img * a.Hi * a.Wi;
-        yx0[p] = ((ho * a.sy + a.oy0) << 16) | ((wo * a.sx + a.ox0) & 0xffff);
-    }
-    const int RS = a.R * a.S;
-    const int cchunks = a.Cin / 32;
-    const int ksteps = RS * cchunks;
-    const int wrow = RS * a.Cin;
-    int wbase[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) wbase[p] = min(n0 + lr + 128 * p, a.Cout - 1) * wrow + 4 * q;
-
-    int po[2];
-    unsigned tapmask = 0, ldmask = 0;
-    int l_tap = 0, l_cc = 0;
-    auto set_tap = [&](int tap) {
-        const int r = tap / a.S, s = tap - r * a.S;
-        const int dy = r * a.ody, dx = s * a.odx;
-        tapmask = 0;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int iy = (yx0[p] >> 16) + dy, ix = (int)(short)(yx0[p] & 0xffff) + dx;
-            int cy, cx;
-            const bool ok = map_tap(a, iy, ix, cy, cx);
-            po[p] = (pixbase[p] + cy * a.Wi + cx) * a.in_ld + 4 * q;
-            tapmask |= ok ? (1u << p) : 0u;
-        }
-    };
-    float4 ra[2][2];
-    uint2 rbh[2][2], rbl[2][2];
-    auto gload = [&](bool real) {
-        const int koff = real ? l_tap * a.Cin + l_cc * 32 : 0;
-        const int aoff = real ? l_cc * 32 : 0;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float* src = a.in + po[p] + aoff;
-            ra[p][0] = *reinterpret_cast<const float4*>(src);
-            ra[p][1] = *reinterpret_cast<const float4*>(src + 16);
-        }
-        ldmask = tapmask;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            rbh[p][0] = *reinterpret_cast<const uint2*>(a.wgt_hi + wbase[p] + koff);
-            rbh[p][1] = *reinterpret_cast<const uint2*>(a.wgt_hi + wbase[p] + koff + 16);
-            rbl[p][0] = *reinterpret_cast<const uint2*>(a.wgt_lo + wbase[p] + koff);
-            rbl[p][1] = *reinterpret_cast<const uint2*>(a.wgt_lo + wbase[p] + koff + 16);
-        }
-    };
-    auto advance = [&]() {
-        if (++l_cc == cchunks) {
-            l_cc = 0;
-            if (++l_tap < RS) set_tap(l_tap);
-        }
-    };
-    const int wsw = lds_swz(lr);                      // row lr + 128 p keeps lr's swizzle
-    const int woff0 = lr * 64 + ((((q >> 1)) ^ wsw) << 4) + ((q & 1) << 3);
-    const int woff1 = lr * 64 + ((((q >> 1) | 2) ^ wsw) << 4) + ((q & 1) << 3);
-    auto lstore = [&]() {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            uint2 hi, lo;
-            const float f = (ldmask >> p) & 1u ? 1.f : 0.f;
-            if (a.all_inside) split4_nomask(ra[p][0], hi, lo);
-            else split4(ra[p][0], f, hi, lo);
-            *reinterpret_cast<uint2*>(smem_b + p * 8192 + woff0) = hi;
-            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 8192 + woff0) = lo;
-            if (a.all_inside) split4_nomask(ra[p][1], hi, lo);
-            else split4(ra[p][1], f, hi, lo);
-            *reinterpret_cast<uint2*>(smem_b + p * 8192 + woff1) = hi;
-            *reinterpret_cast<uint2*>(smem_b + A_PLANE + p * 8192 + woff1) = lo;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + p * 8192 + woff0) = rbh[p][0];
-            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + p * 8192 + woff1) = rbh[p][1];
-            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + B_PLANE + p * 8192 + woff0) = rbl[p][0];
-            *reinterpret_cast<uint2*>(smem_b + 2 * A_PLANE + B_PLANE + p * 8192 + woff1) = rbl[p][1];
-        }
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15;
-    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
-    const unsigned char* Ah = smem_b + wm * 128 * 64 + foff;
-    const unsigned char* Al = Ah + A_PLANE;
-    const unsigned char* Bh = smem_b + 2 * A_PLANE + wn * 64 * 64 + foff;
-    const unsigned char* Bl = Bh + B_PLANE;
-
-    set_tap(0);
-    gload(true);
-    advance();
-    lstore();
-    __syncthreads();
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const bool more = ks + 1 < ksteps;
-        gload(more);
-        bf16x8_t bh[NT], bl[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
-            bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
-        }
-        bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(Ah);
-        bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(Al);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 2, 0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            bf16x8_t ahn = ah, aln = al;
-            if (i + 1 < MT) {
-                ahn = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 1) * 1024);
-                aln = *reinterpret_cast<const bf16x8_t*>(Al + (i + 1) * 1024);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-            if (i * 2 < 12) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // 12 global loads, two per MFMA group
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
-            ah = ahn;
-            al = aln;
-        }
-        __syncthreads();
-        if (more) {
-            lstore();
-            advance();
-            __syncthreads();
-        }
-    }
-
-    // epilogue: the two 128-row halves go through one 128 x (256 + 4) float stage, drained by all 512 threads
-    float* stage = reinterpret_cast<float*>(smem_b);
-    constexpr int LDS_LD = BN + 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (m0 + h * 128 >= a.M) break;              // uniform over the block
-        if (h) __syncthreads();
-        if (wm == h) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        stage[(i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][e];
-        }
-        __syncthreads();
-        drain_stage<2, TN, EPI, 512>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h);
     }
 }
 
@@ -1595,18 +1393,7 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_x3t8_kernel(ConvArgs a) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + c * 1024),
                                                  (__attribute__((address_space(3))) void*)(bdst + c * 1024), 16, 0, 0);
             ++issued;
-            if (a.tap_inner) {
-                // channel chunk outer, tap inner: tiles that run together walk the same channel chunk at the same time, so
-                // the input rows two tiles share through different taps are still in L2 when the second one asks
-                if (issued < ksteps) {
-                    if (todo == 0) {
-                        todo = live;
-                        ++l_cc;
-                    }
-                    next_tap();
-                    set_tap(l_tap);
-                }
-            } else if (++l_cc == cchunks) {
+            if (++l_cc == cchunks) {
                 l_cc = 0;
                 if (issued < ksteps) {
                     next_tap();
@@ -2669,56 +2456,26 @@ static int conv2d_bf16x3_impl(const float* in, const uint16_t* wgt_hi, const uin
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
                    2.0 * (double)a.M * (double)Cout * (double)(R * S) * (double)Cin);
-    static const bool narrow = [] {
-        const char* e = getenv("DIGA_CONV_X3_TILE");          // "128": the 128-row kernel (A/B runs)
-        return e != nullptr && atoi(e) == 128;
-    }();
     const int tn = Cout > 64 ? 2 : 1;
     a.tiles_n = (int)ceil_div(Cout, 64 * tn);
     // the wide kernel addresses the input and the weights with 32-bit element offsets
     const bool fits32 = N * Hi * Wi * in_ld < (1ll << 31) && Cout * R * S * Cin < (1ll << 31);
-    DIGA_REQUIRE((!narrow && fits32) || !(a.pad_reflect || a.up_shift), DIGA_EINVAL,
+    DIGA_REQUIRE(fits32 || !(a.pad_reflect || a.up_shift), DIGA_EINVAL,
                  "conv2d_bf16x3: reflect padding / fused upsampling are implemented by the 256-row kernel only");
-    if (!narrow && fits32) {
+    if (fits32) {
         a.tiles_m = (int)ceil_div(a.M, 256);
         const size_t loop = (size_t)2 * 256 * 64 + (size_t)2 * 64 * tn * 64, stage = (size_t)128 * (64 * tn + 4) * sizeof(float);
         const size_t sh = loop > stage ? loop : stage;
         static const bool stamped = getenv("DIGA_CONV_STAMP") != nullptr;      // diagnostic: see the kernel
-        // DIGA_X3W8=1 selects the 256 x 256 tile kernel for Cout >= 256.  Measured (tools/bench_conv.py, C2 1x1 layer
-        // shapes): layer4 3-5 % faster, layer3 0-8 % slower -- halving the activation-split work per MFMA does not help
-        // the 8..32-K-step tiles, whose time goes to the two barriers per K-step and the prologue / epilogue, not to the
-        // vector port.  Off by default; kept as the experiment it is.
-        const char* w8 = getenv("DIGA_X3W8");
-        const bool wide8 = w8 != nullptr && atoi(w8) != 0;
         if (stamped && tn == 2 && a.stats != nullptr) {
-            const int abl = atoi(getenv("DIGA_CONV_STAMP"));                     // 10 + n: ablation n (wrong results)
-#define DIGA_STAMP_LAUNCH(ABL_)                                                                                         \
-    do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2, true, ABL_>,                                      \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                \
-        hipLaunchKernelGGL((conv_fwd_x3w_kernel<2, true, ABL_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256),    \
-                           sh, st, a);                                                                                 \
-    } while (0)
-            if (abl == 11) DIGA_STAMP_LAUNCH(1);
-            else if (abl == 12) DIGA_STAMP_LAUNCH(2);
-            else if (abl == 13) DIGA_STAMP_LAUNCH(3);
-            else DIGA_STAMP_LAUNCH(0);
-#undef DIGA_STAMP_LAUNCH
-        } else if (tn == 2 && getenv("DIGA_CONV_ABL1") != nullptr) {     // timing experiment only (wrong results)
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            hipLaunchKernelGGL((conv_fwd_x3w_kernel<2, false, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
-        } else if (tn == 2 && Cout >= 256 && wide8) {
-            // 256 x 256 tile, 8 waves: half the activation split / staging work per MFMA (see the kernel)
-            a.tiles_n = (int)ceil_div(Cout, 256);
-            const size_t sh8 = (size_t)128 * (256 + 4) * sizeof(float);
-            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w8_kernel<true>), 512, sh8);
-            else DIGA_LAUNCH_K((conv_fwd_x3w8_kernel<false>), 512, sh8);
+            (void)hipFuncSetAttribute((const void*)conv_fwd_x3w_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL((conv_fwd_x3w_kernel<2, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), sh, st, a);
         } else if (tn == 2) {
-            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w_kernel<2, false, 0, true>), 256, sh);
-            else DIGA_LAUNCH_K((conv_fwd_x3w_kernel<2, false, 0, false>), 256, sh);
+            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w_kernel<2, false, true>), 256, sh);
+            else DIGA_LAUNCH_K((conv_fwd_x3w_kernel<2, false, false>), 256, sh);
         } else {
-            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w_kernel<1, false, 0, true>), 256, sh);
-            else DIGA_LAUNCH_K((conv_fwd_x3w_kernel<1, false, 0, false>), 256, sh);
+            if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3w_kernel<1, false, true>), 256, sh);
+            else DIGA_LAUNCH_K((conv_fwd_x3w_kernel<1, false, false>), 256, sh);
         }
     } else if (tn == 2) {
         const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 128 * kRowB);
@@ -2819,15 +2576,11 @@ static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const floa
     // 17 %); pointwise layers 3-12 % faster with 1 once the epilogue stores stream (before that: 1-3 % slower).
     const char* var_env = getenv("DIGA_X3T_VARIANT");
     const int variant = var_env ? atoi(var_env) : 1;
-    a.tap_inner = 0;
     if (variant == 1 && R * S <= 64) {
-        // K order: tap-major (the weight layout's order, bit-identical to the register-staged kernel).  DIGA_TAP_INNER=1
-        // walks channel chunks outer / taps inner instead, to line up in time the re-reads of an input row that tiles
-        // running together make through different vertical taps (the 2048-channel ASPP inputs span 9-37 MB per tap window,
-        // far beyond an XCD's 4 MB L2).  Measured (tools/bench_twin.py --variants 10 11): 8-14 % SLOWER on every shape,
-        // ASPP included -- the loader's per-step tap switch costs more than the locality returns.  Off; kept as a switch.
-        const char* ti = getenv("DIGA_TAP_INNER");
-        a.tap_inner = ti ? atoi(ti) : 0;
+        // K order: tap-major (the weight layout's order, bit-identical to the register-staged kernel).  Walking channel
+        // chunks outer / taps inner instead (to line up in time the re-reads of an input row that tiles running together
+        // make through different vertical taps) measured 8-14 % SLOWER on every shape, ASPP included: the loader's
+        // per-step tap switch costs more than the locality returns (commit 78ff4b5 has the switch).
         const size_t stg = (size_t)2 * 128 * (64 * tn + 4) * sizeof(float);
         const size_t sh8 = sh > stg ? sh : stg;
         if (tn == 2) {

@@ -28,7 +28,7 @@ SHAPES = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 1],
-                    help="DIGA_X3T_VARIANT values; 11 = variant 1 with channel-chunk-major K order (DIGA_TAP_INNER=1), 10 = tap-major")
+                    help="DIGA_X3T_VARIANT values (0: 8-wave kernel, 1: 12-wave kernel)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--images", type=int, default=16)
@@ -53,15 +53,8 @@ def main():
         outs = {v: torch.empty((n, hw, hw, cout), device=dev) for v in a.variants}
 
         def run(v):
-            for key in ("DIGA_X3T_VARIANT", "DIGA_TAP_INNER"):
-                os.environ.pop(key, None)
-            vsel = v
-            if v >= 10:
-                os.environ["DIGA_X3T_VARIANT"] = "1"
-                os.environ["DIGA_TAP_INNER"] = str(v - 10)
-            else:
-                os.environ["DIGA_X3T_VARIANT"] = str(v)
-            _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), None, _lib.ptr(outs[vsel]), n, hw, hw, cin, hw, hw, cout,
+            os.environ["DIGA_X3T_VARIANT"] = str(v)
+            _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), None, _lib.ptr(outs[v]), n, hw, hw, cin, hw, hw, cout,
                       cout, k, k, 1, 1, -pad, -pad, dil, dil, _lib.ptr(stats), 11, _lib.stream())
 
         for v in a.variants:
