@@ -1271,323 +1271,17 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_x3t_kernel(ConvArgs a) {
     }
 }
 
-// Two pointwise-layer experiments were measured against the 12-wave kernel below and removed again (commit 78ff4b5 has
-// them): a persistent 8-wave kernel whose MFMA waves store from registers while the loader waves prefetch the next
-// tile (1-6 % faster on K <= 512 into >= 1024 channels without statistics, 2-9 % slower elsewhere; +-0 on the step), and a
-// self-loading 4-wave 128 x 128 kernel at two blocks per CU (6-12 % slower).  In-kernel stamps from the first one gave the
-// number that mattered: a CU stores ~7.4 B/cycle with plain stores, ~12 B/cycle with non-temporal ones (store4_stream).
-
-// ---------------------------------------------------------------------------------------------
-// Pointwise (1x1) layers on twins with the STORE HIDDEN under the next tile's K loop ("x3ta", alternating groups).
-//
-// A pointwise tile is K-loop (8-64 steps) + a 128 KB store, and in the one-tile-per-block kernels nothing in the CU runs
-// under the store.  Here a persistent block of 8 waves = two groups of 4 (one wave of each group per SIMD) walks a list
-// of 256 x 128 tiles; the groups alternate roles tile by tile:
-//   * the COMPUTE group (wave tile 128 x 64, 128 accumulator registers) reads fragments from the three-stage ring and
-//     issues MFMAs;
-//   * the other group keeps the accumulators of the tile it computed just before and, round by round, stores one eighth
-//     of them straight from registers (transposed accumulators: four 16-byte streaming stores per lane and round, BatchNorm
-//     statistics by DPP row reductions) and then issues the LDS-DMA loads of the step two rounds ahead -- it is the
-//     loader of the tile being computed.
-// One raw barrier per K-step.  vmcnt bookkeeping with loads and stores on one counter: a round issues its stores FIRST,
-// then its 12 LDS-DMA loads, then waits vmcnt(12) -- LDS-DMA loads complete in order among themselves, so "at most 12
-// outstanding" can only be this round's loads whatever the stores do; the compute group waits vmcnt(0) (its own loads
-// from its last loader round).  Needs Cin >= 256 (eight store slices per tile), Cout % 128 == 0, no bias.
-// Same operand formats, split and per-accumulator MFMA order as the other twin kernels: bit-identical outputs; the
-// statistics' fp32 summation order is its own.
-// ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_row_shr(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-// sum over the 16 lanes of a DPP row; the total ends up in lane 16 r + 15
-__device__ __forceinline__ float row16_total_in_lane15(float v) {
-    v += dpp_row_shr<0x111>(v);     // row_shr:1
-    v += dpp_row_shr<0x112>(v);     // row_shr:2
-    v += dpp_row_shr<0x114>(v);     // row_shr:4
-    v += dpp_row_shr<0x118>(v);     // row_shr:8
-    return v;
-}
-
-// Running state of a tile's store: acc[i][j] is the TRANSPOSED 16 x 16 tile (weight fragment = the MFMA's row operand):
-// lane (lc = lane & 15, lg = lane >> 4), register e = channel ncol0 + 16 j + 4 lg + e of pixel mrow0 + 16 i + lc.
-struct TaStore {
-    float s1[2][4], s2[2][4];       // statistics of the two 16-channel column tiles in flight
-};
-
-// lane 0 of every DPP row (16 lanes) to all lanes of that row: one v_mov_b32 with row_share:0
-__device__ __forceinline__ float dpp_row_first(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150, 0xf, 0xf, true));
-}
-
-// Store slice SL of 8: column tiles j = 2 (SL >> 2) + {0, 1} (128 contiguous bytes per pixel over the two store
-// instructions of a row), row tiles i = 2 (SL & 3) + {0, 1}.  The statistics of a column-tile pair are accumulated over its
-// four slices (16 registers of state) and written with the fourth.
-template <int SL, bool STATS>
-__device__ __forceinline__ void ta_store_slice(const f32x4 (&acc)[8][4], TaStore& st, const ConvArgs& a, int mrow0, int ncol0,
-                                               int lane, int chunk) {
-    const int lc = lane & 15, lg = lane >> 4;
-    constexpr int JP = SL >> 2, IP = SL & 3;
-    if constexpr (IP == 0 && STATS) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st.s1[jj][e] = st.s2[jj][e] = 0.f;
-    }
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-        constexpr int I0 = 2 * IP;
-        const int m = mrow0 + (I0 + ii) * 16 + lc;
-        const bool ok = m < a.M;
-        float* o = a.out + (int64_t)(ok ? m : 0) * a.out_ld + ncol0 + JP * 32 + lg * 4;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const f32x4 v = acc[I0 + ii][2 * JP + jj];
-            if (ok) store4_stream(o + jj * 16, v[0], v[1], v[2], v[3]);
-            if constexpr (STATS) {
-                // shift = the chunk's first row (pixel mrow0: lane 0 of the DPP row, row tile 0), taken again every time
-                // instead of living in registers
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = v[e] - dpp_row_first(acc[0][2 * JP + jj][e]);
-                    st.s1[jj][e] += ok ? d : 0.f;
-                    st.s2[jj][e] += ok ? d * d : 0.f;
-                }
-            }
-        }
-    }
-    if constexpr (IP == 3 && STATS) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            float sh[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                st.s1[jj][e] = row16_total_in_lane15(st.s1[jj][e]);
-                st.s2[jj][e] = row16_total_in_lane15(st.s2[jj][e]);
-                sh[e] = dpp_row_first(acc[0][2 * JP + jj][e]);
-            }
-            if (lc == 15) {
-                float* sp = a.stats + (int64_t)chunk * 3 * a.Cout + ncol0 + (2 * JP + jj) * 16 + lg * 4;
-                *reinterpret_cast<float4*>(sp) = make_float4(st.s1[jj][0], st.s1[jj][1], st.s1[jj][2], st.s1[jj][3]);
-                *reinterpret_cast<float4*>(sp + a.Cout) = make_float4(st.s2[jj][0], st.s2[jj][1], st.s2[jj][2], st.s2[jj][3]);
-                *reinterpret_cast<float4*>(sp + 2 * a.Cout) = make_float4(sh[0], sh[1], sh[2], sh[3]);
-            }
-        }
-    }
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(512, 1) void conv_fwd_x3ta_kernel(ConvArgs a) {
-    constexpr int TN = 2, BM = 256, BN = 128, NT = 4, MT = 8;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
-    extern __shared__ __align__(16) unsigned char smem_b[];
-    const int t = threadIdx.x & 255, lane = t & 63, wv = t >> 6;
-    const int grp = threadIdx.x >> 8;
-    // tile schedule: blocks b, b + 8, ... share an XCD (observed round-robin placement; speed only): XCD x takes the
-    // contiguous tile range [x * per_xcd, (x + 1) * per_xcd), its blocks take consecutive tiles of it, stride nslots --
-    // the N-tiles of one 256-row panel run on one XCD at about the same time (panel fetched from HBM once)
-    const int total = a.tiles_m * a.tiles_n;
-    const int nslots = gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per_xcd = (total + 7) >> 3;
-    const int t_begin = xcd * per_xcd + slot;
-    const int t_end = min(total, (xcd + 1) * per_xcd);
-    const int ntiles = t_begin < t_end ? (t_end - t_begin + nslots - 1) / nslots : 0;
-    if (ntiles == 0) return;
-    const int cchunks = a.Cin / 32;                              // K-steps per tile, >= 8
-    const int total_steps = ntiles * cchunks;
-
-    // ---- loader state: both groups keep it in step (the load stream runs two steps ahead of the compute stream)
-    const unsigned char* twin = reinterpret_cast<const unsigned char*>(a.in);
-    const int lrow = lane >> 2;
-    const int kslot = (lane & 3) ^ lds_swz(lrow);
-    const int64_t rowb = (int64_t)a.in_ld * 4;
-    const int HoWo = a.Ho * a.Wo;
-    const bool identity = a.Hi == a.Ho && a.Wi == a.Wo && a.sy == 1 && a.sx == 1 && a.oy0 == 0 && a.ox0 == 0 &&
-                          !a.pad_reflect && !a.up_shift;         // output pixel m reads input pixel m
-    // rows lrow + 16 j (j = 0..3) of the wave's 64-row share: one base pointer + a per-row step; rows past M read row
-    // M - 1's address range start (any valid bytes: their outputs are never stored)
-    const unsigned char* pa0 = nullptr;                          // identity map: row (tile_m * BM + wv * 64 + lrow)
-    const unsigned char* pa[4];                                  // general map (strided / shifted 1x1): per-row pointers
-    const unsigned char* bimg = nullptr;
-    int l_tile = t_begin, l_cc = 0, l_rows = 0;
-    auto setup = [&](int tl) {
-        const int tile_n = tl % a.tiles_n, tile_m = tl / a.tiles_n;
-        if (identity) {
-            const int m = tile_m * BM + wv * 64 + lrow;
-            l_rows = a.M - m;                                    // row j is valid while 16 j < l_rows
-            pa0 = twin + (int64_t)min(m, a.M - 1) * rowb + kslot * 32;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = min(tile_m * BM + wv * 64 + 16 * j + lrow, a.M - 1);
-                const int img = m / HoWo, rem = m - img * HoWo;
-                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-                int cy, cx;
-                const bool ok = map_tap(a, ho * a.sy + a.oy0, wo * a.sx + a.ox0, cy, cx);
-                pa[j] = ok ? twin + ((int64_t)img * a.Hi * a.Wi + (int64_t)cy * a.Wi + cx) * rowb + kslot * 32 : nullptr;
-            }
-        }
-        bimg = a.wgt_img + (int64_t)tile_n * cchunks * (2 * B_PLANE) + (wv * 2 * TN) * 1024 + lane * 16;
-    };
-    auto issue = [&](int buf) {
-        unsigned char* stage = smem_b + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned char* src;
-            const unsigned char* src_lo;
-            if (identity) {
-                src = pa0 + (16 * j < l_rows ? (int64_t)(16 * j) * rowb : 0) + l_cc * 128;
-                src_lo = src + 16;
-            } else {
-                src = pa[j] != nullptr ? pa[j] + l_cc * 128 : g_zero16;
-                src_lo = pa[j] != nullptr ? src + 16 : g_zero16;
-            }
-            unsigned char* dst = stage + (wv * 64 + 16 * j) * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lo,
-                                             (__attribute__((address_space(3))) void*)(dst + A_PLANE), 16, 0, 0);
-        }
-        const unsigned char* bsrc = bimg + (int64_t)l_cc * (2 * B_PLANE);
-        unsigned char* bdst = stage + 2 * A_PLANE + (wv * 2 * TN) * 1024;
-#pragma unroll
-        for (int c = 0; c < 2 * TN; ++c)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + c * 1024),
-                                             (__attribute__((address_space(3))) void*)(bdst + c * 1024), 16, 0, 0);
-    };
-    auto advance = [&]() {
-        if (++l_cc == cchunks) {
-            l_cc = 0;
-            l_tile += nslots;
-            if (l_tile < t_end) setup(l_tile);
-        }
-    };
-
-    // ---- fragment offsets (compute role)
-    const int wm = wv >> 1, wn = wv & 1;
-    const int frow = lane & 15;
-    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
-    const int aoff = wm * 128 * 64 + foff;
-    const int boff = 2 * A_PLANE + wn * 32 * TN * 64 + foff;
-
-    // ---- prologue: steps 0 and 1 (group 1 is the loader of tile 0)
-    setup(l_tile);
-    if (grp == 1) issue(0);
-    advance();
-    if (total_steps > 1) {
-        if (grp == 1) issue(1);
-        advance();
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else if (grp == 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                                // step 0 has landed
-
-    int g = 0, cur = 0, nx = 2;
-    f32x4 acc[MT][NT];
-    int my_tile = -1;                                            // tile whose accumulators this group still holds
-    auto end_round = [&]() {
-        __builtin_amdgcn_s_barrier();
-        cur = cur == 2 ? 0 : cur + 1;
-        nx = nx == 2 ? 0 : nx + 1;
-        ++g;
-        advance();
-    };
-    for (int it = 0, tile = t_begin; it < ntiles; ++it, tile += nslots) {
-        if ((it & 1) == grp) {
-            // ---------------- compute role
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < cchunks; ++ks) {
-                const unsigned char* Ah = smem_b + cur * STAGE + aoff;
-                const unsigned char* Al = Ah + A_PLANE;
-                const unsigned char* Bh = smem_b + cur * STAGE + boff;
-                const unsigned char* Bl = Bh + B_PLANE;
-                bf16x8_t bh[NT], bl[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
-                    bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
-                }
-                bf16x8_t fa[MT][2];
-                fa[0][0] = *reinterpret_cast<const bf16x8_t*>(Ah);
-                fa[0][1] = *reinterpret_cast<const bf16x8_t*>(Al);
-                fa[1][0] = *reinterpret_cast<const bf16x8_t*>(Ah + 1024);
-                fa[1][1] = *reinterpret_cast<const bf16x8_t*>(Al + 1024);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 4, 0);
-#pragma unroll
-                for (int i = 0; i < MT; i += 2) {
-                    if (i + 2 < MT) {
-                        fa[i + 2][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 2) * 1024);
-                        fa[i + 2][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 2) * 1024);
-                        fa[i + 3][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 3) * 1024);
-                        fa[i + 3][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 3) * 1024);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    }
-                    // transposed tiles: the weight fragment is the MFMA's row operand (see TaStore)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], fa[i + u][1], acc[i + u][j], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], fa[i + u][0], acc[i + u][j], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], fa[i + u][0], acc[i + u][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own loads of my last loader rounds; fragment reads done
-                end_round();
-            }
-            my_tile = tile;
-        } else {
-            // ---------------- store + load role
-            const bool pending = my_tile >= 0;                   // uniform
-            const int p_tile_n = pending ? my_tile % a.tiles_n : 0, p_tile_m = pending ? my_tile / a.tiles_n : 0;
-            const int mrow0 = p_tile_m * BM + wm * 128, ncol0 = p_tile_n * BN + wn * 64;
-            const bool st_ok = pending && mrow0 < a.M;           // uniform over the wave
-            TaStore st;
-            auto load_round = [&]() {
-                const bool ahead = g + 2 < total_steps;
-                if (ahead) {
-                    issue(nx);
-                    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                end_round();
-            };
-#define DIGA_TA_SLICE(SL_)                                                                             \
-            if (st_ok) ta_store_slice<SL_, STATS>(acc, st, a, mrow0, ncol0, lane, p_tile_m * 2 + wm);  \
-            load_round();
-            DIGA_TA_SLICE(0) DIGA_TA_SLICE(1) DIGA_TA_SLICE(2) DIGA_TA_SLICE(3)
-            DIGA_TA_SLICE(4) DIGA_TA_SLICE(5) DIGA_TA_SLICE(6) DIGA_TA_SLICE(7)
-            for (int ks = 8; ks < cchunks; ++ks) load_round();
-            my_tile = -1;
-        }
-    }
-    if (my_tile >= 0) {                                          // the block's last tile: nothing left to hide it under
-        const int p_tile_n = my_tile % a.tiles_n, p_tile_m = my_tile / a.tiles_n;
-        const int mrow0 = p_tile_m * BM + wm * 128, ncol0 = p_tile_n * BN + wn * 64;
-        if (mrow0 < a.M) {
-            TaStore st;
-#define DIGA_TA_LAST(SL_) ta_store_slice<SL_, STATS>(acc, st, a, mrow0, ncol0, lane, p_tile_m * 2 + wm);
-            DIGA_TA_LAST(0) DIGA_TA_LAST(1) DIGA_TA_LAST(2) DIGA_TA_LAST(3)
-            DIGA_TA_LAST(4) DIGA_TA_LAST(5) DIGA_TA_LAST(6) DIGA_TA_LAST(7)
-#undef DIGA_TA_LAST
-        }
-    }
-#undef DIGA_TA_SLICE
-}
+// Three pointwise-layer experiments were measured against the 12-wave kernel below and removed again:
+//  * (commit 78ff4b5) a persistent 8-wave kernel whose MFMA waves store from registers while the loader waves prefetch the
+//    next tile: 1-6 % faster on K <= 512 into >= 1024 channels without statistics, 2-9 % slower elsewhere; +-0 on the step;
+//  * (78ff4b5) a self-loading 4-wave 128 x 128 kernel at two blocks per CU: 6-12 % slower;
+//  * (7ede725) a persistent kernel whose two wave groups alternate per tile between computing and storing the previous
+//    tile from registers + issuing the LDS-DMA loads (the store fully hidden under the next tile's K loop): -33 % on
+//    256 -> 1024 channels with the operands warm in the Infinity Cache (a 154 MB twin re-read by every timed launch), but
+//    +-0 (-2 ... +18 % with the BatchNorm statistics) with the operands cold in HBM as they are inside a training step
+//    (tools/bench_twin.py --cold), and +2 ms on the step.
+// In-kernel stamps from the first one gave the number that mattered: a CU stores ~7.4 B/cycle with plain stores,
+// ~12 B/cycle with non-temporal ones (store4_stream).  The lesson of the third: time conv kernels COLD.
 
 // Taps of which at least one row of the block's M-tile reads inside the image (bit r*S + s), conservatively: a tile
 // inside one image covers the output rows ho0..ho1 (and every column once it spans a full row); a tap whose input rows
@@ -2888,31 +2582,6 @@ static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const floa
     // 17 %); pointwise layers 3-12 % faster with 1 once the epilogue stores stream (before that: 1-3 % slower).
     const char* var_env = getenv("DIGA_X3T_VARIANT");
     const int variant = var_env ? atoi(var_env) : 1;
-    {
-        // pointwise layers with >= 8 K-steps and no backward epilogue: alternating-group persistent kernel (store hidden
-        // under the next tile's K loop); DIGA_X3TA=0: the 12-wave one-tile kernel
-        const char* ta = getenv("DIGA_X3TA");
-        const int ta_mode = ta ? atoi(ta) : 1;                   // 2: also for launches of few tiles (tests)
-        const bool use_ta = ta_mode != 0;
-        const int64_t total = (int64_t)a.tiles_m * a.tiles_n;
-        // where it wins (tools/bench_twin.py --variants 1 41, C2 shapes): 8 K-steps per tile -33 % (-20 % with the
-        // statistics), 16 K-steps -10 % (+6 % with statistics), 32 K-steps -9 % (0 %), 64 K-steps +2 %
-        const bool pays = Cin <= 256 || (a.stats == nullptr && Cin <= 1024) || ta_mode == 2;
-        if (use_ta && pays && R * S == 1 && tn == 2 && epi == nullptr && a.act == 0 && a.bias == nullptr && Cin % 256 == 0 &&
-            Cout % 128 == 0 && a.out_ld % 4 == 0 && aligned16(a.out) && (total >= 512 || ta_mode == 2)) {
-            static const int n_cu = [] {
-                int dev = 0, v = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
-                return v > 8 ? v : 256;
-            }();
-            const int nb = n_cu - n_cu % 8;
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3ta_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            (void)hipFuncSetAttribute((const void*)conv_fwd_x3ta_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            if (a.stats != nullptr) hipLaunchKernelGGL(conv_fwd_x3ta_kernel<true>, dim3((unsigned)nb), dim3(512), sh, st, a);
-            else hipLaunchKernelGGL(conv_fwd_x3ta_kernel<false>, dim3((unsigned)nb), dim3(512), sh, st, a);
-            return launch_status("diga_conv2d_nhwc_twin");
-        }
-    }
     if (variant == 1 && R * S <= 64) {
         // K order: tap-major (the weight layout's order, bit-identical to the register-staged kernel).  Walking channel
         // chunks outer / taps inner instead (to line up in time the re-reads of an input row that tiles running together

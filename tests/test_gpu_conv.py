@@ -232,53 +232,6 @@ def test_twin_path_matches_register_staged_path_and_is_shared(bf16x3, monkeypatc
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,hw,cin,cout", [(2, 33, 256, 128), (1, 47, 512, 384), (3, 29, 256, 1024), (1, 16, 1024, 256)],
-                         ids=["256to128", "512to384", "256to1024", "1024to256"])
-def test_pointwise_alternating_group_kernel(n, hw, cin, cout, bf16x3, monkeypatch):
-    """conv_fwd_x3ta_kernel (persistent blocks, two wave groups alternating compute / store+load roles) against the
-    12-wave one-tile kernel on the same twins: bit-identical outputs (same split, same MFMA order per accumulator), and
-    its BatchNorm statistics partials (per 128-row chunk: sum(y-s), sum((y-s)^2), s) against float64 sums of its own
-    output.  Ragged M (rows past the last 256-row tile), one and several tiles per block (DIGA_X3TA=2 forces the kernel on
-    small launches)."""
-    from diga_amd import _lib
-    g = synth.gen(n * 100 + cin + cout)
-    x = (torch.randn((n, hw, hw, cin), generator=g) + 0.5).to(DEV)
-    w = (torch.randn((cout, 1, 1, cin), generator=g) * (2.0 / cin) ** 0.5).to(DEV)
-    m = n * hw * hw
-    twin = torch.empty(m * cin * 4, dtype=torch.uint8, device=DEV)
-    _lib.call("diga_make_twin", _lib.ptr(x), cin, _lib.ptr(twin), m, cin, _lib.stream())
-    img = torch.empty(_lib.lib.diga_split_bf16_image_bytes(cout, 1, cin), dtype=torch.uint8, device=DEV)
-    _lib.call("diga_split_bf16_image", _lib.ptr(w), _lib.ptr(img), cout, 1, cin, _lib.stream())
-    nst = _lib.lib.diga_conv2d_stats_floats(n, hw, hw, cout)
-    outs, stats = {}, {}
-    for mode in ("0", "2"):
-        monkeypatch.setenv("DIGA_X3TA", mode)
-        for with_stats in (False, True):
-            y = torch.full((n, hw, hw, cout), float("nan"), device=DEV)
-            st = torch.full((nst,), float("nan"), device=DEV) if with_stats else None
-            _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), None, _lib.ptr(y), n, hw, hw, cin, hw, hw, cout,
-                      cout, 1, 1, 1, 1, 0, 0, 1, 1, _lib.ptr(st), 11, _lib.stream())
-            torch.cuda.synchronize()
-            outs[(mode, with_stats)] = y
-            stats[(mode, with_stats)] = st
-    ref = outs[("0", False)]
-    assert torch.isfinite(ref).all()
-    for k, y in outs.items():
-        assert torch.equal(y, ref), k
-    # statistics partials of the new kernel against float64 sums over its output
-    nchunk = (m + 127) // 128
-    st = stats[("2", True)].double().cpu().view(nchunk, 3, cout)
-    yd = ref.double().cpu().view(m, cout)
-    for c in range(nchunk):
-        rows = yd[c * 128:(c + 1) * 128]
-        sh = st[c, 2]
-        assert torch.equal(sh.float(), rows[0].float()), f"chunk {c}: shift is the chunk's first row"
-        d = rows - sh[None, :]
-        scale = float(d.abs().sum(0).max())
-        assert float((st[c, 0] - d.sum(0)).abs().max()) <= 1e-5 * scale + 1e-6, f"chunk {c} sum"
-        assert float((st[c, 1] - (d * d).sum(0)).abs().max()) <= 1e-5 * float((d * d).sum(0).max()) + 1e-6, f"chunk {c} sumsq"
-
-
 def test_split_formats_byte_exact():
     """The pre-split operand formats (activation twin, weight LDS images) against their numpy restatement: byte exact,
     including values that round up across a bf16 exponent boundary, denormal-sized residuals and negative zero."""
