@@ -339,8 +339,10 @@ class _Conv2dFn(torch.autograd.Function):
             if ctx.chain is not None and not ctx.chain.get("disabled") and ctx.chain["remaining"] > 0:
                 dx = None                           # the running sum travels on through the chain; the last member returns it
         if ctx.needs_input_grad[1]:
-            dwp = torch.empty((kp, r, s, cp), dtype=torch.float32, device=w.device)
             dw = torch.empty_strided((k, c_true, r, s), w_strides, dtype=torch.float32, device=w.device)
+            # the kernels write [K][R][S][C]: for an unpadded channels_last weight that IS dw's memory (no copy afterwards)
+            alias = kp == k and cp == c_true and dw.permute(0, 2, 3, 1).is_contiguous()
+            dwp = dw.permute(0, 2, 3, 1) if alias else torch.empty((kp, r, s, cp), dtype=torch.float32, device=w.device)
 
             dy_twin = None
             if use_tw:
@@ -355,7 +357,8 @@ class _Conv2dFn(torch.autograd.Function):
                 _lib.call("diga_conv2d_wgrad_twin", _lib.ptr(dy_twin), _lib.ptr(x_twin), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
                           n, hi, wi, cp, ho, wo, kp, r, s, stride[0], stride[1], -padding[0], -padding[1], dilation[0],
                           dilation[1], _lib.stream())
-                dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
+                if not alias:
+                    dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
 
             def run():
                 if use_tw:
@@ -365,7 +368,8 @@ class _Conv2dFn(torch.autograd.Function):
                 _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
                           n, hi, wi, cp, xn.stride(2), ho, wo, kp, gyp.stride(2), r, s, stride[0], stride[1],
                           -padding[0], -padding[1], dilation[0], dilation[1], _lib.stream())
-                dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
+                if not alias:
+                    dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
 
             # The weight gradient is a leaf of the backward graph: under the step driver it runs on a second stream
             # next to the backward-data / BatchNorm chain (the driver joins the streams before the optimizer step).
