@@ -139,9 +139,23 @@ class _StemConvFn(torch.autograd.Function):
         wo = (w_ + 2 * padding[1] - (s - 1) - 1) // stride[1] + 1
         kk = r * s * c
         kp = _pad_to(kk)
-        xcol = torch.empty((n, ho, wo, kp), dtype=torch.float32, device=x.device)
-        _lib.call("diga_im2col_nchw", _lib.ptr(xc), _lib.ptr(xcol), n, c, h, w_, r, s, stride[0], padding[0], ho, wo, kp,
-                  _lib.stream())
+        # student and teacher read the very same image batch (train_step.py: both get `cat`): the gathered rows depend on
+        # the images and the geometry only, so the second stem to arrive reuses them (the entry rides on the input tensor
+        # and dies with it; an event orders the two streams)
+        key = (r, s, stride[0], padding[0], kp, x._version, x.data_ptr())
+        hit = getattr(x, "_diga_xcol", None)
+        cur = torch.cuda.current_stream(x.device)
+        if hit is not None and hit[0] == key:
+            xcol = hit[1]
+            cur.wait_event(hit[2])
+            xcol.record_stream(cur)
+        else:
+            xcol = torch.empty((n, ho, wo, kp), dtype=torch.float32, device=x.device)
+            _lib.call("diga_im2col_nchw", _lib.ptr(xc), _lib.ptr(xcol), n, c, h, w_, r, s, stride[0], padding[0], ho, wo, kp,
+                      _lib.stream())
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            x._diga_xcol = (key, xcol, ev)
         w2 = _pad_last(weight.detach().permute(0, 2, 3, 1).reshape(k, 1, 1, kk).contiguous(), kp)
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
