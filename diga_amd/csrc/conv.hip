@@ -27,8 +27,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <map>
-#include <mutex>
 
 #include "common.h"
 
@@ -77,9 +75,6 @@ struct ConvArgs {
     int pad_reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d in front of the conv)
     int up_shift;                // the conv reads the 2^up_shift nearest-neighbour upsampling of `in` (nn.Upsample in front)
     int act;                     // 1: tanh on the output
-    // stream-K launch (conv_fwd_x3t8k_kernel + conv_sk_fixup_kernel): K-steps per block and the partial-tile workspace
-    int sk_steps;
-    float* sk_ws;                // [boundary][2][256][128] fp32: head part (block b's last tile) and tail part (block b+1's first)
 };
 
 // Logical input coordinate (in the optionally upsampled image, before padding) -> source pixel of `in`.
@@ -1287,6 +1282,10 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_x3t_kernel(ConvArgs a) {
 //    (tools/bench_twin.py --cold), and +2 ms on the step.
 // In-kernel stamps from the first one gave the number that mattered: a CU stores ~7.4 B/cycle with plain stores,
 // ~12 B/cycle with non-temporal ones (store4_stream).  The lesson of the third: time conv kernels COLD.
+// Also tried and removed (commit 9129c47): a stream-K launch of the 12-wave kernel against the 0.6-round tile tail (groups of
+// N-tile blocks walking equal ranges of (panel, K-step) in step + a fix-up kernel for the cut tiles): -13 % stand-alone on
+// the self-training 3x3 layers, +-0 on the C2 shapes, and -3 ... -6 ms per step LOST inside the two-stream step, whose
+// second stream already fills the tails.
 
 // Taps of which at least one row of the block's M-tile reads inside the image (bit r*S + s), conservatively: a tile
 // inside one image covers the output rows ho0..ho1 (and every column once it spans a full row); a tap whose input rows
@@ -1513,271 +1512,6 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_x3t8_kernel(ConvArgs a) {
                 stage[((wm & 1) * 64 + i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 32 * TN + j * 16 + (lane & 15)] = acc[i][j][e];
     __syncthreads();
     drain_stage<2, TN, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h, m0 + h * 128 < a.M);
-}
-
-// ---------------------------------------------------------------------------------------------
-// conv_fwd_x3t8_kernel as a STREAM-K launch: M = 150 544 output rows make 1178 tiles of 256 x 128 for a 256-channel
-// layer -- 4.6 rounds on 256 CUs, i.e. the fifth round runs 60 % full (8 % of the layer's time idle); the 512 x 1024
-// self-training crops leave 2.05 rounds (a third of the time idle).  Here the grid is one persistent block per CU and the
-// flattened (tile, K-step) space is cut into equal ranges: a block computes the tail of its first tile, whole tiles, and
-// the head of its last one.  Whole tiles take the usual epilogue; a head / tail part leaves its raw 256 x 128 fp32
-// accumulator tile in a workspace slot, and a second small kernel (conv_sk_fixup_kernel) adds the two parts of every cut
-// tile in fixed order (head + tail) and runs the same epilogue (statistics / backward epilogue included) -- no flags, no
-// spinning, bit-reproducible.  Needs >= one tile per block (a tile is cut at most once).  K-steps of dead taps are
-// skipped inside a range as before (ranges are balanced on nominal steps).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int sk_live_steps(uint64_t live, int RS, int cchunks, int ks0, int ks1) {
-    int n = 0, tap = ks0 / cchunks, cc = ks0 - tap * cchunks;
-    for (int ks = ks0; ks < ks1;) {
-        const int take = min(cchunks - cc, ks1 - ks);
-        if (RS > 64 || ((live >> tap) & 1ull)) n += take;
-        ks += take;
-        cc = 0;
-        ++tap;
-    }
-    return n;
-}
-
-template <bool EPI>
-__global__ __launch_bounds__(768, 3) void conv_fwd_x3t8k_kernel(ConvArgs a) {
-    constexpr int TN = 2, BM = 256, BN = 128, NT = 4, MT = 4;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
-    constexpr int LDS_LD = BN + 4;
-    extern __shared__ __align__(16) unsigned char smem_b[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool loader = wv >= 8;
-    const int RS = a.R * a.S;
-    const int cchunks = a.Cin / 32;
-    const int knom = RS * cchunks;                               // nominal K-steps per tile
-    // The flattened space is (256-row panel, K-step); a GROUP of tiles_n consecutive logical blocks walks the same range,
-    // one N-tile each, in step: the panel's activation rows are fetched from HBM once and shared through the XCD's L2
-    // (blocks walking the N-tiles of a panel one after the other doubled the HBM traffic of the 2048-channel ASPP
-    // layers: +22-34 %).
-    const int total_iters = a.tiles_m * knom;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);             // neighbouring blocks (one group, adjacent panels) on one XCD
-    const int grp = lb / a.tiles_n, tile_n = lb - grp * a.tiles_n;
-    int it = grp * a.sk_steps;
-    const int it_end = min(it + a.sk_steps, total_iters);
-    const int epi_syncs = EPI ? (a.e_partials != nullptr ? 2 : 0) : (a.stats != nullptr ? 2 : 0);   // barriers inside drain_stage
-
-    // loader-wave constants
-    const int lw = wv - 8;
-    const unsigned char* twin = reinterpret_cast<const unsigned char*>(a.in);
-    const int lrow = lane >> 2;
-    const int kslot = (lane & 3) ^ lds_swz(lrow);
-    const int HoWo = a.Ho * a.Wo;
-    const int64_t rowb = (int64_t)a.in_ld * 4;
-    // MFMA-wave constants
-    const int wm = wv >> 1, wn = wv & 1;                          // 4 x 2 MFMA waves
-    const int frow = lane & 15;
-    const int foff = frow * 64 + (((lane >> 4) ^ lds_swz(frow)) << 4);
-    const int aoff = wm * 64 * 64 + foff;
-    const int boff = 2 * A_PLANE + wn * 32 * TN * 64 + foff;
-
-    while (it < it_end) {                                        // uniform over the block
-        const int tile_m = it / knom, ks0 = it - tile_m * knom;
-        const int ks1 = min(knom, ks0 + (it_end - it));
-        const int m0 = tile_m * BM, n0 = tile_n * BN;
-        const uint64_t live = RS <= 64 ? live_taps(a, m0, BM) : ~0ull;
-        const int nlive = sk_live_steps(live, RS, cchunks, ks0, ks1);
-        const bool whole = ks0 == 0 && ks1 == knom;
-
-        if (loader) {
-            int pixbase[4], yx0[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = min(m0 + lw * 64 + 16 * j + lrow, a.M - 1);
-                const int img = m / HoWo, rem = m - img * HoWo;
-                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-                pixbase[j] = img * a.Hi * a.Wi;
-                yx0[j] = ((ho * a.sy + a.oy0) << 16) | ((wo * a.sx + a.ox0) & 0xffff);
-            }
-            const unsigned char* pa[4];
-            int l_tap = ks0 / cchunks, l_cc = ks0 - (ks0 / cchunks) * cchunks;
-            auto skip_dead = [&]() {
-                if (RS <= 64)
-                    while (l_tap < RS && !((live >> l_tap) & 1ull)) {
-                        ++l_tap;
-                        l_cc = 0;
-                    }
-            };
-            auto set_tap = [&](int tap) {
-                const int r = tap / a.S, q = tap - r * a.S;
-                const int dy = r * a.ody, dx = q * a.odx;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int iy = (yx0[j] >> 16) + dy, ix = (int)(short)(yx0[j] & 0xffff) + dx;
-                    int cy, cx;
-                    const bool ok = map_tap(a, iy, ix, cy, cx);
-                    pa[j] = ok ? twin + (int64_t)(pixbase[j] + cy * a.Wi + cx) * rowb + kslot * 32 : nullptr;
-                }
-            };
-            const unsigned char* bimg = a.wgt_img + (int64_t)tile_n * knom * (2 * B_PLANE) + (lw * 2 * TN) * 1024 + lane * 16;
-            int issued = 0;
-            auto issue = [&](int buf) {
-                unsigned char* stage = smem_b + buf * STAGE;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned char* src = pa[j] != nullptr ? pa[j] + l_cc * 128 : g_zero16;
-                    const unsigned char* src_lo = pa[j] != nullptr ? src + 16 : g_zero16;
-                    unsigned char* dst = stage + (lw * 64 + 16 * j) * 64;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lo,
-                                                     (__attribute__((address_space(3))) void*)(dst + A_PLANE), 16, 0, 0);
-                }
-                const unsigned char* bsrc = bimg + (int64_t)(l_tap * cchunks + l_cc) * (2 * B_PLANE);
-                unsigned char* bdst = stage + 2 * A_PLANE + (lw * 2 * TN) * 1024;
-#pragma unroll
-                for (int c = 0; c < 2 * TN; ++c)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + c * 1024),
-                                                     (__attribute__((address_space(3))) void*)(bdst + c * 1024), 16, 0, 0);
-                ++issued;
-                if (++l_cc == cchunks) {
-                    l_cc = 0;
-                    ++l_tap;
-                    skip_dead();
-                    if (issued < nlive) set_tap(l_tap);
-                } else if (issued == 1 && nlive > 1) {
-                    // (nothing: same tap)
-                }
-            };
-            auto wait_next = [&](bool newest_in_flight) {
-                if (newest_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            };
-            skip_dead();
-            if (nlive > 0) {
-                set_tap(l_tap);
-                issue(0);
-                if (nlive > 1) issue(1);
-            }
-            wait_next(nlive > 1);
-            int nx = 2;
-            for (int ks = 0; ks < nlive; ++ks) {
-                const bool ahead = ks + 2 < nlive;
-                if (ahead) issue(nx);
-                wait_next(ahead);
-                nx = nx == 2 ? 0 : nx + 1;
-            }
-            // the epilogue belongs to the MFMA waves; keep their barrier count
-            __syncthreads();                                     // (A) everyone is out of the ring
-            __syncthreads();                                     // (B) tile staged
-            if (whole)
-                for (int i = 0; i < epi_syncs; ++i) __syncthreads();
-            __syncthreads();                                     // (C) LDS free for the next tile's ring
-        } else {
-            f32x4 acc[MT][NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_s_barrier();                        // stage 0 has landed
-            int cur = 0;
-            for (int ks = 0; ks < nlive; ++ks) {
-                const unsigned char* Ah = smem_b + cur * STAGE + aoff;
-                const unsigned char* Al = Ah + A_PLANE;
-                const unsigned char* Bh = smem_b + cur * STAGE + boff;
-                const unsigned char* Bl = Bh + B_PLANE;
-                bf16x8_t bh[NT], bl[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8_t*>(Bh + j * 1024);
-                    bl[j] = *reinterpret_cast<const bf16x8_t*>(Bl + j * 1024);
-                }
-                bf16x8_t fa[MT][2];
-                fa[0][0] = *reinterpret_cast<const bf16x8_t*>(Ah);
-                fa[0][1] = *reinterpret_cast<const bf16x8_t*>(Al);
-                fa[1][0] = *reinterpret_cast<const bf16x8_t*>(Ah + 1024);
-                fa[1][1] = *reinterpret_cast<const bf16x8_t*>(Al + 1024);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 4, 0);
-#pragma unroll
-                for (int i = 0; i < MT; i += 2) {
-                    if (i + 2 < MT) {
-                        fa[i + 2][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 2) * 1024);
-                        fa[i + 2][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 2) * 1024);
-                        fa[i + 3][0] = *reinterpret_cast<const bf16x8_t*>(Ah + (i + 3) * 1024);
-                        fa[i + 3][1] = *reinterpret_cast<const bf16x8_t*>(Al + (i + 3) * 1024);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][1], bh[j], acc[i + u][j], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][0], bl[j], acc[i + u][j], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i + u][0], bh[j], acc[i + u][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                cur = cur == 2 ? 0 : cur + 1;
-            }
-            __syncthreads();                                     // (A)
-            const int h = wv >> 2, t = threadIdx.x & 255;
-            float* stage = reinterpret_cast<float*>(smem_b) + h * (128 * LDS_LD);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        stage[((wm & 1) * 64 + i * 16 + (lane >> 4) * 4 + e) * LDS_LD + wn * 32 * TN + j * 16 + (lane & 15)] = acc[i][j][e];
-            __syncthreads();                                     // (B)
-            if (whole) {
-                drain_stage<2, TN, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h, m0 + h * 128 < a.M);
-            } else {
-                // raw partial tile -> workspace slot of the cut this part touches: head part = the group's last panel
-                // (cut grp, side 0), tail part = the group's first panel (cut grp - 1, side 1)
-                const int64_t slot = ks0 == 0 ? ((int64_t)grp * a.tiles_n + tile_n) * 2
-                                              : ((int64_t)(grp - 1) * a.tiles_n + tile_n) * 2 + 1;
-                float* ws = a.sk_ws + slot * (BM * BN) + (int64_t)h * 128 * BN;
-                for (int idx = t; idx < 128 * (BN / 4); idx += 256) {
-                    const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
-                    *reinterpret_cast<float4*>(ws + row * BN + c4 * 4) = *reinterpret_cast<const float4*>(stage + row * LDS_LD + c4 * 4);
-                }
-            }
-            __syncthreads();                                     // (C)
-        }
-        it += ks1 - ks0;
-    }
-}
-
-// Second kernel of a stream-K launch: block (cut, N-tile, half h) adds the head and the tail part of the tile that the cut
-// between the ranges of groups `cut` and `cut + 1` falls into (nothing to do when the cut sits on a panel boundary) and
-// runs the forward kernels' epilogue on the sum.
-template <bool EPI>
-__global__ __launch_bounds__(256) void conv_sk_fixup_kernel(ConvArgs a, int ngroups) {
-    constexpr int TN = 2, BM = 256, BN = 128, LDS_LD = BN + 4;
-    extern __shared__ __align__(16) unsigned char smem_b[];
-    float* stage = reinterpret_cast<float*>(smem_b);
-    const int b = blockIdx.x >> 1, h = blockIdx.x & 1, t = threadIdx.x;      // b = cut * tiles_n + tile_n
-    const int knom = a.R * a.S * (a.Cin / 32);
-    const int total_iters = a.tiles_m * knom;
-    const int grp = b / a.tiles_n, tile_n = b - grp * a.tiles_n;
-    const int64_t cut = (int64_t)(grp + 1) * a.sk_steps;
-    if (grp + 1 >= ngroups || cut >= total_iters || cut % knom == 0) return;      // uniform over the block
-    const int tile_m = (int)(cut / knom);
-    const float* head = a.sk_ws + ((int64_t)b * 2) * (BM * BN) + (int64_t)h * 128 * BN;
-    const float* tail = head + BM * BN;
-    for (int idx = t; idx < 128 * (BN / 4); idx += 256) {
-        const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
-        const float4 u = *reinterpret_cast<const float4*>(head + row * BN + c4 * 4);
-        const float4 v = *reinterpret_cast<const float4*>(tail + row * BN + c4 * 4);
-        *reinterpret_cast<float4*>(stage + row * LDS_LD + c4 * 4) = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
-    }
-    __syncthreads();
-    const int m0 = tile_m * BM + h * 128;
-    drain_stage<2, TN, EPI>(stage, a, m0, tile_n * BN, t, tile_m * 2 + h, m0 < a.M);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2787,28 +2521,6 @@ extern "C" int diga_conv2d_nhwc_bf16x3_epi(const float* in, const uint16_t* wgt_
 // ---- "twin" path: activations and weights pre-split, staged by LDS-DMA (conv_fwd_x3t_kernel)
 static int64_t image_bn(int64_t K) { return K > 64 ? 128 : 64; }
 
-// Partial-tile workspace of the stream-K launches: one buffer per (device, stream), allocated on first use and kept (two
-// streams run convolutions concurrently in a training step; a launch's partials are consumed by its own fix-up kernel on
-// the same stream).
-static float* sk_workspace(hipStream_t st, size_t bytes) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> pool;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    auto& e = pool[{dev, st}];
-    if (e.first != nullptr && e.second >= bytes) return e.first;
-    if (e.first != nullptr) {                      // (grows only when the block count was raised: wait for its users)
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(e.first);
-        e = {nullptr, 0};
-    }
-    float* p = nullptr;
-    if (hipMalloc((void**)&p, bytes) != hipSuccess) return nullptr;
-    e = {p, bytes};
-    return p;
-}
-
 extern "C" int diga_make_twin(const float* x, int64_t ld, void* twin, int64_t M, int64_t C, void* stream) {
     DIGA_REQUIRE(x && twin && M > 0 && C > 0 && C % 8 == 0 && ld >= C && ld % 4 == 0, DIGA_EINVAL, "make_twin: C must be a multiple of 8");
     DIGA_REQUIRE(aligned16(x) && aligned16(twin), DIGA_EALIGN, "make_twin: pointers must be 16-byte aligned");
@@ -2882,42 +2594,6 @@ static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const floa
         const size_t stg = (size_t)2 * 128 * (64 * tn + 4) * sizeof(float);
         const size_t sh8 = sh > stg ? sh : stg;
         if (tn == 2) {
-            // Stream-K launch when the last round of one-tile blocks would run mostly empty (see the kernel).
-            // DIGA_STREAMK=0: never; =2: whenever there is at least one tile per block (tests); DIGA_STREAMK_BLOCKS
-            // overrides the block count (default: one per CU).
-            static const int n_cu = [] {
-                int dev = 0, v = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
-                return v > 8 ? v : 256;
-            }();
-            const char* ske = getenv("DIGA_STREAMK");
-            const int sk_mode = ske ? atoi(ske) : 1;
-            const char* skb = getenv("DIGA_STREAMK_BLOCKS");
-            const int nb = skb ? std::max(2, std::min(atoi(skb), n_cu)) : n_cu;
-            const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
-            const int knom = (int)(R * S * (Cin / 32));
-            const int64_t rounds_up = ceil_div(tiles, nb);
-            const double waste = 1.0 - (double)tiles / (double)(rounds_up * nb);
-            const int ngroups = nb / a.tiles_n;                  // a group = the N-tiles of a panel range, one block each
-            if (sk_mode != 0 && nb % a.tiles_n == 0 && ngroups >= 2 && a.tiles_m >= ngroups &&
-                (int64_t)a.tiles_m * knom < (1ll << 31) && (waste >= 0.04 || sk_mode == 2)) {
-                a.sk_steps = (int)ceil_div((int64_t)a.tiles_m * knom, ngroups);
-                a.sk_ws = sk_workspace(st, (size_t)nb * 2 * 256 * 128 * sizeof(float));
-                DIGA_REQUIRE(a.sk_ws != nullptr, DIGA_EWORKSPACE, "conv2d_twin: cannot allocate the stream-K workspace");
-                const size_t fsh = (size_t)128 * (128 + 4) * sizeof(float);
-                if (epi != nullptr) {
-                    (void)hipFuncSetAttribute((const void*)conv_fwd_x3t8k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh8);
-                    (void)hipFuncSetAttribute((const void*)conv_sk_fixup_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsh);
-                    hipLaunchKernelGGL((conv_fwd_x3t8k_kernel<true>), dim3((unsigned)nb), dim3(768), sh8, st, a);
-                    hipLaunchKernelGGL((conv_sk_fixup_kernel<true>), dim3((unsigned)(2 * (ngroups - 1) * a.tiles_n)), dim3(256), fsh, st, a, ngroups);
-                } else {
-                    (void)hipFuncSetAttribute((const void*)conv_fwd_x3t8k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh8);
-                    (void)hipFuncSetAttribute((const void*)conv_sk_fixup_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsh);
-                    hipLaunchKernelGGL((conv_fwd_x3t8k_kernel<false>), dim3((unsigned)nb), dim3(768), sh8, st, a);
-                    hipLaunchKernelGGL((conv_sk_fixup_kernel<false>), dim3((unsigned)(2 * (ngroups - 1) * a.tiles_n)), dim3(256), fsh, st, a, ngroups);
-                }
-                return launch_status("diga_conv2d_nhwc_twin");
-            }
             if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3t8_kernel<2, true>), 768, sh8);
             else DIGA_LAUNCH_K((conv_fwd_x3t8_kernel<2, false>), 768, sh8);
         } else {

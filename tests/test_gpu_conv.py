@@ -232,67 +232,6 @@ def test_twin_path_matches_register_staged_path_and_is_shared(bf16x3, monkeypatc
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,hw,cin,cout,k,dil,blocks", [(2, 40, 256, 256, 1, 1, 24), (2, 33, 64, 256, 3, 6, 16), (1, 64, 128, 384, 3, 1, 39),
-                                                       (3, 29, 512, 128, 1, 1, 8)],
-                         ids=["1x1_24", "3x3d6_16", "3x3_39", "1x1_8"])
-def test_stream_k_launch_matches_one_tile_per_block(n, hw, cin, cout, k, dil, blocks, bf16x3, monkeypatch):
-    """conv_fwd_x3t8k_kernel + conv_sk_fixup_kernel (persistent blocks over equal ranges of the flattened (tile, K-step)
-    space; tiles cut between two blocks are summed head + tail by the fix-up kernel) against the one-tile-per-block kernel
-    on the same twins: outputs equal up to the fp32 summation order of the cut tiles, BatchNorm statistics partials and the
-    backward epilogue (addend, ReLU mask from forward coefficients, sum g / sum g*xhat) likewise.  DIGA_STREAMK_BLOCKS makes
-    small launches qualify (>= one tile per block); dilated taps outside the image are skipped inside a range."""
-    import ctypes
-    from diga_amd import _lib
-    g = synth.gen(n * 1000 + cin + cout + k)
-    pad = dil * (k // 2)
-    x = (torch.randn((n, hw, hw, cin), generator=g) + 0.3).to(DEV)
-    w = (torch.randn((cout, k, k, cin), generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
-    m = n * hw * hw
-    twin = torch.empty(m * cin * 4, dtype=torch.uint8, device=DEV)
-    _lib.call("diga_make_twin", _lib.ptr(x), cin, _lib.ptr(twin), m, cin, _lib.stream())
-    img = torch.empty(_lib.lib.diga_split_bf16_image_bytes(cout, k * k, cin), dtype=torch.uint8, device=DEV)
-    _lib.call("diga_split_bf16_image", _lib.ptr(w), _lib.ptr(img), cout, k * k, cin, _lib.stream())
-    nst = _lib.lib.diga_conv2d_stats_floats(n, hw, hw, cout)
-    add = torch.randn((m, cout), generator=g).to(DEV)
-    bx = torch.randn((m, cout), generator=g).to(DEV)
-    ab = torch.cat([1 + 0.1 * torch.randn(cout, generator=g), 0.1 * torch.randn(cout, generator=g)]).to(DEV)
-    mean, invstd = (0.1 * torch.randn(cout, generator=g)).to(DEV), (1 + 0.1 * torch.rand(cout, generator=g)).to(DEV)
-    monkeypatch.setenv("DIGA_STREAMK_BLOCKS", str(blocks))
-    res = {}
-    for mode in ("0", "2"):
-        monkeypatch.setenv("DIGA_STREAMK", mode)
-        y = torch.full((n, hw, hw, cout), float("nan"), device=DEV)
-        st = torch.full((nst,), float("nan"), device=DEV)
-        _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), None, _lib.ptr(y), n, hw, hw, cin, hw, hw, cout,
-                  cout, k, k, 1, 1, -pad, -pad, dil, dil, _lib.ptr(st), 11, _lib.stream())
-        ye = torch.full((n, hw, hw, cout), float("nan"), device=DEV)
-        part = torch.full((((m + 127) // 128) * 2 * cout,), float("nan"), device=DEV)
-        epi = _lib.BwdEpilogue()
-        epi.addend, epi.addend_ld = _lib.ptr(add), cout
-        epi.x, epi.x_ld = _lib.ptr(bx), cout
-        epi.relu_ab = _lib.ptr(ab)
-        epi.mean, epi.invstd, epi.partials = _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(part)
-        _lib.call("diga_conv2d_nhwc_twin_epi", _lib.ptr(twin), _lib.ptr(img), _lib.ptr(ye), n, hw, hw, cin, hw, hw, cout, cout,
-                  k, k, 1, 1, -pad, -pad, dil, dil, ctypes.byref(epi), 12, _lib.stream())
-        torch.cuda.synchronize()
-        res[mode] = (y, st, ye, part)
-    (y0, s0, e0, p0), (y1, s1, e1, p1) = res["0"], res["2"]
-    assert torch.isfinite(y0).all() and torch.isfinite(y1).all() and torch.isfinite(e1).all() and torch.isfinite(p1).all()
-    scale = float(y0.abs().max())
-    assert float((y1 - y0).abs().max()) <= 2e-6 * scale
-    assert float((y1 != y0).float().mean()) < 0.9, "whole tiles are bit-identical; only cut tiles may differ in the last bits"
-    # statistics partials: shift (third plane) is the chunk's first row; sums agree to rounding
-    nchunk = (m + 127) // 128
-    a0, a1 = s0.view(nchunk, 3, cout).double(), s1.view(nchunk, 3, cout).double()
-    mu0 = a0[:, 2] + a0[:, 0] / 128.0
-    mu1 = a1[:, 2] + a1[:, 0] / 128.0
-    assert float((mu0 - mu1).abs().max()) <= 1e-5 * scale
-    assert float((a0[:, 1] - a1[:, 1]).abs().max()) <= 1e-4 * float(a0[:, 1].abs().max())
-    # backward epilogue: masked outputs may flip where fma(x, a, b) is at zero -- it is computed from bx only, so the masks agree
-    assert float((e1 - e0).abs().max()) <= 2e-6 * float(e0.abs().max())
-    assert float((p1 - p0).abs().max()) <= 1e-4 * float(p0.abs().max())
-
-
 def test_split_formats_byte_exact():
     """The pre-split operand formats (activation twin, weight LDS images) against their numpy restatement: byte exact,
     including values that round up across a bf16 exponent boundary, denormal-sized residuals and negative zero."""

@@ -28,7 +28,7 @@ SHAPES = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 1],
-                    help="DIGA_X3T_VARIANT values (0: 8-wave kernel, 1: 12-wave kernel); 50 / 51: 12-wave kernel without / with stream-K")
+                    help="DIGA_X3T_VARIANT values (0: 8-wave kernel, 1: 12-wave kernel)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--images", type=int, default=16)
@@ -56,12 +56,7 @@ def main():
         outs = {v: torch.empty((n, hw, hw, cout), device=dev) for v in a.variants}
 
         def run(v):
-            if v >= 50:                       # 50 / 51: 12-wave kernel as one-tile-per-block / stream-K launch
-                os.environ["DIGA_X3T_VARIANT"] = "1"
-                os.environ["DIGA_STREAMK"] = str(v - 50)
-            else:
-                os.environ["DIGA_X3T_VARIANT"] = str(v)
-                os.environ["DIGA_STREAMK"] = "0"
+            os.environ["DIGA_X3T_VARIANT"] = str(v)
             _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), None, _lib.ptr(outs[v]), n, hw, hw, cin, hw, hw, cout,
                       cout, k, k, 1, 1, -pad, -pad, dil, dil, _lib.ptr(stats), 11, _lib.stream())
 
