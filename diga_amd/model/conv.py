@@ -457,8 +457,8 @@ class DigaConv2d(nn.Conv2d):
         if x_is_twin and fn is not _Conv2dFn:
             raise RuntimeError("DigaConv2d: twin-only input on the stem path")
         bn_box = getattr(x, "_diga_bn_box", None)
-        if bn_box is not None and (self.share_twin or fn is not _Conv2dFn or not torch.is_grad_enabled()):
-            bn_box = None                     # several convs read this tensor / no backward: autograd keeps the plain path
+        if bn_box is not None and (self.share_twin or chain is not None or fn is not _Conv2dFn or not torch.is_grad_enabled()):
+            bn_box = None                     # several convs read this tensor (the chain carries the box) / no backward
         if opts is not None and any(opts):
             if fn is not _Conv2dFn or stats is not None:
                 raise RuntimeError("DigaConv2d: folded padding / upsampling / activation need the implicit-GEMM path without BN statistics")

@@ -75,18 +75,31 @@ class Bottleneck(nn.Module):
         # ... and the dx of bn2's backward is read only by conv2's backward-data and backward-weight: a twin as well
         # Under autograd the same holds for conv3 (bn2's output / bn3's dx): its weight gradient is 35-39 % faster on twins.
         grad = torch.is_grad_enabled()
-        if self.downsample is not None and getattr(x, "_diga_bn_box", None) is not None:
-            # two convolutions read x here (conv1 and the downsample conv): their gradients meet in an autograd add, so
-            # the BatchNorm that produced x keeps its own mask / reduce passes (no backward-epilogue fusion)
-            x._diga_bn_box = None
+        chain = None
+        if self.downsample is not None:
+            # two convolutions read x here (conv1 and the downsample conv).  Where both are eligible (stride 1) their
+            # input gradients are summed through the backward-data epilogues like the ASPP branches' (model/conv.py,
+            # `chain`), and the one that runs last also finishes the gradient of the BatchNorm that produced x; else
+            # they meet in an autograd add and that BatchNorm keeps its own mask / reduce passes
+            box = getattr(x, "_diga_bn_box", None)
+            if (grad and x.requires_grad and dn.fuse_backward_enabled() and tuple(self.conv1.stride) == (1, 1)
+                    and tuple(self.downsample[0].stride) == (1, 1) and os.environ.get("DIGA_JUNCTION_CHAIN", "1") != "0"):
+                chain = {"remaining": 2, "acc": None, "box": box}
+            elif box is not None:
+                x._diga_bn_box = None
         tw2 = takes_twin_only_input(self.conv2)
-        # (round 2: pointwise layers on twins run on the persistent kernel, which also pays without a weight gradient --
-        #  the no-grad teacher takes it too; DIGA_TWIN_CONV3=2 restricts it to autograd passes as in round 1)
+        # (round 2: with streaming epilogue stores the twin kernel is also the faster one for pointwise layers without a
+        #  weight gradient -- the no-grad teacher takes it too; DIGA_TWIN_CONV3=2 restricts it to autograd passes as in round 1)
         c3 = os.environ.get("DIGA_TWIN_CONV3", "1")
         tw3 = (grad or c3 != "2") and c3 != "0" and takes_twin_only_input(self.conv3, pointwise_ok=True)
-        y = self.bn1(self.conv1(x), relu=True, twin_out=tw2)
+        y = self.bn1(self.conv1(x, chain=chain), relu=True, twin_out=tw2)
         y = self.bn2(self.conv2(y, twin_grad=tw2 and grad), relu=True, twin_out=tw3, dx_twin=tw2 and grad)
-        skip = x if self.downsample is None else self.downsample(x)
+        if self.downsample is None:
+            skip = x
+        elif chain is not None:
+            skip = self.downsample[1](self.downsample[0](x, chain=chain))
+        else:
+            skip = self.downsample(x)
         return self.bn3(self.conv3(y, twin_grad=tw3), residual=skip, relu=True, dx_twin=tw3)
 
 
