@@ -8,6 +8,8 @@ The reference is single-process, so this layer is new funct
   * gather_class_sums -- all-gather of the per-image class sums/counts of the centroid update so that
     every rank applies the order-dependent EMA in the global (rank-major, image-major, class-minor)
     order: bit-identical to one process that saw the concatenated batch.
+  * allreduce_class_means / apply_mean_of_vectors -- the approximate "centroid all-reduce" of BASELINE
+    configs[3]: [19,256] sums of class means + [19] vector counts in one all-reduce.
 BatchNorm statistics stay local and the EMA teacher is recomputed on every rank from the (identical)
 all-reduced student, exactly as a per-rank run of the reference would.
 """
@@ -29,10 +31,22 @@ def init_from_env(backend=None):
         if backend is None:
             backend = os.environ.get("DIGA_DDP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            # one process per GPU; with fewer devices than ranks (single-GPU smoke test over gloo) ranks share a device
-            local = local % max(torch.cuda.device_count(), 1)
+            ndev = max(torch.cuda.device_count(), 1)
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            if ndev >= local_world:
+                # the production layout: ONE process per GPU, device index = LOCAL_RANK, nothing shared
+                if not 0 <= local < ndev:
+                    raise RuntimeError(f"LOCAL_RANK={local} but this node has {ndev} GPUs")
+            elif backend == "nccl":
+                raise RuntimeError(f"{local_world} ranks on {ndev} GPU(s): RCCL needs one device per rank "
+                                   "(only the gloo smoke configuration may share a device)")
+            else:
+                local = local % ndev          # single-GPU smoke test over gloo: ranks share the device
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if dist.get_world_size() != world or dist.get_rank() != rank:
+            raise RuntimeError(f"process group came up as rank {dist.get_rank()}/{dist.get_world_size()}, "
+                               f"environment says {rank}/{world}")
         if backend == "gloo" and torch.cuda.is_available():
             # gloo reduces GPU tensors through host-synchronous copies on its own streams; next to the step driver's
             # side streams (teacher forward, weight gradients) that degenerates to seconds per step on this stack
@@ -61,8 +75,14 @@ class GradReducer:
     rest of the backward pass; `reduce()` starts whatever is still pending (gradients that were set by
     hand), waits, and unpacks with one multi-tensor copy per bucket."""
 
-    def __init__(self, params, bucket_bytes=128 << 20, group=None, overlap=True):
+    def __init__(self, params, bucket_bytes=None, group=None, overlap=True):
         self.group = group
+        if bucket_bytes is None:
+            # ~25 MB buckets (SURVEY 5.8): 260 MB of ResNet-101 gradients leave in ~11 ring all-reduces while backward is
+            # still running and only the last one (stem .. first layer-1 blocks, produced at the very end) is exposed; with
+            # the 128 MB buckets of round 2 the exposed tail was a third of the payload.  Per-link xGMI time of a 25 MB
+            # ring all-reduce on 8 GPUs: 2*(7/8)*25 MB / ~50 GB/s effective ~ 0.9 ms -- far above launch latency.
+            bucket_bytes = int(os.environ.get("DIGA_DDP_BUCKET_MB", "25")) << 20
         seen, uniq = set(), []
         for p in params:
             if p.requires_grad and id(p) not in seen:
@@ -150,15 +170,50 @@ class GradReducer:
 
 
 def gather_class_sums(sums, counts, group=None):
-    """[N,K,D] sums and [N,K] counts of every rank, concatenated rank-major along the image axis."""
+    """[N,K,D] sums and [N,K] counts of every rank, concatenated rank-major along the image axis: the exact exchange
+    (every rank then applies the order-dependent EMA in global order, bit-identical to one process on the concatenated
+    batch).  ONE collective per call: sums and counts travel packed as [N,K,D+1] fp32 (a count is at most h*w < 2^24,
+    exact in fp32)."""
     w = world_size()
     if w == 1:
         return sums, counts
-    s_all = [torch.empty_like(sums) for _ in range(w)]
-    c_all = [torch.empty_like(counts) for _ in range(w)]
-    dist.all_gather(s_all, sums.contiguous(), group=group)
-    dist.all_gather(c_all, counts.contiguous(), group=group)
-    return torch.cat(s_all, 0), torch.cat(c_all, 0)
+    n, k, d = sums.shape
+    packed = torch.empty((n, k, d + 1), dtype=torch.float32, device=sums.device)
+    packed[..., :d] = sums
+    packed[..., d] = counts.to(torch.float32)
+    out = torch.empty((w * n, k, d + 1), dtype=torch.float32, device=sums.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    return out[..., :d].contiguous(), out[..., d].round().to(counts.dtype)
+
+
+def allreduce_class_means(sums, counts, min_pixels, group=None):
+    """The cheaper exchange BASELINE configs[3] names ("centroid all-reduce"): every rank folds its images'
+    valid class means (count >= min_pixels and a non-zero vector, the reference's skip rules, calc_centroids.py:131,148)
+    into [K,D] sums of means + [K] numbers of vectors, ONE all-reduce of the packed [K,D+1] buffer, and the centroid
+    bank takes the n_k vectors of a class in one closed-form step (`apply_mean_of_vectors`).  Approximate: the reference
+    applies the vectors one by one (calc_centroids.py:147-164); replacing them by their mean changes the result by
+    O(momentum^2 * n_k) -- measured in tests/test_host_cpu.py.  Returns (mean_sums [K,D], n_vectors [K]) of ALL ranks."""
+    n, k, d = sums.shape
+    cnt = counts.to(torch.float32)
+    means = sums / cnt.clamp_min(1.0)[..., None]
+    valid = (counts >= max(int(min_pixels), 1)) & (means.sum(-1) != 0)
+    packed = torch.empty((k, d + 1), dtype=torch.float32, device=sums.device)
+    packed[:, :d] = (means * valid[..., None]).sum(0)
+    packed[:, d] = valid.sum(0).to(torch.float32)
+    if world_size() > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed[:, :d].contiguous(), packed[:, d].contiguous()
+
+
+def apply_mean_of_vectors(cents, nums, mean_sums, n_vectors, momentum, cap=3000.0):
+    """n_k EMA steps of class k towards the MEAN of its n_k vectors, in closed form and in place:
+    c_k <- (1-m)^n_k c_k + (1 - (1-m)^n_k) * mean_k ; num_k <- min(num_k + n_k, cap)  (calc_centroids.py:147-164 with
+    every vector replaced by the class mean).  A few [19,256] torch ops on the device, no host sync."""
+    keep = torch.pow(torch.full_like(n_vectors, 1.0 - float(momentum)), n_vectors)
+    mean = mean_sums / n_vectors.clamp_min(1.0)[:, None]
+    has = (n_vectors > 0)[:, None]
+    cents.copy_(torch.where(has, keep[:, None] * cents + (1.0 - keep)[:, None] * mean, cents))
+    nums.copy_(torch.clamp(nums + n_vectors.to(nums.dtype), max=cap))
 
 
 def broadcast_module(module, src=0, group=None):

@@ -309,8 +309,19 @@ class _Conv2dFn(torch.autograd.Function):
                 chain = ctx.chain if (ctx.chain is not None and not ctx.chain.get("disabled")) else None
                 last_of_chain = False
                 if chain is not None:
+                    # `remaining` counts the members whose backward has not run yet IN THIS backward pass.  The running sum
+                    # only reaches autograd through the member that brings it to 0, so a pass in which a member never runs
+                    # (its output unused / detached) or a second pass over a retained graph would hand the trunk a missing
+                    # or stale sum: both are refused loudly instead.
+                    if chain.get("done"):
+                        raise RuntimeError("DigaConv2d: a second backward pass through convolutions that chain their input "
+                                           "gradients (retain_graph) is not supported; run the forward again")
                     chain["remaining"] -= 1
+                    if chain["remaining"] < 0:
+                        raise RuntimeError("DigaConv2d: gradient chain ran more members than it has")
                     last_of_chain = chain["remaining"] == 0
+                    if last_of_chain:
+                        chain["done"] = True
                     prev = chain.get("acc")
                     cbox = chain.get("box") if (last_of_chain and chain.get("box_ok")) else None
                     if prev is not None or cbox is not None:
@@ -331,7 +342,11 @@ class _Conv2dFn(torch.autograd.Function):
                     # gradient, ReLU mask, sum g / sum g*xhat per 128-row chunk (include/diga_hip.h, diga_bwd_epilogue_t)
                     m_rows = n * hi * wi
                     part = torch.empty(((m_rows + 127) // 128) * 2 * cp, dtype=torch.float32, device=w.device)
-                    add = box.pop("dres", None) if box["has_res"] else None
+                    # the residual-branch gradient of the tensor this conv reads, left by the BatchNorm that took it as
+                    # residual -- whether or not the producing BN itself had a residual (the epilogue combines `addend`
+                    # with either mask form)
+                    add = box.pop("dres", None)
+                    box["consumed"] = True          # a residual gradient arriving from now on must go through autograd
                     epi = _lib.BwdEpilogue()
                     epi.addend, epi.addend_ld = _lib.ptr(add), cp
                     _set_mask(epi, box, xn, cp)

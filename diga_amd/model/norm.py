@@ -124,7 +124,7 @@ class _BnFn(torch.autograd.Function):
             _lib.call("diga_bn_bwd", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(save_ab), _lib.ptr(weight),
                       _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dres), c, m, c,
                       1 if training else 0, 1 if ctx.dx_twin else 0, _lib.ptr(ws), ws.numel(), _lib.stream())
-        if dres is not None and ctx.res_box is not None:
+        if dres is not None and ctx.res_box is not None and not ctx.res_box.get("consumed"):
             # hand the residual-branch gradient to the conv that reads the same tensor: its backward-data epilogue adds it
             # (autograd gets None here and therefore launches no add kernel)
             ctx.res_box["dres"] = dres

@@ -22,12 +22,18 @@ from diga_amd.util import utils as U
 
 class DigaTrainer:
     def __init__(self, student, teacher, base_lr=2.5e-4, max_iter=80000, power=0.9, momentum=0.9,
-                 weight_decay=5e-4, rng=random, distill_scale=0.5):
+                 weight_decay=5e-4, rng=random, distill_scale=0.5, centroid_exchange=None):
         self.student, self.teacher = student, teacher
         self.base_lr, self.max_iter, self.power = base_lr, max_iter, power
         self.rng = rng
         self.distill_scale = distill_scale
         self.world = ddp.world_size()
+        # self-training, N > 1: "allgather" = exact (every rank applies all ranks' class means in global order, bit-identical
+        # to one process on the concatenated batch); "allreduce" = BASELINE configs[3]'s cheaper, approximate exchange
+        # (diga_amd/ddp.py::allreduce_class_means).  One collective per centroid pass either way.
+        self.centroid_exchange = centroid_exchange or os.environ.get("DIGA_CENTROID_EXCHANGE", "allgather")
+        if self.centroid_exchange not in ("allgather", "allreduce"):
+            raise ValueError(f"centroid_exchange must be 'allgather' or 'allreduce', not {self.centroid_exchange!r}")
         self.opt = U.DigaSGD(student.optim_parameters(base_lr), lr=base_lr, momentum=momentum,
                              weight_decay=weight_decay, grad_scale=1.0 / self.world)
         self.reducer = ddp.GradReducer([p for p in student.parameters() if p.requires_grad])
@@ -118,6 +124,11 @@ class DigaTrainer:
             # centroid EMA: target (filtered pseudo-labels) first, then source (teacher feats of the mixed view)
             for feat, out, lab in ((tt_feat, tt_lr, pseudo), (t_feat[B:], t_lr[B:], labels)):
                 sums, counts = class_features._class_sums(feat, out, labels_full=lab)[:2]
+                if self.centroid_exchange == "allreduce":
+                    ms, nv = ddp.allreduce_class_means(sums, counts, class_features.min_pixels)
+                    cents, nums = class_features._state_on(sums.device)
+                    ddp.apply_mean_of_vectors(cents, nums, ms, nv, class_features.centroid_momentum)
+                    continue
                 sums, counts = ddp.gather_class_sums(sums, counts)
                 class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
         _, _, c_lr, _ = self.student(cross_mix)

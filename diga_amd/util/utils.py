@@ -265,8 +265,8 @@ class DigaSGD(torch.optim.Optimizer):
     foreach path on GPU would treat them differently: shared buffer multiplied k times, all d = g + wd*p formed before
     any update) -- the reference pins torch 1.7.1, which has only the single-tensor path.  momentum and weight_decay
     are one scalar each for the launch: every group must carry the same values (the reference's two groups do).
-    Momentum buffers live in `self.state[p]['momentum_buffer']`, so state_dict()/load_state_dict() round-trip them
-    (the 'first step' flag travels as state['first'] of the first parameter's entry)."""
+    Momentum buffers live in `self.state[p]['momentum_buffer']`, so state_dict()/load_state_dict() round-trip them; the
+    'first step' condition is not stored: it is inferred from the absence of momentum buffers (as torch does)."""
 
     def __init__(self, params, lr=2.5e-4, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
         groups = []

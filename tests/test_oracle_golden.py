@@ -306,6 +306,22 @@ def test_model_forward_eval_and_train(golden):
     assert_close(sd["layer4.2.bn3.running_var"], g.t("rv_after"), 1e-4, 1e-6, "running var")
 
 
+def test_model_forward_benchmark_geometry(golden):
+    """The oracle at the 512x1024 benchmark geometry (65x129 map) against the capture of the reference: train-mode
+    forward (batch-statistics BN), the size bench.py's cpu_baseline leg and the full-size GPU tests lean on."""
+    g = golden("full512x1024")
+    _, H, W = (int(v) for v in g["geometry"])
+    gen = synth.gen(int(g["seed"]))
+    x = torch.rand((2, 3, H, W), generator=gen) * 2 - 1
+    sd = detweights.state_dict(od.RESNET101)
+    with torch.no_grad():
+        _, dp, out, feat = od.forward(sd, x, od.Arch(droprate=0.0), training=True, keep_mask=torch.ones(2, 256))
+    want = g.t("out")
+    assert float((out - want).abs().max()) < 2e-4 * float(want.abs().max())
+    assert float(feat.abs().sum()) == pytest.approx(float(g["feat_sum"][1]), rel=1e-5)
+    assert float(dp.abs().sum()) == pytest.approx(float(g["deep_sum"][1]), rel=1e-5)
+
+
 # ----------------------------------------------------------------------------- whole warm-up step
 @pytest.mark.timeout(900)
 def test_warmup_three_steps(golden):

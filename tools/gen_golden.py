@@ -421,6 +421,62 @@ def gen_model():
     save("model", **res)
 
 
+# ------------------------------------------------------------------ G-fullsize (benchmark geometries, round 3)
+FULLSIZE_GRADS = ["layer0.0.weight", "layer1.0.conv1.weight", "layer1.0.downsample.0.weight", "layer2.0.conv2.weight",
+                  "layer2.3.conv3.weight", "layer3.0.downsample.0.weight", "layer3.11.conv2.weight", "layer3.22.conv1.weight",
+                  "layer4.0.downsample.0.weight", "layer4.0.conv1.weight", "layer4.2.conv2.weight", "layer4.2.conv3.weight",
+                  "final.conv2d_list.0.0.weight", "final.conv2d_list.1.0.weight", "final.conv2d_list.2.0.weight",
+                  "final.conv2d_list.3.0.weight", "final.conv2d_list.4.0.weight", "final.conv2d_list.1.1.weight",
+                  "final.bottleneck.0.se.0.weight", "final.bottleneck.1.weight", "final.bottleneck.1.bias",
+                  "final.bottleneck.2.weight"]
+
+
+def _gen_fullsize(name, H, W, seed):
+    """Reference SegModel (model_noaux.py:28-46), train mode (batch-statistics BN), Dropout2d off, deterministic
+    weights, on TWO crops of the benchmark geometry: 768x768 -> 97x97 map (BASELINE configs[1]) and 512x1024 -> 65x129
+    (configs[3]).  The input and the gradient probe are regenerated from their seeds by the test; stored are the
+    reference's logits in full, strided samples + checksums of feat and of 22 weight gradients (all four ASPP dilations,
+    every stride / downsample transition), the head gradient in full, and BN running statistics after the pass."""
+    m = _ref_model()
+    m.train()
+    m.final.head[0].p = 0.0
+    g = synth.gen(seed)
+    x = torch.rand((2, 3, H, W), generator=g) * 2 - 1
+    sh, dp, out, feat = m(x)
+    probe = torch.randn(out.shape, generator=g)
+    (out * probe).sum().backward()
+    res = dict(seed=np.array(seed), geometry=np.array([2, H, W]), out=out, feat_sample=feat.detach().reshape(-1)[::61].clone(),
+               feat_sum=np.array([synth.checksum(feat), float(feat.detach().abs().sum())]),
+               shallow_sum=np.array([synth.checksum(sh), float(sh.detach().abs().sum())]),
+               deep_sum=np.array([synth.checksum(dp), float(dp.detach().abs().sum())]),
+               deep_sample=dp.detach().reshape(-1)[::9973].clone())
+    named = dict(m.named_parameters())
+    for n in FULLSIZE_GRADS:
+        gr = named[n].grad
+        key = "g_" + n.replace(".", "_")
+        res[key + "__sum"] = np.array([synth.checksum(gr), float(gr.abs().sum()), float(gr.norm())])
+        step = max(1, gr.numel() // 4096)
+        res[key + "__sample"] = gr.reshape(-1)[::step].clone()
+        res[key + "__step"] = np.array(step)
+    res["g_head"] = named["final.head.1.weight"].grad
+    sd = m.state_dict()
+    res["rm_layer1"] = sd["layer1.0.bn1.running_mean"]
+    res["rv_layer4"] = sd["layer4.2.bn3.running_var"]
+    res["rm_layer3"] = sd["layer3.22.bn3.running_mean"]
+    m.eval()
+    with torch.no_grad():
+        res["out_eval"] = m(x)[2]
+    save(name, **res)
+
+
+def gen_full768():
+    _gen_fullsize("full768", 768, 768, 8768)
+
+
+def gen_full512x1024():
+    _gen_fullsize("full512x1024", 512, 1024, 8512)
+
+
 # ------------------------------------------------------------------ G-step (warm-up, 3 steps)
 def gen_step():
     import torch.optim as optim
@@ -691,7 +747,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
