@@ -82,7 +82,9 @@ def parse():
     ap.add_argument("--no-bandwidth-kernels", action="store_true")
     ap.add_argument("--no-miou", action="store_true", help="skip the fixed-seed validation-mIoU parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run the CPU leg and print its JSON")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: run one CPU measurement and print its JSON")
+    ap.add_argument("--cpu-threads", type=int, default=8)
+    ap.add_argument("--cpu-part", default="768", choices=["768", "256"])
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel families with HIP events")
     ap.add_argument("--lean", action="store_true",
                     help="only the timed steps (= --no-other-precision --no-other-configs --no-bandwidth-kernels "
@@ -101,24 +103,20 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline():
-    """The oracle's warm-up step (PyTorch-CPU restatement of the reference, pinned by tests/golden) timed on this box's
-    host cores AT THE BENCHMARK GEOMETRY: ResNet-101, B=1 source crop of 768x768 (= 2 student + 2 teacher images per
-    step), one step, measured twice: with every host core the process may use and with 32 threads (beyond ~32 threads
-    torch's CPU convolutions stop scaling on these hosts); `value` is the better of the two, in 768x768 crops/s, nothing
-    scaled.  Cross-checks: the 256x256 B=2 sample of earlier rounds (FLOP-scaled, reported separately) and BASELINE
-    configs[0] as the build can state it (small backbone, 2x256x256, exact size)."""
+def cpu_baseline(threads, part):
+    """One measurement of the CPU leg in this process (child of cpu_baseline_subprocess): the oracle's warm-up step
+    (PyTorch-CPU restatement of the reference, pinned by tests/golden) with `threads` torch threads.
+      part "768": ResNet-101, B=1 source crop of 768x768 (= 2 student + 2 teacher images per step) -- the benchmark geometry,
+                  one step after a small warm-up of the thread pool, measured, nothing scaled;
+      part "256": the B=2 256x256 sample of earlier rounds (cross-check, FLOP-scaled) + BASELINE configs[0] as the build can
+                  state it (small backbone, 2x256x256, exact size)."""
     import torch
     from oracle import deeplab as od
     from oracle import detweights, synth
     from oracle import step as ost
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
+    torch.set_num_threads(threads)
 
-    def timed(arch, seed, b, hw, nsteps, threads):
-        torch.set_num_threads(threads)
+    def timed(arch, seed, b, hw, nsteps):
         tr = ost.Trainer(detweights.state_dict(arch), detweights.state_dict(arch), arch=arch)
         rng = random.Random(5)
         dt = None
@@ -129,47 +127,60 @@ def cpu_baseline():
             dt = time.perf_counter() - t0
         return dt
 
-    runs = {}
-    t_start = time.perf_counter()
-    for threads in sorted({avail, min(avail, 32)}, reverse=True):
-        if runs and time.perf_counter() - t_start > 90:
-            break                                 # bounded: the second thread count only when the first was quick
-        runs[threads] = timed(od.RESNET101, 320, 1, 768, 1, threads)
-    cores = min(runs, key=runs.get)
-    dt768 = runs[cores]
-    torch.set_num_threads(min(avail, 32))
-    dt256 = timed(od.RESNET101, 300, 2, 256, 2, min(avail, 32))
-    dt1 = timed(od.TINY, 310, 2, 256, 2, min(avail, 32))
-    return {"value": 1.0 / dt768, "unit": "crops/s", "cores": cores, "kind": "port",
-            "host_cores_total": os.cpu_count(), "host_cores_available": avail,
-            "seconds_per_step_by_threads": {str(k): v for k, v in runs.items()},
-            "sample": f"oracle warm-up step, ResNet-101, B=1 source crop of 768x768 fp32 (2 student + 2 teacher images), one "
-                      f"step, measured (not scaled): {dt768:.2f} s with {cores} threads"
-                      + "".join(f"; {v:.2f} s with {k} threads" for k, v in runs.items() if k != cores)
-                      + f"; host has {os.cpu_count()} cores",
-            "cross_check_256": {"value": (2.0 / dt256) * FWD_GFLOP_256 / FWD_GFLOP_768, "unit": "crops/s (FLOP-scaled)",
-                                "cores": min(avail, 32),
-                                "sample": f"B=2 crops of 256x256, 2nd of 2 steps: {dt256:.2f} s/step, scaled to 768x768 crops by "
-                                          f"forward FLOPs ({FWD_GFLOP_256}/{FWD_GFLOP_768} GFLOP)"},
-            "c1": {"value": 2.0 / dt1, "unit": "256x256 crops/s", "cores": min(avail, 32),
-                   "sample": f"oracle warm-up step, configs[0] stand-in (small backbone), B=2 crops of 256x256, 2nd of 2 "
-                             f"steps: {dt1:.3f} s/step (exact size, no scaling)"}}
+    if part == "768":
+        timed(od.TINY, 330, 1, 128, 1)                         # spin the thread pool / oneDNN primitives up
+        return {"threads": threads, "s_per_step_768": timed(od.RESNET101, 320, 1, 768, 1)}
+    return {"threads": threads, "s_per_step_256": timed(od.RESNET101, 300, 2, 256, 2), "s_per_step_c1": timed(od.TINY, 310, 2, 256, 2)}
 
 
-def cpu_baseline_subprocess(limit_s=420):
-    """Run the CPU leg in a child process (started before this process touches the GPU) so that a slow or
-    memory-hungry host cannot take the GPU measurement down with it."""
+def cpu_baseline_subprocess():
+    """The CPU leg: child processes (started before this process touches the GPU) so that a slow or memory-hungry host cannot
+    take the GPU measurement down with it.  The 768x768 step is measured with 32 threads (beyond ~32 threads torch's CPU
+    convolutions stop scaling on these hosts) and, time permitting, with every core the process may use; `value` is the
+    better of the two."""
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
-                           text=True, timeout=limit_s)
-        for ln in reversed(r.stdout.splitlines()):
-            if ln.startswith("{"):
-                return json.loads(ln)
-        return {"value": None, "unit": "crops/s", "cores": None, "kind": "port",
-                "sample": f"CPU leg failed (rc={r.returncode}): {r.stderr[-300:]}"}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "crops/s", "cores": None, "kind": "port",
-                "sample": f"CPU leg did not finish its oracle steps within {limit_s} s"}
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+
+    def child(threads, part, limit_s):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-threads", str(threads),
+                                "--cpu-part", part], capture_output=True, text=True, timeout=limit_s)
+            for ln in reversed(r.stdout.splitlines()):
+                if ln.startswith("{"):
+                    return json.loads(ln)
+            return {"error": f"rc={r.returncode}: {r.stderr[-300:]}"}
+        except subprocess.TimeoutExpired:
+            return {"error": f"not finished within {limit_s} s"}
+
+    base = min(avail, 32)
+    t0 = time.perf_counter()
+    runs = {base: child(base, "768", 300)}
+    if avail > base and time.perf_counter() - t0 < 100:
+        runs[avail] = child(avail, "768", 150)
+    small = child(base, "256", 120)
+    ok = {k: v["s_per_step_768"] for k, v in runs.items() if "s_per_step_768" in v}
+    out = {"value": None, "unit": "crops/s", "cores": None, "kind": "port", "host_cores_total": os.cpu_count(),
+           "host_cores_available": avail, "runs": {str(k): v for k, v in runs.items()}}
+    if ok:
+        cores = min(ok, key=ok.get)
+        out.update(value=1.0 / ok[cores], cores=cores,
+                   sample=f"oracle warm-up step, ResNet-101, B=1 source crop of 768x768 fp32 (2 student + 2 teacher images), one "
+                          f"step, measured (not scaled): {ok[cores]:.2f} s with {cores} threads"
+                          + "".join(f"; {v:.2f} s with {k} threads" for k, v in ok.items() if k != cores)
+                          + f"; host has {os.cpu_count()} cores")
+    else:
+        out["sample"] = "768x768 CPU step failed: " + "; ".join(f"{k} threads: {v.get('error')}" for k, v in runs.items())
+    if "s_per_step_256" in small:
+        out["cross_check_256"] = {"value": (2.0 / small["s_per_step_256"]) * FWD_GFLOP_256 / FWD_GFLOP_768,
+                                  "unit": "crops/s (FLOP-scaled)", "cores": base,
+                                  "sample": f"B=2 crops of 256x256, 2nd of 2 steps: {small['s_per_step_256']:.2f} s/step, scaled to "
+                                            f"768x768 crops by forward FLOPs ({FWD_GFLOP_256}/{FWD_GFLOP_768} GFLOP)"}
+        out["c1"] = {"value": 2.0 / small["s_per_step_c1"], "unit": "256x256 crops/s", "cores": base,
+                     "sample": f"oracle warm-up step, configs[0] stand-in (small backbone), B=2 crops of 256x256, 2nd of 2 steps: "
+                               f"{small['s_per_step_c1']:.3f} s/step (exact size, no scaling)"}
+    return out
 
 
 def miou_parity_subprocess(limit_s=300):
@@ -504,7 +515,7 @@ def bandwidth_kernels(dev):
 def main():
     a = parse()
     if a.cpu_baseline_only:
-        print(json.dumps(cpu_baseline()), flush=True)
+        print(json.dumps(cpu_baseline(a.cpu_threads, a.cpu_part)), flush=True)
         return 0
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         return spawn_workers(a)

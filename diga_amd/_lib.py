@@ -24,7 +24,7 @@ F32 = C.c_float
 INT = C.c_int
 SZ = C.c_size_t
 
-# name -> (restype, argtypes); mirrors include/diga_hip.h one to one
+# name -> (restype, argtypes); mirrors include/diga_hip.h and include/diga_mit.h one to one
 SIGNATURES = {
     "diga_version": (INT, []),
     "diga_last_error_string": (C.c_char_p, []),
@@ -83,6 +83,26 @@ SIGNATURES = {
     "diga_maxpool3x3s2_fwd": (INT, [P, P, P, I64, I64, I64, I64, I64, I64, P]),
     "diga_maxpool3x3s2_bwd": (INT, [P, P, P, I64, I64, I64, I64, I64, I64, P]),
     "diga_color_aug_view": (INT, [P, P, P, P, I64, I64, I64, F32, P, P, P]),
+    # ---- include/diga_mit.h
+    "diga_mit_gemm_nt": (INT, [P, I64, P, I64, P, P, I64, INT, P, I64, P, I64, INT, F32, I64, I64, I64, P]),
+    "diga_mit_gemm_tn_workspace_bytes": (SZ, [I64, I64, I64]),
+    "diga_mit_gemm_tn": (INT, [P, I64, P, I64, P, F32, INT, P, SZ, I64, I64, I64, P]),
+    "diga_mit_colsum_workspace_bytes": (SZ, [I64, I64]),
+    "diga_mit_colsum": (INT, [P, I64, P, F32, INT, P, SZ, I64, I64, P]),
+    "diga_mit_cast_transpose": (INT, [P, P, P, I64, I64, P]),
+    "diga_mit_cast_scale": (INT, [P, P, I64, F32, P]),
+    "diga_mit_row_scale": (INT, [P, P, P, I64, I64, I64, P]),
+    "diga_mit_layernorm_fwd": (INT, [P, I64, P, P, P, P, I64, P, P, I64, I64, F32, P]),
+    "diga_mit_layernorm_bwd_workspace_bytes": (SZ, [I64, I64]),
+    "diga_mit_layernorm_bwd": (INT, [P, INT, I64, F32, P, I64, P, P, P, P, I64, P, P, I64, P, P, F32, INT, P, SZ, I64, I64, P]),
+    "diga_mit_dwconv_gelu_fwd": (INT, [P, P, P, P, P, I64, I64, I64, I64, P]),
+    "diga_mit_dwconv_bwd_workspace_bytes": (SZ, [I64, I64, I64]),
+    "diga_mit_dwconv_gelu_bwd": (INT, [P, P, P, P, P, P, P, P, F32, INT, P, SZ, I64, I64, I64, I64, P]),
+    "diga_mit_im2col": (INT, [P, INT, P] + [I64] * 11 + [P]),
+    "diga_mit_col2im": (INT, [P, P, INT, F32] + [I64] * 11 + [P]),
+    "diga_mit_attention_fwd": (INT, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, F32, P]),
+    "diga_mit_attention_bwd_workspace_bytes": (SZ, [I64, I64, I64, I64]),
+    "diga_mit_attention_bwd": (INT, [P, I64, P, I64, P, P, I64, P, P, P, P, SZ, I64, I64, I64, I64, F32, P]),
     "diga_prof_enable": (INT, [INT]),
     "diga_prof_reset": (INT, []),
     "diga_prof_query": (INT, [INT, P, P]),
@@ -98,7 +118,8 @@ class BwdEpilogue(C.Structure):
 # enum order of include/diga_hip.h
 PROF_TAGS = ["ce2d", "distill", "upsample_loss", "ema", "sgd", "classmix_hist", "classmix_paste",
              "centroid_weights", "consensus", "class_means", "centroid_apply", "conv_fwd", "conv_bwd_data",
-             "conv_bwd_weight", "norm", "elementwise"]
+             "conv_bwd_weight", "norm", "elementwise", "mit_gemm", "mit_wgrad", "mit_attn_fwd", "mit_attn_bwd", "mit_norm",
+             "mit_dwconv", "mit_misc"]
 
 
 def prof_query(tag):

@@ -1,0 +1,59 @@
+// Shared device helpers of the MiT / SegFormer kernels (mit_*.hip): fp16 storage, fp32 accumulation, gfx950 only.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "../../include/diga_mit.h"
+
+namespace diga {
+namespace mit {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+
+// blocks b and b+8 share an XCD (round-robin dispatch): give every XCD a contiguous range of tiles (bijective)
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// 64-byte LDS rows (32 halves = one K-step): the four 16-byte k-slots of row r sit at slot ^ swz64(r); conflict-free for
+// the ds_read_b128 fragment reads of a 16-row tile (same function as the conv kernels' lds_swz)
+__device__ __forceinline__ int swz64(int r) { return ((0x78 >> (((r >> 2) & 3) * 2)) & 3) ^ (((r >> 1) & 1) << 1); }
+
+// 128-byte LDS rows (64 halves, attention K / V / Q / dO images): chunk c (16 B) of row r sits at c ^ swz128(r).
+// k = (r >> 1) & 7 -> v = ((k & 3) << 1) | (k >> 2): a permutation of 0..7 over 8 rows of one parity (ds_read_b128 of a
+// 16-row tile touches 16 distinct 16-byte slots of the 256-byte bank row) whose upper two bits are distinct over 4
+// consecutive row pairs (the transposing read of 8 rows x 32 bytes touches 8 distinct 32-byte positions).
+__device__ __forceinline__ int swz128(int r) {
+    const int k = (r >> 1) & 7;
+    return ((k & 3) << 1) | (k >> 2);
+}
+
+// 256-byte LDS rows read with the transposing ds_read_b64_tr_b16 (weight-gradient GEMM): chunk ^ (tr_key(r) << 1)
+__device__ __forceinline__ int tr_key(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+__device__ __forceinline__ f16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f16x8, v);
+}
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float u) {
+    return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+}
+
+}  // namespace mit
+}  // namespace diga

@@ -1,0 +1,649 @@
+// HBM-bound kernels of the MiT / SegFormer student (BASELINE configs[4]): LayerNorm forward / backward
+// (G5/model/networks/MixTransfomer.py:152,160,176-177,202,220 -- nn.LayerNorm(eps=1e-6)), the Mix-FFN's depthwise 3x3
+// convolution + bias + GELU (:54-55,72-74,409-423) forward / backward, and the row gathers (im2col / col2im) that turn the
+// overlapping patch embeddings (:187-228) and the spatial-reduction convolution (:104-106,126-128) into GEMMs.
+// Token matrices are [rows = B*H*W][channels], channels contiguous (= NHWC); fp32 residual stream, fp16 branch tensors.
+#include "mit_common.h"
+
+namespace diga {
+namespace mit {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm.  16 lanes per row, lane l of a row group handles float4 number l + 16 t (t < NV): a wave-instruction
+// reads 4 rows x 256 contiguous bytes.  C <= 256 * NV, C % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, _Float16* __restrict__ y16,
+                                                            float* __restrict__ y32, int64_t ldy, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l16 = lane & 15, rsub = lane >> 4;
+    const int nq = C / 4;
+    float4 g[NV], b[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int q = l16 + 16 * t;
+        g[t] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[t] = q < nq ? reinterpret_cast<const float4*>(beta)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float inv_c = 1.f / (float)C;
+    for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wv) * 4; r0 < M; r0 += (int64_t)gridDim.x * 16) {
+        const int64_t r = r0 + rsub;
+        const bool ok = r < M;
+        const int64_t rr = ok ? r : (int64_t)M - 1;
+        float4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int q = l16 + 16 * t;
+            v[t] = q < nq ? reinterpret_cast<const float4*>(x + rr * ldx)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+        }
+        const float mean = sum16(s) * inv_c;
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int q = l16 + 16 * t;
+            if (q < nq) {
+                const float a0 = v[t].x - mean, a1 = v[t].y - mean, a2 = v[t].z - mean, a3 = v[t].w - mean;
+                ss += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = rsqrtf(sum16(ss) * inv_c + eps);
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const int q = l16 + 16 * t;
+                if (q >= nq) continue;
+                const float o0 = (v[t].x - mean) * rstd * g[t].x + b[t].x, o1 = (v[t].y - mean) * rstd * g[t].y + b[t].y;
+                const float o2 = (v[t].z - mean) * rstd * g[t].z + b[t].z, o3 = (v[t].w - mean) * rstd * g[t].w + b[t].w;
+                if (y16 != nullptr)
+                    *reinterpret_cast<f16x4*>(y16 + r * ldy + 4 * q) = (f16x4){(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
+                if (y32 != nullptr) *reinterpret_cast<float4*>(y32 + r * ldy + 4 * q) = make_float4(o0, o1, o2, o3);
+            }
+            if (l16 == 0 && mean_out != nullptr) {
+                mean_out[r] = mean;
+                rstd_out[r] = rstd;
+            }
+        }
+    }
+}
+
+// Backward: g = gscale * dy (fp16 or fp32), xhat = (x - mean) * rstd,
+//   dx = dres + rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat))      -> dx32 (fp32) and/or dx16 (fp16)
+//   partial[block][0][c] = sum_rows g * xhat, partial[block][1][c] = sum_rows g      (dgamma / dbeta, reduced afterwards)
+template <int NV, typename GT>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const GT* __restrict__ dy, int64_t ldg, const float* __restrict__ x,
+                                                            int64_t ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            const float* __restrict__ dres, int64_t ldr, float* __restrict__ dx32,
+                                                            _Float16* __restrict__ dx16, int64_t ldo, float* __restrict__ partial,
+                                                            int M, int C, int rows_per_block, float gscale) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l16 = lane & 15, rsub = lane >> 4;
+    const int nq = C / 4;
+    float4 gm[NV];
+    float4 sg[NV], sb[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int q = l16 + 16 * t;
+        gm[t] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float inv_c = 1.f / (float)C;
+    const int64_t blk0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t blk1 = blk0 + rows_per_block < M ? blk0 + rows_per_block : (int64_t)M;
+    for (int64_t r0 = blk0 + wv * 4; r0 < blk1; r0 += 16) {
+        const int64_t r = r0 + rsub;
+        const bool ok = r < blk1;
+        const int64_t rr = ok ? r : blk1 - 1;
+        const float mean = mean_in[rr], rstd = rstd_in[rr];
+        float4 gv[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int q = l16 + 16 * t;
+            if (q < nq) {
+                float4 d;
+                if constexpr (sizeof(GT) == 2) {
+                    const f16x4 h = *reinterpret_cast<const f16x4*>(dy + rr * ldg + 4 * q);
+                    d = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                } else {
+                    d = *reinterpret_cast<const float4*>(dy + rr * ldg + 4 * q);
+                }
+                d.x *= gscale; d.y *= gscale; d.z *= gscale; d.w *= gscale;
+                const float4 xv = reinterpret_cast<const float4*>(x + rr * ldx)[q];
+                xh[t] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                gv[t] = d;
+                const float a0 = d.x * gm[t].x, a1 = d.y * gm[t].y, a2 = d.z * gm[t].z, a3 = d.w * gm[t].w;
+                s1 += (a0 + a1) + (a2 + a3);
+                s2 += (a0 * xh[t].x + a1 * xh[t].y) + (a2 * xh[t].z + a3 * xh[t].w);
+            } else {
+                gv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                xh[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float m1 = sum16(s1) * inv_c, m2 = sum16(s2) * inv_c;
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const int q = l16 + 16 * t;
+                if (q >= nq) continue;
+                float o0 = rstd * (gv[t].x * gm[t].x - m1 - xh[t].x * m2), o1 = rstd * (gv[t].y * gm[t].y - m1 - xh[t].y * m2);
+                float o2 = rstd * (gv[t].z * gm[t].z - m1 - xh[t].z * m2), o3 = rstd * (gv[t].w * gm[t].w - m1 - xh[t].w * m2);
+                if (dres != nullptr) {
+                    const float4 dr = *reinterpret_cast<const float4*>(dres + r * ldr + 4 * q);
+                    o0 += dr.x; o1 += dr.y; o2 += dr.z; o3 += dr.w;
+                }
+                if (dx32 != nullptr) *reinterpret_cast<float4*>(dx32 + r * ldo + 4 * q) = make_float4(o0, o1, o2, o3);
+                if (dx16 != nullptr)
+                    *reinterpret_cast<f16x4*>(dx16 + r * ldo + 4 * q) = (f16x4){(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
+                sg[t].x += gv[t].x * xh[t].x; sg[t].y += gv[t].y * xh[t].y; sg[t].z += gv[t].z * xh[t].z; sg[t].w += gv[t].w * xh[t].w;
+                sb[t].x += gv[t].x; sb[t].y += gv[t].y; sb[t].z += gv[t].z; sb[t].w += gv[t].w;
+            }
+        }
+    }
+    // fold the 4 row slots of a wave (lanes l, l+16, l+32, l+48), then the 4 waves through LDS, fixed order
+    __shared__ float red[4][2][NV * 64];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        float* pg = reinterpret_cast<float*>(&sg[t]);
+        float* pb = reinterpret_cast<float*>(&sb[t]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = pg[e], bsum = pb[e];
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            bsum += __shfl_xor(bsum, 16, 64);
+            bsum += __shfl_xor(bsum, 32, 64);
+            if (rsub == 0) {
+                red[wv][0][(l16 + 16 * t) * 4 + e] = a;
+                red[wv][1][(l16 + 16 * t) * 4 + e] = bsum;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        partial[((int64_t)blockIdx.x * 2 + which) * C + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int blocks, int C, float scale, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    const int which = i / C, c = i - which * C;
+    float s = 0.f;
+    for (int k = 0; k < blocks; ++k) s += partial[((int64_t)k * 2 + which) * C + c];
+    s *= scale;
+    float* dst = which == 0 ? dgamma : dbeta;
+    if (accumulate) s += dst[c];
+    dst[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise 3x3 (stride 1, zero padding 1) on [B][H][W][C] fp16.  A thread owns 8 channels of a strip of PX pixels
+// along x: its 72 weights live in registers and the 3 x (PX + 2) input vectors are loaded once.
+//   MODE 0 (forward):        u = dw(x) + bias -> u16 ; h = gelu(u) -> out16                 (MixTransfomer.py:72-74)
+//   MODE 1 (backward-data):  out = dw_flipped(x) (x = du), no bias, no activation
+// Weights arrive as wt[9][C] fp32 (tap-major), MODE 1 passes the taps flipped.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDwPX = 4;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const _Float16* __restrict__ x, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, _Float16* __restrict__ u16,
+                                                        _Float16* __restrict__ out16, int B, int H, int W, int C) {
+    const int cg = C / 8;
+    const int strips = (W + kDwPX - 1) / kDwPX;
+    const int64_t total = (int64_t)B * H * strips * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(idx % cg);
+        int64_t rest = idx / cg;
+        const int sx = (int)(rest % strips);
+        rest /= strips;
+        const int y = (int)(rest % H);
+        const int b = (int)(rest / H);
+        const int x0 = sx * kDwPX;
+        float w[9][8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 w0 = *reinterpret_cast<const float4*>(wt + (int64_t)t * C + c8 * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(wt + (int64_t)t * C + c8 * 8 + 4);
+            w[t][0] = w0.x; w[t][1] = w0.y; w[t][2] = w0.z; w[t][3] = w0.w;
+            w[t][4] = w1.x; w[t][5] = w1.y; w[t][6] = w1.z; w[t][7] = w1.w;
+        }
+        float acc[kDwPX][8];
+#pragma unroll
+        for (int p = 0; p < kDwPX; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const _Float16* row = x + (((int64_t)b * H + yy) * W) * C + c8 * 8;
+#pragma unroll
+            for (int j = 0; j < kDwPX + 2; ++j) {
+                const int xx = x0 + j - 1;
+                if (xx < 0 || xx >= W) continue;
+                const f16x8 v = *reinterpret_cast<const f16x8*>(row + (int64_t)xx * C);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int p = j - dx;                          // output pixel x0 + p reads input x0 + p + dx - 1 = x0 + j - 1
+                    if (p < 0 || p >= kDwPX) continue;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[p][e] += w[dy * 3 + dx][e] * (float)v[e];
+                }
+            }
+        }
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0 && bias != nullptr) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        }
+#pragma unroll
+        for (int p = 0; p < kDwPX; ++p) {
+            if (x0 + p >= W) break;
+            const int64_t o = (((int64_t)b * H + y) * W + x0 + p) * C + c8 * 8;
+            f16x8 uo, ho;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = acc[p][e] + bv[e];
+                uo[e] = (_Float16)u;
+                // GELU of the ROUNDED pre-activation: the backward pass re-derives gelu'(u) from the stored fp16 u
+                ho[e] = MODE == 0 ? (_Float16)gelu_f((float)uo[e]) : (_Float16)u;
+            }
+            if (MODE == 0 && u16 != nullptr) *reinterpret_cast<f16x8*>(u16 + o) = uo;
+            *reinterpret_cast<f16x8*>(out16 + o) = ho;
+        }
+    }
+}
+
+// du = dh * gelu'(u) -> du16; per-block partial sums of the depthwise weight / bias gradients:
+//   dw[t][c] = sum_p du[p][c] * x[p + t][c],  db[c] = sum_p du[p][c]     (x = the conv input, zero outside the image)
+// A block covers `rows_per_block` image rows of one image; thread -> (8-channel group, x phase).  partial[block][10][C].
+__global__ __launch_bounds__(256) void dwconv_bwd_prep_kernel(const _Float16* __restrict__ dh, const _Float16* __restrict__ u,
+                                                              const _Float16* __restrict__ x, _Float16* __restrict__ du16,
+                                                              float* __restrict__ partial, int B, int H, int W, int C,
+                                                              int rows_per_block) {
+    const int cg = C / 8;
+    const int blocks_per_img = (H + rows_per_block - 1) / rows_per_block;
+    const int b = blockIdx.x / blocks_per_img;
+    const int y0 = (blockIdx.x - b * blocks_per_img) * rows_per_block;
+    const int y1 = min(y0 + rows_per_block, H);
+    extern __shared__ float red[];                                 // [256][10 * 8] would be 80 KB: reduce tap by tap instead
+    for (int gbase = 0; gbase < cg; gbase += 256) {
+        const int gw = min(cg - gbase, 256);
+        const int phases = max(256 / gw, 1);
+        const int gi = threadIdx.x % gw, ph = threadIdx.x / gw;
+        const int c0 = (gbase + gi) * 8;
+        float s[10][8];
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[t][e] = 0.f;
+        if (ph < phases) {
+            for (int y = y0; y < y1; ++y) {
+                for (int xx = ph; xx < W; xx += phases) {
+                    const int64_t o = (((int64_t)b * H + y) * W + xx) * C + c0;
+                    const f16x8 g8 = *reinterpret_cast<const f16x8*>(dh + o);
+                    const f16x8 u8 = *reinterpret_cast<const f16x8*>(u + o);
+                    f16x8 d8;
+                    float d[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        d8[e] = (_Float16)((float)g8[e] * gelu_grad_f((float)u8[e]));
+                        d[e] = (float)d8[e];
+                        s[9][e] += d[e];
+                    }
+                    *reinterpret_cast<f16x8*>(du16 + o) = d8;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int yy = y + dy - 1;
+                        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int xi = xx + dx - 1;
+                            if (xi < 0 || xi >= W) continue;
+                            const f16x8 v = *reinterpret_cast<const f16x8*>(x + (((int64_t)b * H + yy) * W + xi) * C + c0);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) s[dy * 3 + dx][e] += d[e] * (float)v[e];
+                        }
+                    }
+                }
+            }
+        }
+        // fold the x phases in fixed order, one tap at a time through LDS (256 x 8 floats)
+        for (int t = 0; t < 10; ++t) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[t][e];
+            __syncthreads();
+            if (threadIdx.x < gw) {
+                float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int p = 0; p < phases; ++p)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) tot[e] += red[(p * gw + threadIdx.x) * 8 + e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) partial[((int64_t)blockIdx.x * 10 + t) * C + (gbase + threadIdx.x) * 8 + e] = tot[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dw [C][3][3] (torch's [C,1,3,3] memory) and db [C] from the partials; scale = 1 / loss scale
+__global__ __launch_bounds__(256) void dwconv_param_grad_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                float* __restrict__ db, int blocks, int C, float scale, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 10 * C) return;
+    const int t = i / C, c = i - t * C;
+    float s = 0.f;
+    for (int k = 0; k < blocks; ++k) s += partial[((int64_t)k * 10 + t) * C + c];
+    s *= scale;
+    float* dst = t < 9 ? dw + (int64_t)c * 9 + t : db + c;
+    if (accumulate) s += *dst;
+    *dst = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row gathers.  Patch (oy, ox) of image b = the R x S window at (oy * stride - pad, ox * stride - pad); its row in `cols`
+// holds k = (ky * S + kx) * C + c for the taps inside the image, zeros elsewhere, zero-padded to Kp columns.
+//   SRC 0: src fp32 [B][H][W][C]     SRC 1: src fp16 [B][H][W][C]     SRC 2: src fp32 NCHW [B][C][H][W] (the image)
+// ---------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ src, _Float16* __restrict__ cols, int B, int H, int W,
+                                                     int C, int R, int S, int stride, int pad, int Ho, int Wo, int Kp) {
+    if constexpr (SRC == 2) {
+        const int64_t total = (int64_t)B * Ho * Wo * Kp;
+        const float* s = static_cast<const float*>(src);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int k = (int)(i % Kp);
+            int64_t m = i / Kp;
+            const int ox = (int)(m % Wo);
+            m /= Wo;
+            const int oy = (int)(m % Ho);
+            const int b = (int)(m / Ho);
+            float v = 0.f;
+            if (k < R * S * C) {
+                const int tap = k / C, c = k - tap * C;
+                const int ky = tap / S, kx = tap - ky * S;
+                const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = s[(((int64_t)b * C + c) * H + iy) * W + ix];
+            }
+            cols[i] = (_Float16)v;
+        }
+    } else {
+        const int cg = C / 8, kg = Kp / 8;
+        const int64_t total = (int64_t)B * Ho * Wo * kg;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int g = (int)(i % kg);
+            int64_t m = i / kg;
+            const int ox = (int)(m % Wo);
+            m /= Wo;
+            const int oy = (int)(m % Ho);
+            const int b = (int)(m / Ho);
+            f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (g < R * S * cg) {
+                const int tap = g / cg, c8 = g - tap * cg;
+                const int ky = tap / S, kx = tap - ky * S;
+                const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const int64_t off = (((int64_t)b * H + iy) * W + ix) * C + c8 * 8;
+                    if constexpr (SRC == 0) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(static_cast<const float*>(src) + off);
+                        const float4 v1 = *reinterpret_cast<const float4*>(static_cast<const float*>(src) + off + 4);
+                        o = (f16x8){(_Float16)v0.x, (_Float16)v0.y, (_Float16)v0.z, (_Float16)v0.w,
+                                    (_Float16)v1.x, (_Float16)v1.y, (_Float16)v1.z, (_Float16)v1.w};
+                    } else {
+                        o = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(src) + off);
+                    }
+                }
+            }
+            *reinterpret_cast<f16x8*>(cols + i * 8) = o;
+        }
+    }
+}
+
+// Adjoint gather (deterministic, no atomics): dst[b][iy][ix][c] (+)= sum over the taps (ky, kx) with
+// (iy + pad - ky) % stride == 0, (ix + pad - kx) % stride == 0 and the patch inside [0,Ho)x[0,Wo) of dcols[patch][(ky*S+kx)*C + c].
+//   OUT32: dst fp32, overwritten (x gscale)      else: dst fp16, accumulated (dst += value)
+template <bool OUT32>
+__global__ __launch_bounds__(256) void col2im_kernel(const _Float16* __restrict__ dcols, void* __restrict__ dst, int B, int H, int W,
+                                                     int C, int R, int S, int stride, int pad, int Ho, int Wo, int Kp, float gscale) {
+    const int cg = C / 8;
+    const int64_t total = (int64_t)B * H * W * cg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(i % cg);
+        int64_t m = i / cg;
+        const int ix = (int)(m % W);
+        m /= W;
+        const int iy = (int)(m % H);
+        const int b = (int)(m / H);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ky = (iy + pad) % stride; ky < R; ky += stride) {
+            const int oy = (iy + pad - ky) / stride;
+            if (oy < 0 || oy >= Ho) continue;
+            for (int kx = (ix + pad) % stride; kx < S; kx += stride) {
+                const int ox = (ix + pad - kx) / stride;
+                if (ox < 0 || ox >= Wo) continue;
+                const f16x8 v = *reinterpret_cast<const f16x8*>(dcols + (((int64_t)b * Ho + oy) * Wo + ox) * Kp + (ky * S + kx) * C + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        }
+        if constexpr (OUT32) {
+            float* o = static_cast<float*>(dst) + i * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0] * gscale, acc[1] * gscale, acc[2] * gscale, acc[3] * gscale);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4] * gscale, acc[5] * gscale, acc[6] * gscale, acc[7] * gscale);
+        } else {
+            _Float16* o = static_cast<_Float16*>(dst) + i * 8;
+            const f16x8 old = *reinterpret_cast<const f16x8*>(o);
+            f16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (_Float16)((float)old[e] + acc[e] * gscale);
+            *reinterpret_cast<f16x8*>(o) = r;
+        }
+    }
+}
+
+// fp32 -> fp16 with a scale (gradients entering the fp16 backward pass carry the loss scale)
+__global__ __launch_bounds__(256) void cast_scale_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n4, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<f16x4*>(y)[i] = (f16x4){(_Float16)(v.x * scale), (_Float16)(v.y * scale), (_Float16)(v.z * scale), (_Float16)(v.w * scale)};
+    }
+}
+
+// y[m][:] = x[m][:] * seg_scale[m / rows_per_seg]  (fp16; the backward of a DropPath-scaled branch, MixTransfomer.py:176-177)
+__global__ __launch_bounds__(256) void row_scale_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y,
+                                                        const float* __restrict__ seg_scale, int64_t n8, int c8, int rows_per_seg) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float s = seg_scale[(i / c8) / rows_per_seg];
+        const f16x8 v = reinterpret_cast<const f16x8*>(x)[i];
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)v[e] * s);
+        reinterpret_cast<f16x8*>(y)[i] = o;
+    }
+}
+
+}  // namespace mit
+}  // namespace diga
+
+using namespace diga;
+using namespace diga::mit;
+
+static inline unsigned grid_for(int64_t items, int per_block = 256, int64_t cap = 256 * 32) {
+    int64_t b = ceil_div(items, per_block);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" int diga_mit_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y16, float* y32,
+                                      int64_t ldy, float* mean, float* rstd, int64_t M, int64_t C, float eps, void* stream) {
+    DIGA_REQUIRE(x && gamma && beta && (y16 || y32) && M > 0 && C > 0, DIGA_EINVAL, "mit_layernorm_fwd: null pointer / empty shape");
+    DIGA_REQUIRE(C % 4 == 0 && C <= 512 && ldx % 4 == 0 && ldy % 4 == 0 && M < (1ll << 31), DIGA_EINVAL,
+                 "mit_layernorm_fwd: C %% 4 == 0, C <= 512 (C=%lld)", (long long)C);
+    DIGA_REQUIRE((mean == nullptr) == (rstd == nullptr), DIGA_EINVAL, "mit_layernorm_fwd: mean and rstd go together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DIGA_PROF_MIT_NORM, st, (double)M * C * (4.0 + (y16 ? 2.0 : 0.0) + (y32 ? 4.0 : 0.0)));
+    const unsigned grid = grid_for(M, 16);
+    const int nv = (int)ceil_div(C, 64);
+    _Float16* y = static_cast<_Float16*>(y16);
+#define DIGA_LN_FWD(NV_) hipLaunchKernelGGL(layernorm_fwd_kernel<NV_>, dim3(grid), dim3(256), 0, st, x, ldx, gamma, beta, y, y32, ldy, mean, rstd, (int)M, (int)C, eps)
+    if (nv <= 1) DIGA_LN_FWD(1);
+    else if (nv == 2) DIGA_LN_FWD(2);
+    else if (nv <= 5) DIGA_LN_FWD(5);
+    else DIGA_LN_FWD(8);
+#undef DIGA_LN_FWD
+    return launch_status("mit_layernorm_fwd");
+}
+
+static constexpr int kLnRowsPerBlock = 256;
+
+extern "C" size_t diga_mit_layernorm_bwd_workspace_bytes(int64_t M, int64_t C) {
+    return (size_t)ceil_div(M, kLnRowsPerBlock) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int diga_mit_layernorm_bwd(const void* dy, int dy_is_f32, int64_t ldg, float gscale, const float* x, int64_t ldx,
+                                      const float* gamma, const float* mean, const float* rstd, const float* dres, int64_t ldr,
+                                      float* dx32, void* dx16, int64_t ldo, float* dgamma, float* dbeta, float param_scale,
+                                      int accumulate, void* workspace, size_t workspace_bytes, int64_t M, int64_t C, void* stream) {
+    DIGA_REQUIRE(dy && x && gamma && mean && rstd && (dx32 || dx16) && dgamma && dbeta && workspace && M > 0 && C > 0, DIGA_EINVAL,
+                 "mit_layernorm_bwd: null pointer / empty shape");
+    DIGA_REQUIRE(C % 4 == 0 && C <= 512 && ldx % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && M < (1ll << 31), DIGA_EINVAL,
+                 "mit_layernorm_bwd: C %% 4 == 0, C <= 512");
+    const int blocks = (int)ceil_div(M, kLnRowsPerBlock);
+    DIGA_REQUIRE(workspace_bytes >= (size_t)blocks * 2 * (size_t)C * sizeof(float), DIGA_EWORKSPACE, "mit_layernorm_bwd: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DIGA_PROF_MIT_NORM, st, (double)M * C * ((dy_is_f32 ? 4.0 : 2.0) + 4.0 + (dres ? 4.0 : 0.0) + (dx32 ? 4.0 : 0.0) + (dx16 ? 2.0 : 0.0)));
+    float* part = static_cast<float*>(workspace);
+    _Float16* d16 = static_cast<_Float16*>(dx16);
+    const int nv = (int)ceil_div(C, 64);
+#define DIGA_LN_BWD(NV_, GT_) hipLaunchKernelGGL((layernorm_bwd_kernel<NV_, GT_>), dim3(blocks), dim3(256), 0, st, static_cast<const GT_*>(dy), ldg, x, ldx, gamma, mean, rstd, dres, ldr, dx32, d16, ldo, part, (int)M, (int)C, kLnRowsPerBlock, gscale)
+#define DIGA_LN_BWD_T(GT_)                \
+    do {                                  \
+        if (nv <= 1) DIGA_LN_BWD(1, GT_); \
+        else if (nv == 2) DIGA_LN_BWD(2, GT_); \
+        else if (nv <= 5) DIGA_LN_BWD(5, GT_); \
+        else DIGA_LN_BWD(8, GT_);         \
+    } while (0)
+    if (dy_is_f32) DIGA_LN_BWD_T(float);
+    else DIGA_LN_BWD_T(_Float16);
+#undef DIGA_LN_BWD_T
+#undef DIGA_LN_BWD
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)ceil_div(2 * C, 256)), dim3(256), 0, st, part, dgamma, dbeta, blocks, (int)C,
+                       param_scale, accumulate);
+    return launch_status("mit_layernorm_bwd");
+}
+
+extern "C" int diga_mit_dwconv_gelu_fwd(const void* x, const float* wt9, const float* bias, void* u16, void* h16, int64_t B, int64_t H,
+                                        int64_t W, int64_t C, void* stream) {
+    DIGA_REQUIRE(x && wt9 && h16 && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DIGA_EINVAL, "mit_dwconv_gelu_fwd: bad argument");
+    DIGA_REQUIRE(aligned16(x) && aligned16(h16) && aligned16(wt9), DIGA_EALIGN, "mit_dwconv_gelu_fwd: alignment");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);
+    ProfScope prof(DIGA_PROF_MIT_DWCONV, st, (double)B * H * W * C * (u16 ? 6.0 : 4.0));
+    hipLaunchKernelGGL(dwconv3x3_kernel<0>, dim3(grid_for(items, 256, 1 << 20)), dim3(256), 0, st, static_cast<const _Float16*>(x), wt9, bias,
+                       static_cast<_Float16*>(u16), static_cast<_Float16*>(h16), (int)B, (int)H, (int)W, (int)C);
+    return launch_status("mit_dwconv_gelu_fwd");
+}
+
+static constexpr int kDwRowsPerBlock = 4;
+
+extern "C" size_t diga_mit_dwconv_bwd_workspace_bytes(int64_t B, int64_t H, int64_t C) {
+    return (size_t)B * (size_t)ceil_div(H, kDwRowsPerBlock) * 10 * (size_t)C * sizeof(float);
+}
+
+/* dh: gradient wrt gelu output, u: saved pre-activation, x: the conv input (fc1 output); du16: scratch for du [B,H,W,C];
+ * wt9_flipped: the taps in reverse order ([8 - t][C]); dx16 = dw^T(du); dw [C][9] / db [C] get scale * sums. */
+extern "C" int diga_mit_dwconv_gelu_bwd(const void* dh, const void* u, const void* x, const float* wt9_flipped, void* du16, void* dx16,
+                                        float* dw, float* db, float param_scale, int accumulate, void* workspace, size_t workspace_bytes,
+                                        int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+    DIGA_REQUIRE(dh && u && x && wt9_flipped && du16 && dx16 && dw && db && workspace && B > 0 && H > 0 && W > 0 && C % 8 == 0 && C > 0,
+                 DIGA_EINVAL, "mit_dwconv_gelu_bwd: bad argument");
+    const int blocks = (int)(B * ceil_div(H, kDwRowsPerBlock));
+    DIGA_REQUIRE(workspace_bytes >= (size_t)blocks * 10 * (size_t)C * sizeof(float), DIGA_EWORKSPACE, "mit_dwconv_gelu_bwd: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DIGA_PROF_MIT_DWCONV, st, (double)B * H * W * C * 12.0);
+    hipLaunchKernelGGL(dwconv_bwd_prep_kernel, dim3(blocks), dim3(256), 256 * 8 * sizeof(float), st, static_cast<const _Float16*>(dh),
+                       static_cast<const _Float16*>(u), static_cast<const _Float16*>(x), static_cast<_Float16*>(du16),
+                       static_cast<float*>(workspace), (int)B, (int)H, (int)W, (int)C, kDwRowsPerBlock);
+    hipLaunchKernelGGL(dwconv_param_grad_kernel, dim3((unsigned)ceil_div(10 * C, 256)), dim3(256), 0, st, static_cast<const float*>(workspace), dw,
+                       db, blocks, (int)C, param_scale, accumulate);
+    const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);
+    hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3(grid_for(items, 256, 1 << 20)), dim3(256), 0, st, static_cast<const _Float16*>(du16), wt9_flipped,
+                       (const float*)nullptr, (_Float16*)nullptr, static_cast<_Float16*>(dx16), (int)B, (int)H, (int)W, (int)C);
+    return launch_status("mit_dwconv_gelu_bwd");
+}
+
+extern "C" int diga_mit_im2col(const void* src, int src_kind, void* cols, int64_t B, int64_t H, int64_t W, int64_t C, int64_t R, int64_t S,
+                               int64_t stride, int64_t pad, int64_t Ho, int64_t Wo, int64_t Kp, void* stream) {
+    DIGA_REQUIRE(src && cols && B > 0 && H > 0 && W > 0 && C > 0 && R > 0 && S > 0 && stride > 0 && Ho > 0 && Wo > 0, DIGA_EINVAL,
+                 "mit_im2col: bad argument");
+    DIGA_REQUIRE(Kp >= R * S * C && Kp % 8 == 0 && src_kind >= 0 && src_kind <= 2 && (src_kind == 2 || C % 8 == 0), DIGA_EINVAL,
+                 "mit_im2col: Kp %% 8 == 0, Kp >= R*S*C, C %% 8 == 0 for NHWC sources");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DIGA_PROF_MIT_MISC, st, (double)B * Ho * Wo * Kp * 2.0 * 2.0);
+    _Float16* c = static_cast<_Float16*>(cols);
+    if (src_kind == 2) {
+        hipLaunchKernelGGL(im2col_kernel<2>, dim3(grid_for(B * Ho * Wo * Kp)), dim3(256), 0, st, src, c, (int)B, (int)H, (int)W, (int)C, (int)R,
+                           (int)S, (int)stride, (int)pad, (int)Ho, (int)Wo, (int)Kp);
+    } else if (src_kind == 0) {
+        hipLaunchKernelGGL(im2col_kernel<0>, dim3(grid_for(B * Ho * Wo * (Kp / 8))), dim3(256), 0, st, src, c, (int)B, (int)H, (int)W, (int)C,
+                           (int)R, (int)S, (int)stride, (int)pad, (int)Ho, (int)Wo, (int)Kp);
+    } else {
+        hipLaunchKernelGGL(im2col_kernel<1>, dim3(grid_for(B * Ho * Wo * (Kp / 8))), dim3(256), 0, st, src, c, (int)B, (int)H, (int)W, (int)C,
+                           (int)R, (int)S, (int)stride, (int)pad, (int)Ho, (int)Wo, (int)Kp);
+    }
+    return launch_status("mit_im2col");
+}
+
+extern "C" int diga_mit_col2im(const void* dcols, void* dst, int dst_f32, float gscale, int64_t B, int64_t H, int64_t W, int64_t C, int64_t R,
+                               int64_t S, int64_t stride, int64_t pad, int64_t Ho, int64_t Wo, int64_t Kp, void* stream) {
+    DIGA_REQUIRE(dcols && dst && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && Kp >= R * S * C && Kp % 8 == 0 && stride > 0, DIGA_EINVAL,
+                 "mit_col2im: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DIGA_PROF_MIT_MISC, st, (double)B * Ho * Wo * Kp * 2.0 + (double)B * H * W * C * (dst_f32 ? 4.0 : 4.0));
+    const unsigned grid = grid_for(B * H * W * (C / 8));
+    if (dst_f32)
+        hipLaunchKernelGGL(col2im_kernel<true>, dim3(grid), dim3(256), 0, st, static_cast<const _Float16*>(dcols), dst, (int)B, (int)H, (int)W,
+                           (int)C, (int)R, (int)S, (int)stride, (int)pad, (int)Ho, (int)Wo, (int)Kp, gscale);
+    else
+        hipLaunchKernelGGL(col2im_kernel<false>, dim3(grid), dim3(256), 0, st, static_cast<const _Float16*>(dcols), dst, (int)B, (int)H, (int)W,
+                           (int)C, (int)R, (int)S, (int)stride, (int)pad, (int)Ho, (int)Wo, (int)Kp, gscale);
+    return launch_status("mit_col2im");
+}
+
+extern "C" int diga_mit_cast_scale(const float* x, void* y16, int64_t n, float scale, void* stream) {
+    DIGA_REQUIRE(x && y16 && n > 0 && n % 4 == 0, DIGA_EINVAL, "mit_cast_scale: n %% 4 == 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DIGA_PROF_MIT_MISC, st, (double)n * 6.0);
+    hipLaunchKernelGGL(cast_scale_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, static_cast<_Float16*>(y16), n / 4, scale);
+    return launch_status("mit_cast_scale");
+}
+
+extern "C" int diga_mit_row_scale(const void* x16, void* y16, const float* seg_scale, int64_t rows_per_seg, int64_t M, int64_t C,
+                                  void* stream) {
+    DIGA_REQUIRE(x16 && y16 && seg_scale && rows_per_seg > 0 && M > 0 && C > 0 && C % 8 == 0, DIGA_EINVAL, "mit_row_scale: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(DIGA_PROF_MIT_MISC, st, (double)M * C * 4.0);
+    hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for(M * C / 8)), dim3(256), 0, st, static_cast<const _Float16*>(x16),
+                       static_cast<_Float16*>(y16), seg_scale, M * C / 8, (int)(C / 8), (int)rows_per_seg);
+    return launch_status("mit_row_scale");
+}

@@ -453,6 +453,13 @@ enum {
     DIGA_PROF_CONV_BWD_WEIGHT,
     DIGA_PROF_NORM,
     DIGA_PROF_ELEMENTWISE,
+    DIGA_PROF_MIT_GEMM,        /* fp16 Linear / patch-embedding GEMMs, forward and backward-data (include/diga_mit.h) */
+    DIGA_PROF_MIT_WGRAD,       /* fp16 weight-gradient GEMMs */
+    DIGA_PROF_MIT_ATTN_FWD,    /* spatial-reduction attention, forward */
+    DIGA_PROF_MIT_ATTN_BWD,    /* spatial-reduction attention, backward (dQ, dK/dV) */
+    DIGA_PROF_MIT_NORM,        /* LayerNorm forward / backward */
+    DIGA_PROF_MIT_DWCONV,      /* depthwise 3x3 + GELU (Mix-FFN), forward / backward */
+    DIGA_PROF_MIT_MISC,        /* im2col / col2im, casts, column sums */
     DIGA_PROF_NTAGS
 };
 int diga_prof_enable(int on);

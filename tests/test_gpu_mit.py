@@ -1,0 +1,306 @@
+"""GPU parity of the MiT / SegFormer student (BASELINE configs[4], include/diga_mit.h): every kernel against float64 torch
+ops on the SAME fp16-rounded operands (so the bound is the kernel's own fp32-accumulate / fp16-store error), then the whole
+mit_b5 encoder, forward and backward, against the capture of the REFERENCE module (tests/golden/mit.npz) and mit_b1 at the
+benchmark geometry (768x768: 36864 queries x 576 keys) against tests/golden/mit768.npz.
+
+Tolerances (fp16 storage = 2^-11 relative per stored element): kernels 2e-3 of the output scale; encoder features 1e-2 of
+scale after 52 blocks of fp16 branches on an fp32 residual stream (measured ~2e-3); parameter-gradient norms 3e-2."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mit as om
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _lib():
+    from diga_amd import _lib
+    return _lib
+
+
+def _rel(got, want):
+    want = want.detach().double().cpu()
+    return float((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def h16(t):
+    return t.to(torch.float16)
+
+
+GEMM_CASES = [(300, 64, 64), (1000, 256, 64), (513, 320, 1280), (129, 1280, 320), (64, 2048, 512), (777, 160, 4096), (5, 64, 160)]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_CASES)
+def test_gemm_nt_epilogues(m, n, k):
+    from diga_amd.model.networks.MixTransfomer import _Ops
+    g = synth.gen(m + n + k)
+    a = h16(torch.randn((m, k), generator=g)).to(DEV)
+    w = h16(torch.randn((n, k), generator=g) / k ** 0.5).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn((m, n), generator=g).to(DEV)
+    rps = (m + 2) // 3
+    seg = torch.tensor([1.0, 0.0, 1.25, 2.0][: (m + rps - 1) // rps]).to(DEV)
+    ops = _Ops(torch.device(DEV))
+    ref = a.double() @ w.double().t()
+    assert _rel(ops.gemm(a, w, None, n, out_f32=True), ref) < 1e-5
+    assert _rel(ops.gemm(a, w, bias, n), ref + bias.double()) < 2e-3
+    segrow = seg[torch.arange(m, device=DEV) // rps].double()[:, None]
+    want = res.double() + segrow * (0.5 * ref + bias.double())
+    assert _rel(ops.gemm(a, w, bias, n, out_f32=True, residual=res, seg=seg, rows_per_seg=rps, alpha=0.5), want) < 1e-5
+    base = h16(torch.randn((m, n), generator=g)).to(DEV)
+    out = base.clone()
+    ops.gemm(a, w, None, n, out=out, accumulate=True)
+    assert _rel(out, base.double() + ref) < 2e-3
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 64, 256), (5000, 320, 1280), (37, 72, 24), (40000, 64, 64), (300, 512, 160), (33, 128, 2880)])
+def test_gemm_tn_weight_gradient(m, n, k):
+    from diga_amd.model.networks.MixTransfomer import _Ops
+    g = synth.gen(7 * m + n + k)
+    dy = h16(torch.randn((m, n), generator=g)).to(DEV)
+    x = h16(torch.randn((m, k), generator=g)).to(DEV)
+    ops = _Ops(torch.device(DEV))
+    dw = ops.wgrad(dy, x, 0.25)
+    assert tuple(dw.shape) == (n, k)
+    assert _rel(dw, 0.25 * dy.double().t() @ x.double()) < 2e-5
+    assert torch.equal(dw, ops.wgrad(dy, x, 0.25)), "split-K slabs must reduce in a fixed order"
+    cs = ops.colsum(dy, 2.0) if n % 8 == 0 else None
+    if cs is not None:
+        assert _rel(cs, 2.0 * dy.double().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("c", [64, 128, 320, 512, 32, 160])
+def test_layernorm_forward_backward(c):
+    from diga_amd.model.networks.MixTransfomer import _Ops
+    g = synth.gen(c)
+    m = 1037
+    x = (torch.randn((m, c), generator=g) * 2 + 0.5).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(c, generator=g)).to(DEV)
+    ops = _Ops(torch.device(DEV))
+    y16, y32, mean, rstd = ops.ln_fwd(x, gamma, beta, 1e-6, want16=True, want32=True)
+    xr = x.double().cpu().requires_grad_()
+    gr, br = gamma.double().cpu().requires_grad_(), beta.double().cpu().requires_grad_()
+    yr = F.layer_norm(xr, (c,), gr, br, 1e-6)
+    assert _rel(y32, yr) < 2e-6 and _rel(y16, yr) < 1e-3
+    dy = h16(torch.randn((m, c), generator=g)).to(DEV)
+    dres = torch.randn((m, c), generator=g).to(DEV)
+    (yr * (3.0 * dy.double().cpu())).sum().backward()
+    dx32, dx16, dg, db = ops.ln_bwd(dy, x, gamma, mean, rstd, dres, True, True, 0.5, gscale=3.0)
+    assert _rel(dx32, xr.grad + dres.double().cpu()) < 1e-5
+    assert _rel(dx16, xr.grad + dres.double().cpu()) < 1e-3
+    assert _rel(dg, 0.5 * gr.grad) < 1e-5 and _rel(db, 0.5 * br.grad) < 1e-5
+    dx32b, _, dg2, _ = ops.ln_bwd(3.0 * dy.float(), x, gamma, mean, rstd, None, True, False, 0.5)
+    assert _rel(dx32b, xr.grad) < 1e-5 and _rel(dg2, 0.5 * gr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("b,h,w,c", [(2, 9, 7, 64), (1, 33, 18, 256), (2, 6, 5, 1280), (1, 48, 48, 40)])
+def test_dwconv_gelu_forward_backward(b, h, w, c):
+    lib = _lib()
+    P = lib.ptr
+    g = synth.gen(b * h + w + c)
+    x = h16(torch.randn((b, h, w, c), generator=g)).to(DEV)
+    wt = (0.4 * torch.randn((c, 1, 3, 3), generator=g)).to(DEV)
+    bias = (0.1 * torch.randn(c, generator=g)).to(DEV)
+    wt9 = wt.reshape(c, 9).t().contiguous()
+    u = torch.empty_like(x)
+    hh = torch.empty_like(x)
+    lib.call("diga_mit_dwconv_gelu_fwd", P(x), P(wt9), P(bias), P(u), P(hh), b, h, w, c, lib.stream())
+    xr = x.double().cpu().permute(0, 3, 1, 2).requires_grad_()
+    wr, br = wt.double().cpu().requires_grad_(), bias.double().cpu().requires_grad_()
+    ur = F.conv2d(xr, wr, br, 1, 1, 1, c)
+    assert _rel(u.permute(0, 3, 1, 2), ur) < 1e-3
+    # the kernel applies GELU to the fp16-ROUNDED pre-activation (what the backward pass re-reads)
+    assert _rel(hh.permute(0, 3, 1, 2), F.gelu(u.double().cpu().permute(0, 3, 1, 2))) < 1e-3
+    dh = h16(torch.randn((b, h, w, c), generator=g)).to(DEV)
+    u_leaf = u.double().cpu().permute(0, 3, 1, 2).requires_grad_()
+    (F.gelu(u_leaf) * dh.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    du_ref = u_leaf.grad                                           # gelu'(u16) * dh
+    ur.backward(h16(du_ref).double())                              # the kernel stores du in fp16 before the conv adjoint
+    du = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    dw = torch.empty((c, 9), device=DEV)
+    dbias = torch.empty(c, device=DEV)
+    ws = torch.empty(lib.lib.diga_mit_dwconv_bwd_workspace_bytes(b, h, c), dtype=torch.uint8, device=DEV)
+    lib.call("diga_mit_dwconv_gelu_bwd", P(dh), P(u), P(x), P(wt9.flip(0).contiguous()), P(du), P(dx), P(dw), P(dbias), 2.0, 0, P(ws),
+             ws.numel(), b, h, w, c, lib.stream())
+    assert _rel(du.permute(0, 3, 1, 2), du_ref) < 1e-3
+    assert _rel(dx.permute(0, 3, 1, 2), xr.grad) < 2e-3
+    assert _rel(dw.reshape(c, 1, 3, 3), 2.0 * wr.grad) < 1e-4
+    assert _rel(dbias, 2.0 * br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("kind,c,k,stride,pad,hw", [(2, 3, 7, 4, 3, (37, 29)), (0, 64, 3, 2, 1, (17, 12)), (1, 128, 4, 4, 0, (16, 12)),
+                                                    (1, 64, 8, 8, 0, (24, 16)), (0, 320, 3, 2, 1, (9, 7))])
+def test_im2col_gemm_is_the_convolution_and_col2im_its_adjoint(kind, c, k, stride, pad, hw):
+    from diga_amd.model.networks.MixTransfomer import _conv16, _Ops
+    g = synth.gen(kind * 100 + c + k)
+    b, (h, w) = 2, hw
+    cout = 96
+    x = h16(torch.randn((b, c, h, w), generator=g)).float()
+    wt = h16(torch.randn((cout, c, k, k), generator=g) / (c * k * k) ** 0.5).float()
+    ops = _Ops(torch.device(DEV))
+    src = x.to(DEV) if kind == 2 else x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    if kind == 1:
+        src = src.half()
+    w16, wt16, kp = _conv16(wt.to(DEV), True)
+    cols, ho, wo = ops.im2col(src, kind, b, h, w, c, k, stride, pad, kp)
+    y = ops.gemm(cols, w16, None, cout, out_f32=True).view(b, ho, wo, cout).permute(0, 3, 1, 2)
+    xr = x.double().requires_grad_()
+    yr = F.conv2d(xr, wt.double(), None, stride, pad)
+    assert tuple(y.shape) == tuple(yr.shape) and _rel(y, yr) < 1e-5
+    if kind == 2:
+        return
+    dy = h16(torch.randn(yr.shape, generator=g))
+    yr.backward(dy.double())
+    d_cols = ops.gemm(dy.permute(0, 2, 3, 1).reshape(-1, cout).contiguous().to(DEV), wt16, None, kp)
+    dx32 = torch.empty((b, h, w, c), device=DEV)
+    ops.col2im(d_cols, dx32, True, b, h, w, c, k, stride, pad, ho, wo, kp, gscale=2.0)
+    assert _rel(dx32.permute(0, 3, 1, 2), 2.0 * xr.grad) < 2e-3
+    base = h16(torch.randn((b, h, w, c), generator=g)).to(DEV)
+    acc = base.clone()
+    ops.col2im(d_cols, acc, False, b, h, w, c, k, stride, pad, ho, wo, kp)
+    assert _rel(acc.permute(0, 3, 1, 2), base.double().cpu().permute(0, 3, 1, 2) + xr.grad) < 3e-3
+
+
+ATTN_CASES = [(2, 2, 300, 12), (1, 1, 600, 576), (1, 5, 70, 130), (2, 8, 12, 12), (1, 2, 257, 64), (1, 1, 2304, 576)]
+
+
+@pytest.mark.parametrize("b,heads,n,nk", ATTN_CASES)
+def test_attention_forward_backward(b, heads, n, nk):
+    lib = _lib()
+    P = lib.ptr
+    g = synth.gen(b * 1000 + heads * 100 + n + nk)
+    c = heads * 64
+    q = h16(torch.randn((b * n, c), generator=g)).to(DEV)
+    kv = h16(torch.randn((b * nk, 2 * c), generator=g)).to(DEV)
+    scale = 0.125
+    out = torch.empty_like(q)
+    lse = torch.empty((b, heads, n), device=DEV)
+    lib.call("diga_mit_attention_fwd", P(q), c, P(kv), 2 * c, P(out), c, P(lse), b, heads, n, nk, scale, lib.stream())
+    qr = q.double().cpu().requires_grad_()
+    kvr = kv.double().cpu().requires_grad_()
+    qh = qr.reshape(b, n, heads, 64).permute(0, 2, 1, 3)
+    kvh = kvr.reshape(b, nk, 2, heads, 64).permute(2, 0, 3, 1, 4)
+    att = ((qh @ kvh[0].transpose(-2, -1)) * scale).softmax(-1)
+    ref = (att @ kvh[1]).transpose(1, 2).reshape(b * n, c)
+    assert _rel(out, ref) < 2e-3
+    lse_ref = torch.logsumexp((qh @ kvh[0].transpose(-2, -1)) * scale, -1) / np.log(2.0)
+    assert float((lse.double().cpu() - lse_ref).abs().max()) < 1e-3
+    d_out = h16(torch.randn((b * n, c), generator=g)).to(DEV)
+    ref.backward(d_out.double().cpu())
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    ws = torch.empty(lib.lib.diga_mit_attention_bwd_workspace_bytes(b, heads, n, nk), dtype=torch.uint8, device=DEV)
+    lib.call("diga_mit_attention_bwd", P(q), c, P(kv), 2 * c, P(out), P(d_out), c, P(lse), P(dq), P(dkv), P(ws), ws.numel(), b, heads, n,
+             nk, scale, lib.stream())
+    assert _rel(dq, qr.grad) < 4e-3
+    assert _rel(dkv, kvr.grad) < 4e-3
+    dkv2 = torch.empty_like(kv)
+    lib.call("diga_mit_attention_bwd", P(q), c, P(kv), 2 * c, P(out), P(d_out), c, P(lse), P(dq), P(dkv2), P(ws), ws.numel(), b, heads, n,
+             nk, scale, lib.stream())
+    assert torch.equal(dkv, dkv2), "dK / dV partial slabs must reduce in a fixed order"
+
+
+def _model(arch_name):
+    from diga_amd.model.networks import MixTransfomer as M
+    m = getattr(M, arch_name)()
+    m.load_state_dict(om.state_dict(getattr(om, arch_name.upper())))
+    return m.to(DEV)
+
+
+def test_state_dict_keys_and_shapes_match_reference(golden):
+    g = golden("mit")
+    m = _model("mit_b5")
+    assert list(m.state_dict().keys()) == g["keys"].tolist()
+    assert sum(p.numel() for p in m.parameters()) == 81443008
+
+
+def test_mit_b5_forward_backward_vs_reference_capture(golden):
+    g = golden("mit")
+    m = _model("mit_b5").eval()                                    # eval(): DropPath off, as in the capture
+    outs = m(g.t("x").to(DEV))
+    worst = 0.0
+    for i, o in enumerate(outs):
+        want = g.t(f"c{i + 1}")
+        assert tuple(o.shape) == tuple(want.shape)
+        e = _rel(o, want)
+        worst = max(worst, e)
+        assert e < 1e-2, (i, e)
+    sum((o * g.t(f"probe{i + 1}").to(DEV)).sum() for i, o in enumerate(outs)).backward()
+    named = dict(m.named_parameters())
+    keys = g["keys"].tolist()
+    norms = np.array([float(named[k].grad.norm()) for k in keys])
+    ratio = norms / np.maximum(g["grad_norms"], 1e-12)
+    bad = [(k, r) for k, r in zip(keys, ratio) if not 0.97 < r < 1.03]
+    assert not bad, bad[:10]
+    gworst = 0.0
+    for k in [n[2:] for n in g if n.startswith("g_")]:
+        name = [n for n in keys if n.replace(".", "_") == k][0]
+        step = int(g["gstep_" + k])
+        want = g.t("g_" + k)
+        e = _rel(named[name].grad.reshape(-1)[::step], want)
+        gworst = max(gworst, e)
+        assert e < 3e-2, (name, e)
+    print(f"mit_b5 vs reference: features max err {worst:.2e} of scale, sampled gradients {gworst:.2e}, "
+          f"gradient-norm ratios {ratio.min():.4f} .. {ratio.max():.4f}")
+
+
+def test_loss_scale_does_not_change_the_gradients(golden):
+    g = golden("mit")
+    res = []
+    for ls in (64.0, 4096.0):
+        m = _model("mit_b1").eval()
+        m.loss_scale = ls
+        outs = m(g.t("x").to(DEV))
+        sum((o * g.t(f"probe{i + 1}").to(DEV)[:, : o.shape[1]]).sum() for i, o in enumerate(outs)).backward()
+        res.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for k in res[0]:
+        assert _rel(res[0][k], res[1][k]) < 2e-2, k
+
+
+def test_mit_b1_benchmark_geometry_vs_reference_capture(golden):
+    """768x768: stage 1 runs 36864 queries against 576 keys (9 key blocks, 144 query blocks per image)."""
+    g = golden("mit768")
+    x = torch.rand((1, 3, 768, 768), generator=synth.gen(int(g["seed"]))) * 2 - 1
+    m = _model("mit_b1").eval()
+    with torch.no_grad():
+        outs = m(x.to(DEV))
+    assert [tuple(o.shape) for o in outs] == [(1, 64, 192, 192), (1, 128, 96, 96), (1, 320, 48, 48), (1, 512, 24, 24)]
+    for o, key, step, mx in zip(outs, ("c1_sample", "c2_sample", "c3_sample", "c4_sample"), (211, 53, 7, 3), g["maxs"]):
+        e = float((o.float().cpu().reshape(-1)[::step] - g.t(key)).abs().max()) / float(mx)
+        assert e < 1e-2, (key, e)
+    sums = np.array([float(o.abs().sum()) for o in outs])
+    assert np.allclose(sums, g["sums"], rtol=2e-3)
+
+
+def test_drop_path_training_mode_statistics():
+    """Train mode draws a per-image keep mask per branch (timm DropPath): with rate p the expected output equals the eval
+    output; with p = 0 train and eval agree exactly."""
+    m = _model("mit_b1")
+    x = (torch.rand((2, 3, 64, 64), generator=synth.gen(3)) * 2 - 1).to(DEV)
+    m.reset_drop_path(0.0)
+    m.train()
+    with torch.no_grad():
+        a = m(x)[3]
+    m.eval()
+    with torch.no_grad():
+        b = m(x)[3]
+    assert torch.equal(a, b)
+    m.reset_drop_path(0.5)
+    m.train()
+    torch.manual_seed(0)
+    with torch.no_grad():
+        c = m(x)[3]
+    assert not torch.equal(c, b) and bool(torch.isfinite(c).all())
+    # backward through a dropped branch
+    m.zero_grad()
+    torch.manual_seed(1)
+    m(x)[3].sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())

@@ -21,9 +21,12 @@ from oracle import synth
 
 
 def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "diga_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(diga_[a-z0-9_]+)\s*\(", src)))
+    syms = set()
+    for name in ("diga_hip.h", "diga_mit.h"):
+        src = open(os.path.join(ROOT, "include", name)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        syms |= set(re.findall(r"\b(diga_[a-z0-9_]+)\s*\(", src))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol():
@@ -31,11 +34,11 @@ def test_library_exports_every_declared_symbol():
     syms = _header_symbols()
     assert len(syms) >= 20
     for s in syms:
-        assert hasattr(_lib.lib, s), f"{s} declared in include/diga_hip.h but not exported"
+        assert hasattr(_lib.lib, s), f"{s} declared in include/*.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in diga_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(syms)
     assert _lib.lib.diga_version() == 1
-    assert len(_lib.PROF_TAGS) == 16
+    assert len(_lib.PROF_TAGS) == 23
 
 
 def test_abi_argument_errors_without_gpu():

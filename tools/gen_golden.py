@@ -477,6 +477,90 @@ def gen_full512x1024():
     _gen_fullsize("full512x1024", 512, 1024, 8512)
 
 
+# ------------------------------------------------------------------ G-mit (MiT-B5 encoder, BASELINE configs[4])
+def _import_reference_mit():
+    """The reference's model/networks/MixTransfomer.py imports timm and mmcv (both absent here).  What it takes from them
+    is NOT arithmetic of the forward pass: `DropPath` (stochastic depth: the identity in eval(), which is how the capture
+    runs), `to_2tuple` (int -> pair), `trunc_normal_` (initialisation; the capture loads its own deterministic weights),
+    `register_model` / `_cfg` (registry decorators, unused), mmcv's `load_checkpoint` / `get_logger` (I/O).  Stand-ins for
+    exactly those names let the reference module import; every nn.Module and every tensor op that runs is the reference's."""
+    import importlib.util
+
+    class _DropPath(torch.nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            assert not self.training, "the capture runs in eval(): DropPath is the identity"
+            return x
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mod("timm")
+    mod("timm.models")
+    mod("timm.models.layers", DropPath=_DropPath, to_2tuple=lambda v: (v, v) if not isinstance(v, tuple) else v,
+        trunc_normal_=lambda t, std=1.0, **k: t)
+    mod("timm.models.registry", register_model=lambda f: f)
+    mod("timm.models.vision_transformer", _cfg=lambda **k: k)
+    mod("mmcv")
+    mod("mmcv.runner", load_checkpoint=lambda *a, **k: None)
+    mod("mmcv.utils", get_logger=lambda *a, **k: None)
+    spec = importlib.util.spec_from_file_location("ref_mit", os.path.join(REF, "model", "networks", "MixTransfomer.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def gen_mit():
+    from oracle import mit as om
+    ref = _import_reference_mit()
+    torch.manual_seed(0)
+    net = ref.mit_b5()
+    sd = om.state_dict(om.MIT_B5)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    net.eval()                                                  # DropPath off; nothing else depends on the mode
+    g = synth.gen(55)
+    x = torch.rand((2, 3, 128, 96), generator=g) * 2 - 1        # H != W; stage maps 32x24, 16x12, 8x6, 4x3; 12 keys per stage
+    outs = net(x)
+    probes = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+    res = {"x": x, "keys": np.array(list(sd.keys()))}
+    for i, (o, p) in enumerate(zip(outs, probes)):
+        res[f"c{i + 1}"] = o
+        res[f"probe{i + 1}"] = p
+    named = dict(net.named_parameters())
+    res["grad_norms"] = np.array([float(named[k].grad.norm()) for k in sd.keys()])
+    res["grad_sums"] = np.array([synth.checksum(named[k].grad) for k in sd.keys()])
+    for k in ["patch_embed1.proj.weight", "patch_embed3.proj.weight", "block1.0.attn.sr.weight", "block1.2.attn.q.weight",
+              "block2.3.attn.kv.weight", "block3.0.norm1.weight", "block3.20.mlp.fc1.weight", "block3.39.mlp.dwconv.dwconv.weight",
+              "block3.39.mlp.fc2.bias", "block4.1.attn.proj.weight", "block4.2.attn.kv.bias", "norm2.weight", "norm4.bias",
+              "block2.0.attn.norm.weight", "patch_embed2.norm.bias"]:
+        gr = named[k].grad
+        step = max(1, gr.numel() // 2048)
+        res["g_" + k.replace(".", "_")] = gr.reshape(-1)[::step].clone()
+        res["gstep_" + k.replace(".", "_")] = np.array(step)
+    save("mit", **res)
+    # a second, single-stage-sized capture for the attention geometry of the benchmark: 576 keys (24x24 after sr 8 of a
+    # 192x192 map) needs a 768x768 input -- too slow for a CPU capture of B5; mit_b1 on one image is enough to pin indexing
+    net1 = ref.mit_b1()
+    sd1 = om.state_dict(om.MIT_B1)
+    net1.load_state_dict(sd1)
+    net1.eval()
+    x1 = torch.rand((1, 3, 768, 768), generator=synth.gen(56)) * 2 - 1
+    with torch.no_grad():
+        o1 = net1(x1)
+    save("mit768", seed=np.array(56), c1_sample=o1[0].reshape(-1)[::211].clone(), c2_sample=o1[1].reshape(-1)[::53].clone(),
+         c3_sample=o1[2].reshape(-1)[::7].clone(), c4_sample=o1[3].reshape(-1)[::3].clone(),
+         sums=np.array([float(o.abs().sum()) for o in o1]), maxs=np.array([float(o.abs().max()) for o in o1]))
+
+
 # ------------------------------------------------------------------ G-step (warm-up, 3 steps)
 def gen_step():
     import torch.optim as optim
@@ -747,7 +831,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(mit=gen_mit, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
