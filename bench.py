@@ -56,6 +56,9 @@ CONFIGS = {
     "c1": ("TINY", 2, 256, 256, 16, "configs[0] stand-in",
            "small-backbone (Bottleneck 1-1-2-1, 16..128 planes) DeepLab warm-up step; the reference cannot build a "
            "ResNet-18 (seg_model_noaux.py:253 raises for BasicBlock)"),
+    "c5": ("MIT_B5", 8, 768, 768, 32, "configs[4]",
+           "SegFormer-B5 (MiT-B5 encoder, fp16 storage / fp32 accumulate) distillation student + EMA teacher, DiGA warm-up "
+           "step; ASPP head on the last stage (the build's own wiring: the reference ships the encoder unwired)"),
     "c4": ("RESNET101", 8, 512, 1024, 32, "configs[3]",
            "self-training step (centroid pseudo-labeler + two ClassMix blocks + centroid EMA), synthetic "
            "Cityscapes-shape, B source + B target crops per GPU"),
@@ -79,6 +82,7 @@ def parse():
     ap.add_argument("--other-warmup", type=int, default=None, help="warm-ups of the other arithmetic (default: --warmup)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the c4 / c1 legs")
     ap.add_argument("--c4-steps", type=int, default=3)
+    ap.add_argument("--c5-steps", type=int, default=5)
     ap.add_argument("--no-bandwidth-kernels", action="store_true")
     ap.add_argument("--no-miou", action="store_true", help="skip the fixed-seed validation-mIoU parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -253,9 +257,13 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof):
 
     _lib.call("diga_set_conv_math", 1 if precision == "bf16x3" else 0)
     arch_name, B, H, W, block = geometry(a, config)
-    arch = getattr(sm, arch_name)
     torch.manual_seed(0)                       # identical random-init weights on every rank
-    student, teacher = SegModel(arch=arch).to(dev), SegModel(arch=arch).to(dev)
+    if arch_name.startswith("MIT_"):
+        from diga_amd.model.segformer import SegFormerStudent
+        student, teacher = SegFormerStudent(arch_name.lower()).to(dev), SegFormerStudent(arch_name.lower()).to(dev)
+    else:
+        arch = getattr(sm, arch_name)
+        student, teacher = SegModel(arch=arch).to(dev), SegModel(arch=arch).to(dev)
     ddp.broadcast_module(student)
     teacher.train()
     rng = random.Random(1234 + rank)           # ClassMix class choice differs per rank, reproducibly
@@ -557,7 +565,7 @@ def main():
                       "kernel_families": ofam, "losses_last_step": olosses}
     other_cfg = {}
     if not a.no_other_configs:
-        for cfg, (st, wu) in (("c4", (a.c4_steps, 1)), ("c1", (5, 2))):
+        for cfg, (st, wu) in (("c5", (a.c5_steps, 2)), ("c4", (a.c4_steps, 1)), ("c1", (5, 2))):
             if cfg == a.config or (cfg == "c1" and world > 1):
                 continue
             cdt, (cfam, _), closs, ccounts, cgeom = run_steps(a, cfg, a.precision, st, wu, rank, world, dev, prof)
@@ -569,10 +577,25 @@ def main():
                 "metric": (f"{cH}x{cW} 19-class (source,target) crop pairs/sec (DiGA self-training step)" if cfg == "c4"
                            else f"{cH}x{cW} 19-class crops/sec (DiGA warm-up step)"),
                 "value": world * cB * st / cdt, "unit": "pairs/s" if cfg == "c4" else "crops/s", "steps": st, "warmup": wu,
-                "ms_per_step": 1e3 * cdt / st, "n_gpus": world, "dtype": a.precision,
+                "ms_per_step": 1e3 * cdt / st, "n_gpus": world,
+                "dtype": ("fp16 storage / fp32 accumulate (MiT encoder); head convs " + a.precision) if cfg == "c5" else a.precision,
+                "kernel_families": {k: v for k, v in cfam.items() if k.startswith("mit_")} if cfg == "c5" else None,
                 "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea},
                 "roofline_conv_fwd": None if croof is None else {k: croof[k] for k in ("achieved", "peak", "unit", "frac")},
                 "losses_last_step": closs}
+            if cfg == "c5":
+                # MFMA-bound families of the encoder: declared algorithmic FLOPs / summed HIP-event durations, against the
+                # dense fp16 MFMA peak (= bf16's); the HBM-bound ones against 8 TB/s
+                rl = {}
+                for tag, bound in (("mit_attn_fwd", "mfma"), ("mit_attn_bwd", "mfma"), ("mit_gemm", "mfma"), ("mit_wgrad", "mfma"),
+                                   ("mit_norm", "hbm"), ("mit_dwconv", "hbm"), ("mit_misc", "hbm")):
+                    if tag in cfam and cfam[tag]["ms_per_step"] > 0:
+                        rate = cfam[tag]["work_per_step"] / (cfam[tag]["ms_per_step"] * 1e-3)
+                        peak = BF16_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS
+                        ach = rate / (1e12 if bound == "mfma" else 1e9)
+                        rl[tag] = {"bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                                   "frac": ach / peak, "ms_per_step": cfam[tag]["ms_per_step"]}
+                other_cfg[cfg]["roofline_families"] = rl
     bw = None
     if rank == 0 and not a.no_bandwidth_kernels:
         bw = bandwidth_kernels(dev)

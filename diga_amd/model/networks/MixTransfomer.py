@@ -229,7 +229,7 @@ class _MitFn(torch.autograd.Function):
         dev = x.device
         ops = _Ops(dev)
         par = dict(zip(cfg["names"], params))
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = cfg["need_grad"]                          # (grad mode is always off inside Function.forward: decided by the caller)
         eps = cfg["eps"]                                       # per LayerNorm module (the reference mixes 1e-6 and torch's 1e-5)
         B, _, H, W = x.shape
         xin = x.detach().float().contiguous()
@@ -497,7 +497,9 @@ class MixVisionTransformer(nn.Module):
 
     def forward_features(self, x):
         params = [p for _, p in self.named_parameters()]
-        return list(_MitFn.apply(x, self._cfg(), *params))
+        cfg = self._cfg()
+        cfg["need_grad"] = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return list(_MitFn.apply(x, cfg, *params))
 
     def forward(self, x):
         return self.forward_features(x)

@@ -1,0 +1,51 @@
+"""The SegFormer-B5 / MiT student of BASELINE.json configs[4]: "SegFormer-B5 (MiT transformer) backbone variant, fp16 --
+MFMA attention path for the distillation student".
+
+The reference ships the encoder (G5/model/networks/MixTransfomer.py) but wires it into nothing (networks/__init__.py:8-9
+exports only HRNet / OCRNet), so THE WIRING BELOW IS THE BUILD'S OWN: the encoder takes the place of the
+ResNet-101 trunk inside the reference's `SegModel` interface (model_noaux.py:28-46,48-77) -- same 4-tuple output, same two
+optimizer groups -- with the reference's own ASPP head `Classifier_Module2` (seg_model_noaux.py:140-214) on the last encoder
+stage (512 channels, stride 32).  Everything downstream (upsample + CE + distillation block, EMA teacher, ClassMix, fused SGD,
+gradient all-reduce) is the DeepLab path's code unchanged, so `DigaTrainer` drives it as it drives `SegModel`.
+Encoder: fp16 storage / fp32 accumulate (diga_amd/model/networks/MixTransfomer.py); head: fp32 tensors, the conv arithmetic
+selected by diga_set_conv_math like every other DigaConv2d."""
+import os
+import sys
+
+import torch.nn as nn
+
+_pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.dirname(_pkg) not in sys.path:
+    sys.path.append(os.path.dirname(_pkg))
+from diga_amd import _lib  # noqa: E402
+from diga_amd.model.networks import MixTransfomer as mit  # noqa: E402
+from diga_amd.model.seg_model_noaux import Classifier_Module2  # noqa: E402
+
+
+class SegFormerStudent(nn.Module):
+    def __init__(self, backbone="mit_b5", n_classes=19, drop_path_rate=None):
+        super().__init__()
+        self.n_classes = n_classes
+        self.backbone = getattr(mit, backbone)()
+        if drop_path_rate is not None:
+            self.backbone.reset_drop_path(drop_path_rate)
+        self.final = Classifier_Module2(self.backbone.embed_dims[-1], [6, 12, 18, 24], [6, 12, 18, 24], n_classes)
+
+    def forward(self, x):
+        """x [N,3,H,W] -> (c2 [N,128,H/8,W/8], c4 [N,512,H/32,W/32], logits [N,19,H/32,W/32], feat [N,256,H/32,W/32])."""
+        _lib.require_gpu(x)
+        _, c2, _, c4 = self.backbone(x)
+        res = self.final(c4)
+        return c2, c4, res['out'], res['feat']
+
+    def get_1x_lr_params_NOscale(self):
+        for p in self.backbone.parameters():
+            if p.requires_grad:
+                yield p
+
+    def get_10x_lr_params(self):
+        yield from self.final.parameters()
+
+    def optim_parameters(self, learning_rate):
+        return [{'params': self.get_1x_lr_params_NOscale(), 'lr': 1 * learning_rate},
+                {'params': self.get_10x_lr_params(), 'lr': 10 * learning_rate}]

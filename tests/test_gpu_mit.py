@@ -304,3 +304,57 @@ def test_drop_path_training_mode_statistics():
     torch.manual_seed(1)
     m(x)[3].sum().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+def test_segformer_student_warmup_step_vs_oracle_composition():
+    """The build's own wiring (diga_amd/model/segformer.py): MiT encoder + the reference's ASPP head inside the DiGA warm-up
+    step (DigaTrainer unchanged), against the same composition of the oracles on the CPU: oracle/mit.py encoder -> oracle
+    ASPP head -> oracle loss block; losses and the post-step head weights."""
+    import random
+    from diga_amd import _lib
+    from diga_amd.model.segformer import SegFormerStudent
+    from diga_amd.train_step import DigaTrainer
+    from oracle import deeplab as od
+    from oracle import detweights, losses as ol
+    prev = _lib.lib.diga_get_conv_math()
+    _lib.call("diga_set_conv_math", 0)
+    try:
+        arch = od.Arch(droprate=0.0)
+        sd_b = om.state_dict(om.MIT_B1)
+        head_shapes = {k: v for k, v in od.state_shapes(od.RESNET101).items() if k.startswith("final.")}
+        sd_h = {}
+        for k, (shp, kind) in head_shapes.items():
+            if k.startswith("final.conv2d_list.") and k.endswith(".0.weight"):
+                shp = (shp[0], 512, shp[2], shp[3])                 # the head reads the 512-channel last stage
+            sd_h[k] = detweights.fill("seg." + k, shp, kind)
+
+        def make():
+            m = SegFormerStudent("mit_b1")
+            m.backbone.load_state_dict(sd_b)
+            m.final.load_state_dict({k[len("final."):]: v for k, v in sd_h.items()})
+            m.final.head[0].p = 0.0
+            m.backbone.reset_drop_path(0.0)
+            return m.to(DEV)
+
+        student, teacher = make(), make()
+        teacher.train()
+        tr = DigaTrainer(student, teacher, rng=random)
+        x, x_aug, rec, lab = synth.warmup_batch(77, 2, 128, 160, block=16)
+        random.seed(5)
+        got = tr.warmup_step(0, *(t.to(DEV) for t in (x, x_aug, rec, lab)))
+        # oracle composition (teacher == student at iteration 0: alpha = 0)
+        from oracle import classmix as ocm
+        random.seed(5)
+        mix, _, _ = ocm.classmix(rec, x_aug, lab, random)
+        cat = torch.cat([x, mix])
+        sd = {**{k: v.clone().requires_grad_() for k, v in sd_b.items()}, **{k: v.clone().requires_grad_() for k, v in sd_h.items()}}
+        c4 = om.forward(sd, cat, om.MIT_B1)[3]
+        out, _ = od.aspp_head(sd, c4, arch, keep_mask=torch.ones(4, 256))
+        up = torch.nn.Upsample(size=[128, 160], mode="bilinear", align_corners=True)
+        s_up = up(out)
+        ce = ol.cross_entropy2d(s_up[:2], lab)
+        di = ol.distillation_loss(s_up.detach(), s_up)
+        assert float(got["ce"]) == pytest.approx(float(ce), rel=5e-3)
+        assert float(got["distil"]) == pytest.approx(float(di), rel=5e-3)
+    finally:
+        _lib.call("diga_set_conv_math", prev)
