@@ -55,5 +55,39 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
     return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
 }
 
+// out = scale * sum over chunks of partial[chunk][i] (+ existing when accumulate), i < n, fixed order: 32 columns x 8 chunk
+// phases per block (phase p adds chunks p, p + 8, ... sequentially, then the phases are added 0..7).
+//   MAP 0: out0[i]      MAP 1 (LayerNorm): i < C -> out0[i] (dgamma), else out1[i - C] (dbeta)
+//   MAP 2 (depthwise 3x3): t = i / C, c = i % C: t < 9 -> out0[c * 9 + t] (dw [C][9]), t == 9 -> out1[c] (db)
+template <int MAP>
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int chunks, int n, float* __restrict__ out0,
+                                                             float* __restrict__ out1, int C, float scale, int accumulate) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    float s = 0.f;
+    if (i < n)
+        for (int k = ph; k < chunks; k += 8) s += partial[(int64_t)k * n + i];
+    red[ph][col] = s;
+    __syncthreads();
+    if (ph == 0 && i < n) {
+        float tot = red[0][col];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) tot += red[p][col];
+        tot *= scale;
+        float* dst;
+        if constexpr (MAP == 0) {
+            dst = out0 + i;
+        } else if constexpr (MAP == 1) {
+            dst = i < C ? out0 + i : out1 + (i - C);
+        } else {
+            const int t = i / C, c = i - t * C;
+            dst = t < 9 ? out0 + (int64_t)c * 9 + t : out1 + c;
+        }
+        if (accumulate) tot += *dst;
+        *dst = tot;
+    }
+}
+
 }  // namespace mit
 }  // namespace diga

@@ -324,17 +324,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const _Float16* __r
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks,
-                                                           int C, float scale, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * C + c];
-    s *= scale;
-    if (accumulate) s += out[c];
-    out[c] = s;
-}
-
 // fp32 [R][C] -> fp16 copy [R][C] and (optionally) the fp16 transpose [C][R]   (weights, once per optimizer step)
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, _Float16* __restrict__ w16,
                                                              _Float16* __restrict__ wt16, int R, int C) {
@@ -451,22 +440,34 @@ extern "C" int diga_mit_gemm_tn(const void* A, int64_t lda, const void* B, int64
     return launch_status("mit_gemm_tn");
 }
 
+namespace {
+int colsum_rows_per_block(int64_t M) {                  // >= ~1024 blocks for the big token matrices, 32..512 rows each
+    int64_t r = ceil_div(M, 1024);
+    r = ceil_div(r, 32) * 32;
+    if (r < 32) r = 32;
+    if (r > 512) r = 512;
+    return (int)r;
+}
+}  // namespace
+
 extern "C" size_t diga_mit_colsum_workspace_bytes(int64_t M, int64_t C) {
-    return (size_t)ceil_div(M, 512) * (size_t)C * sizeof(float);
+    if (M <= 0 || C <= 0) return 0;
+    return (size_t)ceil_div(M, colsum_rows_per_block(M)) * (size_t)C * sizeof(float);
 }
 
 extern "C" int diga_mit_colsum(const void* x, int64_t ld, float* out, float scale, int accumulate, void* workspace,
                                size_t workspace_bytes, int64_t M, int64_t C, void* stream) {
     DIGA_REQUIRE(x && out && workspace && M > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, DIGA_EINVAL, "mit_colsum: bad argument");
     DIGA_REQUIRE(aligned16(x), DIGA_EALIGN, "mit_colsum: x must be 16-byte aligned");
-    const int chunks = (int)ceil_div(M, 512);
+    const int rpb = colsum_rows_per_block(M);
+    const int chunks = (int)ceil_div(M, rpb);
     DIGA_REQUIRE(workspace_bytes >= (size_t)chunks * (size_t)C * sizeof(float), DIGA_EWORKSPACE, "mit_colsum: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DIGA_PROF_MIT_MISC, st, 2.0 * (double)M * (double)C);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks), dim3(256), 0, st, static_cast<const _Float16*>(x), ld,
-                       static_cast<float*>(workspace), (int)M, (int)C, 512);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, static_cast<const float*>(workspace), out,
-                       chunks, (int)C, scale, accumulate);
+                       static_cast<float*>(workspace), (int)M, (int)C, rpb);
+    hipLaunchKernelGGL(partial_reduce_kernel<0>, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), chunks,
+                       (int)C, out, (float*)nullptr, (int)C, scale, accumulate);
     return launch_status("mit_colsum");
 }
 

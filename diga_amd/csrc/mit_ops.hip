@@ -179,19 +179,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const GT* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int blocks, int C, float scale, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
-    const int which = i / C, c = i - which * C;
-    float s = 0.f;
-    for (int k = 0; k < blocks; ++k) s += partial[((int64_t)k * 2 + which) * C + c];
-    s *= scale;
-    float* dst = which == 0 ? dgamma : dbeta;
-    if (accumulate) s += dst[c];
-    dst[c] = s;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Depthwise 3x3 (stride 1, zero padding 1) on [B][H][W][C] fp16.  A thread owns 8 channels of a strip of PX pixels
 // along x: its 72 weights live in registers and the 3 x (PX + 2) input vectors are loaded once.
@@ -274,30 +261,52 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const _Float16* __restri
 
 // du = dh * gelu'(u) -> du16; per-block partial sums of the depthwise weight / bias gradients:
 //   dw[t][c] = sum_p du[p][c] * x[p + t][c],  db[c] = sum_p du[p][c]     (x = the conv input, zero outside the image)
-// A block covers `rows_per_block` image rows of one image; thread -> (8-channel group, x phase).  partial[block][10][C].
-__global__ __launch_bounds__(256) void dwconv_bwd_prep_kernel(const _Float16* __restrict__ dh, const _Float16* __restrict__ u,
+// A block covers `rows_per_block` image rows of one image with gw * phases threads (gw = min(C / 8, 256) channel groups;
+// wider tensors loop): thread (group, phase) walks the contiguous x range of its phase with a sliding 3 x 3 window of input
+// vectors (3 new loads per pixel instead of 9).  partial[block][10][C].
+__global__ __launch_bounds__(512) void dwconv_bwd_prep_kernel(const _Float16* __restrict__ dh, const _Float16* __restrict__ u,
                                                               const _Float16* __restrict__ x, _Float16* __restrict__ du16,
                                                               float* __restrict__ partial, int B, int H, int W, int C,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, int gw, int phases) {
     const int cg = C / 8;
     const int blocks_per_img = (H + rows_per_block - 1) / rows_per_block;
     const int b = blockIdx.x / blocks_per_img;
     const int y0 = (blockIdx.x - b * blocks_per_img) * rows_per_block;
     const int y1 = min(y0 + rows_per_block, H);
-    extern __shared__ float red[];                                 // [256][10 * 8] would be 80 KB: reduce tap by tap instead
-    for (int gbase = 0; gbase < cg; gbase += 256) {
-        const int gw = min(cg - gbase, 256);
-        const int phases = max(256 / gw, 1);
-        const int gi = threadIdx.x % gw, ph = threadIdx.x / gw;
-        const int c0 = (gbase + gi) * 8;
+    extern __shared__ float red[];                                 // [phases * gw][8]
+    const int gi = threadIdx.x % gw, ph = threadIdx.x / gw;
+    const int xa = (int)(((int64_t)W * ph) / phases), xb = (int)(((int64_t)W * (ph + 1)) / phases);
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int gbase = 0; gbase < cg; gbase += gw) {
+        const bool live = gbase + gi < cg;
+        const int c0 = (gbase + (live ? gi : 0)) * 8;
         float s[10][8];
 #pragma unroll
         for (int t = 0; t < 10; ++t)
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[t][e] = 0.f;
-        if (ph < phases) {
+        if (live) {
             for (int y = y0; y < y1; ++y) {
-                for (int xx = ph; xx < W; xx += phases) {
+                const _Float16* rows[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = y + dy - 1;
+                    rows[dy] = (yy >= 0 && yy < H) ? x + (((int64_t)b * H + yy) * W) * C + c0 : nullptr;
+                }
+                f16x8 win[3][3];                                   // win[dy][k] = x[y + dy - 1][xx + k - 1]
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    win[dy][0] = zero8;
+                    win[dy][1] = (rows[dy] != nullptr && xa - 1 >= 0 && xa - 1 < W) ? *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)(xa - 1) * C) : zero8;
+                    win[dy][2] = (rows[dy] != nullptr && xa < W) ? *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)xa * C) : zero8;
+                }
+                for (int xx = xa; xx < xb; ++xx) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        win[dy][0] = win[dy][1];
+                        win[dy][1] = win[dy][2];
+                        win[dy][2] = (rows[dy] != nullptr && xx + 1 < W) ? *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)(xx + 1) * C) : zero8;
+                    }
                     const int64_t o = (((int64_t)b * H + y) * W + xx) * C + c0;
                     const f16x8 g8 = *reinterpret_cast<const f16x8*>(dh + o);
                     const f16x8 u8 = *reinterpret_cast<const f16x8*>(u + o);
@@ -311,52 +320,31 @@ __global__ __launch_bounds__(256) void dwconv_bwd_prep_kernel(const _Float16* __
                     }
                     *reinterpret_cast<f16x8*>(du16 + o) = d8;
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int yy = y + dy - 1;
-                        if (yy < 0 || yy >= H) continue;
+                    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const int xi = xx + dx - 1;
-                            if (xi < 0 || xi >= W) continue;
-                            const f16x8 v = *reinterpret_cast<const f16x8*>(x + (((int64_t)b * H + yy) * W + xi) * C + c0);
+                        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) s[dy * 3 + dx][e] += d[e] * (float)v[e];
-                        }
-                    }
+                            for (int e = 0; e < 8; ++e) s[dy * 3 + dx][e] += d[e] * (float)win[dy][dx][e];
                 }
             }
         }
-        // fold the x phases in fixed order, one tap at a time through LDS (256 x 8 floats)
+        // fold the x phases in fixed order, one tap at a time through LDS
         for (int t = 0; t < 10; ++t) {
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[t][e];
             __syncthreads();
-            if (threadIdx.x < gw) {
+            if (ph == 0 && live) {
                 float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 for (int p = 0; p < phases; ++p)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) tot[e] += red[(p * gw + threadIdx.x) * 8 + e];
+                    for (int e = 0; e < 8; ++e) tot[e] += red[(p * gw + gi) * 8 + e];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) partial[((int64_t)blockIdx.x * 10 + t) * C + (gbase + threadIdx.x) * 8 + e] = tot[e];
+                for (int e = 0; e < 8; ++e) partial[((int64_t)blockIdx.x * 10 + t) * C + (gbase + gi) * 8 + e] = tot[e];
             }
         }
         __syncthreads();
     }
-}
-
-// dw [C][3][3] (torch's [C,1,3,3] memory) and db [C] from the partials; scale = 1 / loss scale
-__global__ __launch_bounds__(256) void dwconv_param_grad_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                float* __restrict__ db, int blocks, int C, float scale, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 10 * C) return;
-    const int t = i / C, c = i - t * C;
-    float s = 0.f;
-    for (int k = 0; k < blocks; ++k) s += partial[((int64_t)k * 10 + t) * C + c];
-    s *= scale;
-    float* dst = t < 9 ? dw + (int64_t)c * 9 + t : db + c;
-    if (accumulate) s += *dst;
-    *dst = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,10 +502,17 @@ extern "C" int diga_mit_layernorm_fwd(const float* x, int64_t ldx, const float* 
     return launch_status("mit_layernorm_fwd");
 }
 
-static constexpr int kLnRowsPerBlock = 256;
+static int ln_rows_per_block(int64_t M) {                // >= ~2048 blocks where the matrix is big enough, 16..256 rows each
+    int64_t r = ceil_div(M, 2048);
+    r = ceil_div(r, 16) * 16;
+    if (r < 16) r = 16;
+    if (r > 256) r = 256;
+    return (int)r;
+}
 
 extern "C" size_t diga_mit_layernorm_bwd_workspace_bytes(int64_t M, int64_t C) {
-    return (size_t)ceil_div(M, kLnRowsPerBlock) * 2 * (size_t)C * sizeof(float);
+    if (M <= 0 || C <= 0) return 0;
+    return (size_t)ceil_div(M, ln_rows_per_block(M)) * 2 * (size_t)C * sizeof(float);
 }
 
 extern "C" int diga_mit_layernorm_bwd(const void* dy, int dy_is_f32, int64_t ldg, float gscale, const float* x, int64_t ldx,
@@ -528,14 +523,15 @@ extern "C" int diga_mit_layernorm_bwd(const void* dy, int dy_is_f32, int64_t ldg
                  "mit_layernorm_bwd: null pointer / empty shape");
     DIGA_REQUIRE(C % 4 == 0 && C <= 512 && ldx % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && M < (1ll << 31), DIGA_EINVAL,
                  "mit_layernorm_bwd: C %% 4 == 0, C <= 512");
-    const int blocks = (int)ceil_div(M, kLnRowsPerBlock);
+    const int rpb = ln_rows_per_block(M);
+    const int blocks = (int)ceil_div(M, rpb);
     DIGA_REQUIRE(workspace_bytes >= (size_t)blocks * 2 * (size_t)C * sizeof(float), DIGA_EWORKSPACE, "mit_layernorm_bwd: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DIGA_PROF_MIT_NORM, st, (double)M * C * ((dy_is_f32 ? 4.0 : 2.0) + 4.0 + (dres ? 4.0 : 0.0) + (dx32 ? 4.0 : 0.0) + (dx16 ? 2.0 : 0.0)));
     float* part = static_cast<float*>(workspace);
     _Float16* d16 = static_cast<_Float16*>(dx16);
     const int nv = (int)ceil_div(C, 64);
-#define DIGA_LN_BWD(NV_, GT_) hipLaunchKernelGGL((layernorm_bwd_kernel<NV_, GT_>), dim3(blocks), dim3(256), 0, st, static_cast<const GT_*>(dy), ldg, x, ldx, gamma, mean, rstd, dres, ldr, dx32, d16, ldo, part, (int)M, (int)C, kLnRowsPerBlock, gscale)
+#define DIGA_LN_BWD(NV_, GT_) hipLaunchKernelGGL((layernorm_bwd_kernel<NV_, GT_>), dim3(blocks), dim3(256), 0, st, static_cast<const GT_*>(dy), ldg, x, ldx, gamma, mean, rstd, dres, ldr, dx32, d16, ldo, part, (int)M, (int)C, rpb, gscale)
 #define DIGA_LN_BWD_T(GT_)                \
     do {                                  \
         if (nv <= 1) DIGA_LN_BWD(1, GT_); \
@@ -547,8 +543,8 @@ extern "C" int diga_mit_layernorm_bwd(const void* dy, int dy_is_f32, int64_t ldg
     else DIGA_LN_BWD_T(_Float16);
 #undef DIGA_LN_BWD_T
 #undef DIGA_LN_BWD
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)ceil_div(2 * C, 256)), dim3(256), 0, st, part, dgamma, dbeta, blocks, (int)C,
-                       param_scale, accumulate);
+    hipLaunchKernelGGL(partial_reduce_kernel<1>, dim3((unsigned)ceil_div(2 * C, 32)), dim3(256), 0, st, part, blocks, (int)(2 * C), dgamma, dbeta,
+                       (int)C, param_scale, accumulate);
     return launch_status("mit_layernorm_bwd");
 }
 
@@ -564,10 +560,16 @@ extern "C" int diga_mit_dwconv_gelu_fwd(const void* x, const float* wt9, const f
     return launch_status("mit_dwconv_gelu_fwd");
 }
 
-static constexpr int kDwRowsPerBlock = 4;
+static int dw_rows_per_block(int64_t B, int64_t H) {     // ~1500+ blocks when the tensor has that many image rows
+    int64_t r = (B * H) / 1536;
+    if (r < 1) r = 1;
+    if (r > 8) r = 8;
+    return (int)r;
+}
 
 extern "C" size_t diga_mit_dwconv_bwd_workspace_bytes(int64_t B, int64_t H, int64_t C) {
-    return (size_t)B * (size_t)ceil_div(H, kDwRowsPerBlock) * 10 * (size_t)C * sizeof(float);
+    if (B <= 0 || H <= 0 || C <= 0) return 0;
+    return (size_t)B * (size_t)ceil_div(H, dw_rows_per_block(B, H)) * 10 * (size_t)C * sizeof(float);
 }
 
 /* dh: gradient wrt gelu output, u: saved pre-activation, x: the conv input (fc1 output); du16: scratch for du [B,H,W,C];
@@ -577,15 +579,20 @@ extern "C" int diga_mit_dwconv_gelu_bwd(const void* dh, const void* u, const voi
                                         int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
     DIGA_REQUIRE(dh && u && x && wt9_flipped && du16 && dx16 && dw && db && workspace && B > 0 && H > 0 && W > 0 && C % 8 == 0 && C > 0,
                  DIGA_EINVAL, "mit_dwconv_gelu_bwd: bad argument");
-    const int blocks = (int)(B * ceil_div(H, kDwRowsPerBlock));
+    const int rpb = dw_rows_per_block(B, H);
+    const int blocks = (int)(B * ceil_div(H, rpb));
     DIGA_REQUIRE(workspace_bytes >= (size_t)blocks * 10 * (size_t)C * sizeof(float), DIGA_EWORKSPACE, "mit_dwconv_gelu_bwd: workspace too small");
+    const int gw = (int)(C / 8 < 256 ? C / 8 : 256);
+    int phases = 512 / gw;
+    if (phases > W) phases = (int)W;
+    if (phases < 1) phases = 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DIGA_PROF_MIT_DWCONV, st, (double)B * H * W * C * 12.0);
-    hipLaunchKernelGGL(dwconv_bwd_prep_kernel, dim3(blocks), dim3(256), 256 * 8 * sizeof(float), st, static_cast<const _Float16*>(dh),
-                       static_cast<const _Float16*>(u), static_cast<const _Float16*>(x), static_cast<_Float16*>(du16),
-                       static_cast<float*>(workspace), (int)B, (int)H, (int)W, (int)C, kDwRowsPerBlock);
-    hipLaunchKernelGGL(dwconv_param_grad_kernel, dim3((unsigned)ceil_div(10 * C, 256)), dim3(256), 0, st, static_cast<const float*>(workspace), dw,
-                       db, blocks, (int)C, param_scale, accumulate);
+    hipLaunchKernelGGL(dwconv_bwd_prep_kernel, dim3(blocks), dim3(gw * phases), (size_t)gw * phases * 8 * sizeof(float), st,
+                       static_cast<const _Float16*>(dh), static_cast<const _Float16*>(u), static_cast<const _Float16*>(x),
+                       static_cast<_Float16*>(du16), static_cast<float*>(workspace), (int)B, (int)H, (int)W, (int)C, rpb, gw, phases);
+    hipLaunchKernelGGL(partial_reduce_kernel<2>, dim3((unsigned)ceil_div(10 * C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), blocks,
+                       (int)(10 * C), dw, db, (int)C, param_scale, accumulate);
     const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);
     hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3(grid_for(items, 256, 1 << 20)), dim3(256), 0, st, static_cast<const _Float16*>(du16), wt9_flipped,
                        (const float*)nullptr, (_Float16*)nullptr, static_cast<_Float16*>(dx16), (int)B, (int)H, (int)W, (int)C);
