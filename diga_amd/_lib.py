@@ -86,7 +86,7 @@ SIGNATURES = {
     # ---- include/diga_mit.h
     "diga_mit_gemm_nt": (INT, [P, I64, P, I64, P, P, I64, INT, P, I64, P, I64, INT, F32, I64, I64, I64, P]),
     "diga_mit_gemm_tn_workspace_bytes": (SZ, [I64, I64, I64]),
-    "diga_mit_gemm_tn": (INT, [P, I64, P, I64, P, F32, INT, P, SZ, I64, I64, I64, P]),
+    "diga_mit_gemm_tn": (INT, [P, I64, P, I64, P, P, F32, INT, P, SZ, I64, I64, I64, P]),
     "diga_mit_colsum_workspace_bytes": (SZ, [I64, I64]),
     "diga_mit_colsum": (INT, [P, I64, P, F32, INT, P, SZ, I64, I64, P]),
     "diga_mit_cast_transpose": (INT, [P, P, P, I64, I64, P]),

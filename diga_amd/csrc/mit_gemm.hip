@@ -183,6 +183,7 @@ struct WgradArgs {
     const _Float16* B;
     int64_t ldb;
     float* slab;
+    float* bias_slab;         // [splits][N] column sums of A (the bias gradient), or null
     int M, N, K;
     int tiles_n, tiles_k, splits, steps_per_split;
 };
@@ -227,10 +228,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs a) {
     };
 
     f32x4 acc[MT][NT];
+    float bsum[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        bsum[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // the bias gradient (column sums of A = dY) rides along: the A fragments pass through registers anyway
+    const bool do_bias = a.bias_slab != nullptr && tile_k == 0 && wn == 0;
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int row0 = 8 * g + q, row1 = row0 + 4;
     const int key0 = tr_key(row0) << 1, key1 = tr_key(row1) << 1;
@@ -253,10 +259,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs a) {
             const f16x8 fa = tr_frag(As + off(wm * 4 + i, row0, key0), As + off(wm * 4 + i, row1, key1));
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[j], acc[i][j], 0, 0, 0);
+            if (do_bias)
+                bsum[i] += (((float)fa[0] + (float)fa[1]) + ((float)fa[2] + (float)fa[3])) + (((float)fa[4] + (float)fa[5]) + ((float)fa[6] + (float)fa[7]));
         }
         wait_next(ahead);
         cur = cur == 2 ? 0 : cur + 1;
         nx = nx == 2 ? 0 : nx + 1;
+    }
+    if (do_bias) {                                         // uniform per wave
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = n0 + wm * 64 + i * 16 + (lane & 15);
+            if (g == 0 && n < a.N) a.bias_slab[(int64_t)split * a.N + n] = v;
+        }
     }
     float* out = a.slab + (int64_t)split * a.N * a.K;
 #pragma unroll
@@ -399,7 +417,7 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t K) {
     p.tiles_k = (int)ceil_div(K, 128);
     const int64_t steps = ceil_div(M, 32);
     const int64_t tiles = (int64_t)p.tiles_n * p.tiles_k;
-    int64_t splits = ceil_div(1024, tiles);                         // ~2 rounds of 2 blocks per CU
+    int64_t splits = ceil_div(512, tiles);                          // one round of 2 blocks per CU: the slabs cost HBM traffic
     if (splits > ceil_div(steps, 8)) splits = ceil_div(steps, 8);   // at least 8 K-steps per block
     if (splits < 1) splits = 1;
     p.steps_per_split = (int)ceil_div(steps, splits);
@@ -411,24 +429,25 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t K) {
 extern "C" size_t diga_mit_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const TnPlan p = tn_plan(M, N, K);
-    return (size_t)p.splits * (size_t)N * (size_t)K * sizeof(float);
+    return (size_t)p.splits * ((size_t)N * (size_t)K + (size_t)N) * sizeof(float);
 }
 
-extern "C" int diga_mit_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* dw, float scale, int accumulate,
-                                void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, void* stream) {
+extern "C" int diga_mit_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* dw, float* dbias, float scale,
+                                int accumulate, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, void* stream) {
     DIGA_REQUIRE(A && B && dw && workspace && M > 0 && N > 0 && K > 0, DIGA_EINVAL, "mit_gemm_tn: null pointer / empty shape");
     DIGA_REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, DIGA_EINVAL,
                  "mit_gemm_tn: N, K and the leading dimensions must be multiples of 8");
     DIGA_REQUIRE(aligned16(A) && aligned16(B), DIGA_EALIGN, "mit_gemm_tn: operands must be 16-byte aligned");
     DIGA_REQUIRE(M < (1ll << 31), DIGA_EINVAL, "mit_gemm_tn: too many rows");
     const TnPlan p = tn_plan(M, N, K);
-    DIGA_REQUIRE(workspace_bytes >= (size_t)p.splits * (size_t)N * (size_t)K * sizeof(float), DIGA_EWORKSPACE,
+    DIGA_REQUIRE(workspace_bytes >= (size_t)p.splits * ((size_t)N * (size_t)K + (size_t)N) * sizeof(float), DIGA_EWORKSPACE,
                  "mit_gemm_tn: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     WgradArgs a;
     a.A = static_cast<const _Float16*>(A); a.lda = lda;
     a.B = static_cast<const _Float16*>(B); a.ldb = ldb;
     a.slab = static_cast<float*>(workspace);
+    a.bias_slab = dbias != nullptr ? a.slab + (size_t)p.splits * (size_t)N * (size_t)K : nullptr;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.splits = p.splits; a.steps_per_split = p.steps_per_split;
     ProfScope prof(DIGA_PROF_MIT_WGRAD, st, 2.0 * (double)M * (double)N * (double)K);
@@ -437,6 +456,9 @@ extern "C" int diga_mit_gemm_tn(const void* A, int64_t lda, const void* B, int64
     const int64_t n = N * K;
     hipLaunchKernelGGL(slab_reduce_scaled_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, a.slab, dw, n, p.splits, scale,
                        accumulate);
+    if (dbias != nullptr)
+        hipLaunchKernelGGL(partial_reduce_kernel<0>, dim3((unsigned)ceil_div(N, 32)), dim3(256), 0, st, a.bias_slab, p.splits, (int)N, dbias,
+                           (float*)nullptr, (int)N, scale, accumulate);
     return launch_status("mit_gemm_tn");
 }
 

@@ -138,15 +138,17 @@ class _Ops:
                   float(alpha), m, n, k, _lib.stream())
         return out
 
-    def wgrad(self, dy, x, scale):
+    def wgrad(self, dy, x, scale, bias=False):
+        """dW [n,k] = scale * dy^T x (fp32); with bias=True also the bias gradient (column sums of dy) from the same pass."""
         m, n = dy.shape
         k = x.shape[1]
         dw = self.empty((n, k), torch.float32)
+        db = self.empty((n,), torch.float32) if bias else None
         nbytes = _lib.lib.diga_mit_gemm_tn_workspace_bytes(m, n, k)
         ws = _lib.workspace(nbytes, self.dev, "mit_wgrad")
-        _lib.call("diga_mit_gemm_tn", P(dy), dy.stride(0), P(x), x.stride(0), P(dw), float(scale), 0, P(ws), ws.numel(), m, n, k,
+        _lib.call("diga_mit_gemm_tn", P(dy), dy.stride(0), P(x), x.stride(0), P(dw), P(db), float(scale), 0, P(ws), ws.numel(), m, n, k,
                   _lib.stream())
-        return dw
+        return (dw, db) if bias else dw
 
     def colsum(self, x, scale):
         m, c = x.shape
@@ -344,8 +346,7 @@ class _MitFn(torch.autograd.Function):
                 # ---- Mix-FFN branch: x2 = x1 + seg * fc2(gelu(dw(fc1(norm2(x1)))))
                 dxs = ops.row_scale(dx16, bs["seg_m"], rps)
                 d_h2 = ops.gemm(dxs, bs["w2t"], None, hid)
-                grads[bp + ".mlp.fc2.weight"] = ops.wgrad(dxs, bs["h2"], inv)
-                grads[bp + ".mlp.fc2.bias"] = ops.colsum(dxs, inv)
+                grads[bp + ".mlp.fc2.weight"], grads[bp + ".mlp.fc2.bias"] = ops.wgrad(dxs, bs["h2"], inv, bias=True)
                 du = ops.empty((M, hid))
                 dwd = ops.empty((hid, 9), torch.float32)
                 dbd = ops.empty((hid,), torch.float32)
@@ -357,16 +358,14 @@ class _MitFn(torch.autograd.Function):
                 grads[bp + ".mlp.dwconv.dwconv.weight"] = dwd.view(hid, 1, 3, 3)
                 grads[bp + ".mlp.dwconv.dwconv.bias"] = dbd
                 d_b16 = ops.gemm(d_h1, bs["w1t"], None, C)
-                grads[bp + ".mlp.fc1.weight"] = ops.wgrad(d_h1, bs["b16"], inv)
-                grads[bp + ".mlp.fc1.bias"] = ops.colsum(d_h1, inv)
+                grads[bp + ".mlp.fc1.weight"], grads[bp + ".mlp.fc1.bias"] = ops.wgrad(d_h1, bs["b16"], inv, bias=True)
                 dx32, dx16, dg, db = ops.ln_bwd(d_b16, bs["x1"], par[bp + ".norm2.weight"], bs["m2"], bs["r2"], dx32, True, True, inv)
                 grads[bp + ".norm2.weight"], grads[bp + ".norm2.bias"] = dg, db
                 del d_h2, d_h1, du, d_b16
                 # ---- attention branch: x1 = x + seg * proj(attn(norm1(x)))
                 dxs = ops.row_scale(dx16, bs["seg_a"], rps)
                 d_o = ops.gemm(dxs, bs["wprt"], None, C)
-                grads[bp + ".attn.proj.weight"] = ops.wgrad(dxs, bs["o16"], inv)
-                grads[bp + ".attn.proj.bias"] = ops.colsum(dxs, inv)
+                grads[bp + ".attn.proj.weight"], grads[bp + ".attn.proj.bias"] = ops.wgrad(dxs, bs["o16"], inv, bias=True)
                 nk = bs["nk"]
                 dq = ops.empty((M, C))
                 dkv = ops.empty((B * nk, 2 * C))
@@ -374,25 +373,24 @@ class _MitFn(torch.autograd.Function):
                 _lib.call("diga_mit_attention_bwd", P(bs["q16"]), C, P(bs["kv16"]), 2 * C, P(bs["o16"]), P(d_o), C, P(bs["lse"]), P(dq),
                           P(dkv), P(ws), ws.numel(), B, heads, ho * wo, nk, float(st["scale"]), _lib.stream())
                 d_a = ops.gemm(dq, bs["wqt"], None, C)
-                grads[bp + ".attn.q.weight"] = ops.wgrad(dq, bs["a16"], inv)
-                if (bp + ".attn.q.bias") in par:
-                    grads[bp + ".attn.q.bias"] = ops.colsum(dq, inv)
-                if (bp + ".attn.kv.bias") in par:
-                    grads[bp + ".attn.kv.bias"] = ops.colsum(dkv, inv)
+                has_qb, has_kvb = (bp + ".attn.q.bias") in par, (bp + ".attn.kv.bias") in par
+                gq = ops.wgrad(dq, bs["a16"], inv, bias=has_qb)
+                grads[bp + ".attn.q.weight"], grads[bp + ".attn.q.bias"] = gq if has_qb else (gq, None)
                 if sr > 1:
                     d_r = ops.gemm(dkv, bs["wkvt"], None, C)
-                    grads[bp + ".attn.kv.weight"] = ops.wgrad(dkv, bs["r16"], inv)
+                    gkv = ops.wgrad(dkv, bs["r16"], inv, bias=has_kvb)
+                    grads[bp + ".attn.kv.weight"], grads[bp + ".attn.kv.bias"] = gkv if has_kvb else (gkv, None)
                     _, d_s, dg, db = ops.ln_bwd(d_r, bs["s32"], par[bp + ".attn.norm.weight"], bs["ms"], bs["rs"], None, False, True, inv)
                     grads[bp + ".attn.norm.weight"], grads[bp + ".attn.norm.bias"] = dg, db
                     kps = bs["kps"]
                     d_pc = ops.gemm(d_s, bs["wsrt"], None, kps)
-                    dwsr = ops.wgrad(d_s, bs["pc"], inv)
+                    dwsr, grads[bp + ".attn.sr.bias"] = ops.wgrad(d_s, bs["pc"], inv, bias=True)
                     grads[bp + ".attn.sr.weight"] = dwsr[:, :sr * sr * C].reshape(C, sr, sr, C).permute(0, 3, 1, 2)
-                    grads[bp + ".attn.sr.bias"] = ops.colsum(d_s, inv)
                     ops.col2im(d_pc, d_a, False, B, ho, wo, C, sr, sr, 0, bs["hk"], bs["wk"], kps)
                 else:
                     ops.gemm(dkv, bs["wkvt"], None, C, out=d_a, accumulate=True)
-                    grads[bp + ".attn.kv.weight"] = ops.wgrad(dkv, bs["a16"], inv)
+                    gkv = ops.wgrad(dkv, bs["a16"], inv, bias=has_kvb)
+                    grads[bp + ".attn.kv.weight"], grads[bp + ".attn.kv.bias"] = gkv if has_kvb else (gkv, None)
                 dx32, dx16, dg, db = ops.ln_bwd(d_a, bs["x"], par[bp + ".norm1.weight"], bs["m1"], bs["r1"], dx32, True, True, inv)
                 grads[bp + ".norm1.weight"], grads[bp + ".norm1.bias"] = dg, db
                 del bs
@@ -401,9 +399,8 @@ class _MitFn(torch.autograd.Function):
             _, d_y, dg, db = ops.ln_bwd(dx32, ss["y32"], par[pre + ".norm.weight"], ss["e_mean"], ss["e_rstd"], None, False, True, inv)
             grads[pre + ".norm.weight"], grads[pre + ".norm.bias"] = dg, db
             k = st["patch"]
-            dwp = ops.wgrad(d_y, ss["cols"], inv)
+            dwp, grads[pre + ".proj.bias"] = ops.wgrad(d_y, ss["cols"], inv, bias=True)
             grads[pre + ".proj.weight"] = dwp[:, :k * k * sc].reshape(C, k, k, sc).permute(0, 3, 1, 2)
-            grads[pre + ".proj.bias"] = ops.colsum(d_y, inv)
             if si > 0:
                 d_cols = ops.gemm(d_y, ss["wt16"], None, ss["kp"])
                 down = ops.empty((B * sh * sw, sc), torch.float32)

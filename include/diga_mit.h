@@ -30,9 +30,10 @@ int diga_mit_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, con
                      int accumulate, float alpha, int64_t M, int64_t N, int64_t K, void* stream);
 
 /* nn.Linear backward-weight: dw[N,K] (fp32) = scale * sum_m A[m,N] * B[m,K]  (+ dw when accumulate); A = dY, B = X, fp16,
- * N % 8 == 0, K % 8 == 0.  Split over rows, fp32 slabs in the workspace summed in fixed order (deterministic). */
+ * N % 8 == 0, K % 8 == 0.  dbias [N] (nullable) = scale * column sums of A, from the same pass (the bias gradient).
+ * Split over rows, fp32 slabs in the workspace summed in fixed order (deterministic). */
 size_t diga_mit_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int diga_mit_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* dw, float scale, int accumulate,
+int diga_mit_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* dw, float* dbias, float scale, int accumulate,
                      void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, void* stream);
 
 /* Bias gradient: out[C] (fp32) = scale * column sums of the fp16 matrix x[M][ld] (+ out when accumulate).  C % 8 == 0. */

@@ -65,12 +65,20 @@ def test_benchmark_geometry_vs_reference(golden, conv_math, name):
     named = dict(m.named_parameters())
     ref = g.t("g_head")
     assert_close(named["final.head.1.weight"].grad, ref, 5e-3, 2e-3 * float(ref.abs().max()), "head gradient")
-    # Weight gradients of 22 layers (every stride / downsample transition, all four ASPP dilations, SE, GN).  At these
-    # sizes a weight's gradient sums 10^4..10^5 pixels, so the ReLU flips that made the 128x128 captures noisy average
-    # out: L1 and L2 norms within 1e-2 (fp32: 3e-3) and the strided sample within 3e-2 (fp32: 1.5e-2) of its scale (measured
-    # fp32: norms <= 1e-3, worst sample 6.5e-3 on the ASPP 1x1 branch -- a handful of flipped ReLUs; an indexing error moves
-    # these by O(1)).
-    tol_n, tol_s = (3e-3, 1.5e-2) if conv_math == 0 else (1e-2, 3e-2)
+    # Weight gradients of 22 layers (every stride / downsample transition, all four ASPP dilations, SE, GN).  Measured
+    # (tools/diag/fullsize_grad_errors.py, both geometries):
+    #   * norms (L1, L2) agree to <= 2e-4 in fp32 and <= 9e-4 in bf16x3 everywhere;
+    #   * layers whose gradient does not pass back through a trunk ReLU (bottleneck conv / GN / SE, the branch GroupNorms)
+    #     agree elementwise to 1e-5 (fp32) / 2e-4 (bf16x3) of scale;
+    #   * every layer below a ReLU deviates by a uniform 2e-3..6e-3 (fp32) / 1e-2..3e-2 (bf16x3) in relative L2, largest
+    #     elements 2e-2 / 4e-2: the gradients are discontinuous where a pre-activation crosses zero (a
+    #     2e-7 weight perturbation moves them by 4e-3 in L2 on the CPU reference itself), and 1e-6 / 1e-5-level forward
+    #     differences flip a few of the 10^9 ReLUs.  An indexing error moves norms and samples by O(1).
+    fp32 = conv_math == 0
+    tol_norm = 1e-3 if fp32 else 3e-3
+    tol_l2, tol_max = (1.2e-2, 4e-2) if fp32 else (5e-2, 8e-2)
+    tol_smooth = 1e-4 if fp32 else 1e-3
+    smooth = ("final_bottleneck_0_se_0_weight", "final_bottleneck_1_bias", "final_bottleneck_1_weight", "final_bottleneck_2_weight")
     keys = sorted(k[2:-5] for k in g if k.startswith("g_") and k.endswith("__sum"))
     assert len(keys) == 22
     by_flat = {n.replace(".", "_"): n for n in named}
@@ -78,13 +86,17 @@ def test_benchmark_geometry_vs_reference(golden, conv_math, name):
     for k in keys:
         gr = named[by_flat[k]].grad.detach().cpu()
         _, l1, l2 = (float(v) for v in g["g_" + k + "__sum"])
-        assert float(gr.abs().sum()) == pytest.approx(l1, rel=tol_n), k
-        assert float(gr.norm()) == pytest.approx(l2, rel=tol_n), k
+        assert float(gr.abs().sum()) == pytest.approx(l1, rel=tol_norm), k
+        assert float(gr.norm()) == pytest.approx(l2, rel=tol_norm), k
         step = int(g["g_" + k + "__step"])
         smp = g.t("g_" + k + "__sample")
-        e = float((gr.reshape(-1)[::step] - smp).abs().max()) / float(smp.abs().max())
-        worst = max(worst, e)
-        assert e < tol_s, (k, e)
+        d = gr.reshape(-1)[::step] - smp
+        e_max, e_l2 = float(d.abs().max() / smp.abs().max()), float(d.norm() / smp.norm())
+        worst = max(worst, e_l2)
+        if k in smooth:
+            assert e_max < tol_smooth, (k, e_max)
+        else:
+            assert e_l2 < tol_l2 and e_max < tol_max, (k, e_l2, e_max)
     sd = m.state_dict()
     assert_close(sd["layer1.0.bn1.running_mean"], g.t("rm_layer1"), 1e-4, 1e-6, "running mean layer1")
     assert_close(sd["layer3.22.bn3.running_mean"], g.t("rm_layer3"), 1e-3, 1e-5, "running mean layer3")
@@ -95,7 +107,7 @@ def test_benchmark_geometry_vs_reference(golden, conv_math, name):
         oe = m(x.to(DEV))[2]
     we = g.t("out_eval")
     assert float((oe.cpu() - we).abs().max()) < 1e-3 * float(we.abs().max())
-    print(f"{name} math={conv_math}: logits max err {err / scale:.2e} of scale, worst gradient sample {worst:.2e}")
+    print(f"{name} math={conv_math}: logits max err {err / scale:.2e} of scale, worst gradient-sample relative L2 {worst:.2e}")
 
 
 ASPP_CASES = [("d6", 6, 256), ("d12", 12, 256), ("d18", 18, 288), ("d24", 24, 256), ("d24_wide", 24, 512)]

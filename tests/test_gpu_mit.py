@@ -66,13 +66,12 @@ def test_gemm_tn_weight_gradient(m, n, k):
     dy = h16(torch.randn((m, n), generator=g)).to(DEV)
     x = h16(torch.randn((m, k), generator=g)).to(DEV)
     ops = _Ops(torch.device(DEV))
-    dw = ops.wgrad(dy, x, 0.25)
+    dw, db = ops.wgrad(dy, x, 0.25, bias=True)
     assert tuple(dw.shape) == (n, k)
     assert _rel(dw, 0.25 * dy.double().t() @ x.double()) < 2e-5
+    assert _rel(db, 0.25 * dy.double().sum(0)) < 2e-5              # the bias gradient rides along with the weight gradient
     assert torch.equal(dw, ops.wgrad(dy, x, 0.25)), "split-K slabs must reduce in a fixed order"
-    cs = ops.colsum(dy, 2.0) if n % 8 == 0 else None
-    if cs is not None:
-        assert _rel(cs, 2.0 * dy.double().sum(0)) < 2e-5
+    assert _rel(ops.colsum(dy, 2.0), 2.0 * dy.double().sum(0)) < 2e-5
 
 
 @pytest.mark.parametrize("c", [64, 128, 320, 512, 32, 160])
