@@ -257,7 +257,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof):
     from diga_amd.model.model_noaux import SegModel
     from diga_amd.train_step import DigaTrainer
 
-    _lib.call("diga_set_conv_math", 1 if precision == "bf16x3" else 0)
+    _lib.set_conv_math(1 if precision == "bf16x3" else 0)
     arch_name, B, H, W, block = geometry(a, config)
     torch.manual_seed(0)                       # identical random-init weights on every rank
     if arch_name.startswith("MIT_"):
@@ -435,7 +435,7 @@ def translator_leg(dev, precision):
     import torch
     from diga_amd import _lib
     from diga_amd.model.model_noaux import ImgDecoder, ImgEncoder
-    _lib.call("diga_set_conv_math", 1 if precision == "bf16x3" else 0)
+    _lib.set_conv_math(1 if precision == "bf16x3" else 0)
     torch.manual_seed(3)
     enc, dec = ImgEncoder().to(dev).eval(), ImgDecoder().to(dev).eval()
     for m in (enc, dec):

@@ -58,11 +58,11 @@ SIGNATURES = {
     "diga_split_bf16_image_bytes": (SZ, [I64, I64, I64]),
     "diga_split_bf16_image": (INT, [P, P, I64, I64, I64, P]),
     "diga_conv2d_nhwc_twin": (INT, [P, P, P, P] + [I64] * 16 + [P, INT, P]),
-    "diga_conv2d_next_options": (INT, [INT, INT, INT]),
-    "diga_set_conv_math": (INT, [INT]),
-    "diga_get_conv_math": (INT, []),
+    "diga_conv2d_nhwc_f32_opts": (INT, [P, P, P, P] + [I64] * 17 + [P, INT, P]),
+    "diga_conv2d_nhwc_bf16x3_opts": (INT, [P, P, P, P, P] + [I64] * 17 + [P, INT, P]),
+    "diga_conv2d_nhwc_twin_opts": (INT, [P, P, P, P] + [I64] * 16 + [P, INT, P]),
     "diga_conv2d_wgrad_workspace_bytes": (SZ, [I64] * 7),
-    "diga_conv2d_wgrad_nhwc_f32": (INT, [P, P, P, P, SZ] + [I64] * 17 + [P]),
+    "diga_conv2d_wgrad_nhwc_f32": (INT, [P, P, P, P, SZ] + [I64] * 17 + [INT, P]),
     "diga_conv2d_wgrad_twin_workspace_bytes": (SZ, [I64] * 7),
     "diga_conv2d_wgrad_twin": (INT, [P, P, P, P, SZ] + [I64] * 15 + [P]),
     "diga_weight_transpose": (INT, [P, P, I64, I64, I64, P]),
@@ -109,6 +109,11 @@ SIGNATURES = {
     "diga_prof_query_work": (INT, [INT, P]),
 }
 
+class ConvOptions(C.Structure):
+    """diga_conv_options_t of include/diga_hip.h."""
+    _fields_ = [("reflect_pad", INT), ("upsample_shift", INT), ("activation", INT)]
+
+
 class BwdEpilogue(C.Structure):
     """diga_bwd_epilogue_t of include/diga_hip.h."""
     _fields_ = [("addend", P), ("addend_ld", I64), ("mask_y", P), ("mask_ld", I64), ("x", P), ("x_ld", I64),
@@ -139,6 +144,26 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+# ---- conv arithmetic: host-side policy (the library keeps no process-wide mode; include/diga_hip.h, DIGA_CONV_MATH_*)
+CONV_MATH_F32, CONV_MATH_BF16X3 = 0, 1
+_conv_math = CONV_MATH_BF16X3 if os.environ.get("DIGA_CONV_MATH", "") in ("bf16x3", "1") else CONV_MATH_F32
+
+
+def set_conv_math(mode):
+    """0 / "f32": exact fp32 on the fp32 matrix cores; 1 / "bf16x3": fp32 operands split into bf16 hi+lo, three bf16 MFMAs
+    per product.  Selects which entry points DigaConv2d calls from now on; graphs already built keep the arithmetic of
+    their forward pass only where they hold split-twin tensors (DigaConv2d checks and raises otherwise)."""
+    global _conv_math
+    mode = {"f32": 0, "bf16x3": 1}.get(mode, mode)
+    if mode not in (CONV_MATH_F32, CONV_MATH_BF16X3):
+        raise ValueError(f"conv math must be 0 / 'f32' or 1 / 'bf16x3', not {mode!r}")
+    _conv_math = int(mode)
+
+
+def get_conv_math():
+    return _conv_math
 
 
 def last_error():

@@ -2286,11 +2286,6 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
 
 // process-wide arithmetic of the forward / backward-data kernels (diga_set_conv_math); the default can be
 // chosen with DIGA_CONV_MATH=bf16x3 in the environment
-static std::atomic<int> g_conv_math{[] {
-    const char* e = getenv("DIGA_CONV_MATH");
-    return (e && (strcmp(e, "bf16x3") == 0 || strcmp(e, "1") == 0)) ? DIGA_CONV_MATH_BF16X3 : DIGA_CONV_MATH_F32;
-}()};
-
 static int check_conv_common(const char* who, int64_t Cin, int64_t in_ld, int64_t out_ld, int64_t Cout,
                              const void* in, const void* w, const void* out) {
     DIGA_REQUIRE(Cin > 0 && Cin % 32 == 0, DIGA_EINVAL, "%s: Cin=%lld must be a multiple of 32", who, (long long)Cin);
@@ -2300,17 +2295,18 @@ static int check_conv_common(const char* who, int64_t Cin, int64_t in_ld, int64_
     return DIGA_OK;
 }
 
-// diga_conv2d_next_options: consumed by the next forward-convolution call of this thread
-struct NextOpts {
-    int reflect = 0, up_shift = 0, act = 0;
-};
-static thread_local NextOpts g_next_opts;
+// input-map / activation options of a forward convolution (include/diga_hip.h, diga_conv_options_t); nullptr = none
+static void set_options(ConvArgs& a, const diga_conv_options_t* o) {
+    a.pad_reflect = o ? o->reflect_pad : 0;
+    a.up_shift = o ? o->upsample_shift : 0;
+    a.act = o ? o->activation : 0;
+}
 
-static void take_next_options(ConvArgs& a) {
-    a.pad_reflect = g_next_opts.reflect;
-    a.up_shift = g_next_opts.up_shift;
-    a.act = g_next_opts.act;
-    g_next_opts = NextOpts();
+static int check_options(const diga_conv_options_t* o, const char* who) {
+    if (o == nullptr) return DIGA_OK;
+    DIGA_REQUIRE(o->reflect_pad >= 0 && o->reflect_pad <= 1 && o->upsample_shift >= 0 && o->upsample_shift <= 2 && o->activation >= 0 &&
+                     o->activation <= 1, DIGA_EINVAL, "%s: bad options (reflect_pad 0/1, upsample_shift 0..2, activation 0/1)", who);
+    return DIGA_OK;
 }
 
 // fills the backward-epilogue fields of ConvArgs from the public descriptor (nullptr = plain convolution)
@@ -2348,7 +2344,8 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
                                     int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo,
                                     int64_t Cout, int64_t out_ld, int64_t R, int64_t S, int64_t stride_y,
                                     int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
-                                    float* stats_partial, int prof_tag, void* stream, const diga_bwd_epilogue_t* epi) {
+                                    float* stats_partial, int prof_tag, void* stream, const diga_bwd_epilogue_t* epi,
+                                    const diga_conv_options_t* opts = nullptr) {
     DIGA_REQUIRE(in && wgt && out, DIGA_EINVAL, "conv2d: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d: bad shape");
     int rc = check_conv_common("conv2d", Cin, in_ld, out_ld, Cout, in, wgt, out);
@@ -2363,7 +2360,9 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
     a.M = (int)(N * Ho * Wo);
     a.all_inside = 0;
     a.tiles_m = (int)ceil_div(a.M, 128);
-    take_next_options(a);
+    rc = check_options(opts, "conv2d");
+    if (rc) return rc;
+    set_options(a, opts);
     rc = set_bwd_epilogue(a, epi, "conv2d");
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -2382,27 +2381,16 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
         if (epi != nullptr && BK_ == 32) DIGA_LAUNCH_K((conv_fwd_kernel<TN_, 32, true>), 256, sh);                      \
         else DIGA_LAUNCH_K((conv_fwd_kernel<TN_, BK_, false>), 256, sh);                                                \
     } while (0)
-#define DIGA_X3_LAUNCH(TN_)                                                                                            \
-    do {                                                                                                               \
-        const size_t sh = (size_t)2 * (2 * 128 * kRowB + 2 * 64 * TN_ * kRowB);                                         \
-        if (epi != nullptr) DIGA_LAUNCH_K((conv_fwd_x3_kernel<TN_, true>), 256, sh);                                    \
-        else DIGA_LAUNCH_K((conv_fwd_x3_kernel<TN_, false>), 256, sh);                                                  \
-    } while (0)
-    const bool x3 = g_conv_math.load(std::memory_order_relaxed) == DIGA_CONV_MATH_BF16X3;
-    DIGA_REQUIRE(!x3 || !(a.pad_reflect || a.up_shift), DIGA_EINVAL, "conv2d: input map options need the f32 kernel here");
     if (Cout > 64) {
         a.tiles_n = (int)ceil_div(Cout, 128);
-        if (x3) DIGA_X3_LAUNCH(2);
-        else if (bk == 16) DIGA_FWD_LAUNCH(2, 16);
+        if (bk == 16) DIGA_FWD_LAUNCH(2, 16);
         else DIGA_FWD_LAUNCH(2, 32);
     } else {
         a.tiles_n = 1;
-        if (x3) DIGA_X3_LAUNCH(1);
-        else if (bk == 16) DIGA_FWD_LAUNCH(1, 16);
+        if (bk == 16) DIGA_FWD_LAUNCH(1, 16);
         else DIGA_FWD_LAUNCH(1, 32);
     }
 #undef DIGA_FWD_LAUNCH
-#undef DIGA_X3_LAUNCH
     return launch_status("diga_conv2d_nhwc_f32");
 }
 
@@ -2439,7 +2427,7 @@ static int conv2d_bf16x3_impl(const float* in, const uint16_t* wgt_hi, const uin
                                        int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
                                        int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
                                        int64_t off_dx, float* stats_partial, int prof_tag, void* stream,
-                                       const diga_bwd_epilogue_t* epi) {
+                                       const diga_bwd_epilogue_t* epi, const diga_conv_options_t* opts = nullptr) {
     DIGA_REQUIRE(in && wgt_hi && wgt_lo && out, DIGA_EINVAL, "conv2d_bf16x3: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_bf16x3: bad shape");
     int rc = check_conv_common("conv2d_bf16x3", Cin, in_ld, out_ld, Cout, in, in, out);
@@ -2459,7 +2447,9 @@ static int conv2d_bf16x3_impl(const float* in, const uint16_t* wgt_hi, const uin
         const int64_t x_lo = off_x0 + std::min<int64_t>(0, (S - 1) * off_dx), x_hi = (Wo - 1) * stride_x + off_x0 + std::max<int64_t>(0, (S - 1) * off_dx);
         a.all_inside = y_lo >= 0 && y_hi < Hi && x_lo >= 0 && x_hi < Wi;
     }
-    take_next_options(a);
+    rc = check_options(opts, "conv2d_bf16x3");
+    if (rc) return rc;
+    set_options(a, opts);
     if (a.pad_reflect || a.up_shift) a.all_inside = 0;
     rc = set_bwd_epilogue(a, epi, "conv2d_bf16x3");
     if (rc) return rc;
@@ -2554,7 +2544,7 @@ static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const floa
                                      int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld,
                                      int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
                                      int64_t off_dy, int64_t off_dx, float* stats_partial, int prof_tag, void* stream,
-                                     const diga_bwd_epilogue_t* epi) {
+                                     const diga_bwd_epilogue_t* epi, const diga_conv_options_t* opts = nullptr) {
     DIGA_REQUIRE(in_twin && wgt_img && out, DIGA_EINVAL, "conv2d_twin: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cout > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_twin: bad shape");
     DIGA_REQUIRE(Cin > 0 && Cin % 32 == 0 && out_ld >= Cout, DIGA_EINVAL, "conv2d_twin: Cin must be a multiple of 32");
@@ -2572,9 +2562,11 @@ static int conv2d_twin_impl(const void* in_twin, const void* wgt_img, const floa
     a.all_inside = 0;
     const int tn = Cout > 64 ? 2 : 1;
     a.tiles_n = (int)ceil_div(Cout, 64 * tn);
-    take_next_options(a);
     {
-        const int rc = set_bwd_epilogue(a, epi, "conv2d_twin");
+        int rc = check_options(opts, "conv2d_twin");
+        if (rc) return rc;
+        set_options(a, opts);
+        rc = set_bwd_epilogue(a, epi, "conv2d_twin");
         if (rc) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -2629,27 +2621,40 @@ extern "C" int diga_conv2d_nhwc_twin_epi(const void* in_twin, const void* wgt_im
                             off_x0, off_dy, off_dx, nullptr, prof_tag, stream, epi);
 }
 
-extern "C" int diga_conv2d_next_options(int reflect_pad, int upsample_shift, int activation) {
-    DIGA_REQUIRE((reflect_pad == 0 || reflect_pad == 1) && upsample_shift >= 0 && upsample_shift <= 2 &&
-                     (activation == 0 || activation == 1),
-                 DIGA_EINVAL, "conv2d_next_options: reflect_pad in {0,1}, upsample_shift in 0..2, activation in {0 none, 1 tanh}");
-    g_next_opts.reflect = reflect_pad;
-    g_next_opts.up_shift = upsample_shift;
-    g_next_opts.act = activation;
-    return DIGA_OK;
+// The same three forward entry points with the translator's input map / output activation folded in (diga_conv_options_t):
+// explicit per call -- no state survives a call.
+extern "C" int diga_conv2d_nhwc_f32_opts(const float* in, const float* wgt, const float* bias, float* out, int64_t N, int64_t Hi,
+                                         int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld,
+                                         int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
+                                         int64_t off_dy, int64_t off_dx, const diga_conv_options_t* opts, int prof_tag, void* stream) {
+    DIGA_REQUIRE(opts != nullptr, DIGA_EINVAL, "conv2d_opts: null options");
+    return conv2d_f32_impl(in, wgt, bias, out, N, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x, off_y0, off_x0,
+                           off_dy, off_dx, nullptr, prof_tag, stream, nullptr, opts);
+}
+
+extern "C" int diga_conv2d_nhwc_bf16x3_opts(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, const float* bias, float* out,
+                                            int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo,
+                                            int64_t Cout, int64_t out_ld, int64_t R, int64_t S, int64_t stride_y, int64_t stride_x,
+                                            int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
+                                            const diga_conv_options_t* opts, int prof_tag, void* stream) {
+    DIGA_REQUIRE(opts != nullptr, DIGA_EINVAL, "conv2d_bf16x3_opts: null options");
+    return conv2d_bf16x3_impl(in, wgt_hi, wgt_lo, bias, out, N, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x, off_y0,
+                              off_x0, off_dy, off_dx, nullptr, prof_tag, stream, nullptr, opts);
+}
+
+extern "C" int diga_conv2d_nhwc_twin_opts(const void* in_twin, const void* wgt_img, const float* bias, float* out, int64_t N, int64_t Hi,
+                                          int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R,
+                                          int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
+                                          int64_t off_dx, const diga_conv_options_t* opts, int prof_tag, void* stream) {
+    DIGA_REQUIRE(opts != nullptr, DIGA_EINVAL, "conv2d_twin_opts: null options");
+    return conv2d_twin_impl(in_twin, wgt_img, bias, out, N, Hi, Wi, Cin, Ho, Wo, Cout, out_ld, R, S, stride_y, stride_x, off_y0, off_x0,
+                            off_dy, off_dx, nullptr, prof_tag, stream, nullptr, opts);
 }
 
 extern "C" size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout) {
     return (size_t)ceil_div(N * Ho * Wo, 128) * 3 * (size_t)Cout;
 }
 
-extern "C" int diga_set_conv_math(int mode) {
-    DIGA_REQUIRE(mode == DIGA_CONV_MATH_F32 || mode == DIGA_CONV_MATH_BF16X3, DIGA_EINVAL, "set_conv_math: unknown mode %d", mode);
-    g_conv_math.store(mode, std::memory_order_relaxed);
-    return DIGA_OK;
-}
-
-extern "C" int diga_get_conv_math(void) { return g_conv_math.load(std::memory_order_relaxed); }
 
 namespace {
 struct WgradPlan {
@@ -2694,7 +2699,7 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
                                           size_t workspace_bytes, int64_t N, int64_t Hi, int64_t Wi, int64_t Cin,
                                           int64_t x_ld, int64_t Ho, int64_t Wo, int64_t Cout, int64_t dy_ld, int64_t R,
                                           int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0,
-                                          int64_t off_x0, int64_t off_dy, int64_t off_dx, void* stream) {
+                                          int64_t off_x0, int64_t off_dy, int64_t off_dx, int math, void* stream) {
     DIGA_REQUIRE(dy && x && dw, DIGA_EINVAL, "conv2d_wgrad: null pointer");
     DIGA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && R > 0 && S > 0, DIGA_EINVAL, "conv2d_wgrad: bad shape");
     DIGA_REQUIRE(Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 4 == 0 && x_ld >= Cin && x_ld % 4 == 0 && dy_ld >= Cout &&
@@ -2703,7 +2708,8 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
     DIGA_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw), DIGA_EALIGN, "conv2d_wgrad: pointers must be 16-byte aligned");
     DIGA_REQUIRE(N * Hi * Wi < (1ll << 31) && N * Ho * Wo < (1ll << 31), DIGA_EINVAL, "conv2d_wgrad: too many pixels");
     const int64_t RS = R * S, M = N * Ho * Wo;
-    const bool x3 = g_conv_math.load(std::memory_order_relaxed) == DIGA_CONV_MATH_BF16X3;
+    DIGA_REQUIRE(math == DIGA_CONV_MATH_F32 || math == DIGA_CONV_MATH_BF16X3, DIGA_EINVAL, "conv2d_wgrad: math must be DIGA_CONV_MATH_F32 or _BF16X3");
+    const bool x3 = math == DIGA_CONV_MATH_BF16X3;
     const WgradPlan p = plan_wgrad(M, Cout, Cin, RS, x3);
     const bool wide = p.tm == 4;
     const size_t slab_bytes = wgrad_slab_bytes(p, Cout, Cin, RS);

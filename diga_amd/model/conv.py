@@ -52,7 +52,7 @@ def takes_twin_only_input(conv, pointwise_ok=False):
     pointwise_ok: also for 1x1 layers (worth it only when both of its twins are free, i.e. under autograd where the
     weight gradient gains 35-39 %; the forward kernel alone gains nothing on 8-step tiles)."""
     taps = conv.kernel_size[0] * conv.kernel_size[1]
-    return (_lib.lib.diga_get_conv_math() == 1 and os.environ.get("DIGA_CONV_TWIN", "3") != "0"
+    return (_lib.get_conv_math() == 1 and os.environ.get("DIGA_CONV_TWIN", "3") != "0"
             and os.environ.get("DIGA_TWIN_ONLY", "1") != "0"
             and (taps > 1 or pointwise_ok) and conv.in_channels % 32 == 0 and conv.in_channels > 64 and conv.out_channels >= 256 and conv.out_channels % 8 == 0
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
@@ -63,17 +63,19 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x.
     epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue.
-    opts: (reflect_pad, upsample_shift, activation) of diga_conv2d_next_options -- x is then the SOURCE tensor of the
+    opts: (reflect_pad, upsample_shift, activation) = a diga_conv_options_t handed to the `_opts` entry points -- x is then the SOURCE tensor of the
     (virtually) upsampled / mirrored input."""
     import ctypes
 
-    def arm():
-        if opts is not None and any(opts):
-            _lib.call("diga_conv2d_next_options", int(opts[0]), int(opts[1]), int(opts[2]))
+    copt = None
+    if opts is not None and any(opts):
+        if stats is not None or epi is not None:
+            raise RuntimeError("DigaConv2d: folded padding / upsampling / activation cannot be combined with BN statistics or a backward epilogue")
+        copt = _lib.ConvOptions(int(opts[0]), int(opts[1]), int(opts[2]))
     n, hi, wi, cin = x.shape
     _, ho, wo, k = out.shape
     _, r, s, _ = w_krsc.shape
-    if (_lib.lib.diga_get_conv_math() == 1 and _use_twin(cin, k, r * s, twin_box is not None)
+    if (_lib.get_conv_math() == 1 and _use_twin(cin, k, r * s, twin_box is not None)
             and n * hi * wi * cin * 4 < (1 << 40)):
         # split-bf16 arithmetic without register staging: both operands pre-split, copied global -> LDS by LDS-DMA
         twin = twin_box[0] if twin_box is not None else None
@@ -90,7 +92,10 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                       out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], ctypes.byref(epi), tag,
                       _lib.stream())
             return twin
-        arm()
+        if copt is not None:
+            _lib.call("diga_conv2d_nhwc_twin_opts", _lib.ptr(twin), _lib.ptr(img), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin, ho, wo, k,
+                      out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], ctypes.byref(copt), tag, _lib.stream())
+            return twin
         _lib.call("diga_conv2d_nhwc_twin", _lib.ptr(twin), _lib.ptr(img), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin, ho, wo, k,
                   out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1], _lib.ptr(stats), tag,
                   _lib.stream())
@@ -98,7 +103,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
     if must_twin:
         raise RuntimeError("DigaConv2d: the input holds split-twin bytes but the twin kernel is not selected "
                            "(conv math or DIGA_CONV_TWIN changed since the producer ran)")
-    if _lib.lib.diga_get_conv_math() == 1:
+    if _lib.get_conv_math() == 1:
         # split-bf16 arithmetic: the weights are split once here (two bf16 arrays), the activations inside the kernel
         nel = w_krsc.numel()
         w_hi = torch.empty(nel, dtype=torch.int16, device=w_krsc.device)
@@ -109,7 +114,11 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                       n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                       doff[0], doff[1], ctypes.byref(epi), tag, _lib.stream())
             return None
-        arm()
+        if copt is not None:
+            _lib.call("diga_conv2d_nhwc_bf16x3_opts", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(bias), _lib.ptr(out),
+                      n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
+                      doff[0], doff[1], ctypes.byref(copt), tag, _lib.stream())
+            return None
         _lib.call("diga_conv2d_nhwc_bf16x3", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(bias), _lib.ptr(out),
                   n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                   doff[0], doff[1], _lib.ptr(stats), tag, _lib.stream())
@@ -119,7 +128,11 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                   x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
                   ctypes.byref(epi), tag, _lib.stream())
         return None
-    arm()
+    if copt is not None:
+        _lib.call("diga_conv2d_nhwc_f32_opts", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin,
+                  x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
+                  ctypes.byref(copt), tag, _lib.stream())
+        return None
     _lib.call("diga_conv2d_nhwc_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), n, hi, wi, cin,
               x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
               _lib.ptr(stats), tag, _lib.stream())
@@ -245,7 +258,7 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         ctx.uses = uses
         # the arithmetic / twin decisions of this forward bind its backward: saved tensors may hold twin bytes
-        ctx.math = _lib.lib.diga_get_conv_math()
+        ctx.math = _lib.get_conv_math()
         ctx.x_is_twin = bool(x_is_twin)
         # the BatchNorm that produced x lets this conv's backward-data epilogue finish its incoming gradient (norm._BnFn)
         ctx.bn_box = None
@@ -273,8 +286,8 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         xn, w = ctx.saved_tensors
         stride, padding, dilation, c_true, has_bias, w_strides = ctx.geom
-        if (ctx.x_is_twin or ctx.dy_is_twin or ctx.x_twin is not None) and _lib.lib.diga_get_conv_math() != ctx.math:
-            raise RuntimeError("DigaConv2d: diga_set_conv_math() changed between forward and backward of a graph that "
+        if (ctx.x_is_twin or ctx.dy_is_twin or ctx.x_twin is not None) and _lib.get_conv_math() != ctx.math:
+            raise RuntimeError("DigaConv2d: the conv arithmetic (_lib.set_conv_math) changed between forward and backward of a graph that "
                                "holds split-twin tensors (their bytes are only readable by the twin kernels)")
         if ctx.x_is_twin and ctx.needs_input_grad[1] and ctx.x_twin is None:
             raise RuntimeError("DigaConv2d: twin-only input saved for backward but the weight gradient is off the twin kernel")
@@ -289,10 +302,10 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         st = _lib.stream()
         x_twin = getattr(ctx, "x_twin", None)
-        use_tw = x_twin is not None and ctx.needs_input_grad[1] and _lib.lib.diga_get_conv_math() == 1 and kp == k
+        use_tw = x_twin is not None and ctx.needs_input_grad[1] and _lib.get_conv_math() == 1 and kp == k
         dy_box = [None] if use_tw else None            # the twin of dy: built once, read by backward-data and -weight
         if ctx.dy_is_twin:          # the BatchNorm after this conv wrote its dx as a twin (same bytes per element)
-            if not (kp == k and _lib.lib.diga_get_conv_math() == 1 and cp > 64 and (use_tw or not ctx.needs_input_grad[1])):
+            if not (kp == k and _lib.get_conv_math() == 1 and cp > 64 and (use_tw or not ctx.needs_input_grad[1])):
                 raise RuntimeError("DigaConv2d: twin gradient on a layer that is not on the twin kernels")
             dy_box = [gyp.reshape(-1).view(torch.uint8)]
         if ctx.needs_input_grad[0]:
@@ -396,7 +409,7 @@ class _Conv2dFn(torch.autograd.Function):
                 ws = _lib.workspace(nbytes, w.device, "wgrad")
                 _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
                           n, hi, wi, cp, xn.stride(2), ho, wo, kp, gyp.stride(2), r, s, stride[0], stride[1],
-                          -padding[0], -padding[1], dilation[0], dilation[1], _lib.stream())
+                          -padding[0], -padding[1], dilation[0], dilation[1], _lib.get_conv_math(), _lib.stream())
                 if not alias:
                     dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
 
@@ -446,7 +459,7 @@ class DigaConv2d(nn.Conv2d):
     def forward(self, x, twin_grad=False, opts=None, chain=None):
         """twin_grad: the gradient of this conv's output will arrive as a split twin (the BatchNorm that consumes the
         output was called with dx_twin=True).  opts = (reflect_pad, upsample_shift, activation): inference-only input
-        map / output activation folded into the kernel (diga_conv2d_next_options)."""
+        map / output activation folded into the kernel (diga_conv_options_t, the `_opts` entry points)."""
         fn = _Conv2dFn
         if (self.in_channels < 8 and not x.requires_grad and tuple(self.dilation) == (1, 1)
                 and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]):

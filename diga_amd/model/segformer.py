@@ -8,7 +8,7 @@ optimizer groups -- with the reference's own ASPP head `Classifier_Module2` (seg
 stage (512 channels, stride 32).  Everything downstream (upsample + CE + distillation block, EMA teacher, ClassMix, fused SGD,
 gradient all-reduce) is the DeepLab path's code unchanged, so `DigaTrainer` drives it as it drives `SegModel`.
 Encoder: fp16 storage / fp32 accumulate (diga_amd/model/networks/MixTransfomer.py); head: fp32 tensors, the conv arithmetic
-selected by diga_set_conv_math like every other DigaConv2d."""
+selected by _lib.set_conv_math like every other DigaConv2d."""
 import os
 import sys
 

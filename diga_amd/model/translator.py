@@ -5,7 +5,7 @@ It runs every step under no_grad right before the scoped path (warm_up.py:235-23
 row 1).  Everything but the residual adds runs on the HIP kernels: the convolutions on the implicit-GEMM kernels with
 the reflection padding folded into their tap addressing, the decoder's nearest-neighbour x2 upsampling folded into the
 loader of the conv that follows (the 4x larger tensor is never written), tanh in the last conv's epilogue
-(diga_conv2d_next_options), InstanceNorm (+ReLU) on the GroupNorm kernels with one group per channel.  With autograd
+(diga_conv_options_t of the `_opts` conv entry points), InstanceNorm (+ReLU) on the GroupNorm kernels with one group per channel.  With autograd
 enabled the same modules fall back to explicit pad / upsample / tanh ops around the conv (the translator is frozen on
 the DiGA path; its GAN training is out of scope).
 Keys: `model.<i>.conv.{weight,bias}` for plain blocks, `model.<i>.model.<j>.model.<k>.conv.{weight,bias}`

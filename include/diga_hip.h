@@ -270,25 +270,31 @@ int diga_conv2d_nhwc_twin_epi(const void* in_twin, const void* wgt_img, float* o
                               int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy,
                               int64_t off_dx, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
 
-/* Options of the NEXT forward convolution call of the calling thread (diga_conv2d_nhwc_f32 / _bf16x3 / _twin; consumed
- * and reset by it) -- the non-conv ops around the translator's convolutions (G5/model/model_util.py:21-61: ReflectionPad2d
- * -> Conv2d -> [norm] -> [activation]; G5/model/model_noaux.py:100-117: nn.Upsample(scale_factor=2) in front of a block)
- * folded into the kernel's addressing instead of separate passes over HBM:
+/* Options of ONE forward convolution call (the `_opts` entry points below) -- the non-conv ops around the translator's
+ * convolutions (G5/model/model_util.py:21-61: ReflectionPad2d -> Conv2d -> [norm] -> [activation];
+ * G5/model/model_noaux.py:100-117: nn.Upsample(scale_factor=2) in front of a block) folded into the kernel's addressing
+ * instead of separate passes over HBM:
  *   reflect_pad     1: taps outside the image read the mirrored pixel (index -i -> i, H-1+i -> H-1-i) instead of zero
  *   upsample_shift  s: the conv reads the 2^s nearest-neighbour upsampling of `in` ([N,Hi,Wi,Cin] stays the SOURCE tensor;
  *                      Ho/Wo and the tap offsets are those of the upsampled image)
  *   activation      1: tanh on the (biased) output
- * Not combinable with BatchNorm statistics output or a backward epilogue. */
-int diga_conv2d_next_options(int reflect_pad, int upsample_shift, int activation);
+ * Passed explicitly with the call; the library keeps no per-thread or per-process mode.  Not combinable with BatchNorm
+ * statistics output or a backward epilogue. */
+typedef struct diga_conv_options {
+    int reflect_pad;
+    int upsample_shift;
+    int activation;
+} diga_conv_options_t;
 
-/* Arithmetic of diga_conv2d_nhwc_f32 (process-wide; default from the environment variable DIGA_CONV_MATH):
- *   DIGA_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, exact fp32 (k-ordered fmaf chain)            [default]
- *   DIGA_CONV_MATH_BF16X3 operands split into bf16 hi+lo while staged, hi*hi + hi*lo + lo*hi on
- *                         v_mfma_f32_32x32x16_bf16 with fp32 accumulate (~1e-5 relative per product) */
+/* Conv arithmetic.  The exact-fp32 and the split-bf16 kernels are SEPARATE entry points (diga_conv2d_nhwc_f32 vs
+ * diga_conv2d_nhwc_bf16x3 / _twin); the one entry point that serves both, diga_conv2d_wgrad_nhwc_f32, takes the arithmetic
+ * as an argument.  Which one a model runs in is host-side policy (diga_amd/_lib.py: set_conv_math, default from the
+ * environment variable DIGA_CONV_MATH) -- the library holds no process-wide mode.
+ *   DIGA_CONV_MATH_F32    v_mfma_f32_32x32x2_f32, exact fp32 (k-ordered fmaf chain)
+ *   DIGA_CONV_MATH_BF16X3 operands split into bf16 hi+lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
+ *                         accumulate (~1e-5 relative per product) */
 #define DIGA_CONV_MATH_F32 0
 #define DIGA_CONV_MATH_BF16X3 1
-int diga_set_conv_math(int mode);
-int diga_get_conv_math(void);
 
 /* Tuned split-bf16 forward / backward-data: same contract as diga_conv2d_nhwc_f32 in DIGA_CONV_MATH_BF16X3, but the
  * weights are passed already split (diga_split_bf16 of the [Cout][R][S][Cin] array, once per step), so the kernel
@@ -317,16 +323,32 @@ int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, const float*
                           int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
                           float* stats_partial, int prof_tag, void* stream);
 
+/* diga_conv2d_nhwc_f32 / _bf16x3 / _twin with a diga_conv_options_t (non-null; inference-only: no statistics output). */
+int diga_conv2d_nhwc_f32_opts(const float* in, const float* wgt, const float* bias, float* out, int64_t N, int64_t Hi, int64_t Wi,
+                              int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                              int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
+                              const diga_conv_options_t* opts, int prof_tag, void* stream);
+int diga_conv2d_nhwc_bf16x3_opts(const float* in, const uint16_t* wgt_hi, const uint16_t* wgt_lo, const float* bias, float* out,
+                                 int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo, int64_t Cout,
+                                 int64_t out_ld, int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0,
+                                 int64_t off_x0, int64_t off_dy, int64_t off_dx, const diga_conv_options_t* opts, int prof_tag,
+                                 void* stream);
+int diga_conv2d_nhwc_twin_opts(const void* in_twin, const void* wgt_img, const float* bias, float* out, int64_t N, int64_t Hi,
+                               int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,
+                               int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
+                               const diga_conv_options_t* opts, int prof_tag, void* stream);
+
 /* dw[k][r][s][c] = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride_y + off_y0 + r*off_dy, wo*stride_x + off_x0 + s*off_dx, c]
  * Split over pixel ranges into fp32 slabs in `workspace`, summed in fixed order (deterministic).
- * Cin % 4 == 0, Cout % 4 == 0. */
+ * math = DIGA_CONV_MATH_F32 (exact fp32 MFMA) or DIGA_CONV_MATH_BF16X3 (operands split in the kernel).  Cin % 4 == 0,
+ * Cout % 4 == 0. */
 size_t diga_conv2d_wgrad_workspace_bytes(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout, int64_t Cin,
                                          int64_t R, int64_t S);
 int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes,
                                int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t x_ld,
                                int64_t Ho, int64_t Wo, int64_t Cout, int64_t dy_ld, int64_t R, int64_t S,
                                int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
-                               int64_t off_dy, int64_t off_dx, void* stream);
+                               int64_t off_dy, int64_t off_dx, int math, void* stream);
 
 /* Backward-weight of the same convolution on the split twins (diga_make_twin of dy [N,Ho,Wo,Cout] and of x
  * [N,Hi,Wi,Cin], both dense): operands staged by LDS-DMA, fragments read with transposing LDS reads.  dw [Cout][R][S][Cin].

@@ -48,10 +48,10 @@ def conv_math(request):
     """Runs a GPU test under both convolution arithmetics: exact fp32 (library default) and the split-bf16 mode that
     bench.py times (twin kernels, twin-only tensors and DIGA_TWIN_CONV3 at their defaults = on)."""
     from diga_amd import _lib
-    prev = _lib.lib.diga_get_conv_math()
-    _lib.call("diga_set_conv_math", request.param)
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(request.param)
     yield request.param
-    _lib.call("diga_set_conv_math", prev)
+    _lib.set_conv_math(prev)
 
 
 def assert_close(a, b, rtol=1e-5, atol=1e-6, what=""):

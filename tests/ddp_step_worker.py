@@ -23,7 +23,7 @@ def main(out_dir):
     from oracle import detweights, synth
     rank, world, local = ddp.init_from_env()
     dev = torch.device("cuda", local)
-    _lib.call("diga_set_conv_math", int(os.environ.get("DIGA_TEST_MATH", "0")))
+    _lib.set_conv_math(int(os.environ.get("DIGA_TEST_MATH", "0")))
 
     def make():
         m = SegModel(arch=sm.TINY)

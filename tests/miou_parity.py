@@ -38,8 +38,8 @@ def run(conv_math, dev="cuda"):
     with np.load(os.path.join(ROOT, "tests", "golden", "valmiou.npz")) as z:
         g = {k: z[k] for k in z.files}
     n_img, H, W = (int(v) for v in g["geometry"])
-    prev = _lib.lib.diga_get_conv_math()
-    _lib.call("diga_set_conv_math", conv_math)
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(conv_math)
     try:
         m = SegModel()
         m.load_state_dict(detweights.state_dict(od.RESNET101))
@@ -55,7 +55,7 @@ def run(conv_math, dev="cuda"):
         with contextlib.redirect_stdout(io.StringIO()):
             score, cls_iu = rs.get_scores()
     finally:
-        _lib.call("diga_set_conv_math", prev)
+        _lib.set_conv_math(prev)
     miou = float(score["Mean IoU : \t"])
     return {"miou": miou, "miou_reference": float(g["miou"]), "miou_delta_points": 100.0 * abs(miou - float(g["miou"])),
             "pixels": n_img * H * W, "pixels_argmax_differs": n_img * H * W - agree,

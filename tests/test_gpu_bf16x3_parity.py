@@ -25,10 +25,10 @@ DEV = "cuda"
 @pytest.fixture
 def bf16x3():
     from diga_amd import _lib
-    prev = _lib.lib.diga_get_conv_math()
-    _lib.call("diga_set_conv_math", 1)
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(1)
     yield
-    _lib.call("diga_set_conv_math", prev)
+    _lib.set_conv_math(prev)
 
 
 def _block_state(pfx, inplanes, planes, has_down):
@@ -233,10 +233,10 @@ def test_c2_fullsize_step_bf16x3_vs_f32():
     sd = detweights.state_dict(od.RESNET101)
     batch = [t.to(DEV) for t in synth.warmup_batch(4242, B, H, W, block=32)]
     res = {}
-    prev = _lib.lib.diga_get_conv_math()
+    prev = _lib.get_conv_math()
     try:
         for math in (0, 1):
-            _lib.call("diga_set_conv_math", math)
+            _lib.set_conv_math(math)
             student, teacher = SegModel(), SegModel()
             for mdl in (student, teacher):
                 mdl.load_state_dict(sd)
@@ -256,7 +256,7 @@ def test_c2_fullsize_step_bf16x3_vs_f32():
             del tr, student, teacher
             torch.cuda.empty_cache()
     finally:
-        _lib.call("diga_set_conv_math", prev)
+        _lib.set_conv_math(prev)
     (l0, g0, h0, o0), (l1, g1, h1, o1) = res[0], res[1]
     print(f"\nC2 step f32: {l0} |g|={g0:.6g}\nC2 step bf16x3: {l1} |g|={g1:.6g}")
     for k in ("ce", "distil", "total"):

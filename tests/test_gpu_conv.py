@@ -79,9 +79,9 @@ def test_conv_fwd_bwd(case):
 @pytest.fixture
 def bf16x3():
     from diga_amd import _lib
-    _lib.call("diga_set_conv_math", 1)
+    _lib.set_conv_math(1)
     yield
-    _lib.call("diga_set_conv_math", 0)
+    _lib.set_conv_math(0)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -90,7 +90,7 @@ def test_conv_bf16x3_mode(case, bf16x3):
     errors stay at the 1e-5 level of the output scale, two orders inside the path's 1e-3 logit tolerance."""
     from diga_amd import _lib
     from diga_amd.model.conv import DigaConv2d
-    assert _lib.lib.diga_get_conv_math() == 1
+    assert _lib.get_conv_math() == 1
     name, n, cin, h, w, cout, k, stride, pad, dil, bias = case
     g = synth.gen(zlib.crc32(name.encode()) % 10000 + 1)
     x = torch.randn((n, cin, h, w), generator=g)
@@ -183,8 +183,8 @@ def test_conv_epilogue_bn_statistics(case, math):
             for p in bn.parameters():
                 p.requires_grad = False
     conv, bn_a, bn_b = conv.to(DEV).train(), bn_a.to(DEV).train(), bn_b.to(DEV).train()
-    prev = _lib.lib.diga_get_conv_math()
-    _lib.lib.diga_set_conv_math(math)
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(math)
     try:
         conv.emit_bn_stats = True
         y = conv(x.to(DEV))
@@ -192,7 +192,7 @@ def test_conv_epilogue_bn_statistics(case, math):
         fused = bn_a(y, relu=True)
         plain = bn_b(y.detach().clone(), relu=True)          # no partials attached: statistics re-read y
     finally:
-        _lib.lib.diga_set_conv_math(prev)
+        _lib.set_conv_math(prev)
     yd = y.detach().double().cpu()
     mean, var = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
     ref = torch.relu((yd - mean[None, :, None, None]) / torch.sqrt(var + bn_a.eps)[None, :, None, None]

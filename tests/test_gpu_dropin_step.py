@@ -30,7 +30,7 @@ assert _m.__file__.startswith(sys.argv[1]), _m.__file__
 sys.path.append(sys.argv[2])
 from oracle import deeplab as od, detweights, synth           # test infrastructure: deterministic weights + inputs
 from diga_amd import _lib
-_lib.call("diga_set_conv_math", int(sys.argv[3]))
+_lib.set_conv_math(int(sys.argv[3]))
 foreach = {"0": False, "1": True, "none": None}[sys.argv[4]]
 
 batch_size, H, W = 2, 128, 128

@@ -188,8 +188,8 @@ def test_conv_fullsize_split_bf16_vs_exact_fp32(geom):
     yy = torch.randn((n, cout, hw, hw), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
 
     def run(mode):
-        prev = _lib.lib.diga_get_conv_math()
-        _lib.lib.diga_set_conv_math(mode)
+        prev = _lib.get_conv_math()
+        _lib.set_conv_math(mode)
         try:
             m.weight.grad = None
             m.emit_bn_stats = True
@@ -200,7 +200,7 @@ def test_conv_fullsize_split_bf16_vs_exact_fp32(geom):
             (y * yy).sum().backward()
             return y.detach(), x.grad.detach(), m.weight.grad.detach().clone(), stats
         finally:
-            _lib.lib.diga_set_conv_math(prev)
+            _lib.set_conv_math(prev)
 
     y1, dx1, dw1, st1 = run(1)
     y0, dx0, dw0, _ = run(0)

@@ -315,8 +315,8 @@ def test_segformer_student_warmup_step_vs_oracle_composition():
     from diga_amd.train_step import DigaTrainer
     from oracle import deeplab as od
     from oracle import detweights, losses as ol
-    prev = _lib.lib.diga_get_conv_math()
-    _lib.call("diga_set_conv_math", 0)
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(0)
     try:
         arch = od.Arch(droprate=0.0)
         sd_b = om.state_dict(om.MIT_B1)
@@ -356,4 +356,4 @@ def test_segformer_student_warmup_step_vs_oracle_composition():
         assert float(got["ce"]) == pytest.approx(float(ce), rel=5e-3)
         assert float(got["distil"]) == pytest.approx(float(di), rel=5e-3)
     finally:
-        _lib.call("diga_set_conv_math", prev)
+        _lib.set_conv_math(prev)

@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"])
     a = ap.parse_args()
-    _lib.call("diga_set_conv_math", 1 if a.math == "bf16x3" else 0)
+    _lib.set_conv_math(1 if a.math == "bf16x3" else 0)
     global PEAK
     PEAK = 2500.0 / 3.0 if a.math == "bf16x3" else 157.3
     dev = "cuda"

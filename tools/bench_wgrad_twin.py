@@ -27,7 +27,7 @@ def timed(fn, reps=5):
 
 
 def main():
-    _lib.call("diga_set_conv_math", 1)
+    _lib.set_conv_math(1)
     dev, n, hw = "cuda", 16, 97
     m = n * hw * hw
     for name, cin, cout, k, dil in SHAPES:
@@ -49,7 +49,7 @@ def main():
 
         def staged():
             _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw2), _lib.ptr(ws2), ws2.numel(), n, hw, hw, cin,
-                      cin, hw, hw, cout, cout, k, k, 1, 1, -pad, -pad, dil, dil, _lib.stream())
+                      cin, hw, hw, cout, cout, k, k, 1, 1, -pad, -pad, dil, dil, 1, _lib.stream())
 
         t1, t2 = timed(twin), timed(staged)
         gf = 2.0 * m * cin * cout * k * k / 1e9

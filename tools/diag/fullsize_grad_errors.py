@@ -18,7 +18,7 @@ for name in ("full512x1024", "full768"):
     g = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
     _, H, W = (int(v) for v in g["geometry"])
     for math in (0, 1):
-        _lib.call("diga_set_conv_math", math)
+        _lib.set_conv_math(math)
         gen = synth.gen(int(g["seed"]))
         x = torch.rand((2, 3, H, W), generator=gen) * 2 - 1
         m = SegModel(arch=sm.RESNET101)

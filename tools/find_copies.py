@@ -20,7 +20,7 @@ from diga_amd.train_step import DigaTrainer  # noqa: E402
 
 def main():
     dev = "cuda"
-    _lib.call("diga_set_conv_math", 1)
+    _lib.set_conv_math(1)
     torch.manual_seed(0)
     student, teacher = SegModel(arch=sm.RESNET101).to(dev), SegModel(arch=sm.RESNET101).to(dev)
     teacher.train()

@@ -11,7 +11,7 @@ from diga_amd import _lib, synthetic
 from diga_amd.model import seg_model_noaux as sm
 from diga_amd.model.model_noaux import SegModel
 from diga_amd.train_step import DigaTrainer
-_lib.call("diga_set_conv_math", 1)
+_lib.set_conv_math(1)
 torch.manual_seed(0)
 dev = "cuda"
 student, teacher = SegModel(arch=sm.RESNET101).to(dev), SegModel(arch=sm.RESNET101).to(dev)

@@ -13,7 +13,7 @@ ddp.world_size = lambda: 2            # make the reducer (and its hooks) believe
 from diga_amd.model import seg_model_noaux as sm
 from diga_amd.model.model_noaux import SegModel
 from diga_amd.train_step import DigaTrainer
-_lib.call("diga_set_conv_math", 1)
+_lib.set_conv_math(1)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 student, teacher = SegModel(arch=sm.RESNET101).to(dev), SegModel(arch=sm.RESNET101).to(dev)

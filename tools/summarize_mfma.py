@@ -23,6 +23,8 @@ def short(name):
 
 def main():
     tag, d = sys.argv[1:3]
+    note_cmd = sys.argv[3] if len(sys.argv) > 3 else ("bench.py --lean --no-prof --serial-streams --steps 1 --warmup 1 "
+                                                       "(config c2)")
     cnt = collections.defaultdict(lambda: collections.defaultdict(float))
     nl = collections.defaultdict(set)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -50,8 +52,8 @@ def main():
     path = os.path.join(ROOT, "profiles", f"{tag}_mfma_busy_summary.json")
     with open(path, "w") as fh:
         json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
-                           "GRBM_GUI_ACTIVE --kernel-trace of bench.py --lean --no-prof --serial-streams --steps 1 --warmup 1 "
-                           "(config c2); profiled passes hold a lower clock than un-profiled ones",
+                           "GRBM_GUI_ACTIVE --kernel-trace of " + note_cmd + "; profiled passes hold a lower clock than "
+                           "un-profiled ones",
                    "kernels": out}, fh, indent=1)
     print("wrote", path)
     for k, v in list(out.items())[:10]:
