@@ -195,7 +195,7 @@ class _StemConvFn(torch.autograd.Function):
             nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kq, kp, 1, 1)
             ws = _lib.workspace(nbytes, xcol.device, "wgrad")
             _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xcol), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
-                      n, ho, wo, kp, kp, ho, wo, kq, kq, 1, 1, 1, 1, 0, 0, 1, 1, _lib.stream())
+                      n, ho, wo, kp, kp, ho, wo, kq, kq, 1, 1, 1, 1, 0, 0, 1, 1, _lib.get_conv_math(), _lib.stream())
             dw = torch.empty_strided((k, c, r, s), w_strides, dtype=torch.float32, device=xcol.device)
             dw.copy_(dwp[:k, 0, 0, :kk].reshape(k, r, s, c).permute(0, 3, 1, 2))
         if has_bias and ctx.needs_input_grad[2]:
