@@ -144,34 +144,37 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
         f16x8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
+            // m tracks the RAW score maximum (scale > 0); p = exp2(scale_log2e * (s - m)) as one fma per element
             float bm = -1e30f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = s[kt][t][e] * a.scale_log2e;
-                    if (tail && kb * 64 + 16 * kt + 4 * g + e >= a.Nk) v = -1e30f;
-                    s[kt][t][e] = v;
-                    bm = fmaxf(bm, v);
+                    if (tail && kb * 64 + 16 * kt + 4 * g + e >= a.Nk) s[kt][t][e] = -1e30f;
+                    bm = fmaxf(bm, s[kt][t][e]);
                 }
             bm = group_max(bm);
             const float mn = fmaxf(m[t], bm);
-            const float alpha = exp2f(m[t] - mn);
-            m[t] = mn;
+            if (__any(mn > m[t])) {                                 // wave-uniform: the running maximum rarely moves after the first blocks
+                const float alpha = exp2f((m[t] - mn) * a.scale_log2e);
+                l[t] *= alpha;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[d][t][e] *= alpha;
+                m[t] = mn;
+            }
+            const float off = -mn * a.scale_log2e;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p = exp2f(s[kt][t][e] - mn);
+                    const float p = exp2f(fmaf(s[kt][t][e], a.scale_log2e, off));
                     s[kt][t][e] = p;
                     ps += p;
                 }
-            l[t] = l[t] * alpha + ps;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[d][t][e] *= alpha;
+            l[t] += ps;
             pf[t][0] = pack8(s[0][t], s[1][t]);
             pf[t][1] = pack8(s[2][t], s[3][t]);
         }
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
             for (int d = 0; d < 4; ++d)
                 *reinterpret_cast<f16x4*>(op + 16 * d) = (f16x4){(_Float16)(o[d][t][0] * inv), (_Float16)(o[d][t][1] * inv),
                                                                  (_Float16)(o[d][t][2] * inv), (_Float16)(o[d][t][3] * inv)};
-            if (g == 0 && a.lse != nullptr) a.lse[((int64_t)b * a.heads + h) * a.N + q] = m[t] + log2f(lt);
+            if (g == 0 && a.lse != nullptr) a.lse[((int64_t)b * a.heads + h) * a.N + q] = m[t] * a.scale_log2e + log2f(lt);
         }
     }
 }

@@ -50,9 +50,28 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+// GELU(u) = u * Phi(u) and its derivative Phi(u) + u * phi(u), Phi = 0.5 (1 + erf(u / sqrt 2)).  erf by Abramowitz & Stegun
+// 7.1.26 (|error| <= 1.5e-7, far inside the fp16 storage of both results): one v_rcp, one v_exp and five fmas; the same
+// exponential exp(-u^2 / 2) serves erf and the density phi.  (erff() costs ~25 VALU instructions per element: it was the
+// largest single cost of the depthwise-conv kernels.)
+__device__ __forceinline__ void gelu_terms(float u, float& cdf, float& pdf) {
+    const float x = fabsf(u) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.f + 0.3275911f * x);
+    const float e = __expf(-x * x);                                  // = exp(-u^2 / 2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.f - poly * e;
+    cdf = 0.5f * (1.f + copysignf(erf_abs, u));
+    pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float u) {
+    float cdf, pdf;
+    gelu_terms(u, cdf, pdf);
+    return u * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float u) {
-    return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+    float cdf, pdf;
+    gelu_terms(u, cdf, pdf);
+    return cdf + u * pdf;
 }
 
 // out = scale * sum over chunks of partial[chunk][i] (+ existing when accumulate), i < n, fixed order: 32 columns x 8 chunk

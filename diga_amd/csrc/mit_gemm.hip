@@ -290,18 +290,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs a) {
     }
 }
 
-// dw[i] = scale * sum over splits of slab[s][i]  (+ dw[i] when accumulate), fixed order
-__global__ __launch_bounds__(256) void slab_reduce_scaled_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n,
-                                                                 int splits, float scale, int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = slab[i];
-    for (int k = 1; k < splits; ++k) s += slab[(int64_t)k * n + i];
-    s *= scale;
-    if (accumulate) s += dw[i];
-    dw[i] = s;
-}
-
 // ---------------------------------------------------------------------------------------------
 // column sums of an fp16 matrix (bias gradients): partial[chunk][c] over 256-row chunks, then a fixed-order reduce
 // ---------------------------------------------------------------------------------------------
@@ -454,8 +442,9 @@ extern "C" int diga_mit_gemm_tn(const void* A, int64_t lda, const void* B, int64
     constexpr int SH = 3 * 2 * 32 * 256;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(256), SH, st, a);
     const int64_t n = N * K;
-    hipLaunchKernelGGL(slab_reduce_scaled_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, a.slab, dw, n, p.splits, scale,
-                       accumulate);
+    // fixed-order sum of the split slabs (32 columns x 8 split phases per block: short latency chains even for 500 splits)
+    hipLaunchKernelGGL(partial_reduce_kernel<0>, dim3((unsigned)ceil_div(n, 32)), dim3(256), 0, st, a.slab, p.splits, (int)n, dw,
+                       (float*)nullptr, (int)n, scale, accumulate);
     if (dbias != nullptr)
         hipLaunchKernelGGL(partial_reduce_kernel<0>, dim3((unsigned)ceil_div(N, 32)), dim3(256), 0, st, a.bias_slab, p.splits, (int)N, dbias,
                            (float*)nullptr, (int)N, scale, accumulate);

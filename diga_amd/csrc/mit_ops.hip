@@ -503,7 +503,8 @@ extern "C" int diga_mit_layernorm_fwd(const float* x, int64_t ldx, const float* 
 }
 
 static int ln_rows_per_block(int64_t M) {                // >= ~2048 blocks where the matrix is big enough, 16..256 rows each
-    int64_t r = ceil_div(M, 2048);
+    static const int target = [] { const char* e = getenv("DIGA_MIT_LN_BLOCKS"); return e ? atoi(e) : 2048; }();
+    int64_t r = ceil_div(M, target);
     r = ceil_div(r, 16) * 16;
     if (r < 16) r = 16;
     if (r > 256) r = 256;
