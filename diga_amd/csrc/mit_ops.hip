@@ -216,16 +216,29 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const _Float16* __restri
         for (int p = 0; p < kDwPX; ++p)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+        // all 3 x (PX + 2) input vectors are fetched up front from clamped addresses (no branch between the loads: they
+        // issue back to back) and zeroed afterwards where the tap lies outside the image
+        f16x8 in[3][kDwPX + 2];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int yy = y + dy - 1;
-            if (yy < 0 || yy >= H) continue;
-            const _Float16* row = x + (((int64_t)b * H + yy) * W) * C + c8 * 8;
+            const int yc = min(max(yy, 0), H - 1);
+            const _Float16* row = x + (((int64_t)b * H + yc) * W) * C + c8 * 8;
 #pragma unroll
             for (int j = 0; j < kDwPX + 2; ++j) {
                 const int xx = x0 + j - 1;
-                if (xx < 0 || xx >= W) continue;
-                const f16x8 v = *reinterpret_cast<const f16x8*>(row + (int64_t)xx * C);
+                in[dy][j] = *reinterpret_cast<const f16x8*>(row + (int64_t)min(max(xx, 0), W - 1) * C);
+            }
+        }
+        const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            const bool yok = yy >= 0 && yy < H;
+#pragma unroll
+            for (int j = 0; j < kDwPX + 2; ++j) {
+                const int xx = x0 + j - 1;
+                const f16x8 v = (yok && xx >= 0 && xx < W) ? in[dy][j] : zero8;
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int p = j - dx;                          // output pixel x0 + p reads input x0 + p + dx - 1 = x0 + j - 1
@@ -287,29 +300,37 @@ __global__ __launch_bounds__(512) void dwconv_bwd_prep_kernel(const _Float16* __
             for (int e = 0; e < 8; ++e) s[t][e] = 0.f;
         if (live) {
             for (int y = y0; y < y1; ++y) {
+                // rows outside the image: clamped address (always loadable), value zeroed by the select below
                 const _Float16* rows[3];
+                bool rok[3];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int yy = y + dy - 1;
-                    rows[dy] = (yy >= 0 && yy < H) ? x + (((int64_t)b * H + yy) * W) * C + c0 : nullptr;
+                    rok[dy] = yy >= 0 && yy < H;
+                    rows[dy] = x + (((int64_t)b * H + min(max(yy, 0), H - 1)) * W) * C + c0;
                 }
                 f16x8 win[3][3];                                   // win[dy][k] = x[y + dy - 1][xx + k - 1]
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
+                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)max(xa - 1, 0) * C);
+                    const f16x8 a2 = *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)min(xa, W - 1) * C);
                     win[dy][0] = zero8;
-                    win[dy][1] = (rows[dy] != nullptr && xa - 1 >= 0 && xa - 1 < W) ? *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)(xa - 1) * C) : zero8;
-                    win[dy][2] = (rows[dy] != nullptr && xa < W) ? *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)xa * C) : zero8;
+                    win[dy][1] = (rok[dy] && xa - 1 >= 0) ? a1 : zero8;
+                    win[dy][2] = (rok[dy] && xa < W) ? a2 : zero8;
                 }
                 for (int xx = xa; xx < xb; ++xx) {
+                    const int64_t o = (((int64_t)b * H + y) * W + xx) * C + c0;
+                    const f16x8 g8 = *reinterpret_cast<const f16x8*>(dh + o);
+                    const f16x8 u8 = *reinterpret_cast<const f16x8*>(u + o);
+                    f16x8 nw[3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) nw[dy] = *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)min(xx + 1, W - 1) * C);
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         win[dy][0] = win[dy][1];
                         win[dy][1] = win[dy][2];
-                        win[dy][2] = (rows[dy] != nullptr && xx + 1 < W) ? *reinterpret_cast<const f16x8*>(rows[dy] + (int64_t)(xx + 1) * C) : zero8;
+                        win[dy][2] = (rok[dy] && xx + 1 < W) ? nw[dy] : zero8;
                     }
-                    const int64_t o = (((int64_t)b * H + y) * W + xx) * C + c0;
-                    const f16x8 g8 = *reinterpret_cast<const f16x8*>(dh + o);
-                    const f16x8 u8 = *reinterpret_cast<const f16x8*>(u + o);
                     f16x8 d8;
                     float d[8];
 #pragma unroll
@@ -502,8 +523,9 @@ extern "C" int diga_mit_layernorm_fwd(const float* x, int64_t ldx, const float* 
     return launch_status("mit_layernorm_fwd");
 }
 
-static int ln_rows_per_block(int64_t M) {                // >= ~2048 blocks where the matrix is big enough, 16..256 rows each
-    static const int target = [] { const char* e = getenv("DIGA_MIT_LN_BLOCKS"); return e ? atoi(e) : 2048; }();
+static int ln_rows_per_block(int64_t M) {                // ~512 blocks where the matrix is big enough, 16..256 rows each
+    // measured (tools/bench_mit_ops.py --cold, MiT-B5 sizes): ~512 blocks beat 1024 / 2048 / 4096 on every stage
+    static const int target = [] { const char* e = getenv("DIGA_MIT_LN_BLOCKS"); return e ? atoi(e) : 512; }();
     int64_t r = ceil_div(M, target);
     r = ceil_div(r, 16) * 16;
     if (r < 16) r = 16;

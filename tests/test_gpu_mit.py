@@ -131,8 +131,9 @@ def test_dwconv_gelu_forward_backward(b, h, w, c):
              ws.numel(), b, h, w, c, lib.stream())
     assert _rel(du.permute(0, 3, 1, 2), du_ref) < 1e-3
     assert _rel(dx.permute(0, 3, 1, 2), xr.grad) < 2e-3
-    assert _rel(dw.reshape(c, 1, 3, 3), 2.0 * wr.grad) < 1e-4
-    assert _rel(dbias, 2.0 * br.grad) < 1e-4
+    # (du is stored in fp16: a 1e-7-level difference in gelu' flips the rounding of a few du elements by one fp16 ulp = 5e-4)
+    assert _rel(dw.reshape(c, 1, 3, 3), 2.0 * wr.grad) < 5e-4
+    assert _rel(dbias, 2.0 * br.grad) < 5e-4
 
 
 @pytest.mark.parametrize("kind,c,k,stride,pad,hw", [(2, 3, 7, 4, 3, (37, 29)), (0, 64, 3, 2, 1, (17, 12)), (1, 128, 4, 4, 0, (16, 12)),
