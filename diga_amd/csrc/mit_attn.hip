@@ -70,20 +70,27 @@ __device__ __forceinline__ f16x8 pack8(const f32x4& a, const f32x4& b) {
     return (f16x8){(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
 }
 
+// reductions over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48) with the VALU lane swaps of gfx950
+// (v_permlane32_swap / v_permlane16_swap: no LDS round trip on the softmax's critical path): swapping a register with itself
+// leaves {lower half twice, upper half twice} resp. {even rows twice, odd rows twice} in the two results
 __device__ __forceinline__ float group_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+template <int QT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
-    constexpr int QT = 2;
     extern __shared__ __align__(16) unsigned char smem[];          // 2 buffers x (K image + V image)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
     const int qb = blk % a.q_blocks;
     blk /= a.q_blocks;
     const int h = blk % a.heads, b = blk / a.heads;
-    const int q0 = qb * 256 + wv * 32;
+    const int q0 = qb * (128 * QT) + wv * (16 * QT);
     const _Float16* Kb = a.K + (int64_t)b * a.Nk * a.ldkv + h * 64;
     const _Float16* Vb = a.V + (int64_t)b * a.Nk * a.ldkv + h * 64;
     const int nkb = (a.Nk + 63) / 64;
@@ -460,10 +467,18 @@ extern "C" int diga_mit_attention_fwd(const void* q, int64_t ldq, const void* kv
     a.Q = static_cast<const _Float16*>(q); a.K = static_cast<const _Float16*>(kv); a.V = a.K + heads * 64;
     a.ldq = ldq; a.ldkv = ldkv; a.O = static_cast<_Float16*>(out); a.ldo = ldo; a.lse = lse;
     a.B = (int)B; a.heads = (int)heads; a.N = (int)N; a.Nk = (int)Nk;
-    a.q_blocks = (int)ceil_div(N, 256);
     a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     ProfScope prof(DIGA_PROF_MIT_ATTN_FWD, st, 4.0 * (double)B * heads * (double)N * (double)Nk * 64.0);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * heads * a.q_blocks)), dim3(512), 4 * kImg, st, a);
+    // 64 queries per wave (K / V fragments read from LDS once per 64 MFMAs) where that still fills the chip, else 32
+    static const int qt_env = [] { const char* e = getenv("DIGA_MIT_ATTN_QT"); return e ? atoi(e) : 0; }();
+    const bool wide = qt_env ? qt_env == 4 : B * heads * ceil_div(N, 512) >= 512;
+    if (wide) {
+        a.q_blocks = (int)ceil_div(N, 512);
+        hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)(B * heads * a.q_blocks)), dim3(512), 4 * kImg, st, a);
+    } else {
+        a.q_blocks = (int)ceil_div(N, 256);
+        hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)(B * heads * a.q_blocks)), dim3(512), 4 * kImg, st, a);
+    }
     return launch_status("mit_attention_fwd");
 }
 
