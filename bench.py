@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the c4 / c1 legs")
     ap.add_argument("--c4-steps", type=int, default=3)
     ap.add_argument("--c5-steps", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="run the launch-bound legs (c1, c5) eagerly instead of from a HIP graph")
     ap.add_argument("--no-bandwidth-kernels", action="store_true")
     ap.add_argument("--no-miou", action="store_true", help="skip the fixed-seed validation-mIoU parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -248,7 +249,7 @@ def geometry(a, config):
     return arch_name, B, H, W, block
 
 
-def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof):
+def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph=False):
     """Build student/teacher, run `warmup` + `steps` iterations of `config`; returns (seconds for `steps` = max over
     ranks, kernel families, last losses, parameter counts, geometry)."""
     import torch
@@ -269,7 +270,9 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof):
     ddp.broadcast_module(student)
     teacher.train()
     rng = random.Random(1234 + rank)           # ClassMix class choice differs per rank, reproducibly
-    tr = DigaTrainer(student, teacher, rng=rng)
+    # graph=True (the launch-bound legs c1 / c5): the static part of the step is captured into a HIP graph and replayed
+    # (diga_amd/train_step.py); kernel-family timings then come from extra eager steps after the timed region
+    tr = DigaTrainer(student, teacher, rng=rng, graph=graph)
     if config == "c4":
         from diga_amd.calc_centroids import Class_Features
         batch = synthetic.selftrain_batch(1234 + rank, B, H, W, block=block, device=dev)
@@ -293,12 +296,15 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof):
             torch.distributed.barrier()
 
     it = 0
+    if graph:
+        warmup = max(warmup, 2)                # step 0 eager, step 1 captures: both outside the timed region
     for _ in range(warmup):
         one_step(it)
         it += 1
     torch.cuda.synchronize()
     barrier()
-    if prof:
+    prof_timed = prof and not graph            # HIP events cannot be recorded into a replayed graph
+    if prof_timed:
         _lib.call("diga_prof_reset")
         _lib.call("diga_prof_enable", 1)
     torch.cuda.synchronize()
@@ -309,7 +315,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof):
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if prof:
+    if prof_timed:
         _lib.call("diga_prof_enable", 0)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -327,9 +333,11 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof):
                             "work_per_step": _lib.prof_work(tag) / nsteps}
         return fam
 
-    families_overlapped = query(steps) if prof else {}
+    families_overlapped = query(steps) if prof_timed else {}
     families = families_overlapped
-    if prof and not a.serial_streams:
+    if graph:
+        tr.use_graph = False                   # the eager steps below time the kernels
+    if prof and (graph or not a.serial_streams):
         # Kernel durations for the roofline: the timed region runs the teacher forward and the weight gradients on a
         # second stream, so the HIP events of a launch there span other kernels sharing the GPU.  Two more steps
         # with the streams serialised time every kernel on its own (all ranks, the step has a collective).
@@ -570,7 +578,8 @@ def main():
         for cfg, (st, wu) in (("c5", (a.c5_steps, 2)), ("c4", (a.c4_steps, 1)), ("c1", (5, 2))):
             if cfg == a.config or (cfg == "c1" and world > 1):
                 continue
-            cdt, (cfam, _), closs, ccounts, cgeom = run_steps(a, cfg, a.precision, st, wu, rank, world, dev, prof)
+            use_graph = cfg in ("c1", "c5") and not a.no_graph and world == 1
+            cdt, (cfam, _), closs, ccounts, cgeom = run_steps(a, cfg, a.precision, st, wu, rank, world, dev, prof, graph=use_graph)
             cB, cH, cW, carch = cgeom
             croof, _ = rooflines(cfg, a.precision, cfam, ccounts, cgeom)
             n_stu, n_tea = images_per_step(cfg, cB)
@@ -583,6 +592,7 @@ def main():
                 "dtype": ("fp16 storage / fp32 accumulate (MiT encoder); head convs " + a.precision) if cfg == "c5" else a.precision,
                 "kernel_families": {k: v for k, v in cfam.items() if k.startswith("mit_")} if cfg == "c5" else None,
                 "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea},
+                "hip_graph": bool(use_graph),
                 "roofline_conv_fwd": None if croof is None else {k: croof[k] for k in ("achieved", "peak", "unit", "frac")},
                 "losses_last_step": closs}
             if cfg == "c5":

@@ -22,7 +22,7 @@ from diga_amd.util import utils as U
 
 class DigaTrainer:
     def __init__(self, student, teacher, base_lr=2.5e-4, max_iter=80000, power=0.9, momentum=0.9,
-                 weight_decay=5e-4, rng=random, distill_scale=0.5, centroid_exchange=None):
+                 weight_decay=5e-4, rng=random, distill_scale=0.5, centroid_exchange=None, graph=None):
         self.student, self.teacher = student, teacher
         self.base_lr, self.max_iter, self.power = base_lr, max_iter, power
         self.rng = rng
@@ -36,7 +36,14 @@ class DigaTrainer:
             raise ValueError(f"centroid_exchange must be 'allgather' or 'allreduce', not {self.centroid_exchange!r}")
         self.opt = U.DigaSGD(student.optim_parameters(base_lr), lr=base_lr, momentum=momentum,
                              weight_decay=weight_decay, grad_scale=1.0 / self.world)
-        self.reducer = ddp.GradReducer([p for p in student.parameters() if p.requires_grad])
+        # graph=True (or DIGA_STEP_GRAPH=1): the static part of the warm-up step -- both forward passes, the loss block and the
+        # whole backward pass, ~1000-2500 launches -- is captured ONCE into a HIP graph (torch.cuda.CUDAGraph: stream capture of
+        # the library's launches on torch's capture stream) and replayed every step; what depends on the iteration or on host
+        # decisions stays outside (learning rate, EMA coefficient, ClassMix class choice, all-reduce, SGD).  For the launch-bound
+        # configurations (small backbone, MiT encoder: hundreds of 5-30 us kernels); the big ResNet-101 step is GPU-bound either way.
+        self.use_graph = bool(int(os.environ.get("DIGA_STEP_GRAPH", "0"))) if graph is None else bool(graph)
+        self._g = None
+        self.reducer = ddp.GradReducer([p for p in student.parameters() if p.requires_grad], overlap=not self.use_graph)
         self._side = None
         U.create_teacher_params(teacher, student)
         for p in teacher.parameters():
@@ -90,9 +97,69 @@ class DigaTrainer:
         self.reducer.reduce()
         self.opt.step()
 
+    # ------------------------------------------------------------------ warm-up step, static part as a HIP graph
+    def _warmup_step_graphed(self, it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil):
+        """Step 0 runs eagerly (lazy initialisations, allocator warm-up); step 1 captures; every later step replays.
+        BatchNorm running statistics, DropPath / Dropout2d draws (torch's graph-safe Philox offsets) and the gradients evolve
+        exactly as in the eager step: capture records, only replays execute."""
+        g = self._g
+        key = (tuple(x.shape), tuple(labels.shape), float(lambda_seg), float(lambda_distil))
+        if g is None:
+            self._g = g = {"calls": 0}
+        if g["calls"] == 0 or g.get("key", key) != key:
+            if g.get("key", key) != key:
+                raise RuntimeError("DigaTrainer(graph=True): the captured step is bound to its input shapes and loss weights")
+            g["calls"] = 1
+            g["key"] = key
+            return self._warmup_step_eager(it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil)
+        self._begin(it)
+        with torch.no_grad():
+            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
+        if "graph" not in g:
+            B = x.shape[0]
+            g["cat"] = torch.empty((2 * B,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+            g["labels"] = torch.empty_like(labels)
+            g["cat"][:B].copy_(x)
+            g["cat"][B:].copy_(mix)
+            g["labels"].copy_(labels)
+            self.opt.zero_grad(set_to_none=True)          # the captured backward ASSIGNS the gradients (static buffers of the graph's pool)
+            saved = {k: os.environ.get(k) for k in ("DIGA_TEACHER_STREAM", "DIGA_WGRAD_STREAM")}
+            os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")      # one capture stream
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    with torch.no_grad():
+                        t_lr = self.teacher(g["cat"])[2]
+                    s_lr = self.student(g["cat"])[2]
+                    total, ce, di = L.upsample_ce_distill(s_lr, t_lr, g["labels"], lambda_seg, lambda_distil, self.distill_scale)
+                    total.backward()
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            g.update(graph=graph, out=(total.detach(), ce, di))
+        else:
+            B = x.shape[0]
+            g["cat"][:B].copy_(x)
+            g["cat"][B:].copy_(mix)
+            g["labels"].copy_(labels)
+        g["graph"].replay()
+        self.reducer.reduce()
+        self.opt.step()
+        total, ce, di = g["out"]
+        return {"total": total, "ce": ce, "distil": di}
+
     # ------------------------------------------------------------------ warm-up step
     def warmup_step(self, it, x, x_aug, rec_s2t, labels, lambda_seg=1.0, lambda_distil=0.5):
         """x, x_aug, rec_s2t [B,3,H,W]; labels [B,H,W] int64.  Returns device scalars (no sync)."""
+        if self.use_graph and x.is_cuda:
+            return self._warmup_step_graphed(it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil)
+        return self._warmup_step_eager(it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil)
+
+    def _warmup_step_eager(self, it, x, x_aug, rec_s2t, labels, lambda_seg=1.0, lambda_distil=0.5):
         self._begin(it)
         with torch.no_grad():
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)

@@ -174,3 +174,46 @@ def test_tiny_model_16_class_step_vs_oracle():
         assert float(got["distil"]) == pytest.approx(want["distil"], rel=1e-3)
     for k in ["layer0.0.weight", "final.head.1.weight", "final.bottleneck.1.weight"]:
         assert_close(student.state_dict()[k], otr.s[k], 2e-3, 2e-5, k)
+
+
+@pytest.mark.parametrize("which", ["tiny_deeplab", "mit_b1"])
+def test_graph_captured_step_equals_eager_step(which, conv_math):
+    """DigaTrainer(graph=True): the static part of the warm-up step replayed from a HIP graph (torch.cuda.CUDAGraph capture of
+    the library's launches) must reproduce the eager step bit for bit -- losses of every step and the parameters after five
+    steps (step 0 eager, step 1 capture + first replay, steps 2-4 replays with fresh inputs and ClassMix choices)."""
+    from diga_amd.train_step import DigaTrainer
+
+    def make():
+        if which == "mit_b1":
+            from diga_amd.model.segformer import SegFormerStudent
+            from oracle import mit as om
+            m = SegFormerStudent("mit_b1")
+            m.backbone.load_state_dict(om.state_dict(om.MIT_B1))
+            m.backbone.reset_drop_path(0.0)
+            torch.manual_seed(5)
+            for p in m.final.parameters():
+                torch.nn.init.normal_(p, std=0.05)
+            m.final.head[0].p = 0.0
+            return m.to(DEV)
+        m = _model("TINY")
+        m.final.head[0].p = 0.0
+        return m
+
+    res = []
+    for graph in (False, True):
+        student, teacher = make(), make()
+        teacher.train()
+        rng = random.Random(11)
+        tr = DigaTrainer(student, teacher, rng=rng, graph=graph)
+        losses = []
+        for it in range(5):
+            batch = [t.to(DEV) for t in synth.warmup_batch(900 + it, 2, 96, 128, block=16)]
+            out = tr.warmup_step(it, *batch)
+            losses.append((float(out["ce"]), float(out["distil"]), float(out["total"])))
+        torch.cuda.synchronize()
+        res.append((losses, {k: v.clone() for k, v in student.state_dict().items()}, {k: v.clone() for k, v in teacher.state_dict().items()}))
+        assert (tr._g is not None and "graph" in tr._g) == graph
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+        assert torch.equal(res[0][2][k], res[1][2][k]), "teacher " + k
