@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kNormThreads) void bwd_partial_kernel(const float* 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int si = seg * st_seg_stride + (c + e) / cdiv;
-            const float xh = (xx[e] - mean[si]) * invstd[si];
+            const float xh = mean != nullptr ? (xx[e] - mean[si]) * invstd[si] : xx[e];      // null statistics: mean 0, invstd 1
             acc[0][e] += gg[e];
             acc[1][e] += gg[e] * xh;
         }
@@ -1043,8 +1043,6 @@ extern "C" int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
     return launch_status("diga_gn_bwd");
 }
 
-__device__ const float g_unit_mean_invstd[2] = {0.f, 1.f};
-
 extern "C" int diga_avgpool_nhwc(const float* x, int64_t ld_x, float* out, int64_t N, int64_t HW, int64_t C, void* workspace,
                                  size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(x && out && workspace && N > 0 && HW > 0, DIGA_EINVAL, "avgpool: bad argument");
@@ -1082,15 +1080,11 @@ extern "C" int diga_channel_dot(const float* dy, int64_t ld_dy, const float* x, 
     ProfScope prof(DIGA_PROF_NORM, st, (double)N * HW * C * 8.0);
     const ColGeom g = make_geom(HW, N, C);
     float* partial = (float*)workspace;
-    // [0] = mean 0, [1] = invstd 1: a constant of the library's device image (round 2 copied the pair from the host stack with
-    // hipMemcpyAsync: a hidden host synchronisation, and under stream capture the graph kept the dangling host pointer)
-    static const float* unit = [] {
-        void* p = nullptr;
-        return hipGetSymbolAddress(&p, HIP_SYMBOL(g_unit_mean_invstd)) == hipSuccess ? static_cast<const float*>(p) : nullptr;
-    }();
-    DIGA_REQUIRE(unit != nullptr, DIGA_EINVAL, "channel_dot: device constant unavailable");
+    // sum g * x: the backward-partial kernel with null statistics (= mean 0, invstd 1).  (Round 2 copied the pair {0, 1} from
+    // the host stack with hipMemcpyAsync: a hidden host synchronisation, and under stream capture a dangling host pointer.)
     hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, (unsigned)N), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x,
-                       (const float*)nullptr, (int64_t)0, unit, unit + 1, 0, (int)C, g, partial, (const float*)nullptr);
+                       (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, 0, (int)C, g, partial,
+                       (const float*)nullptr);
     hipLaunchKernelGGL(seg_dot_kernel, dim3((unsigned)ceil_div(N * C, 256)), dim3(256), 0, st, partial, g, out);
     return launch_status("diga_channel_dot");
 }
