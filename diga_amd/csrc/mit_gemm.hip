@@ -41,11 +41,16 @@ struct GemmArgs {
 // ---------------------------------------------------------------------------------------------
 // NT: A [M][K], B [N][K], both K-contiguous.  K % 32 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int TN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
-    constexpr int BM = 128, BN = 64 * TN, MT = 4, NT = 2 * TN;
+// WM = wave rows: the block tile is (64 WM) x (64 TN) with 2 WM waves as WM x 2, wave tile 64 x (32 TN).  WM = 2: 128-row tile,
+// 4 waves, three blocks per CU.  WM = 4 (TN = 2 only): 256 x 128 tile, 8 waves, 1.33x the MACs per staged byte, two blocks per
+// CU -- taken where the 128-row tiling would leave a mostly empty last round of blocks (diga_mit_gemm_nt below).
+template <int TN, int WM>
+__global__ __launch_bounds__(128 * WM, 2) void gemm_nt_kernel(GemmArgs a) {
+    constexpr int BM = 64 * WM, BN = 64 * TN, MT = 4, NT = 2 * TN, NW = 2 * WM;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-    constexpr int kLoads = 2 + TN;                                // LDS-DMA instructions per wave and stage
+    constexpr int BJ = (BN / 16) / NW;                            // B-tile LDS-DMA instructions per wave and stage
+    static_assert(BJ >= 1 && BJ * NW * 16 == BN, "B tile must split evenly over the waves");
+    constexpr int kLoads = 2 + BJ;                                // LDS-DMA instructions per wave and stage
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wm = wv >> 1, wn = wv & 1;
@@ -58,15 +63,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     const int lrow = lane >> 2;
     const int kslot = (lane & 3) ^ swz64(lrow);
     const unsigned char* pa[2];
-    const unsigned char* pb[TN];
+    const unsigned char* pb[BJ];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = min(m0 + wv * 32 + 16 * j + lrow, a.M - 1);
         pa[j] = reinterpret_cast<const unsigned char*>(a.A + (int64_t)m * a.lda) + kslot * 16;
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = min(n0 + wv * 16 * TN + 16 * j + lrow, a.N - 1);
+    for (int j = 0; j < BJ; ++j) {
+        const int n = min(n0 + wv * 16 * BJ + 16 * j + lrow, a.N - 1);
         pb[j] = reinterpret_cast<const unsigned char*>(a.B + (int64_t)n * a.ldb) + kslot * 16;
     }
     auto issue = [&](int ks, int buf) {
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) glds16(pa[j] + ks * 64, stage + (wv * 32 + 16 * j) * 64);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) glds16(pb[j] + ks * 64, stage + A_BYTES + (wv * 16 * TN + 16 * j) * 64);
+        for (int j = 0; j < BJ; ++j) glds16(pb[j] + ks * 64, stage + A_BYTES + (wv * 16 * BJ + 16 * j) * 64);
     };
     auto wait_next = [&](bool newest_in_flight) {
         if (newest_in_flight) {
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
+    static_assert(kLoads == 3 || kLoads == 4, "vmcnt literals above");
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     float* stage = reinterpret_cast<float*>(smem);
     const int t = threadIdx.x;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < WM; ++h) {
         if (m0 + h * 64 >= a.M) break;                     // uniform over the block
         if (h) __syncthreads();
         if (wm == h) {
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
         }
         __syncthreads();
         constexpr int QUADS = BN / 4;                      // float4 groups per row
-        for (int idx = t; idx < 64 * QUADS; idx += 256) {
+        for (int idx = t; idx < 64 * QUADS; idx += 64 * NW) {
             const int r = idx / QUADS, q = idx - r * QUADS;
             const int m = m0 + h * 64 + r, n = n0 + q * 4;
             if (m >= a.M || n >= a.N) continue;
@@ -380,17 +386,26 @@ extern "C" int diga_mit_gemm_nt(const void* A, int64_t lda, const void* B, int64
     a.seg_scale = seg_scale; a.rows_per_seg = (int)rows_per_seg;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.out_f32 = out_f32; a.accumulate = accumulate; a.alpha = alpha;
     ProfScope prof(DIGA_PROF_MIT_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
-    const int tiles_m = (int)ceil_div(M, 128);
     if (N > 64) {
         a.tiles_n = (int)ceil_div(N, 128);
-        constexpr int SH = 3 * (128 * 64 + 128 * 64);
-        static bool once = [] { return hipFuncSetAttribute((const void*)gemm_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SH) == hipSuccess; }();
-        (void)once;
-        hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3(tiles_m * a.tiles_n), dim3(256), SH, st, a);
+        // 256-row tiles where the 128-row tiling spills a small tail into an extra round of blocks (3 blocks per CU = 768
+        // slots) or runs many rounds anyway: fewer, fatter blocks (2 per CU), 1.33x the MACs per staged byte
+        static const int big_env = [] { const char* e = getenv("DIGA_MIT_GEMM_BIG"); return e ? atoi(e) : -1; }();
+        const int64_t blocks128 = ceil_div(M, 128) * a.tiles_n;
+        const bool big = big_env >= 0 ? big_env != 0 : blocks128 > 768;
+        if (big) {
+            constexpr int SH = 3 * (256 * 64 + 128 * 64);
+            static bool once = [] { return hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SH) == hipSuccess; }();
+            (void)once;
+            hipLaunchKernelGGL((gemm_nt_kernel<2, 4>), dim3((unsigned)(ceil_div(M, 256) * a.tiles_n)), dim3(512), SH, st, a);
+        } else {
+            constexpr int SH = 3 * (128 * 64 + 128 * 64);
+            hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), dim3((unsigned)(ceil_div(M, 128) * a.tiles_n)), dim3(256), SH, st, a);
+        }
     } else {
         a.tiles_n = 1;
         constexpr int SH = 3 * (128 * 64 + 64 * 64);                // >= 64 x 68 x 4 epilogue stage
-        hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3(tiles_m), dim3(256), SH, st, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<1, 2>), dim3((unsigned)ceil_div(M, 128)), dim3(256), SH, st, a);
     }
     return launch_status("mit_gemm_nt");
 }

@@ -358,3 +358,37 @@ def test_segformer_student_warmup_step_vs_oracle_composition():
         assert float(got["distil"]) == pytest.approx(float(di), rel=5e-3)
     finally:
         _lib.set_conv_math(prev)
+
+
+def test_gemm_nt_256_row_tile_variant():
+    """The 8-wave 256 x 128 tile of diga_mit_gemm_nt is selected by size (more than 768 128-row tiles, e.g. 16 crops of 768x768);
+    DIGA_MIT_GEMM_BIG=1 forces it for every N > 64 so that the ragged cases above run through it too (child process: the switch
+    is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from diga_amd.model.networks.MixTransfomer import _Ops
+ops = _Ops(torch.device("cuda"))
+g = torch.Generator().manual_seed(3)
+worst = 0.0
+for m, n, k in [(300, 128, 64), (513, 320, 1280), (129, 1280, 320), (777, 160, 4096), (5, 256, 160), (40000, 320, 320)]:
+    a = torch.randn((m, k), generator=g).half().cuda()
+    w = (torch.randn((n, k), generator=g) / k ** 0.5).half().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    res = torch.randn((m, n), generator=g).cuda()
+    ref = res.double() + a.double() @ w.double().t() + bias.double()
+    out = ops.gemm(a, w, bias, n, out_f32=True, residual=res)
+    worst = max(worst, float((out.double() - ref).abs().max() / ref.abs().max()))
+    out16 = ops.gemm(a, w, bias, n)
+    worst = max(worst, 1e-2 * float((out16.double() - (ref - res.double())).abs().max() / ref.abs().max()))
+print("WORST", worst)
+"""
+    env = dict(os.environ, DIGA_MIT_GEMM_BIG="1")
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("WORST")][-1].split()[1])
+    assert worst < 2e-5, worst
