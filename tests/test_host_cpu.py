@@ -65,7 +65,8 @@ def test_no_cpu_fallback():
                lambda: loss.upsample_ce_distill(x, x, y[:1]),
                lambda: utils.classmix_present(y),
                lambda: Class_Features().get_centroid_weight(torch.zeros(1, 256, 3, 3)),
-               lambda: SegModel(arch=TINY)(torch.zeros(1, 3, 32, 32))):
+               lambda: SegModel(arch=TINY)(torch.zeros(1, 3, 32, 32)),
+               lambda: __import__("diga_amd.model.networks.MixTransfomer", fromlist=["mit_b1"]).mit_b1()(torch.zeros(1, 3, 64, 64))):
         with pytest.raises(RuntimeError, match="GPU only"):
             fn()
     a, b = torch.nn.Linear(3, 3), torch.nn.Linear(3, 3)
