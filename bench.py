@@ -396,6 +396,16 @@ def rooflines(config, precision, families, counts, geom):
         except (OSError, ValueError, KeyError):
             continue
     n_stu, n_tea = images_per_step(config, B)
+    if arch_name.startswith("MIT_") and "mit_gemm" in families:
+        # --config c5 as the main configuration: the dominant family is the encoder's fp16 GEMMs (declared 2*M*N*K per call)
+        fam = families["mit_gemm"]
+        ach = fam["work_per_step"] / (fam["ms_per_step"] * 1e-3) / 1e12
+        n_launch = fam["ms_per_step"] / fam["avg_ms"]
+        roof = {"kernel": "diga::mit::gemm_nt_kernel (fp16 MFMA, fp32 accumulate: Linear forward / backward-data and the patch-embedding / "
+                          "spatial-reduction convolutions of the MiT encoder; all launches of a step)",
+                "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TFLOPS,
+                "traffic": None, "algorithmic_flops_per_launch": fam["work_per_step"] / n_launch, "avg_launch_ms": fam["avg_ms"],
+                "launches_per_step": n_launch}
     if "conv_fwd" in families and arch_name == "RESNET101":
         fam = families["conv_fwd"]
         flops_step = (n_stu + n_tea) * fwd_gflop * 1e9

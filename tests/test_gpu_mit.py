@@ -392,3 +392,22 @@ print("WORST", worst)
     assert r.returncode == 0, r.stderr[-2000:]
     worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("WORST")][-1].split()[1])
     assert worst < 2e-5, worst
+
+
+@pytest.mark.parametrize("hw", [(100, 76), (65, 129)])
+def test_mit_b1_ragged_input_sizes_vs_oracle(hw):
+    """Input sizes that are not multiples of 32: the patch embeddings round down per stage, the spatial-reduction conv drops
+    the rows / columns its stride does not cover (nn.Conv2d semantics), key counts are tiny and uneven (e.g. 3 x 2 keys)."""
+    m = _model("mit_b1").eval()
+    x = torch.rand((2, 3) + hw, generator=synth.gen(hw[0])) * 2 - 1
+    sd = {k: v.clone().requires_grad_() for k, v in om.state_dict(om.MIT_B1).items()}
+    want = om.forward(sd, x, om.MIT_B1)
+    sum((o * o).sum() for o in want).backward()
+    got = m(x.to(DEV))
+    assert [tuple(o.shape) for o in got] == [tuple(o.shape) for o in want]
+    for a, b in zip(got, want):
+        assert _rel(a, b) < 1e-2
+    sum((o * o).sum() for o in got).backward()
+    named = dict(m.named_parameters())
+    ratios = [float(named[k].grad.norm()) / max(float(sd[k].grad.norm()), 1e-12) for k in sd]
+    assert 0.95 < min(ratios) and max(ratios) < 1.05, (min(ratios), max(ratios))
