@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];          // 2 buffers x (K image + V image)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    int blk = blockIdx.x;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);            // the query blocks of one (image, head) share its K / V through one L2
     const int qb = blk % a.q_blocks;
     blk /= a.q_blocks;
     const int h = blk % a.heads, b = blk / a.heads;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    int blk = blockIdx.x;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);            // the query blocks of one (image, head) share its K / V through one L2
     const int qb = blk % a.q_blocks;
     blk /= a.q_blocks;
     const int h = blk % a.heads, b = blk / a.heads;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     float* stat = reinterpret_cast<float*>(smem + 4 * kImg);       // [2 buffers][4 waves][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = lane >> 4, li = lane & 15;
-    int blk = blockIdx.x;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);            // the key blocks of one (image, head, query range) re-read the same Q / dO
     const int kblk = blk % a.k_blocks;
     blk /= a.k_blocks;
     const int split = blk % a.splits;

@@ -195,7 +195,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const _Float16* __restri
     const int cg = C / 8;
     const int strips = (W + kDwPX - 1) / kDwPX;
     const int64_t total = (int64_t)B * H * strips * cg;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    // one item per thread; blocks b, b + 8, ... share an XCD (round-robin dispatch): the remap hands every XCD a contiguous
+    // band of image rows, so the rows y - 1 / y + 1 a strip re-reads were fetched by the same L2 moments before (without
+    // it: 505 MB of HBM traffic per launch against 283 MB algorithmic on the stage-3 tensor -- profiles/r03_mit_b5_pmc_summary.json)
+    {
+        const int64_t idx = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+        if (idx >= total) return;
         const int c8 = (int)(idx % cg);
         int64_t rest = idx / cg;
         const int sx = (int)(rest % strips);
@@ -283,8 +288,9 @@ __global__ __launch_bounds__(512) void dwconv_bwd_prep_kernel(const _Float16* __
                                                               int rows_per_block, int gw, int phases) {
     const int cg = C / 8;
     const int blocks_per_img = (H + rows_per_block - 1) / rows_per_block;
-    const int b = blockIdx.x / blocks_per_img;
-    const int y0 = (blockIdx.x - b * blocks_per_img) * rows_per_block;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);              // neighbouring row groups on one XCD (shared halo rows in its L2)
+    const int b = blk / blocks_per_img;
+    const int y0 = (blk - b * blocks_per_img) * rows_per_block;
     const int y1 = min(y0 + rows_per_block, H);
     extern __shared__ float red[];                                 // [phases * gw][8]
     const int gi = threadIdx.x % gw, ph = threadIdx.x / gw;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(512) void dwconv_bwd_prep_kernel(const _Float16* __
 #pragma unroll
                     for (int e = 0; e < 8; ++e) tot[e] += red[(p * gw + gi) * 8 + e];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) partial[((int64_t)blockIdx.x * 10 + t) * C + (gbase + gi) * 8 + e] = tot[e];
+                for (int e = 0; e < 8; ++e) partial[((int64_t)blk * 10 + t) * C + (gbase + gi) * 8 + e] = tot[e];
             }
         }
         __syncthreads();
@@ -578,7 +584,7 @@ extern "C" int diga_mit_dwconv_gelu_fwd(const void* x, const float* wt9, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);
     ProfScope prof(DIGA_PROF_MIT_DWCONV, st, (double)B * H * W * C * (u16 ? 6.0 : 4.0));
-    hipLaunchKernelGGL(dwconv3x3_kernel<0>, dim3(grid_for(items, 256, 1 << 20)), dim3(256), 0, st, static_cast<const _Float16*>(x), wt9, bias,
+    hipLaunchKernelGGL(dwconv3x3_kernel<0>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, st, static_cast<const _Float16*>(x), wt9, bias,
                        static_cast<_Float16*>(u16), static_cast<_Float16*>(h16), (int)B, (int)H, (int)W, (int)C);
     return launch_status("mit_dwconv_gelu_fwd");
 }
@@ -617,7 +623,7 @@ extern "C" int diga_mit_dwconv_gelu_bwd(const void* dh, const void* u, const voi
     hipLaunchKernelGGL(partial_reduce_kernel<2>, dim3((unsigned)ceil_div(10 * C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), blocks,
                        (int)(10 * C), dw, db, (int)C, param_scale, accumulate);
     const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);
-    hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3(grid_for(items, 256, 1 << 20)), dim3(256), 0, st, static_cast<const _Float16*>(du16), wt9_flipped,
+    hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, st, static_cast<const _Float16*>(du16), wt9_flipped,
                        (const float*)nullptr, (_Float16*)nullptr, static_cast<_Float16*>(dx16), (int)B, (int)H, (int)W, (int)C);
     return launch_status("mit_dwconv_gelu_bwd");
 }
