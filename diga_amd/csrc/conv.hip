@@ -1550,10 +1550,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     wg /= a.tiles_m;
     const int tap = wg % RS;
     const int split = wg / RS;
-    const int r = tap / a.S, s = tap - r * a.S;
-    const int dyo = a.oy0 + r * a.ody, dxo = a.ox0 + s * a.odx;
     const int k0 = tile_m * BM, c0 = tile_n * BN;
-    const int HoWo = a.Ho * a.Wo;
 
     // loader: 32 pixels x BM (or BN) channels per K-step; thread owns 4-float chunks
     constexpr int CA = BM / 4, CB = BN / 4;          // float4 chunks per pixel row
@@ -1564,6 +1561,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     if (p_end > a.M) p_end = a.M;
     const int ksteps = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
 
+    // x-operand pixel of (tap, output pixel): from the table wgrad_pixtab_kernel built (one int per pixel and tap, -1 outside
+    // the image) or, for an identity map (1x1, stride 1, no offset), the output pixel itself -- no divisions or coordinate
+    // arithmetic in the loop (round 3: they sat in front of every K-step's MFMAs; matrix pipe 59 % busy).  Indices are
+    // fetched one K-step ahead of the loads that use them.
+    const int* tab = a.ptab != nullptr ? a.ptab + (int64_t)tap * a.M_pad : nullptr;
+    int bidx[NB];
+    auto load_idx = [&](int ks) {
+        const int pb = p_begin + ks * kBK;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = t + 256 * i;
+            const int p = pb + idx / CB;
+            bidx[i] = p < p_end ? (tab != nullptr ? tab[p] : p) : -1;
+        }
+    };
     auto gload = [&](int ks) {
         const int pb = p_begin + ks * kBK;
 #pragma unroll
@@ -1578,17 +1590,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = t + 256 * i;
-            const int pr = idx / CB, ch = (idx - pr * CB) * 4;
-            const int p = pb + pr;
+            const int ch = (idx % CB) * 4;
             rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < p_end && c0 + ch < a.Cin) {
-                const int img = p / HoWo, rem = p - img * HoWo;
-                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-                const int iy = ho * a.sy + dyo, ix = wo * a.sx + dxo;
-                if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-                    rb[i] = *reinterpret_cast<const float4*>(
-                        a.x + (int64_t)((img * a.Hi + iy) * a.Wi + ix) * a.x_ld + c0 + ch);
-            }
+            if (bidx[i] >= 0 && c0 + ch < a.Cin)
+                rb[i] = *reinterpret_cast<const float4*>(a.x + (int64_t)bidx[i] * a.x_ld + c0 + ch);
         }
     };
     auto lstore = [&](int buf) {
@@ -1618,13 +1623,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 
     const int li = lane & 31, lh = lane >> 5;
     if (ksteps > 0) {
+        load_idx(0);
         gload(0);
         lstore(0);
+        if (ksteps > 1) load_idx(1);
     }
     __syncthreads();
     for (int ks = 0; ks < ksteps; ++ks) {
         const int cur = ks & 1;
-        if (ks + 1 < ksteps) gload(ks + 1);
+        if (ks + 1 < ksteps) {
+            gload(ks + 1);
+            if (ks + 2 < ksteps) load_idx(ks + 2);
+        }
         const float* Ac = As + cur * kBK * kLDW;
         const float* Bc = Bs + cur * kBK * kLDW;
 #pragma unroll
@@ -2714,7 +2724,9 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
     const bool wide = p.tm == 4;
     const size_t slab_bytes = wgrad_slab_bytes(p, Cout, Cin, RS);
     const int64_t M_pad = wgrad_mpad(M);
-    const size_t need = slab_bytes + (wide ? (size_t)RS * M_pad * sizeof(int) + 64 : 0);
+    const bool identity = RS == 1 && stride_y == 1 && stride_x == 1 && off_y0 == 0 && off_x0 == 0 && Hi == Ho && Wi == Wo;
+    const bool f32_tab = !x3 && !identity;               // conv_wgrad_kernel reads the pixel table too (round 3)
+    const size_t need = slab_bytes + ((wide || f32_tab) ? (size_t)RS * M_pad * sizeof(int) + 64 : 0);
     DIGA_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned16(workspace))), DIGA_EWORKSPACE,
                  "conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     WgradArgs a;
@@ -2746,6 +2758,14 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
         }
     } else
     {
+    if (f32_tab) {
+        int* tab = reinterpret_cast<int*>(static_cast<char*>(workspace) + slab_bytes);
+        float* zeros = reinterpret_cast<float*>(tab + RS * M_pad);
+        hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3((unsigned)ceil_div(M_pad, 256), (unsigned)RS), dim3(256), 0, st, tab, zeros,
+                           (int)M, (int)M_pad, (int)Ho, (int)Wo, (int)Hi, (int)Wi, (int)S, (int)stride_y, (int)stride_x,
+                           (int)off_y0, (int)off_x0, (int)off_dy, (int)off_dx);
+        a.ptab = tab;
+    }
     const size_t sh = (size_t)(4 * kBK * kLDW) * sizeof(float);
 #define DIGA_WGRAD_LAUNCH(TM_, TN_)                                                                                   \
     do {                                                                                                               \
