@@ -1637,18 +1637,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         }
         const float* Ac = As + cur * kBK * kLDW;
         const float* Bc = Bs + cur * kBK * kLDW;
+        // fragment reads run one k-pair AHEAD of their MFMAs in a second register set (the compiler's own schedule read each
+        // pair into the same registers right before its four MFMAs and waited for LDS every time: matrix pipe 59 % busy)
+        float av[2][TM], bv[2][TN];
+        auto frag = [&](int kk, int set) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[set][i] = Ac[(kk + lh) * kLDW + wm * 32 * TM + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[set][j] = Bc[(kk + lh) * kLDW + wn * 32 * TN + j * 32 + li];
+        };
+        frag(0, 0);
 #pragma unroll
         for (int kk = 0; kk < kBK; kk += 2) {
-            float av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = Ac[(kk + lh) * kLDW + wm * 32 * TM + i * 32 + li];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bc[(kk + lh) * kLDW + wn * 32 * TN + j * 32 + li];
+            const int set = (kk >> 1) & 1;
+            if (kk + 2 < kBK) frag(kk + 2, set ^ 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);           // the next pair's LDS reads first ...
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][i], bv[set][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);           // ... then this pair's MFMAs
         }
         if (ks + 1 < ksteps) lstore(cur ^ 1);
         __syncthreads();
