@@ -146,6 +146,52 @@ def forward(sd, x, arch=RESNET101, training=False, keep_mask=None, update_stats=
     return shallow, deep, out, feat
 
 
+def forward_fixed_masks(sd, x, arch, masks, keep_mask=None):
+    """SegModel.forward in train mode (batch-statistics BN) with EVERY switch pinned to a given pattern: the stem / bottleneck /
+    ASPP-branch / SE ReLUs become multiplications with 0/1 masks and the 3x3/2 max-pool a gather with given indices
+    (`masks`: "layer0", "pool_idx", "layer{l}.{b}.{1,2,3}", "aspp.{b}", "se" -- the patterns observed on the device under
+    test).  The network's gradients are discontinuous where a pre-activation crosses zero or two pool candidates tie; with
+    the switches pinned the function is smooth around the operating point, so the gradients of ALL layers -- through the stem,
+    the max-pool, the strided / dilated stage transitions and the ASPP chain in one backward pass -- can be compared
+    elementwise with a tight bound (cf. bottleneck_fixed_masks).  Same reference lines as trunk / aspp_head."""
+    y = F.conv2d(x, sd["layer0.0.weight"], stride=2, padding=3)
+    y = _bn(sd, "layer0.1", y, True) * masks["layer0"]
+    idx = masks["pool_idx"]
+    y = y.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    shallow = None
+    inplanes = arch.stem
+    for li in range(4):
+        planes, stride, dil = arch.planes[li], arch.strides[li], arch.dilations[li]
+        for bi in range(arch.layers[li]):
+            first = bi == 0
+            has_down = first and (stride != 1 or inplanes != planes * arch.expansion or dil in (2, 4))
+            pfx = f"layer{li + 1}.{bi}"
+            y = bottleneck_fixed_masks(sd, pfx, y, stride if first else 1, dil, has_down,
+                                       (masks[pfx + ".1"], masks[pfx + ".2"], masks[pfx + ".3"]))
+            inplanes = planes * arch.expansion
+        if li == 1:
+            shallow = y
+    deep = y
+    g = arch.gn_groups
+    branches = []
+    for b in range(1 + len(arch.aspp_dilations)):
+        w, bias = sd[f"final.conv2d_list.{b}.0.weight"], sd[f"final.conv2d_list.{b}.0.bias"]
+        d = 1 if b == 0 else arch.aspp_dilations[b - 1]
+        z = F.conv2d(deep, w, bias) if b == 0 else F.conv2d(deep, w, bias, padding=d, dilation=d)
+        z = F.group_norm(z, g, sd[f"final.conv2d_list.{b}.1.weight"], sd[f"final.conv2d_list.{b}.1.bias"], 1e-5)
+        branches.append(z * masks[f"aspp.{b}"])
+    cat = torch.cat(branches, 1)
+    pooled = cat.mean(dim=(2, 3))
+    z = F.linear(pooled, sd["final.bottleneck.0.se.0.weight"], sd["final.bottleneck.0.se.0.bias"]) * masks["se"]
+    z = torch.sigmoid(F.linear(z, sd["final.bottleneck.0.se.2.weight"], sd["final.bottleneck.0.se.2.bias"]))
+    cat = cat * z[:, :, None, None]
+    y = F.conv2d(cat, sd["final.bottleneck.1.weight"], sd["final.bottleneck.1.bias"], padding=1)
+    y = F.group_norm(y, g, sd["final.bottleneck.2.weight"], sd["final.bottleneck.2.bias"], 1e-5)
+    if keep_mask is not None:
+        y = y * (keep_mask.to(y.dtype) / (1.0 - arch.droprate))[:, :, None, None]
+    return shallow, deep, F.conv2d(y, sd["final.head.1.weight"]), y
+
+
 def state_shapes(arch=RESNET101):
     """Ordered {key: (shape, kind)} in the reference's state_dict order.
     kind in {conv, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, bias, gn_w, gn_b, lin, head}."""
