@@ -451,7 +451,9 @@ def test_whole_model_gradients_vs_float64_with_pinned_switches(conv_math, arch_n
     # ---- float64 oracle with those switches
     trainable = [k for k, (_, kind) in od.state_shapes(arch_o).items() if kind in ("conv", "bias", "gn_w", "gn_b", "lin", "head")]
     sd64 = {k: (v.double().requires_grad_() if k in trainable else v.double()) for k, v in sd32.items()}
-    _, _, out_r, feat_r = od.forward_fixed_masks(sd64, x.double(), arch_o, masks, keep_mask=torch.ones(2, arch_o.aspp_width))
+    import dataclasses
+    _, _, out_r, feat_r = od.forward_fixed_masks(sd64, x.double(), dataclasses.replace(arch_o, droprate=0.0), masks,
+                                                 keep_mask=torch.ones(2, arch_o.aspp_width))      # Dropout2d off, as on the device
     probe = torch.randn(out_r.shape, generator=g)
     probe_f = 0.1 * torch.randn(feat_r.shape, generator=g)
     ((out_r * probe.double()).sum() + (feat_r * probe_f.double()).sum()).backward()
