@@ -407,7 +407,8 @@ def test_whole_model_gradients_vs_float64_with_pinned_switches(conv_math, arch_n
     """ONE backward pass through the whole network -- stem, max-pool, every strided / dilated stage transition, the
     bottleneck junctions, the ASPP chain (five branches, GroupNorm, SE gate, bottleneck conv) -- against a float64 oracle whose
     ReLU patterns and max-pool choices are pinned to the ones the device produced (oracle.deeplab.forward_fixed_masks): every
-    parameter gradient ELEMENTWISE within 2e-5 (fp32 arithmetic) / 1e-4 (split bf16) of its scale.  Closes the gap the
+    parameter gradient ELEMENTWISE within 2e-5 (fp32 arithmetic) / 1e-4 (split bf16) of its scale on the small backbone, 4e-5 / 3e-4
+    on the full ResNet-101 (all 133 trainable tensors).  Closes the gap the
     captured-gradient checks leave (norms and samples against fixed captures are loose because the network's gradients are
     discontinuous at its switches; here the switches cannot move)."""
     import torch.nn.functional as F
@@ -463,7 +464,8 @@ def test_whole_model_gradients_vs_float64_with_pinned_switches(conv_math, arch_n
     assert float((out.detach().cpu().double() - out_r.detach()).abs().max() / out_r.detach().abs().max()) < (1e-5 if conv_math == 0 else 2e-4)
     ((out * probe.to(DEV)).sum() + (feat * probe_f.to(DEV)).sum()).backward()
     named = dict(m.named_parameters())
-    tol = 2e-5 if conv_math == 0 else 1e-4
+    # measured: fp32 2.2e-6 (small backbone) / 1.4e-5 (ResNet-101, 33 blocks deep); split bf16 4.3e-5 / 1.1e-4
+    tol = (4e-5 if conv_math == 0 else 3e-4) if arch_name == "RESNET101" else (2e-5 if conv_math == 0 else 1e-4)
     worst, worst_k = 0.0, None
     for k in trainable:
         ref = sd64[k].grad
