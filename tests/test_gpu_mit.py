@@ -280,6 +280,19 @@ def test_mit_b1_benchmark_geometry_vs_reference_capture(golden):
     assert np.allclose(sums, g["sums"], rtol=2e-3)
 
 
+def test_mit_b5_benchmark_geometry_vs_reference_capture(golden):
+    """The full-depth encoder (3 + 6 + 40 + 3 blocks) on one 768x768 image against the capture of the reference module."""
+    g = golden("mit768")
+    x = torch.rand((1, 3, 768, 768), generator=synth.gen(int(g["seed"]))) * 2 - 1
+    m = _model("mit_b5").eval()
+    with torch.no_grad():
+        outs = m(x.to(DEV))
+    for o, key, step, mx in zip(outs, ("b5_c1_sample", "b5_c2_sample", "b5_c3_sample", "b5_c4_sample"), (211, 53, 7, 3), g["b5_maxs"]):
+        e = float((o.float().cpu().reshape(-1)[::step] - g.t(key)).abs().max()) / float(mx)
+        assert e < 1e-2, (key, e)
+    assert np.allclose(np.array([float(o.abs().sum()) for o in outs]), g["b5_sums"], rtol=3e-3)
+
+
 def test_drop_path_training_mode_statistics():
     """Train mode draws a per-image keep mask per branch (timm DropPath): with rate p the expected output equals the eval
     output; with p = 0 train and eval agree exactly."""

@@ -44,3 +44,14 @@ def test_mit_b1_benchmark_geometry_vs_reference(golden):
     for o, key, step, mx in zip(outs, ("c1_sample", "c2_sample", "c3_sample", "c4_sample"), (211, 53, 7, 3), g["maxs"]):
         assert float((o.reshape(-1)[::step] - g.t(key)).abs().max()) < 2e-5 * float(mx)
     assert np.allclose([float(o.abs().sum()) for o in outs], g["sums"], rtol=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_mit_b5_benchmark_geometry_vs_reference(golden):
+    g = golden("mit768")
+    x = torch.rand((1, 3, 768, 768), generator=synth.gen(int(g["seed"]))) * 2 - 1
+    with torch.no_grad():
+        outs = om.forward(om.state_dict(om.MIT_B5), x, om.MIT_B5)
+    for o, key, step, mx in zip(outs, ("b5_c1_sample", "b5_c2_sample", "b5_c3_sample", "b5_c4_sample"), (211, 53, 7, 3), g["b5_maxs"]):
+        assert float((o.reshape(-1)[::step] - g.t(key)).abs().max()) < 3e-5 * float(mx)
+    assert np.allclose([float(o.abs().sum()) for o in outs], g["b5_sums"], rtol=1e-5)

@@ -556,9 +556,15 @@ def gen_mit():
     x1 = torch.rand((1, 3, 768, 768), generator=synth.gen(56)) * 2 - 1
     with torch.no_grad():
         o1 = net1(x1)
+    # ... and the full-depth mit_b5 (40 blocks in stage 3) on the same image, forward only
+    with torch.no_grad():
+        o5 = net(x1)
     save("mit768", seed=np.array(56), c1_sample=o1[0].reshape(-1)[::211].clone(), c2_sample=o1[1].reshape(-1)[::53].clone(),
          c3_sample=o1[2].reshape(-1)[::7].clone(), c4_sample=o1[3].reshape(-1)[::3].clone(),
-         sums=np.array([float(o.abs().sum()) for o in o1]), maxs=np.array([float(o.abs().max()) for o in o1]))
+         sums=np.array([float(o.abs().sum()) for o in o1]), maxs=np.array([float(o.abs().max()) for o in o1]),
+         b5_c1_sample=o5[0].reshape(-1)[::211].clone(), b5_c2_sample=o5[1].reshape(-1)[::53].clone(),
+         b5_c3_sample=o5[2].reshape(-1)[::7].clone(), b5_c4_sample=o5[3].reshape(-1)[::3].clone(),
+         b5_sums=np.array([float(o.abs().sum()) for o in o5]), b5_maxs=np.array([float(o.abs().max()) for o in o5]))
 
 
 # ------------------------------------------------------------------ G-step (warm-up, 3 steps)
