@@ -146,8 +146,10 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
             raise RuntimeError("DigaBatchNorm2d implements the frozen-affine BN of the DiGA path; "
                                "set requires_grad=False on weight and bias")
         training = self.training or self.running_mean is None
-        if self.training and self.num_batches_tracked is not None and not getattr(self, "_nbt_external", False):
-            self.num_batches_tracked.add_(1)          # (a model may bump all its counters with one launch instead)
+        if getattr(self, "_nbt_external", False):
+            self._nbt_external = False                # the model's forward bumped this counter for THIS call (bump_batches_tracked)
+        elif self.training and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
         twin_out = bool(twin_out and relu and residual is None and x.shape[1] % 8 == 0)
         box = res_box = None
         if training and relu and torch.is_grad_enabled() and x.requires_grad and fuse_backward_enabled():
@@ -167,10 +169,11 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
 
 
 def bump_batches_tracked(model):
-    """num_batches_tracked += 1 for every DigaBatchNorm2d of `model` with ONE launch instead of one per layer (every BN
-    of the DeepLab trunk runs exactly once per forward; the reference's nn.BatchNorm2d bumps its own counter,
-    seg_model_noaux.py:64-76 / torch).  The counters become views of one flat int64 buffer (state-dict keys and values
-    unchanged); the views are rebuilt whenever .to() / load_state_dict() replaced the buffers."""
+    """num_batches_tracked += 1 for every DigaBatchNorm2d of `model` that is in train() mode, with ONE launch instead of one per
+    layer (every BN of the DeepLab trunk runs exactly once per forward; the reference's nn.BatchNorm2d bumps its own counter per
+    module and only while that module trains, seg_model_noaux.py:64-76 / torch).  The counters become views of one flat int64
+    buffer (state-dict keys and values unchanged); the views are rebuilt whenever .to() / load_state_dict() replaced the
+    buffers, the 0/1 increment vector whenever a module's train / eval state changed (e.g. a freeze_bn pattern)."""
     bns = [m for m in model.modules() if isinstance(m, DigaBatchNorm2d) and m.num_batches_tracked is not None]
     if not bns:
         return
@@ -181,9 +184,19 @@ def bump_batches_tracked(model):
         flat = torch.stack([b.num_batches_tracked.detach().reshape(()) for b in bns]).contiguous()
         for i, b in enumerate(bns):
             b.num_batches_tracked = flat[i]
-            b._nbt_external = True
         object.__setattr__(model, "_nbt_flat", flat)
-    flat.add_(1)
+        object.__setattr__(model, "_nbt_inc", None)
+    state = tuple(b.training for b in bns)
+    inc = getattr(model, "_nbt_inc", None)
+    if inc is None or inc[0] != state:
+        inc = (state, torch.tensor([1 if t else 0 for t in state], dtype=torch.int64).to(flat.device))
+        object.__setattr__(model, "_nbt_inc", inc)
+    for b in bns:
+        b._nbt_external = True                 # this forward's increment is done here; the module skips its own
+    if all(state):
+        flat.add_(1)
+    else:
+        flat.add_(inc[1])
 
 
 def _relu_bits_enabled():

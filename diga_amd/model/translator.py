@@ -25,8 +25,9 @@ class FoldedUpsample(nn.Upsample):
     def forward(self, x):
         if torch.is_grad_enabled() or self.mode != "nearest" or float(self.scale_factor) != 2.0 or not x.is_cuda:
             return super().forward(x)
-        x._diga_up_shift = 1
-        return x
+        y = x.view_as(x)                 # a fresh tensor object on the same memory: the tag must not outlive this call on `x`
+        y._diga_up_shift = 1
+        return y
 
 
 class DigaInstanceNorm2d(nn.InstanceNorm2d):
