@@ -90,6 +90,7 @@ SIGNATURES = {
     "diga_mit_colsum_workspace_bytes": (SZ, [I64, I64]),
     "diga_mit_colsum": (INT, [P, I64, P, F32, INT, P, SZ, I64, I64, P]),
     "diga_mit_cast_transpose": (INT, [P, P, P, I64, I64, P]),
+    "diga_mit_weight_prep_multi": (INT, [P, P, I64, I64, P]),
     "diga_mit_cast_scale": (INT, [P, P, I64, F32, P]),
     "diga_mit_row_scale": (INT, [P, P, P, I64, I64, I64, P]),
     "diga_mit_layernorm_fwd": (INT, [P, I64, P, P, P, P, I64, P, P, I64, I64, F32, P]),
@@ -112,6 +113,12 @@ SIGNATURES = {
 class ConvOptions(C.Structure):
     """diga_conv_options_t of include/diga_hip.h."""
     _fields_ = [("reflect_pad", INT), ("upsample_shift", INT), ("activation", INT)]
+
+
+class MitWeightPrep(C.Structure):
+    """diga_mit_weight_prep_t of include/diga_mit.h."""
+    _fields_ = [("src", P), ("out_a", P), ("out_b", P), ("Co", INT), ("Ci", INT), ("RS", INT), ("Kp", INT), ("mode", INT),
+                ("tiles_k", INT)]
 
 
 class BwdEpilogue(C.Structure):

@@ -361,6 +361,60 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+
+// All weights of a model in ONE launch (once per forward): tensor t is a [Co][Ci][R][S] fp32 parameter (Linear: R = S = 1), its
+// GEMM form is rows[co][k], k = (r * S + s) * Ci + ci, zero-padded to Kp columns:
+//   mode 0: w16 [Co][Kp] fp16 and wt16 [Kp][Co] fp16 (forward / backward-data operands)
+//   mode 1: fp32 transposes for the depthwise 3x3 (Ci = 1): out_a [R*S][Co] and out_b = the same with the taps reversed
+// One block per 32 x 32 tile of (co, k); the tile -> tensor map is a prefix array searched per block.
+struct PrepEntry {
+    const float* src;
+    void* out_a;
+    void* out_b;
+    int Co, Ci, RS, Kp, mode, tiles_k;
+};
+
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const PrepEntry* __restrict__ tab, const int64_t* __restrict__ tile_start,
+                                                                int n_tensors) {
+    __shared__ float tile[32][33];
+    const int64_t blk = blockIdx.x;
+    int lo = 0, hi = n_tensors - 1;
+    while (lo < hi) {                                               // last tensor whose first tile <= blk
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= blk) lo = mid; else hi = mid - 1;
+    }
+    const PrepEntry e = tab[lo];
+    const int local = (int)(blk - tile_start[lo]);
+    const int tk = local % e.tiles_k, tc = local / e.tiles_k;
+    const int c0 = tc * 32, k0 = tk * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int K = e.RS * e.Ci;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = c0 + ty + 8 * i, k = k0 + tx;
+        float v = 0.f;
+        if (co < e.Co && k < K) {
+            const int tap = k / e.Ci, ci = k - tap * e.Ci;
+            v = e.src[((int64_t)co * e.Ci + ci) * e.RS + tap];
+        }
+        if (e.mode == 0 && co < e.Co && k < e.Kp) static_cast<_Float16*>(e.out_a)[(int64_t)co * e.Kp + k] = (_Float16)v;
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, co = c0 + tx;
+        if (co >= e.Co || k >= e.Kp) continue;
+        const float v = tile[tx][ty + 8 * i];
+        if (e.mode == 0) {
+            static_cast<_Float16*>(e.out_b)[(int64_t)k * e.Co + co] = (_Float16)v;
+        } else if (k < K) {
+            static_cast<float*>(e.out_a)[(int64_t)k * e.Co + co] = v;
+            static_cast<float*>(e.out_b)[(int64_t)(K - 1 - k) * e.Co + co] = v;
+        }
+    }
+}
+
 }  // namespace mit
 }  // namespace diga
 
@@ -505,4 +559,16 @@ extern "C" int diga_mit_cast_transpose(const float* w, void* w16, void* wt16, in
     hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)ceil_div(C, 32), (unsigned)ceil_div(R, 32)), dim3(256), 0, st, w,
                        static_cast<_Float16*>(w16), static_cast<_Float16*>(wt16), (int)R, (int)C);
     return launch_status("mit_cast_transpose");
+}
+
+static_assert(sizeof(diga::mit::PrepEntry) == sizeof(diga_mit_weight_prep_t), "diga_mit_weight_prep_t mirrors PrepEntry");
+
+extern "C" int diga_mit_weight_prep_multi(const diga_mit_weight_prep_t* table, const int64_t* tile_start, int64_t n_tensors,
+                                          int64_t total_tiles, void* stream) {
+    DIGA_REQUIRE(table && tile_start && n_tensors > 0 && total_tiles > 0 && total_tiles < (1ll << 31), DIGA_EINVAL,
+                 "mit_weight_prep_multi: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(weight_prep_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st,
+                       reinterpret_cast<const PrepEntry*>(table), tile_start, (int)n_tensors);
+    return launch_status("mit_weight_prep_multi");
 }

@@ -237,11 +237,14 @@ class _MitFn(torch.autograd.Function):
         xin = x.detach().float().contiguous()
         saved = {"stages": []}
         outs = []
+        prep = cfg["prep"]
+        if prep is None:
+            raise RuntimeError("diga_amd ops run on the GPU only (HIP kernels, no CPU fallback)")
         src, src_kind, sh, sw, sc = xin, 2, H, W, xin.shape[1]
         for si, st in enumerate(cfg["stages"]):
             pre = st["embed"]
             C, heads, sr, hid = st["dim"], st["heads"], st["sr"], st["hidden"]
-            w16, wt16, kp = _conv16(par[pre + ".proj.weight"], need_grad and si > 0)
+            w16, wt16, kp = prep[pre + ".proj.weight"]
             cols, ho, wo = ops.im2col(src, src_kind, B, sh, sw, sc, st["patch"], st["stride"], st["patch"] // 2, kp)
             M = B * ho * wo
             y32 = ops.gemm(cols, w16, par[pre + ".proj.bias"], C, out_f32=True)
@@ -257,17 +260,17 @@ class _MitFn(torch.autograd.Function):
                     # timm DropPath (:156,176-177): per sample keep / drop, rescaled by 1 / keep; one draw per branch
                     keep = 1.0 - st["drop_path"][bi]
                     seg_a, seg_m = ((torch.rand((2, B), device=dev) < keep).float() / keep).unbind(0)
-                wq, wqt = _lin16(par[bp + ".attn.q.weight"], need_grad)
-                wkv, wkvt = _lin16(par[bp + ".attn.kv.weight"], need_grad)
-                wpr, wprt = _lin16(par[bp + ".attn.proj.weight"], need_grad)
-                w1, w1t = _lin16(par[bp + ".mlp.fc1.weight"], need_grad)
-                w2, w2t = _lin16(par[bp + ".mlp.fc2.weight"], need_grad)
-                wdw = par[bp + ".mlp.dwconv.dwconv.weight"].detach().reshape(hid, 9).t().contiguous()       # [9][hid] fp32
+                wq, wqt, _ = prep[bp + ".attn.q.weight"]
+                wkv, wkvt, _ = prep[bp + ".attn.kv.weight"]
+                wpr, wprt, _ = prep[bp + ".attn.proj.weight"]
+                w1, w1t, _ = prep[bp + ".mlp.fc1.weight"]
+                w2, w2t, _ = prep[bp + ".mlp.fc2.weight"]
+                wdw, wdw_flip, _ = prep[bp + ".mlp.dwconv.dwconv.weight"]                                  # [9][hid] fp32, taps reversed
                 a16, _, m1, r1 = ops.ln_fwd(xcur, par[bp + ".norm1.weight"], par[bp + ".norm1.bias"], eps[bp + ".norm1"], save=need_grad)
                 q16 = ops.gemm(a16, wq, par.get(bp + ".attn.q.bias"), C)
                 bs = {}
                 if sr > 1:
-                    wsr, wsrt, kps = _conv16(par[bp + ".attn.sr.weight"], need_grad)
+                    wsr, wsrt, kps = prep[bp + ".attn.sr.weight"]
                     pc, hk, wk = ops.im2col(a16, 1, B, ho, wo, C, sr, sr, 0, kps)
                     s32 = ops.gemm(pc, wsr, par[bp + ".attn.sr.bias"], C, out_f32=True)
                     r16, _, ms, rs = ops.ln_fwd(s32, par[bp + ".attn.norm.weight"], par[bp + ".attn.norm.bias"], eps[bp + ".attn.norm"],
@@ -293,7 +296,8 @@ class _MitFn(torch.autograd.Function):
                 x2 = ops.gemm(h2, w2, par[bp + ".mlp.fc2.bias"], C, out_f32=True, residual=x1, seg=seg_m, rows_per_seg=ho * wo)
                 if need_grad:
                     bs.update(x=xcur, m1=m1, r1=r1, a16=a16, q16=q16, kv16=kv16, nk=nk, o16=o16, lse=lse, x1=x1, m2=m2, r2=r2,
-                              b16=b16, h1=h1, u16=u16, h2=h2, seg_a=seg_a, seg_m=seg_m, wqt=wqt, wkvt=wkvt, wprt=wprt, w1t=w1t, w2t=w2t, wdw=wdw)
+                              b16=b16, h1=h1, u16=u16, h2=h2, seg_a=seg_a, seg_m=seg_m, wqt=wqt, wkvt=wkvt, wprt=wprt, w1t=w1t, w2t=w2t,
+                              wdw_flip=wdw_flip)
                     ssave["blocks"].append(bs)
                 xcur = x2
             _, out32, n_mean, n_rstd = ops.ln_fwd(xcur, par[st["norm"] + ".weight"], par[st["norm"] + ".bias"], eps[st["norm"]], want16=False,
@@ -351,8 +355,7 @@ class _MitFn(torch.autograd.Function):
                 dwd = ops.empty((hid, 9), torch.float32)
                 dbd = ops.empty((hid,), torch.float32)
                 ws = _lib.workspace(_lib.lib.diga_mit_dwconv_bwd_workspace_bytes(B, ho, hid), dev, "mit_dw")
-                wflip = bs["wdw"].flip(0).contiguous()
-                _lib.call("diga_mit_dwconv_gelu_bwd", P(d_h2), P(bs["u16"]), P(bs["h1"]), P(wflip), P(du), P(d_h2), P(dwd), P(dbd), inv, 0,
+                _lib.call("diga_mit_dwconv_gelu_bwd", P(d_h2), P(bs["u16"]), P(bs["h1"]), P(bs["wdw_flip"]), P(du), P(d_h2), P(dwd), P(dbd), inv, 0,
                           P(ws), ws.numel(), B, ho, wo, hid, _lib.stream())
                 d_h1 = d_h2
                 grads[bp + ".mlp.dwconv.dwconv.weight"] = dwd.view(hid, 1, 3, 3)
@@ -477,6 +480,50 @@ class MixVisionTransformer(nn.Module):
     def no_weight_decay(self):
         return {'pos_embed1', 'pos_embed2', 'pos_embed3', 'pos_embed4', 'cls_token'}
 
+    def _prepare_weights(self):
+        """fp16 GEMM operands of every Linear / conv weight ([Co][Kp] and its transpose [Kp][Co]) and the fp32 tap-major forms of
+        the depthwise weights, refreshed from the fp32 master parameters by ONE launch per forward (diga_mit_weight_prep_multi;
+        the parameters change in place at every SGD / EMA step, so the copies cannot be cached across steps).  The buffers are
+        persistent per model: a backward pass reads the operands of ITS forward, which is the same memory -- valid as long as
+        the parameters are not modified between a forward and its backward (true for every optimizer: they step after)."""
+        import ctypes
+        named = dict(self.named_parameters())
+        sig = (next(iter(named.values())).device,) + tuple(p.data_ptr() for p in named.values())
+        st = getattr(self, "_prep_state", None)
+        if st is None or st["sig"] != sig:
+            dev = sig[0]
+            entries, out, starts, total = [], {}, [], 0
+            for n, p in named.items():
+                if p.dim() == 2:                                           # nn.Linear [Co, Ci]
+                    co, ci, rs, mode = p.shape[0], p.shape[1], 1, 0
+                elif p.dim() == 4 and p.shape[1] == 1 and n.endswith("dwconv.dwconv.weight"):
+                    co, ci, rs, mode = p.shape[0], 1, p.shape[2] * p.shape[3], 1
+                elif p.dim() == 4:                                         # patch-embedding / spatial-reduction conv [Co, Ci, R, S]
+                    co, ci, rs, mode = p.shape[0], p.shape[1], p.shape[2] * p.shape[3], 0
+                else:
+                    continue
+                if not (p.is_contiguous() and p.dtype == torch.float32):
+                    raise RuntimeError(f"MixVisionTransformer: parameter {n} must be a contiguous fp32 tensor")
+                kp = _rup(rs * ci, 32) if mode == 0 else rs
+                if mode == 0:
+                    a = torch.empty((co, kp), dtype=torch.float16, device=dev)
+                    b = torch.empty((kp, co), dtype=torch.float16, device=dev)
+                else:
+                    a = torch.empty((rs, co), dtype=torch.float32, device=dev)
+                    b = torch.empty((rs, co), dtype=torch.float32, device=dev)
+                tiles_k = (kp + 31) // 32
+                entries.append(_lib.MitWeightPrep(p.data_ptr(), a.data_ptr(), b.data_ptr(), co, ci, rs, kp, mode, tiles_k))
+                starts.append(total)
+                total += ((co + 31) // 32) * tiles_k
+                out[n] = (a, b, kp)
+            arr = (_lib.MitWeightPrep * len(entries))(*entries)
+            tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            ts = torch.tensor(starts, dtype=torch.int64).to(dev)
+            st = {"sig": sig, "tab": tab, "starts": ts, "n": len(entries), "total": total, "out": out}
+            object.__setattr__(self, "_prep_state", st)
+        _lib.call("diga_mit_weight_prep_multi", P(st["tab"]), P(st["starts"]), st["n"], st["total"], _lib.stream())
+        return st["out"]
+
     def _cfg(self):
         names = [n for n, _ in self.named_parameters()]
         stages = []
@@ -496,6 +543,7 @@ class MixVisionTransformer(nn.Module):
         params = [p for _, p in self.named_parameters()]
         cfg = self._cfg()
         cfg["need_grad"] = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        cfg["prep"] = self._prepare_weights() if x.is_cuda else None
         return list(_MitFn.apply(x, cfg, *params))
 
     def forward(self, x):

@@ -44,6 +44,22 @@ int diga_mit_colsum(const void* x, int64_t ld, float* out, float scale, int accu
 /* fp32 weight [R][C] -> fp16 copy and/or fp16 transpose [C][R] (once per optimizer step; either output nullable). */
 int diga_mit_cast_transpose(const float* w, void* w16, void* wt16, int64_t R, int64_t C, void* stream);
 
+/* Every weight of a model in ONE launch (per forward; the parameters change in place at every optimizer / EMA step): entry t
+ * describes a [Co][Ci][R][S] fp32 parameter (nn.Linear: R = S = 1; RS = R*S) whose GEMM form is rows[co][k],
+ * k = (r*S + s)*Ci + ci, zero-padded to Kp columns.
+ *   mode 0: out_a = fp16 [Co][Kp], out_b = fp16 [Kp][Co]                        (forward / backward-data operands)
+ *   mode 1: out_a = fp32 [RS][Co], out_b = the same with the taps reversed      (depthwise 3x3 forward / backward, Ci = 1)
+ * `table` [n_tensors] and `tile_start` [n_tensors] (first 32x32 tile of tensor t; tiles = ceil(Co/32) * tiles_k,
+ * tiles_k = ceil(Kp/32)) are DEVICE arrays built once by the caller; total_tiles = grid size. */
+typedef struct diga_mit_weight_prep {
+    const float* src;
+    void* out_a;
+    void* out_b;
+    int Co, Ci, RS, Kp, mode, tiles_k;
+} diga_mit_weight_prep_t;
+int diga_mit_weight_prep_multi(const diga_mit_weight_prep_t* table, const int64_t* tile_start, int64_t n_tensors,
+                               int64_t total_tiles, void* stream);
+
 /* fp32 -> fp16 with a scale (a gradient entering the fp16 backward pass picks up the loss scale).  n % 4 == 0. */
 int diga_mit_cast_scale(const float* x, void* y16, int64_t n, float scale, void* stream);
 
