@@ -5,8 +5,8 @@ Mirror of G5/model/networks/MixTransfomer.py (the reference's file name, typo in
 Attention, Block, OverlapPatchEmbed, DWConv, MixVisionTransformer, mit_b0..mit_b5), same constructor arguments, same
 module tree and therefore the same state-dict keys and parameter shapes (`patch_embed1.proj.weight`,
 `block3.17.attn.sr.weight`, `block1.0.mlp.dwconv.dwconv.weight`, ...), same `forward(x) -> [c1, c2, c3, c4]` (NCHW fp32,
-strides 4/8/16/32).  The modules are parameter containers; the arithmetic of the whole encoder runs in ONE autograd
-function (`_MitFn`) that walks the blocks and calls the HIP kernels:
+strides 4/8/16/32).  The modules are parameter containers; the arithmetic of each encoder stage runs in ONE autograd
+function (`_MitStageFn`: patch embedding, the stage's blocks, the stage norm) that walks the blocks and calls the HIP kernels:
 
   * storage: the residual stream is fp32, every branch tensor (LayerNorm outputs, q / kv, attention output, Mix-FFN
     hidden tensors, gathered patch rows) fp16; master weights fp32 with fp16 copies made per forward;
@@ -221,27 +221,36 @@ def _conv16(w, want_t):
     return w16, wt, kp
 
 
-class _MitFn(torch.autograd.Function):
-    """The whole encoder: forward(x, cfg, *params) -> (c1, c2, c3, c4).  `cfg` describes the stages; `params` are the
-    model's parameters in `cfg['names']` order (so autograd hands their gradients back)."""
+class _MitStageFn(torch.autograd.Function):
+    """ONE encoder stage (patch embedding, its blocks, the stage norm): forward(src, cfg, si, *params) -> the stage output
+    c_{si+1} (NCHW-shaped view of the [B*h*w][C] fp32 matrix).  `src` is the image (stage 0) or the previous stage's output;
+    `params` are this stage's parameters in `cfg['stage_names'][si]` order (so autograd hands their gradients back -- one
+    stage at a time: with data parallelism the gradient buckets of the last stages leave while the first stages still run
+    their backward).  Gradients cross the stage boundaries as TRUE gradients in fp32; the loss scale lives inside a stage."""
 
     @staticmethod
-    def forward(ctx, x, cfg, *params):
-        _lib.require_gpu(x)
-        dev = x.device
+    def forward(ctx, src_t, cfg, si, *params):
+        _lib.require_gpu(src_t)
+        dev = src_t.device
         ops = _Ops(dev)
-        par = dict(zip(cfg["names"], params))
+        names = cfg["stage_names"][si]
+        par = dict(zip(names, params))
         need_grad = cfg["need_grad"]                          # (grad mode is always off inside Function.forward: decided by the caller)
         eps = cfg["eps"]                                       # per LayerNorm module (the reference mixes 1e-6 and torch's 1e-5)
-        B, _, H, W = x.shape
-        xin = x.detach().float().contiguous()
-        saved = {"stages": []}
-        outs = []
         prep = cfg["prep"]
         if prep is None:
             raise RuntimeError("diga_amd ops run on the GPU only (HIP kernels, no CPU fallback)")
-        src, src_kind, sh, sw, sc = xin, 2, H, W, xin.shape[1]
-        for si, st in enumerate(cfg["stages"]):
+        B = src_t.shape[0]
+        if si == 0:
+            src = src_t.detach().float().contiguous()          # the image, NCHW
+            src_kind, sh, sw, sc = 2, src.shape[2], src.shape[3], src.shape[1]
+        else:
+            src = src_t.detach().permute(0, 2, 3, 1)           # previous stage's output: [B][h][w][C] fp32
+            if not (src.is_contiguous() and src.dtype == torch.float32):
+                src = src.float().contiguous()
+            src_kind, sh, sw, sc = 0, src.shape[1], src.shape[2], src.shape[3]
+        st = cfg["stages"][si]
+        if True:                                               # (one stage; the body keeps the indentation of the former stage loop)
             pre = st["embed"]
             C, heads, sr, hid = st["dim"], st["heads"], st["sr"], st["hidden"]
             w16, wt16, kp = prep[pre + ".proj.weight"]
@@ -303,44 +312,35 @@ class _MitFn(torch.autograd.Function):
             _, out32, n_mean, n_rstd = ops.ln_fwd(xcur, par[st["norm"] + ".weight"], par[st["norm"] + ".bias"], eps[st["norm"]], want16=False,
                                                   want32=True, save=need_grad)
             ssave.update(xlast=xcur if need_grad else None, n_mean=n_mean, n_rstd=n_rstd)
-            saved["stages"].append(ssave)
-            outs.append(out32.view(B, ho, wo, C).permute(0, 3, 1, 2))
-            src, src_kind, sh, sw, sc = out32, 0, ho, wo, C
-        ctx.cfg, ctx.saved, ctx.par = cfg, saved if need_grad else None, par if need_grad else None
+        ctx.cfg, ctx.si, ctx.saved, ctx.par = cfg, si, ssave if need_grad else None, par if need_grad else None
         ctx.B = B
         ctx.loss_scale = float(cfg["loss_scale"])
-        return tuple(outs)
+        ctx.src_needs_grad = bool(si > 0 and need_grad)
+        return out32.view(B, ho, wo, C).permute(0, 3, 1, 2)
 
     @staticmethod
-    def backward(ctx, *gouts):
-        cfg, saved, par = ctx.cfg, ctx.saved, ctx.par
-        if saved is None:
+    def backward(ctx, g):
+        cfg, si, ss, par = ctx.cfg, ctx.si, ctx.saved, ctx.par
+        if ss is None:
             raise RuntimeError("MixVisionTransformer: backward without saved activations")
         ctx.saved = None                                       # activations are released as the pass walks down
         S = ctx.loss_scale
         inv = 1.0 / S
         B = ctx.B
-        dev = gouts[[g is not None for g in gouts].index(True)].device
+        dev = g.device
         ops = _Ops(dev)
         grads = {}
-        down = None                                            # fp32 gradient wrt this stage's (normed) output coming from the next stage, x S
-        for si in range(len(cfg["stages"]) - 1, -1, -1):
-            st, ss = cfg["stages"][si], saved["stages"][si]
+        down = None                                            # true (unscaled) fp32 gradient wrt this stage's input
+        if True:
+            st = cfg["stages"][si]
             C, heads, sr, hid = st["dim"], st["heads"], st["sr"], st["hidden"]
             sh, sw, sc, ho, wo = ss["geom"]
             M = B * ho * wo
-            g = gouts[si]
-            gscale = S
-            if g is not None:
-                g = g.permute(0, 2, 3, 1).reshape(M, C)
-                g = g.float().contiguous() if not (g.dtype == torch.float32 and g.is_contiguous()) else g
-            if down is not None:
-                g, gscale = (down if g is None else down + S * g), 1.0
-            if g is None:                                      # nothing downstream used this stage's output (nor any later one)
-                saved["stages"][si] = None
-                continue
+            g = g.permute(0, 2, 3, 1).reshape(M, C)
+            g = g.float().contiguous() if not (g.dtype == torch.float32 and g.is_contiguous()) else g
+            # the incoming gradient is the true one; inside the stage everything carries the loss scale S
             dx32, dx16, dg, db = ops.ln_bwd(g, ss["xlast"], par[st["norm"] + ".weight"], ss["n_mean"], ss["n_rstd"], None, True, True,
-                                            inv, gscale)
+                                            inv, S)
             grads[st["norm"] + ".weight"], grads[st["norm"] + ".bias"] = dg, db
             ss["xlast"] = None
             for bi in range(len(st["blocks"]) - 1, -1, -1):
@@ -404,18 +404,18 @@ class _MitFn(torch.autograd.Function):
             k = st["patch"]
             dwp, grads[pre + ".proj.bias"] = ops.wgrad(d_y, ss["cols"], inv, bias=True)
             grads[pre + ".proj.weight"] = dwp[:, :k * k * sc].reshape(C, k, k, sc).permute(0, 3, 1, 2)
-            if si > 0:
+            if ctx.src_needs_grad and ctx.needs_input_grad[0]:
                 d_cols = ops.gemm(d_y, ss["wt16"], None, ss["kp"])
-                down = ops.empty((B * sh * sw, sc), torch.float32)
-                ops.col2im(d_cols, down, True, B, sh, sw, sc, k, st["stride"], k // 2, ho, wo, ss["kp"])
-            saved["stages"][si] = None
+                down = ops.empty((B, sh, sw, sc), torch.float32)
+                ops.col2im(d_cols, down, True, B, sh, sw, sc, k, st["stride"], k // 2, ho, wo, ss["kp"], gscale=inv)
+                down = down.permute(0, 3, 1, 2)               # NCHW-shaped view, the layout the stage output has
         out = []
-        for n in cfg["names"]:
+        for n in cfg["stage_names"][si]:
             gr = grads.get(n)
             if gr is not None and tuple(gr.shape) != tuple(par[n].shape):
                 gr = gr.reshape(par[n].shape)
             out.append(gr if par[n].requires_grad else None)
-        return (None, None, *out)
+        return (down, None, None, *out)
 
 
 class MixVisionTransformer(nn.Module):
@@ -537,14 +537,22 @@ class MixVisionTransformer(nn.Module):
                            "sr": b0.attn.sr_ratio, "scale": b0.attn.scale, "hidden": b0.mlp.fc1.out_features,
                            "blocks": [f"block{s + 1}.{i}" for i in range(len(blocks))],
                            "drop_path": [float(getattr(b.drop_path, "drop_prob", 0.0)) for b in blocks]})
-        return {"names": names, "stages": stages, "eps": eps, "training": self.training, "loss_scale": self.loss_scale}
+        stage_names = [[n for n in names if n.startswith((f"patch_embed{s + 1}.", f"block{s + 1}.", f"norm{s + 1}."))] for s in range(4)]
+        assert sum(len(v) for v in stage_names) == len(names)
+        return {"names": names, "stage_names": stage_names, "stages": stages, "eps": eps, "training": self.training,
+                "loss_scale": self.loss_scale}
 
     def forward_features(self, x):
         params = [p for _, p in self.named_parameters()]
         cfg = self._cfg()
         cfg["need_grad"] = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         cfg["prep"] = self._prepare_weights() if x.is_cuda else None
-        return list(_MitFn.apply(x, cfg, *params))
+        named = dict(self.named_parameters())
+        outs, src = [], x
+        for si in range(4):
+            src = _MitStageFn.apply(src, cfg, si, *[named[n] for n in cfg["stage_names"][si]])
+            outs.append(src)
+        return outs
 
     def forward(self, x):
         return self.forward_features(x)
