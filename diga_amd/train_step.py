@@ -49,6 +49,31 @@ class DigaTrainer:
         for p in teacher.parameters():
             p.requires_grad_(False)
 
+    # ------------------------------------------------------------------ ClassMix class lists ahead of time
+    def prefetch_classmix(self, labels):
+        """Software pipelining of the step's one host round trip: the class lists ClassMix needs (label histogram on the
+        device, D->H copy) for an UPCOMING step's `labels`, started now on a side stream.  Call it as soon as the labels of
+        the next batch are resident (a data loader's prefetch hook; `labels` must be complete -- nothing here waits for the
+        training stream); the step that receives the same tensor then finds the lists ready instead of draining the GPU to
+        learn which classes are present.  Same kernel, same copy, same RNG draws -- only earlier."""
+        if not labels.is_cuda:
+            return
+        if getattr(self, "_pf_stream", None) is None:
+            self._pf_stream = torch.cuda.Stream(device=labels.device)
+            self._pf = {}
+        host, ev = U.classmix_present_async(labels, self._pf_stream)
+        self._pf[(labels.data_ptr(), labels._version, tuple(labels.shape))] = (host, ev)
+        if len(self._pf) > 4:
+            self._pf.pop(next(iter(self._pf)))
+
+    def _present(self, labels):
+        pf = getattr(self, "_pf", None)
+        hit = pf.pop((labels.data_ptr(), labels._version, tuple(labels.shape)), None) if pf else None
+        if hit is None:
+            return None
+        hit[1].synchronize()
+        return U.present_lists(hit[0])
+
     # ------------------------------------------------------------------ common pieces
     def _begin(self, it):
         self.student.train()
@@ -114,7 +139,7 @@ class DigaTrainer:
             return self._warmup_step_eager(it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil)
         self._begin(it)
         with torch.no_grad():
-            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
+            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng, present=self._present(labels))
         if "graph" not in g:
             B = x.shape[0]
             g["cat"] = torch.empty((2 * B,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
@@ -162,7 +187,7 @@ class DigaTrainer:
     def _warmup_step_eager(self, it, x, x_aug, rec_s2t, labels, lambda_seg=1.0, lambda_distil=0.5):
         self._begin(it)
         with torch.no_grad():
-            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
+            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng, present=self._present(labels))
             cat = torch.cat([x, mix])
         pending = self._teacher_async(cat)
         _, _, s_lr, _ = self.student(cat)
@@ -179,7 +204,10 @@ class DigaTrainer:
         self._begin(it)
         B = x.shape[0]
         with torch.no_grad():
-            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng)
+            present = self._present(labels)
+            if present is None:
+                present = U.classmix_present(labels)          # both ClassMix blocks of the step draw from the same label lists
+            mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng, present=present)
             cat = torch.cat([x, mix])
         pending = self._teacher_async(cat, t_img)
         _, _, s_lr, _ = self.student(cat)
@@ -187,7 +215,7 @@ class DigaTrainer:
         with torch.no_grad():
             # bilateral consensus: keep the offline pseudo-label where the centroid label agrees
             pseudo = class_features.consensus_pseudo_labels(tt_feat, pseudo_prob)
-            cross_mix, cross_lab, _ = U.classmix(t_aug, x, labels, self.rng, bg_labels=pseudo)
+            cross_mix, cross_lab, _ = U.classmix(t_aug, x, labels, self.rng, bg_labels=pseudo, present=present)
             # centroid EMA: target (filtered pseudo-labels) first, then source (teacher feats of the mixed view)
             for feat, out, lab in ((tt_feat, tt_lr, pseudo), (t_feat[B:], t_lr[B:], labels)):
                 sums, counts = class_features._class_sums(feat, out, labels_full=lab)[:2]

@@ -211,6 +211,29 @@ def classmix_present(labels):
     return [np.nonzero(present[i])[0].tolist() for i in range(b)]
 
 
+def classmix_present_async(labels, stream):
+    """classmix_present started on `stream` (a side stream): returns (pinned host tensor [B,256] of 0/1, event).  The caller
+    guarantees that `labels` is complete (its producer has finished); nothing here waits for the current stream, so the D->H copy
+    does not queue behind the training step in flight.  `present_lists(host)` turns the result into the per-image lists."""
+    _lib.require_gpu(labels)
+    lab = _lib.contiguous(labels, torch.int64)
+    b = lab.shape[0]
+    with torch.cuda.stream(stream):
+        hist = torch.zeros((b, 256), dtype=torch.int32, device=lab.device)
+        _lib.call("diga_label_hist256", _lib.ptr(lab), _lib.ptr(hist), b, lab[0].numel(), _lib.stream())
+        host = torch.empty((b, 256), dtype=torch.bool, pin_memory=True)
+        host.copy_(hist != 0, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+    lab.record_stream(stream)
+    return host, ev
+
+
+def present_lists(host):
+    present = host.numpy()
+    return [np.nonzero(present[i])[0].tolist() for i in range(present.shape[0])]
+
+
 def classmix_select(present, rng=random):
     """Reference class choice: random.sample(half of the classes present) from Python's global RNG,
     one call per image, then 255 is force-added (warm_up.py:247-250)."""
@@ -248,9 +271,10 @@ def classmix_paste(background, foreground, labels, selections, bg_labels=None):
     return out if bg_labels is None else (out, lab_out)
 
 
-def classmix(background, foreground, labels, rng=random, bg_labels=None):
-    """The whole cross-domain mixture block.  Returns (mixed[, mixed_labels], selections)."""
-    sels = classmix_select(classmix_present(labels), rng)
+def classmix(background, foreground, labels, rng=random, bg_labels=None, present=None):
+    """The whole cross-domain mixture block.  Returns (mixed[, mixed_labels], selections).  present: the per-image class lists
+    when the caller already has them (DigaTrainer.prefetch_classmix), else one histogram launch + one D->H copy here."""
+    sels = classmix_select(classmix_present(labels) if present is None else present, rng)
     res = classmix_paste(background, foreground, labels, sels, bg_labels)
     return (res, sels) if bg_labels is None else (res[0], res[1], sels)
 

@@ -217,3 +217,29 @@ def test_graph_captured_step_equals_eager_step(which, conv_math):
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
         assert torch.equal(res[0][2][k], res[1][2][k]), "teacher " + k
+
+
+def test_prefetched_classmix_lists_give_the_same_steps():
+    """DigaTrainer.prefetch_classmix (class lists of the next batch fetched on a side stream while a step runs) must not change
+    anything: same histogram, same RNG draws -> identical losses and parameters, eager and graph-replayed."""
+    from diga_amd.train_step import DigaTrainer
+    res = []
+    for prefetch, graph in ((False, False), (True, False), (True, True)):
+        student, teacher = _model("TINY"), _model("TINY")
+        for mdl in (student, teacher):
+            mdl.final.head[0].p = 0.0
+        teacher.train()
+        tr = DigaTrainer(student, teacher, rng=random.Random(3), graph=graph)
+        batches = [[t.to(DEV) for t in synth.warmup_batch(950 + it, 2, 96, 128, block=16)] for it in range(4)]
+        torch.cuda.synchronize()
+        losses = []
+        for it in range(4):
+            out = tr.warmup_step(it, *batches[it])
+            if prefetch and it + 1 < 4:
+                tr.prefetch_classmix(batches[it + 1][3])
+            losses.append((float(out["ce"]), float(out["distil"])))
+        res.append((losses, {k: v.clone() for k, v in student.state_dict().items()}))
+    for other in res[1:]:
+        assert other[0] == res[0][0]
+        for k in res[0][1]:
+            assert torch.equal(other[1][k], res[0][1][k]), k
