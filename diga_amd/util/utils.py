@@ -166,7 +166,9 @@ def update_teacher_params(teacher, student, iteration, stage0=True, mean=False, 
                   float(1 - alpha), _lib.stream())
     else:
         _ema_multi(list(teacher.parameters()), list(student.parameters()), alpha)
-    return teacher.cuda()
+    # the reference returns teacher.cuda(); everything above already required device tensors, and Module.cuda() walks every
+    # module and buffer (~1 ms of host time per step on ResNet-101) only to find nothing to move
+    return teacher
 
 
 # --------------------------------------------------------------------------- normalisation helpers
@@ -360,7 +362,10 @@ class DigaSGD(torch.optim.Optimizer):
             grads.append(g)
         lrs = [float(self.param_groups[gi]["lr"]) for gi in self._group_of]
         if lrs != self._lr_host:
-            self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
+            # (the poly schedule changes the rates every step.)  Asynchronous copy from a fresh PINNED buffer: a blocking copy
+            # from pageable memory here drained the stream once per step -- the host could never run ahead of the GPU; the
+            # caching host allocator keeps the buffer alive until the copy has executed
+            self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32).pin_memory(), non_blocking=True)
             self._lr_host = lrs
         tab = self._tab
         pp = tab.pointers("p", [p.data for p in self._params])
