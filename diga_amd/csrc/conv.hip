@@ -1515,6 +1515,203 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_x3t8_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exact-fp32 forward / backward-data with LDS-DMA operands (round 3): the structure of conv_fwd_x3t8_kernel on the fp32
+// matrix cores.  256 x 128 x 32 block tile, 12 waves = 8 MFMA waves as 4 (M) x 2 (N), wave tile 64 x 64 = 2 x 2 tiles of
+// v_mfma_f32_32x32x2_f32 (64 accumulator registers), + 4 loader waves (one per SIMD) that only issue
+// global_load_lds_dwordx4: activations and weights go global -> LDS with no register staging, no ds_write and no VALU
+// on the way, into a three-stage ring (3 x 48 KB; counted vmcnt, one raw barrier per K-step).
+//
+// Why (conv_fwd_kernel, 128 x 128, register-staged, two LDS buffers, measured on the C2 shapes: matrix pipe 72 % busy):
+// a 128 x 128 x 32 fp32 step is 32 FLOP per operand byte, so at the fp32 MFMA peak the CUs pull 4.9 TB/s out of L2 --
+// every load passes through VGPRs and is written to LDS by the MFMA waves themselves, and a load has one K-step to
+// land.  Here a step is 42.7 FLOP/byte (3.7 TB/s at peak), loads have two K-steps (~16 k cycles) to land, and the MFMA
+// waves do nothing but ds_read_b128 + MFMA.
+//
+// LDS image: rows of 32 floats (128 B, one pixel / output channel x 32 k), unpadded (LDS-DMA writes 1 KB = 8 whole rows
+// per wave instruction); the eight 16-byte chunks of row r live at chunk ^ ((r >> 1) & 7) -- applied to the per-lane
+// SOURCE address -- so that the ds_read_b128 of a fragment (16 lanes = 16 consecutive rows, same logical chunk) covers
+// the 64 banks exactly once.  Fragment / MFMA order per accumulator is conv_fwd_kernel's (k-group t, element e): results
+// are bit-identical to it (skipped dead taps only ever added exact zeros).
+// ---------------------------------------------------------------------------------------------
+template <bool EPI = false>
+__global__ __launch_bounds__(768, 3) void conv_fwd_dma_kernel(ConvArgs a) {
+    constexpr int BM = 256, BN = 128;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool loader = wv >= 8;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int RS = a.R * a.S;
+    const int cchunks = a.Cin / 32;
+    const uint64_t live = RS <= 64 ? live_taps(a, m0, BM) : ~0ull;
+    const int ntaps = RS <= 64 ? __builtin_popcountll(live) : RS;
+    const int ksteps = ntaps * cchunks;
+
+    if (loader) {
+        const int lw = wv - 8;                                   // A rows lw*64 + 8 j + (lane >> 3), B rows lw*32 + 8 c + (lane >> 3)
+        const unsigned char* in_b = reinterpret_cast<const unsigned char*>(a.in);
+        const int lrow = lane >> 3;
+        int pixbase[8], yx0[8];
+        bool mok[8];
+        const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = m0 + lw * 64 + 8 * j + lrow;
+            mok[j] = m < a.M;
+            const int mm = mok[j] ? m : a.M - 1;
+            const int img = mm / HoWo, rem = mm - img * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            pixbase[j] = img * a.Hi * a.Wi;
+            yx0[j] = ((ho * a.sy + a.oy0) << 16) | ((wo * a.sx + a.ox0) & 0xffff);
+        }
+        const int64_t rowb = (int64_t)a.in_ld * 4;
+        const unsigned char* pa[8];
+        const unsigned char* pb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = lw * 32 + 8 * c + lrow, co = n0 + r;
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            pb[c] = co < a.Cout ? reinterpret_cast<const unsigned char*>(a.wgt) + (int64_t)co * RS * a.Cin * 4 + chunk * 16 : nullptr;
+        }
+        uint64_t todo = live;
+        int l_tap = 0, l_cc = 0;
+        auto next_tap = [&]() {
+            if (RS <= 64) {
+                l_tap = __builtin_ctzll(todo);
+                todo &= todo - 1;
+            } else {
+                ++l_tap;
+            }
+        };
+        auto set_tap = [&](int tap) {
+            const int r = tap / a.S, q = tap - r * a.S;
+            const int dy = r * a.ody, dx = q * a.odx;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int iy = (yx0[j] >> 16) + dy, ix = (int)(short)(yx0[j] & 0xffff) + dx;
+                int cy, cx;
+                const bool ok = map_tap(a, iy, ix, cy, cx) && mok[j];
+                const int chunk = (lane & 7) ^ (((8 * j + lrow) >> 1) & 7);
+                pa[j] = ok ? in_b + (int64_t)(pixbase[j] + cy * a.Wi + cx) * rowb + chunk * 16 : nullptr;
+            }
+        };
+        int issued = 0;
+        auto issue = [&](int buf) {
+            unsigned char* stage = smem_b + buf * STAGE;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned char* src = pa[j] != nullptr ? pa[j] + l_cc * 128 : g_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage + (lw * 64 + 8 * j) * 128), 16, 0, 0);
+            }
+            const int64_t boff = ((int64_t)l_tap * a.Cin + l_cc * 32) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned char* src = pb[c] != nullptr ? pb[c] + boff : g_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage + A_BYTES + (lw * 32 + 8 * c) * 128), 16, 0, 0);
+            }
+            ++issued;
+            if (++l_cc == cchunks) {
+                l_cc = 0;
+                if (issued < ksteps) {
+                    next_tap();
+                    set_tap(l_tap);
+                }
+            }
+        };
+        auto wait_next = [&](bool newest_in_flight) {            // 12 loads per stage and loader wave
+            if (newest_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        if (RS <= 64) next_tap();
+        set_tap(l_tap);
+        issue(0);
+        if (ksteps > 1) issue(1);
+        wait_next(ksteps > 1);
+        int nx = 2;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bool ahead = ks + 2 < ksteps;
+            if (ahead) issue(nx);                                // that stage was last read in step ks - 1 (barrier since)
+            wait_next(ahead);
+            nx = nx == 2 ? 0 : nx + 1;
+        }
+        return;                                                  // the epilogue's barriers count the surviving waves
+    }
+
+    const int wm = wv >> 1, wn = wv & 1;                         // 4 x 2 MFMA waves
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    const int fsw = (li >> 1) & 7;
+    int foff[4];                                                 // byte offset of k-group t inside row li
+#pragma unroll
+    for (int t = 0; t < 4; ++t) foff[t] = li * 128 + (((2 * t + lh) ^ fsw) << 4);
+    const int abase = wm * 64 * 128, bbase = A_BYTES + wn * 64 * 128;
+
+    __builtin_amdgcn_s_barrier();                                // stage 0 has landed
+    int cur = 0;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const unsigned char* As = smem_b + cur * STAGE + abase;
+        const unsigned char* Bs = smem_b + cur * STAGE + bbase;
+        float4 fa[2][2], fb[2][2];                               // [parity of t][tile]
+        fa[0][0] = *reinterpret_cast<const float4*>(As + foff[0]);
+        fa[0][1] = *reinterpret_cast<const float4*>(As + foff[0] + 32 * 128);
+        fb[0][0] = *reinterpret_cast<const float4*>(Bs + foff[0]);
+        fb[0][1] = *reinterpret_cast<const float4*>(Bs + foff[0] + 32 * 128);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p = t & 1;
+            if (t + 1 < 4) {
+                fa[p ^ 1][0] = *reinterpret_cast<const float4*>(As + foff[t + 1]);
+                fa[p ^ 1][1] = *reinterpret_cast<const float4*>(As + foff[t + 1] + 32 * 128);
+                fb[p ^ 1][0] = *reinterpret_cast<const float4*>(Bs + foff[t + 1]);
+                fb[p ^ 1][1] = *reinterpret_cast<const float4*>(Bs + foff[t + 1] + 32 * 128);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float av = e == 0 ? fa[p][i].x : e == 1 ? fa[p][i].y : e == 2 ? fa[p][i].z : fa[p][i].w;
+                        const float bv = e == 0 ? fb[p][j].x : e == 1 ? fb[p][j].y : e == 2 ? fb[p][j].z : fb[p][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this step's fragment reads are done before the stage is released
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();                                             // (8 surviving waves) everyone is out of the ring
+
+    // epilogue: thread group h = wv >> 2 (rows 128h .. 128h+127) stages and drains its half
+    constexpr int LDS_LD = BN + 4;
+    const int h = wv >> 2, t = threadIdx.x & 255;
+    float* stage = reinterpret_cast<float*>(smem_b) + h * (128 * LDS_LD);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[((wm & 1) * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDS_LD + wn * 64 + j * 32 + li] = acc[i][j][e];
+    __syncthreads();
+    drain_stage<2, 2, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h, m0 + h * 128 < a.M);
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward-weight
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -2400,7 +2597,25 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
         if (epi != nullptr && BK_ == 32) DIGA_LAUNCH_K((conv_fwd_kernel<TN_, 32, true>), 256, sh);                      \
         else DIGA_LAUNCH_K((conv_fwd_kernel<TN_, BK_, false>), 256, sh);                                                \
     } while (0)
-    if (Cout > 64) {
+    static const int dma_env = [] { const char* e = getenv("DIGA_CONV_F32_DMA"); return e ? atoi(e) : 1; }();
+    // 256 x 128 tiles, LDS-DMA operands (conv_fwd_dma_kernel): one block per CU, so nothing overlaps a tile's epilogue --
+    // measured on the C2 shapes (tools/bench_conv.py, same box) it wins 5-12 % (22 % with dead taps) from K >= 256 into
+    // >= 256 channels and loses 5-10 % on the 128-channel / K = 64 layers, which stay on the 128 x 128 kernel at two
+    // blocks per CU.  DIGA_CONV_F32_DMA=0 / 2: never / wherever it can run.
+    const bool dma_ok = Cout > 64 && bk == 32 && a.M >= 256;
+    if (dma_ok && (dma_env == 2 || (dma_env == 1 && Cout >= 256 && R * S * Cin >= 256))) {
+        // (the BatchNorm partials keep their 128-row chunks)
+        a.tiles_n = (int)ceil_div(Cout, 128);
+        const unsigned grid = (unsigned)(ceil_div(a.M, 256) * a.tiles_n);
+        const size_t sh = 3 * (256 + 128) * 128;
+        if (epi != nullptr) {
+            (void)hipFuncSetAttribute((const void*)conv_fwd_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL(conv_fwd_dma_kernel<true>, dim3(grid), dim3(768), sh, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)conv_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL(conv_fwd_dma_kernel<false>, dim3(grid), dim3(768), sh, st, a);
+        }
+    } else if (Cout > 64) {
         a.tiles_n = (int)ceil_div(Cout, 128);
         if (bk == 16) DIGA_FWD_LAUNCH(2, 16);
         else DIGA_FWD_LAUNCH(2, 32);

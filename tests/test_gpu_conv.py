@@ -2,6 +2,7 @@
 against torch's CPU conv2d in float64 on the same seeded inputs, for every layer geometry the
 DeepLabV2/ResNet-101 model uses (1x1, strided 1x1, dilated 3x3, biased ASPP branches, the 7x7 stem,
 the 19-class head) including ragged sizes that exercise tile edges."""
+import os
 import zlib
 
 import pytest
@@ -10,6 +11,8 @@ import torch.nn.functional as F
 
 from conftest import assert_close
 from oracle import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -279,3 +282,42 @@ def test_wgrad_on_twins_vs_float64(geom, bf16x3):
                   cout, k, k, 1, 1, -pad, -pad, dil, dil, _lib.stream())
     scale = float(want.abs().max())
     assert_close(dw.cpu(), want, rtol=0.0, atol=5e-5 * scale, what="dw from twins")
+
+
+_DMA_EQ_CODE = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+from diga_amd import _lib
+from diga_amd.model.conv import DigaConv2d
+_lib.set_conv_math(0)
+torch.manual_seed(11)                                   # (default initialisers of weight / bias)
+g = torch.Generator().manual_seed(4321)
+# name, N, Cin, H, W, Cout, k, stride, pad, dil
+cases = [("aspp_d24", 1, 256, 97, 97, 256, 3, 1, 24, 24), ("pw_tail", 2, 64, 37, 41, 192, 1, 1, 0, 1),
+         ("stride2", 2, 128, 65, 65, 128, 1, 2, 0, 1), ("d2_3x3", 3, 96, 33, 29, 160, 3, 1, 2, 2), ("d12", 1, 288, 97, 97, 256, 3, 1, 12, 12)]
+for name, n, cin, h, w, cout, k, s, p, d in cases:
+    x = torch.randn((n, cin, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    m = DigaConv2d(cin, cout, k, stride=s, padding=p, dilation=d, bias=(name == "d12")).cuda()
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(m.weight.shape, generator=g).cuda() * 0.05)
+    y = m(x)
+    probe = torch.randn(y.shape, generator=g).cuda()
+    (y * probe).sum().backward()
+    for what, v in (("y", y), ("dx", x.grad)):
+        print(name, what, hashlib.sha256(v.detach().contiguous().cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_f32_dma_kernel_bit_identical_to_register_staged_kernel():
+    """conv_fwd_dma_kernel (256 x 128 tiles, LDS-DMA operands, dead taps skipped) walks K in conv_fwd_kernel's order with the
+    same MFMA per (k-group, element): forward outputs and input gradients are equal bit for bit -- on a dilation-24
+    97 x 97 map, an M / Cout tail, a strided 1x1, and a dilated 3x3 (two processes: the switch is read once)."""
+    import subprocess
+    import sys
+    outs = []
+    for dma in ("0", "2"):
+        env = dict(os.environ, DIGA_CONV_F32_DMA=dma)
+        r = subprocess.run([sys.executable, "-c", _DMA_EQ_CODE, ROOT], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.count(" ") == 2])
+    assert len(outs[0]) == 10 and outs[0] == outs[1], (outs[0], outs[1])
