@@ -2465,6 +2465,160 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_x3t_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact-fp32 backward-weight with LDS-DMA operands (round 3): the structure of conv_fwd_dma_kernel / conv_wgrad_x3t_kernel.
+// 256 (Cout) x 128 (Cin) tile per (tap, pixel range); 8 MFMA waves as 4 x 2 (wave tile 64 x 64 = 2 x 2 tiles of
+// v_mfma_f32_32x32x2_f32) + 4 loader waves; K-step = 32 pixels; three-stage ring of 48 KB stages.  Both operands are
+// pixel-major in memory and stay so in LDS ([pixel][channel], 1 KB / 512 B rows written whole by the LDS-DMA loads):
+// an MFMA operand (one k = pixel per lane half, 32 consecutive channels over the lanes) is a ds_read_b32 with an
+// immediate offset per k-pair.  Rows of odd pixels are stored with their 128-byte halves swapped pairwise (byte ^ 128,
+// applied to the source address), so that the lanes of the two halves (pixels kk, kk + 1) hit the two halves of the bank row.
+// Needs Cout % 256 == 0 and Cin % 128 == 0 (every layer of layer3 / layer4 / the ASPP head); the rest stays on
+// conv_wgrad_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768, 3) void conv_wgrad_dma_kernel(WgradArgs a) {
+    constexpr int BM = 256, BN = 128;
+    constexpr int A_ROW = BM * 4, B_ROW = BN * 4;
+    constexpr int A_BYTES = kBK * A_ROW, B_BYTES = kBK * B_ROW, STAGE = A_BYTES + B_BYTES;      // 48 KB
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool loader = wv >= 8;
+    const int RS = a.R * a.S;
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % a.tiles_n;
+    wg /= a.tiles_n;
+    const int tile_m = wg % a.tiles_m;
+    wg /= a.tiles_m;
+    const int tap = wg % RS;
+    const int split = wg / RS;
+    const int k0 = tile_m * BM, c0 = tile_n * BN;
+    const int p_begin = split * a.steps_per_split * kBK;
+    int p_end = p_begin + a.steps_per_split * kBK;
+    if (p_end > a.M) p_end = a.M;
+    const int ksteps = p_end > p_begin ? (p_end - p_begin + kBK - 1) / kBK : 0;
+
+    if (loader) {
+        const int lw = wv - 8;
+        const unsigned char* dyb = reinterpret_cast<const unsigned char*>(a.dy) + (int64_t)k0 * 4;
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + (int64_t)c0 * 4;
+        const int64_t dy_rowb = (int64_t)a.dy_ld * 4, x_rowb = (int64_t)a.x_ld * 4;
+        const int* tab = a.ptab != nullptr ? a.ptab + (int64_t)tap * a.M_pad : nullptr;
+        // A (dy): 32 pixel rows x 1 KB = 32 instructions, 8 per wave: row 8 lw + j, destination chunk `lane`.
+        // B (x):  32 pixel rows x 512 B = 16 instructions, 4 per wave: rows 8 lw + 2 j + (lane >> 5), chunk lane & 31.
+        const int b_half = lane >> 5;
+        const int b_src = (((lane & 31) ^ (b_half << 3)) << 4);
+        int bidx[4];
+        auto load_idx = [&](int ks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p_begin + ks * kBK + 8 * lw + 2 * j + b_half;
+                bidx[j] = p < p_end ? (tab != nullptr ? tab[p] : p) : -1;
+            }
+        };
+        auto issue = [&](int ks, int stg) {
+            unsigned char* stage = smem_b + stg * STAGE;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = 8 * lw + j;
+                const int p = min(p_begin + ks * kBK + row, a.M - 1);     // rows past p_end meet zero x rows
+                const unsigned char* src = dyb + p * dy_rowb + ((lane ^ ((j & 1) << 3)) << 4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage + row * A_ROW), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned char* src = bidx[j] >= 0 ? xb + bidx[j] * x_rowb + b_src : g_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage + A_BYTES + (8 * lw + 2 * j) * B_ROW), 16, 0, 0);
+            }
+        };
+        auto wait_next = [&](bool newest_in_flight) {      // 12 LDS-DMA loads per stage and wave
+            if (newest_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        if (ksteps > 0) {
+            load_idx(0);
+            issue(0, 0);
+            if (ksteps > 1) {
+                load_idx(1);
+                issue(1, 1);
+            }
+        }
+        wait_next(ksteps > 1);
+        int nx = 2;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bool ahead = ks + 2 < ksteps;
+            if (ahead) {
+                load_idx(ks + 2);
+                issue(ks + 2, nx);
+            }
+            wait_next(ahead);
+            nx = nx == 2 ? 0 : nx + 1;
+        }
+        return;
+    }
+
+    const int wm = wv >> 1, wn = wv & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    int offa[2], offb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offa[i] = lh * A_ROW + (((wm * 64 + i * 32 + li) * 4) ^ (lh << 7));
+        offb[i] = A_BYTES + lh * B_ROW + (((wn * 64 + i * 32 + li) * 4) ^ (lh << 7));
+    }
+
+    __builtin_amdgcn_s_barrier();                          // stage 0 has landed
+    int cur = 0;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const unsigned char* St = smem_b + cur * STAGE;
+        float av[2][2], bv[2][2];
+        auto frag = [&](int kk, int set) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[set][i] = *reinterpret_cast<const float*>(St + offa[i] + kk * A_ROW);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[set][j] = *reinterpret_cast<const float*>(St + offb[j] + kk * B_ROW);
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < kBK; kk += 2) {
+            const int set = (kk >> 1) & 1;
+            if (kk + 2 < kBK) frag(kk + 2, set ^ 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][i], bv[set][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+
+    float* out = a.slab + (int64_t)split * a.Cout * RS * a.Cin;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = c0 + wn * 64 + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                out[((int64_t)k * RS + tap) * a.Cin + c] = acc[i][j][e];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                           int64_t n4, int splits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -2913,6 +3067,36 @@ WgradPlan plan_wgrad(int64_t M, int64_t Cout, int64_t Cin, int64_t RS, bool x3) 
     p.splits = (int)ceil_div(ksteps, p.steps_per_split);
     return p;
 }
+// 256 x 128 tiles at one block per CU (conv_wgrad_dma_kernel, conv_wgrad_x3t_kernel): the split count whose grid fills
+// whole rounds of 256 blocks best (>= 16 K-steps per block)
+WgradPlan plan_wgrad_wide(int64_t M, int64_t Cout, int64_t Cin, int64_t RS) {
+    WgradPlan p;
+    p.tm = 4;
+    p.tn = 2;
+    p.tiles_m = (int)ceil_div(Cout, 256);
+    p.tiles_n = (int)ceil_div(Cin, 128);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * RS, ksteps = ceil_div(M, kBK);
+    int64_t best = 1;
+    double best_eff = 0.0;
+    for (int64_t rounds = 1; rounds <= 4; ++rounds) {
+        int64_t sp = 256 * rounds / tiles;
+        if (sp < 1) sp = 1;
+        if (ksteps / sp < 16) continue;
+        const int64_t blocks = tiles * sp;
+        const double eff = (double)blocks / (256.0 * (double)ceil_div(blocks, 256));
+        if (eff > best_eff + 0.02) {
+            best_eff = eff;
+            best = sp;
+        }
+    }
+    p.steps_per_split = (int)ceil_div(ksteps, best);
+    p.splits = (int)ceil_div(ksteps, p.steps_per_split);
+    return p;
+}
+bool wgrad_dma_ok(int64_t M, int64_t Cout, int64_t Cin) {
+    static const int env = [] { const char* e = getenv("DIGA_CONV_F32_DMA"); return e ? atoi(e) : 1; }();
+    return env != 0 && Cout % 256 == 0 && Cin % 128 == 0 && M >= 1024;
+}
 int64_t wgrad_mpad(int64_t M) { return ceil_div(M, kBK) * kBK + 2 * kBK; }
 size_t wgrad_slab_bytes(const WgradPlan& p, int64_t Cout, int64_t Cin, int64_t RS) {
     return p.splits > 1 ? (size_t)p.splits * Cout * RS * Cin * sizeof(float) : 0;
@@ -2925,7 +3109,8 @@ extern "C" size_t diga_conv2d_wgrad_workspace_bytes(int64_t N, int64_t Ho, int64
                                                     int64_t R, int64_t S) {
     const int64_t M = N * Ho * Wo, RS = R * S;
     const size_t s0 = wgrad_slab_bytes(plan_wgrad(M, Cout, Cin, RS, false), Cout, Cin, RS);
-    const size_t s1 = wgrad_slab_bytes(plan_wgrad(M, Cout, Cin, RS, true), Cout, Cin, RS);
+    size_t s1 = wgrad_slab_bytes(plan_wgrad(M, Cout, Cin, RS, true), Cout, Cin, RS);
+    if (wgrad_dma_ok(M, Cout, Cin)) s1 = std::max(s1, wgrad_slab_bytes(plan_wgrad_wide(M, Cout, Cin, RS), Cout, Cin, RS));
     return (s0 > s1 ? s0 : s1) + (size_t)RS * wgrad_mpad(M) * sizeof(int) + 64;
 }
 
@@ -2944,8 +3129,9 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
     const int64_t RS = R * S, M = N * Ho * Wo;
     DIGA_REQUIRE(math == DIGA_CONV_MATH_F32 || math == DIGA_CONV_MATH_BF16X3, DIGA_EINVAL, "conv2d_wgrad: math must be DIGA_CONV_MATH_F32 or _BF16X3");
     const bool x3 = math == DIGA_CONV_MATH_BF16X3;
-    const WgradPlan p = plan_wgrad(M, Cout, Cin, RS, x3);
-    const bool wide = p.tm == 4;
+    const bool dma = !x3 && wgrad_dma_ok(M, Cout, Cin);
+    const WgradPlan p = dma ? plan_wgrad_wide(M, Cout, Cin, RS) : plan_wgrad(M, Cout, Cin, RS, x3);
+    const bool wide = p.tm == 4 && !dma;
     const size_t slab_bytes = wgrad_slab_bytes(p, Cout, Cin, RS);
     const int64_t M_pad = wgrad_mpad(M);
     const bool identity = RS == 1 && stride_y == 1 && stride_x == 1 && off_y0 == 0 && off_x0 == 0 && Hi == Ho && Wi == Wo;
@@ -2990,6 +3176,11 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
                            (int)off_y0, (int)off_x0, (int)off_dy, (int)off_dx);
         a.ptab = tab;
     }
+    if (dma) {
+        const size_t shd = (size_t)3 * kBK * (256 + 128) * 4;
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shd);
+        hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(grid), dim3(768), shd, st, a);
+    } else {
     const size_t sh = (size_t)(4 * kBK * kLDW) * sizeof(float);
 #define DIGA_WGRAD_LAUNCH(TM_, TN_)                                                                                   \
     do {                                                                                                               \
@@ -3016,6 +3207,7 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
 #undef DIGA_WGRAD_X3_LAUNCH
 #undef DIGA_WGRAD_LAUNCH
     }
+    }
     if (p.splits > 1) {
         const int64_t n4 = Cout * RS * Cin / 4;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
@@ -3026,31 +3218,7 @@ extern "C" int diga_conv2d_wgrad_nhwc_f32(const float* dy, const float* x, float
 
 // ---- backward-weight on the split twins (conv_wgrad_x3t_kernel)
 namespace {
-WgradPlan plan_wgrad_twin(int64_t M, int64_t Cout, int64_t Cin, int64_t RS) {
-    WgradPlan p;
-    p.tm = 4;
-    p.tn = 2;
-    p.tiles_m = (int)ceil_div(Cout, 256);
-    p.tiles_n = (int)ceil_div(Cin, 128);
-    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * RS, ksteps = ceil_div(M, kBK);
-    // one block per CU: pick the split count whose grid fills whole rounds of 256 blocks best (>= 16 K-steps per block)
-    int64_t best = 1;
-    double best_eff = 0.0;
-    for (int64_t rounds = 1; rounds <= 4; ++rounds) {
-        int64_t sp = 256 * rounds / tiles;
-        if (sp < 1) sp = 1;
-        if (ksteps / sp < 16) continue;
-        const int64_t blocks = tiles * sp;
-        const double eff = (double)blocks / (256.0 * (double)ceil_div(blocks, 256));
-        if (eff > best_eff + 0.02) {
-            best_eff = eff;
-            best = sp;
-        }
-    }
-    p.steps_per_split = (int)ceil_div(ksteps, best);
-    p.splits = (int)ceil_div(ksteps, p.steps_per_split);
-    return p;
-}
+WgradPlan plan_wgrad_twin(int64_t M, int64_t Cout, int64_t Cin, int64_t RS) { return plan_wgrad_wide(M, Cout, Cin, RS); }
 }  // namespace
 
 extern "C" size_t diga_conv2d_wgrad_twin_workspace_bytes(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout, int64_t Cin,
