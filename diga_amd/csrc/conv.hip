@@ -75,6 +75,9 @@ struct ConvArgs {
     int pad_reflect;             // out-of-image taps read the mirrored pixel (nn.ReflectionPad2d in front of the conv)
     int up_shift;                // the conv reads the 2^up_shift nearest-neighbour upsampling of `in` (nn.Upsample in front)
     int act;                     // 1: tanh on the output
+    // batched GEMM on conv_fwd_dma_kernel (winograd.hip): 256-row tile tm multiplies weight panel tm / wb_tiles
+    int wb_tiles = 0;            // 0: one weight array for every tile
+    int64_t wb_stride = 0;       // floats between weight panels
 };
 
 // Logical input coordinate (in the optionally upsampled image, before padding) -> source pixel of `in`.
@@ -1573,7 +1576,8 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_dma_kernel(ConvArgs a) {
         for (int c = 0; c < 4; ++c) {
             const int r = lw * 32 + 8 * c + lrow, co = n0 + r;
             const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-            pb[c] = co < a.Cout ? reinterpret_cast<const unsigned char*>(a.wgt) + (int64_t)co * RS * a.Cin * 4 + chunk * 16 : nullptr;
+            const float* wbase = a.wb_tiles > 0 ? a.wgt + (int64_t)(tile_m / a.wb_tiles) * a.wb_stride : a.wgt;
+            pb[c] = co < a.Cout ? reinterpret_cast<const unsigned char*>(wbase) + (int64_t)co * RS * a.Cin * 4 + chunk * 16 : nullptr;
         }
         uint64_t todo = live;
         int l_tap = 0, l_cc = 0;
@@ -2703,6 +2707,34 @@ static int set_bwd_epilogue(ConvArgs& a, const diga_bwd_epilogue_t* e, const cha
     a.e_maskbits = e->mask_bits; a.e_maskbits_ld = (int)e->mask_bits_ld;
     a.e_x = e->x; a.e_x_ld = (int)e->x_ld;
     a.e_relu_ab = e->relu_ab; a.e_mean = e->mean; a.e_invstd = e->invstd; a.e_partials = e->partials;
+    return DIGA_OK;
+}
+
+// `batches` independent products out_b [rows x Cout] = A_b [rows x K] * W_b^T (W_b [Cout][K]) in one launch of
+// conv_fwd_dma_kernel: the operands of all batches are stacked row-wise (A [batches * rows][K], out likewise,
+// W [batches][Cout][K]); rows % 256 == 0 so that no 256-row tile straddles two batches.  Used by winograd.hip.
+int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, int64_t K, const float* W, int64_t Cout,
+                         float* out, hipStream_t st) {
+    DIGA_REQUIRE(rows_per_batch > 0 && rows_per_batch % 256 == 0 && K % 32 == 0 && Cout > 0 && Cout % 4 == 0, DIGA_EINVAL,
+                 "gemm_batched_f32_dma: rows %% 256, K %% 32, Cout %% 4 required");
+    const int64_t M = rows_per_batch * batches;
+    DIGA_REQUIRE(M / 256 < 32768 && M < (1ll << 31), DIGA_EINVAL, "gemm_batched_f32_dma: too many rows");
+    ConvArgs a;
+    a.in = A; a.wgt = W; a.wgt_hi = nullptr; a.wgt_lo = nullptr; a.wgt_img = nullptr; a.bias = nullptr; a.out = out; a.stats = nullptr;
+    a.N = 1; a.Hi = (int)(M / 256); a.Wi = 256; a.Cin = (int)K; a.in_ld = (int)K;
+    a.Ho = a.Hi; a.Wo = 256; a.Cout = (int)Cout; a.out_ld = (int)Cout;
+    a.R = 1; a.S = 1; a.sy = 1; a.sx = 1; a.oy0 = 0; a.ox0 = 0; a.ody = 1; a.odx = 1;
+    a.M = (int)M; a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(Cout, 128); a.all_inside = 1;
+    a.pad_reflect = 0; a.up_shift = 0; a.act = 0;
+    a.e_add = a.e_masky = a.e_x = a.e_relu_ab = a.e_mean = a.e_invstd = nullptr;
+    a.e_partials = nullptr; a.e_maskbits = nullptr;
+    a.e_add_ld = a.e_masky_ld = a.e_x_ld = a.e_maskbits_ld = 0;
+    a.wb_tiles = (int)(rows_per_batch / 256);
+    a.wb_stride = Cout * K;
+    const unsigned grid = (unsigned)((M / 256) * a.tiles_n);
+    const size_t sh = 3 * (256 + 128) * 128;
+    (void)hipFuncSetAttribute((const void*)conv_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(conv_fwd_dma_kernel<false>, dim3(grid), dim3(768), sh, st, a);
     return DIGA_OK;
 }
 

@@ -1,0 +1,264 @@
+// Winograd F(2x2, 3x3) in fp32 for the stride-1 "same" 3x3 convolutions of the trunk and the ASPP head (dilation d,
+// padding d): layer3/layer4 conv2 (d = 2, 4), the ASPP branches (d = 6, 12, 18) and the ASPP bottleneck (d = 1) -- 64 %
+// of the model's convolution FLOPs.  Reference: the nn.Conv2d(3x3) layers of G5/model/seg_model_noaux.py:66-70,
+// 143-150,166-170, which the reference runs through cuDNN (whose fp32 algorithm choice for these shapes is Winograd too).
+//
+// A dilated 3x3 convolution with padding = dilation is d*d independent dense 3x3 convolutions on the sub-images
+// {(a + d*i, b + d*j)} (phase (a, b)).  Each sub-image is cut into 2x2 output tiles; per tile and input channel the 4x4
+// input patch becomes V = B^T d B (wino_input_kernel), per (output, input) channel the 3x3 filter becomes U = G g G^T
+// (wino_weight_kernel), the 16 element-wise products summed over the input channels are 16 independent GEMMs
+//   M_k [tiles x Cout] = V_k [tiles x Cin] * U_k^T [Cin x Cout]         (16 multiplications per 2x2 outputs instead of 36)
+// run as ONE launch of conv_fwd_dma_kernel (exact-fp32 MFMA, LDS-DMA operands; the weight panel is picked per 256-row
+// tile), and y = A^T M A (+ bias) (wino_output_kernel).  B, G, A hold 0, +-1, +-1/2 only: the result differs from the
+// direct convolution by rounding alone (Lavin & Gray 2016 measure F(2x2,3x3) fp32 error BELOW direct convolution's);
+// tests hold both against a float64 convolution with the same bound.
+//
+// Workspace: [tile table int4 x Tp][U 16 x Cout x Cin][V 16 x Tp x Cin][M 16 x Tp x Cout], Tp = tiles rounded up to
+// 256 (rows of padding tiles are zero).  HBM traffic on top of the GEMM: V is written and read once (4x the input
+// tensor), M likewise (4x the output) -- both transforms are plain bandwidth passes.
+#include "common.h"
+
+namespace diga {
+
+int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, int64_t K, const float* W, int64_t Cout,
+                         float* out, hipStream_t st);     // conv.hip
+
+namespace {
+
+struct WinoGeom {
+    int N, H, W, d;
+    int tys, txs;          // tile rows / columns summed over the d phases
+    int64_t T, Tp;
+};
+
+int phase_tiles(int len, int d) {
+    int s = 0;
+    for (int a = 0; a < d; ++a) {
+        const int n = len > a ? (len - a + d - 1) / d : 0;
+        s += (n + 1) / 2;
+    }
+    return s;
+}
+
+WinoGeom make_wino(int64_t N, int64_t H, int64_t W, int64_t d) {
+    WinoGeom g;
+    g.N = (int)N; g.H = (int)H; g.W = (int)W; g.d = (int)d;
+    g.tys = phase_tiles((int)H, (int)d);
+    g.txs = phase_tiles((int)W, (int)d);
+    g.T = N * g.tys * g.txs;
+    g.Tp = ceil_div(g.T, 256) * 256;
+    return g;
+}
+
+// tab[t] = {image, oy, ox, 0}: top-left OUTPUT pixel of tile t (its 2x2 outputs are (oy + d i, ox + d j), its 4x4 input
+// patch (oy + d (i - 1), ox + d (j - 1))); image = -1 for the padding tiles
+__global__ __launch_bounds__(256) void wino_tiles_kernel(int4* __restrict__ tab, WinoGeom g) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Tp) return;
+    if (t >= g.T) {
+        tab[t] = make_int4(-1, 0, 0, 0);
+        return;
+    }
+    const int timg = g.tys * g.txs;
+    const int n = (int)(t / timg), r = (int)(t - (int64_t)n * timg);
+    int R = r / g.txs, Cc = r - R * g.txs;
+    int a = 0, b = 0;
+    for (; a < g.d; ++a) {
+        const int cnt = g.H > a ? (g.H - a + g.d - 1) / g.d : 0;
+        const int tl = (cnt + 1) / 2;
+        if (R < tl) break;
+        R -= tl;
+    }
+    for (; b < g.d; ++b) {
+        const int cnt = g.W > b ? (g.W - b + g.d - 1) / g.d : 0;
+        const int tl = (cnt + 1) / 2;
+        if (Cc < tl) break;
+        Cc -= tl;
+    }
+    tab[t] = make_int4(n, a + 2 * R * g.d, b + 2 * Cc * g.d, 0);
+}
+
+using f32x4nt = __attribute__((ext_vector_type(4))) float;
+// V and M are written once and read once by another kernel, hundreds of MB to GB each: keep them out of L2
+__device__ __forceinline__ void nt_store4(float* p, float4 v) {
+    __builtin_nontemporal_store((f32x4nt){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4nt*>(p));
+}
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+    const f32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4half(float4 a) { return make_float4(0.5f * a.x, 0.5f * a.y, 0.5f * a.z, 0.5f * a.w); }
+
+// U[k = 4 i + j][co][c] = (G g G^T)[i][j], g = w[co][.][.][c] (flip: g[r][s] = w[co][2 - r][2 - s][c], backward-data)
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
+                                                          int flip) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = Cin / 4;
+    if (idx >= (int64_t)Cout * c4n) return;
+    const int co = (int)(idx / c4n), c = (int)(idx - (int64_t)co * c4n) * 4;
+    float4 g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
+            g[r][s] = *reinterpret_cast<const float4*>(w + ((int64_t)co * 9 + rr * 3 + ss) * Cin + c);
+        }
+    float4 t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const float4 sum = f4add(g[0][s], g[2][s]);
+        t[0][s] = g[0][s];
+        t[1][s] = f4half(f4add(sum, g[1][s]));
+        t[2][s] = f4half(f4sub(sum, g[1][s]));
+        t[3][s] = g[2][s];
+    }
+    const int64_t plane = (int64_t)Cout * Cin;
+    float* o = U + (int64_t)co * Cin + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 sum = f4add(t[i][0], t[i][2]);
+        *reinterpret_cast<float4*>(o + (4 * i + 0) * plane) = t[i][0];
+        *reinterpret_cast<float4*>(o + (4 * i + 1) * plane) = f4half(f4add(sum, t[i][1]));
+        *reinterpret_cast<float4*>(o + (4 * i + 2) * plane) = f4half(f4sub(sum, t[i][1]));
+        *reinterpret_cast<float4*>(o + (4 * i + 3) * plane) = t[i][2];
+    }
+}
+
+// V[k][t][c] = (B^T d B)[i][j] of the 4x4 patch of tile t, channel c (zero outside the image / for padding tiles)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
+                                                         float* __restrict__ V, int64_t Tp, int C, int H, int W, int d) {
+    const int c4n = C / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Tp * c4n) return;
+    const int64_t t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * 4;
+    const int4 e = tab[t];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 p[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = e.y + (i - 1) * d;
+        const bool yok = e.x >= 0 && (unsigned)y < (unsigned)H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = e.z + (j - 1) * d;
+            const bool ok = yok && (unsigned)xx < (unsigned)W;
+            p[i][j] = ok ? *reinterpret_cast<const float4*>(x + ((int64_t)(e.x * H + y) * W + xx) * ld + c) : z;
+        }
+    }
+    float4 m[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m[0][j] = f4sub(p[0][j], p[2][j]);
+        m[1][j] = f4add(p[1][j], p[2][j]);
+        m[2][j] = f4sub(p[2][j], p[1][j]);
+        m[3][j] = f4sub(p[1][j], p[3][j]);
+    }
+    float* o = V + t * C + c;
+    const int64_t plane = Tp * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        nt_store4(o + (4 * i + 0) * plane, f4sub(m[i][0], m[i][2]));
+        nt_store4(o + (4 * i + 1) * plane, f4add(m[i][1], m[i][2]));
+        nt_store4(o + (4 * i + 2) * plane, f4sub(m[i][2], m[i][1]));
+        nt_store4(o + (4 * i + 3) * plane, f4sub(m[i][1], m[i][3]));
+    }
+}
+
+// y[2x2 of tile t][co] = A^T M A + bias
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int64_t ld,
+                                                          int64_t T, int64_t Tp, int K, int H, int W, int d) {
+    const int k4n = K / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * k4n) return;
+    const int64_t t = idx / k4n;
+    const int k = (int)(idx - t * k4n) * 4;
+    const int4 e = tab[t];
+    const int64_t plane = Tp * K;
+    const float* src = Mb + t * K + k;
+    float4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = nt_load4(src + (4 * i + j) * plane);
+    float4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = f4add(f4add(m[0][j], m[1][j]), m[2][j]);
+        s[1][j] = f4sub(f4sub(m[1][j], m[2][j]), m[3][j]);
+    }
+    const float4 b = bias != nullptr ? *reinterpret_cast<const float4*>(bias + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int yy = e.y + i * d;
+        if (yy >= H) continue;
+        const float4 o0 = f4add(f4add(f4add(s[i][0], s[i][1]), s[i][2]), b);
+        const float4 o1 = f4add(f4sub(f4sub(s[i][1], s[i][2]), s[i][3]), b);
+        float* row = y + ((int64_t)(e.x * H + yy) * W) * ld + k;
+        *reinterpret_cast<float4*>(row + (int64_t)e.z * ld) = o0;
+        if (e.z + d < W) *reinterpret_cast<float4*>(row + (int64_t)(e.z + d) * ld) = o1;
+    }
+}
+
+struct WinoLayout {
+    size_t tab, U, V, M, total;
+};
+WinoLayout wino_layout(const WinoGeom& g, int64_t Cin, int64_t Cout) {
+    WinoLayout l;
+    size_t o = 0;
+    l.tab = o; o += (size_t)g.Tp * sizeof(int4);
+    l.U = o; o += (size_t)16 * Cout * Cin * sizeof(float);
+    l.V = o; o += (size_t)16 * g.Tp * Cin * sizeof(float);
+    l.M = o; o += (size_t)16 * g.Tp * Cout * sizeof(float);
+    l.total = o + 64;
+    return l;
+}
+
+}  // namespace
+}  // namespace diga
+
+using namespace diga;
+
+extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0) return 0;
+    return wino_layout(make_wino(N, H, W, dilation), Cin, Cout).total;
+}
+
+extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
+                                        size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
+                                        int64_t Cout, int64_t out_ld, int64_t dilation, int flip, int prof_tag, void* stream) {
+    DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
+    DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
+    DIGA_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 && in_ld >= Cin && in_ld % 4 == 0 && out_ld >= Cout && out_ld % 4 == 0,
+                 DIGA_EINVAL, "conv2d_winograd: Cin %% 32, Cout %% 4 (> 64) and leading dimensions %% 4 required");
+    DIGA_REQUIRE(aligned16(in) && aligned16(wgt) && aligned16(out) && aligned16(workspace) && (!bias || aligned16(bias)), DIGA_EALIGN,
+                 "conv2d_winograd: pointers must be 16-byte aligned");
+    DIGA_REQUIRE(N * H * W < (1ll << 31), DIGA_EINVAL, "conv2d_winograd: too many pixels");
+    const WinoGeom g = make_wino(N, H, W, dilation);
+    DIGA_REQUIRE(16 * g.Tp / 256 < 32768, DIGA_EINVAL, "conv2d_winograd: too many tiles for one launch");
+    const WinoLayout l = wino_layout(g, Cin, Cout);
+    DIGA_REQUIRE(workspace_bytes >= l.total, DIGA_EWORKSPACE, "conv2d_winograd: workspace too small (%zu < %zu)", workspace_bytes, l.total);
+    char* ws = static_cast<char*>(workspace);
+    int4* tab = reinterpret_cast<int4*>(ws + l.tab);
+    float* U = reinterpret_cast<float*>(ws + l.U);
+    float* V = reinterpret_cast<float*>(ws + l.V);
+    float* Mb = reinterpret_cast<float*>(ws + l.M);
+    hipStream_t st = (hipStream_t)stream;
+    // priced as the direct convolution it replaces (the algorithmic FLOPs of the layer)
+    ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
+                   2.0 * (double)(N * H * W) * (double)Cout * 9.0 * (double)Cin);
+    hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, wgt, U, (int)Cout,
+                       (int)Cin, flip);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(g.Tp * (Cin / 4), 256)), dim3(256), 0, st, in, in_ld, tab, V, g.Tp,
+                       (int)Cin, (int)H, (int)W, (int)dilation);
+    int rc = gemm_batched_f32_dma(V, g.Tp, 16, Cin, U, Cout, Mb, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(g.T * (Cout / 4), 256)), dim3(256), 0, st, Mb, tab, bias, out, out_ld,
+                       g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
+    return launch_status("diga_conv2d_winograd_f32");
+}

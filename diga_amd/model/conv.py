@@ -58,6 +58,30 @@ def takes_twin_only_input(conv, pointwise_ok=False):
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
 
 
+_WINO_CACHE = {}
+
+
+def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
+    """Exact-fp32 mode: stride-1 'same' 3x3 layers (dilation d = padding, forward or backward-data geometry) go through
+    Winograd F(2x2,3x3) (csrc/winograd.hip) when cutting the d*d sub-images into 2x2 tiles leaves few enough multiplications:
+    (16 per tile) / (36 per 2x2 outputs) of the direct convolution <= DIGA_CONV_WINOGRAD_RATIO (default 0.62; dilation 24 on a
+    97x97 map has 5x5 sub-images -> 0.98 and stays direct, where the kernel also skips the dead taps).
+    DIGA_CONV_WINOGRAD=0 switches the path off."""
+    if os.environ.get("DIGA_CONV_WINOGRAD", "1") == "0":
+        return False
+    d = abs(doff[0])
+    if not (r == 3 and s == 3 and tuple(stride) == (1, 1) and doff[0] == doff[1] and d >= 1 and off0[0] == -doff[0]
+            and off0[1] == -doff[1] and hi == ho and wi == wo and cin % 32 == 0 and cin >= 128 and k % 4 == 0 and k >= 128):
+        return False
+    key = (hi, wi, d)
+    ratio = _WINO_CACHE.get(key)
+    if ratio is None:
+        def tiles(length):
+            return sum((((length - a + d - 1) // d if length > a else 0) + 1) // 2 for a in range(d))
+        ratio = _WINO_CACHE[key] = 16.0 * tiles(hi) * tiles(wi) / (9.0 * hi * wi)
+    return ratio <= float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62")) and 16 * n * hi * wi < (1 << 31)
+
+
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
                  opts=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
@@ -122,6 +146,14 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         _lib.call("diga_conv2d_nhwc_bf16x3", _lib.ptr(x), _lib.ptr(w_hi), _lib.ptr(w_lo), _lib.ptr(bias), _lib.ptr(out),
                   n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                   doff[0], doff[1], _lib.ptr(stats), tag, _lib.stream())
+        return None
+    if (epi is None and copt is None and stats is None
+            and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):
+        d = abs(doff[0])
+        nbytes = _lib.lib.diga_conv2d_winograd_workspace_bytes(n, hi, wi, cin, k, d)
+        ws = _lib.workspace(nbytes, x.device, "winograd")
+        _lib.call("diga_conv2d_winograd_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                  n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, tag, _lib.stream())
         return None
     if epi is not None:
         _lib.call("diga_conv2d_nhwc_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), n, hi, wi, cin,
@@ -469,6 +501,11 @@ class DigaConv2d(nn.Conv2d):
             n, _, h, w = x.shape
             ho = (h + 2 * self.padding[0] - self.dilation[0] * (self.kernel_size[0] - 1) - 1) // self.stride[0] + 1
             wo = (w + 2 * self.padding[1] - self.dilation[1] * (self.kernel_size[1] - 1) - 1) // self.stride[1] + 1
+        if (self.emit_bn_stats and self.training and self.out_channels % 4 == 0
+                and not (_lib.get_conv_math() == 0 and fn is _Conv2dFn and (opts is None or not any(opts))
+                         and _winograd_ok(n, h, w, _pad_to(self.in_channels), self.out_channels, self.kernel_size[0], self.kernel_size[1],
+                                          self.stride, (-self.padding[0], -self.padding[1]), tuple(self.dilation), ho, wo))):
+            # (a Winograd forward has no statistics epilogue: the BatchNorm reads y for them, one pass of a 3x3 layer's output)
             stats = torch.empty(_lib.lib.diga_conv2d_stats_floats(n, ho, wo, self.out_channels), dtype=torch.float32,
                                 device=x.device)
         uses = None

@@ -323,6 +323,17 @@ int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, const float*
                           int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
                           float* stats_partial, int prof_tag, void* stream);
 
+/* Winograd F(2x2,3x3) in fp32 for a stride-1 3x3 convolution with padding = dilation (output H x W = input H x W):
+ * same result as diga_conv2d_nhwc_f32 with R = S = 3, offsets (-dilation, +dilation) up to fp32 rounding (16 instead of 36
+ * multiplications per 2x2 outputs; transforms with coefficients 0, +-1, +-1/2).  flip = 1 reads the taps in reverse order
+ * (w[2-r][2-s]): with wgt = the [Cin][3][3][Cout] transpose this is the backward-data convolution.  No statistics / backward
+ * epilogue.  Cin % 32 == 0, Cout % 4 == 0, Cout > 64.  Replaces the cuDNN call behind nn.Conv2d(3x3, dilation = padding) of
+ * G5/model/seg_model_noaux.py:66-70,143-150,166-170.  workspace: diga_conv2d_winograd_workspace_bytes (16-byte aligned). */
+size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation);
+int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
+                             size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
+                             int64_t out_ld, int64_t dilation, int flip, int prof_tag, void* stream);
+
 /* diga_conv2d_nhwc_f32 / _bf16x3 / _twin with a diga_conv_options_t (non-null; inference-only: no statistics output). */
 int diga_conv2d_nhwc_f32_opts(const float* in, const float* wgt, const float* bias, float* out, int64_t N, int64_t Hi, int64_t Wi,
                               int64_t Cin, int64_t in_ld, int64_t Ho, int64_t Wo, int64_t Cout, int64_t out_ld, int64_t R, int64_t S,

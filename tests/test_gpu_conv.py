@@ -321,3 +321,53 @@ def test_f32_dma_kernel_bit_identical_to_register_staged_kernel():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.count(" ") == 2])
     assert len(outs[0]) == 10 and outs[0] == outs[1], (outs[0], outs[1])
+
+
+WINO_CASES = [("d1_ragged", 3, 128, 33, 29, 160, 1), ("d2_97", 2, 256, 97, 97, 256, 2), ("d4_65x129", 1, 512, 65, 129, 128, 4),
+              ("d6_97", 1, 256, 97, 97, 256, 6), ("d12_97", 1, 128, 97, 97, 128, 12), ("d24_97", 1, 128, 97, 97, 132, 24),
+              ("d3_tiny", 2, 128, 5, 7, 128, 3)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_winograd_f32_vs_float64(case, monkeypatch):
+    """Winograd F(2x2,3x3) (csrc/winograd.hip: sub-image tiling of the dilated conv, input / weight / output transforms around
+    one batched launch of the fp32 LDS-DMA GEMM) against torch's float64 CPU convolution, forward and backward-data (the
+    flipped-tap call), with the bound the direct fp32 kernels are held to; odd map sizes, images whose sub-images are
+    smaller than a tile, a Cout tail, bias.  The multiplication-ratio gate is opened so that every case takes the path."""
+    from diga_amd import _lib
+    from diga_amd.model import conv as dc
+    name, n, cin, h, w, cout, d = case
+    monkeypatch.setenv("DIGA_CONV_WINOGRAD", "1")
+    monkeypatch.setenv("DIGA_CONV_WINOGRAD_RATIO", "10")
+    calls = []
+    real = _lib.call
+
+    def spy(fname, *a):
+        calls.append(fname)
+        return real(fname, *a)
+    monkeypatch.setattr(_lib, "call", spy)
+    g = synth.gen(zlib.crc32(name.encode()) % 10000 + 31)
+    x = torch.randn((n, cin, h, w), generator=g) + 0.5
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.conv2d(xr, wr, br, 1, d, d)
+    probe = torch.randn(yr.shape, generator=g)
+    (yr * probe.double()).sum().backward()
+    m = dc.DigaConv2d(cin, cout, 3, stride=1, padding=d, dilation=d, bias=True)
+    with torch.no_grad():
+        m.weight.copy_(wt)
+        m.bias.copy_(b)
+    m = m.to(DEV)
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(0)
+    try:
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+        y = m(xd)
+        (y * probe.to(DEV)).sum().backward()
+    finally:
+        _lib.set_conv_math(prev)
+    assert calls.count("diga_conv2d_winograd_f32") == 2, calls          # forward + backward-data
+    for got, want, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (m.weight.grad, wr.grad, "dw")):
+        e = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max())
+        assert e < 1e-5, (what, e)
