@@ -204,6 +204,124 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// wino_output_kernel for a backward-data convolution with the fused epilogue of diga_bwd_epilogue_t (same arithmetic, element
+// by element, as drain_stage<EPI> in conv.hip): out = mask(A^T M A + addend) and the BatchNorm-backward column sums
+// { sum g, sum g * xhat }.  Block (g, s): tiles [g * tpb, (g + 1) * tpb) x channels [256 s, 256 s + 256), 64 channel quads x 4
+// tile lanes; its sums go to row g of `partials` ([G][2][K], G = ceil(N H W / 128) rows as the direct kernel fills them --
+// the finaliser only adds the rows up), reduced over the tile lanes in fixed order.
+struct WinoEpi {
+    const float* add;
+    const float* masky;
+    const unsigned char* maskbits;
+    const float* x;
+    const float* relu_ab;
+    const float* mean;
+    const float* invstd;
+    float* partials;
+    int64_t add_ld, masky_ld, x_ld, maskbits_ld;
+};
+
+__global__ __launch_bounds__(256) void wino_output_epi_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+                                                              float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
+                                                              int H, int W, int d, int tpb, WinoEpi ep) {
+    __shared__ float red[2][4][256];
+    const int q = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const int k = (blockIdx.y * 64 + q) * 4;
+    const bool kok = k < K;
+    const int64_t t0 = (int64_t)blockIdx.x * tpb;
+    int64_t t1 = t0 + tpb;
+    if (t1 > T) t1 = T;
+    const int64_t plane = Tp * K;
+    float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kok && ep.relu_ab != nullptr) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ep.relu_ab + k), a1 = *reinterpret_cast<const float4*>(ep.relu_ab + K + k);
+        ra[0] = a0.x; ra[1] = a0.y; ra[2] = a0.z; ra[3] = a0.w;
+        rb[0] = a1.x; rb[1] = a1.y; rb[2] = a1.z; rb[3] = a1.w;
+    }
+    if (kok && ep.partials != nullptr) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ep.mean + k), a1 = *reinterpret_cast<const float4*>(ep.invstd + k);
+        mu[0] = a0.x; mu[1] = a0.y; mu[2] = a0.z; mu[3] = a0.w;
+        is[0] = a1.x; is[1] = a1.y; is[2] = a1.z; is[3] = a1.w;
+    }
+    float sd[4] = {0.f, 0.f, 0.f, 0.f}, sd2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kok) {
+        for (int64_t t = t0 + tl; t < t1; t += 4) {
+            const int4 e = tab[t];
+            const float* src = Mb + t * K + k;
+            float4 m[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[i][j] = nt_load4(src + (4 * i + j) * plane);
+            float4 s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[0][j] = f4add(f4add(m[0][j], m[1][j]), m[2][j]);
+                s[1][j] = f4sub(f4sub(m[1][j], m[2][j]), m[3][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = e.y + i * d;
+                if (yy >= H) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int xx = e.z + j * d;
+                    if (xx >= W) continue;
+                    const float4 o = j == 0 ? f4add(f4add(s[i][0], s[i][1]), s[i][2]) : f4sub(f4sub(s[i][1], s[i][2]), s[i][3]);
+                    const int64_t row = (int64_t)(e.x * H + yy) * W + xx;
+                    float v[4] = {o.x, o.y, o.z, o.w};
+                    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (ep.add != nullptr) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(ep.add + row * ep.add_ld + k);
+                        v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+                    }
+                    if (ep.x != nullptr) {
+                        const float4 x4 = *reinterpret_cast<const float4*>(ep.x + row * ep.x_ld + k);
+                        xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                    }
+                    if (ep.masky != nullptr) {
+                        const float4 y4 = *reinterpret_cast<const float4*>(ep.masky + row * ep.masky_ld + k);
+                        v[0] = y4.x > 0.f ? v[0] : 0.f; v[1] = y4.y > 0.f ? v[1] : 0.f;
+                        v[2] = y4.z > 0.f ? v[2] : 0.f; v[3] = y4.w > 0.f ? v[3] : 0.f;
+                    } else if (ep.maskbits != nullptr) {
+                        const unsigned b = ep.maskbits[row * ep.maskbits_ld + (k >> 3)] >> (k & 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = ((b >> c) & 1u) ? v[c] : 0.f;
+                    } else if (ep.relu_ab != nullptr) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaf(xv[c], ra[c], rb[c]) > 0.f ? v[c] : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(y + row * ld + k) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sd[c] += v[c];
+                        sd2[c] += v[c] * ((xv[c] - mu[c]) * is[c]);
+                    }
+                }
+            }
+        }
+    }
+    if (ep.partials == nullptr) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        red[0][tl][q * 4 + c] = sd[c];
+        red[1][tl][q * 4 + c] = sd2[c];
+    }
+    __syncthreads();
+    const int ch = blockIdx.y * 256 + threadIdx.x;
+    if (ch < K) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            a0 += red[0][l][threadIdx.x];
+            a1 += red[1][l][threadIdx.x];
+        }
+        float* sp = ep.partials + (int64_t)blockIdx.x * 2 * K + ch;
+        sp[0] = a0;
+        sp[K] = a1;
+    }
+}
+
 struct WinoLayout {
     size_t tab, U, V, M, total;
 };
@@ -228,9 +346,10 @@ extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int
     return wino_layout(make_wino(N, H, W, dilation), Cin, Cout).total;
 }
 
-extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
-                                        size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
-                                        int64_t Cout, int64_t out_ld, int64_t dilation, int flip, int prof_tag, void* stream) {
+static int winograd_impl(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
+                         size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
+                         int64_t Cout, int64_t out_ld, int64_t dilation, int flip, const diga_bwd_epilogue_t* epi, int prof_tag,
+                         void* stream) {
     DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
     DIGA_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 && in_ld >= Cin && in_ld % 4 == 0 && out_ld >= Cout && out_ld % 4 == 0,
@@ -258,7 +377,46 @@ extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const
                        (int)Cin, (int)H, (int)W, (int)dilation);
     int rc = gemm_batched_f32_dma(V, g.Tp, 16, Cin, U, Cout, Mb, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(g.T * (Cout / 4), 256)), dim3(256), 0, st, Mb, tab, bias, out, out_ld,
-                       g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
+    if (epi == nullptr) {
+        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(g.T * (Cout / 4), 256)), dim3(256), 0, st, Mb, tab, bias, out,
+                           out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
+    } else {
+        WinoEpi ep;
+        ep.add = epi->addend; ep.add_ld = epi->addend_ld;
+        ep.masky = epi->mask_y; ep.masky_ld = epi->mask_ld;
+        ep.maskbits = epi->mask_bits; ep.maskbits_ld = epi->mask_bits_ld;
+        ep.x = epi->x; ep.x_ld = epi->x_ld;
+        ep.relu_ab = epi->relu_ab; ep.mean = epi->mean; ep.invstd = epi->invstd; ep.partials = epi->partials;
+        const int64_t G = ceil_div(N * H * W, 128);
+        const int tpb = (int)ceil_div(g.T, G);
+        hipLaunchKernelGGL(wino_output_epi_kernel, dim3((unsigned)G, (unsigned)ceil_div(Cout, 256)), dim3(256), 0, st, Mb, tab, out,
+                           out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
+    }
     return launch_status("diga_conv2d_winograd_f32");
+}
+
+extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
+                                        size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
+                                        int64_t Cout, int64_t out_ld, int64_t dilation, int flip, int prof_tag, void* stream) {
+    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, flip, nullptr,
+                         prof_tag, stream);
+}
+
+extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes,
+                                            int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
+                                            int64_t out_ld, int64_t dilation, int flip, const diga_bwd_epilogue_t* e, int prof_tag,
+                                            void* stream) {
+    DIGA_REQUIRE(e != nullptr, DIGA_EINVAL, "conv2d_winograd_epi: null epilogue descriptor");
+    DIGA_REQUIRE(e->addend || e->mask_y || e->mask_bits || e->x, DIGA_EINVAL, "conv2d_winograd_epi: empty epilogue descriptor");
+    DIGA_REQUIRE(!e->addend || (aligned16(e->addend) && e->addend_ld >= Cout && e->addend_ld % 4 == 0), DIGA_EINVAL, "conv2d_winograd_epi: bad addend");
+    DIGA_REQUIRE(!e->mask_y || (aligned16(e->mask_y) && e->mask_ld >= Cout && e->mask_ld % 4 == 0), DIGA_EINVAL, "conv2d_winograd_epi: bad mask_y");
+    DIGA_REQUIRE(!e->x || (aligned16(e->x) && e->x_ld >= Cout && e->x_ld % 4 == 0), DIGA_EINVAL, "conv2d_winograd_epi: bad x");
+    DIGA_REQUIRE((e->mask_y != nullptr) + (e->relu_ab != nullptr) + (e->mask_bits != nullptr) <= 1, DIGA_EINVAL,
+                 "conv2d_winograd_epi: give one of mask_y, mask_bits, relu_ab");
+    DIGA_REQUIRE(!e->mask_bits || e->mask_bits_ld * 8 >= Cout, DIGA_EINVAL, "conv2d_winograd_epi: bad mask_bits");
+    DIGA_REQUIRE(!e->relu_ab || (e->x && aligned16(e->relu_ab)), DIGA_EINVAL, "conv2d_winograd_epi: relu_ab needs x");
+    DIGA_REQUIRE(!e->partials || (e->x && e->mean && e->invstd && aligned16(e->mean) && aligned16(e->invstd)), DIGA_EINVAL,
+                 "conv2d_winograd_epi: partials need x, mean and invstd");
+    return winograd_impl(in, wgt, nullptr, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, flip, e, prof_tag,
+                         stream);
 }

@@ -147,11 +147,14 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                   n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                   doff[0], doff[1], _lib.ptr(stats), tag, _lib.stream())
         return None
-    if (epi is None and copt is None and stats is None
-            and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):
+    if (copt is None and stats is None and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):
         d = abs(doff[0])
         nbytes = _lib.lib.diga_conv2d_winograd_workspace_bytes(n, hi, wi, cin, k, d)
         ws = _lib.workspace(nbytes, x.device, "winograd")
+        if epi is not None:
+            _lib.call("diga_conv2d_winograd_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                      n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, ctypes.byref(epi), tag, _lib.stream())
+            return None
         _lib.call("diga_conv2d_winograd_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                   n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, tag, _lib.stream())
         return None

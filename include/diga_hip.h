@@ -333,6 +333,12 @@ size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int
 int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                              size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
                              int64_t out_ld, int64_t dilation, int flip, int prof_tag, void* stream);
+/* ... with the backward-data epilogue of diga_bwd_epilogue_t (declared above; same arithmetic per element as the `_epi` forms
+ * of the direct kernels; `partials` rows are filled per group of tiles instead of per 128 pixel rows -- the finaliser
+ * diga_bn_bwd_partials only adds the rows up). */
+int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes, int64_t N,
+                                 int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation,
+                                 int flip, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
 
 /* diga_conv2d_nhwc_f32 / _bf16x3 / _twin with a diga_conv_options_t (non-null; inference-only: no statistics output). */
 int diga_conv2d_nhwc_f32_opts(const float* in, const float* wgt, const float* bias, float* out, int64_t N, int64_t Hi, int64_t Wi,

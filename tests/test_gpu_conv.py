@@ -165,10 +165,11 @@ def test_conv_rejects_cpu():
 @pytest.mark.parametrize("case", [c for c in CASES if c[5] % 4 == 0 and not c[10]] +
                          [("stats_merge", 2, 32, 192, 193, 64, 1, 1, 0, 1, False)],     # > 512 tiles: merge stage
                          ids=lambda c: c[0])
-def test_conv_epilogue_bn_statistics(case, math):
+def test_conv_epilogue_bn_statistics(case, math, monkeypatch):
     """Train-mode BN fed by the per-tile {sum d, sum d^2, shift} partials the conv epilogue emits equals BN that
     re-reads the conv output (and a float64 reference), including running-stat updates; the input carries a large
-    mean so a naive sum-of-squares would lose the variance."""
+    mean so a naive sum-of-squares would lose the variance.  (Direct kernels: a Winograd forward emits no partials.)"""
+    monkeypatch.setenv("DIGA_CONV_WINOGRAD", "0")
     from diga_amd import _lib
     from diga_amd.model.conv import DigaConv2d
     from diga_amd.model.norm import DigaBatchNorm2d
