@@ -1729,6 +1729,8 @@ struct WgradArgs {
     const int* ptab;     // conv_wgrad_x3w_kernel: [R*S][M_pad] x-pixel index of (tap, output pixel), -1 = outside the image
     const float* zeros;  // 16 bytes of zeros (what an outside tap loads)
     int M_pad;
+    // batched products on conv_wgrad_dma_kernel (winograd.hip): "tap" t reads dy + t * dy_tap_stride, x + t * x_tap_stride
+    int64_t dy_tap_stride = 0, x_tap_stride = 0;
 };
 
 constexpr int kLDW = 128 + 4;   // wgrad LDS rows: [pixel][channel], channel contiguous
@@ -2503,8 +2505,8 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_dma_kernel(WgradArgs a) {
 
     if (loader) {
         const int lw = wv - 8;
-        const unsigned char* dyb = reinterpret_cast<const unsigned char*>(a.dy) + (int64_t)k0 * 4;
-        const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + (int64_t)c0 * 4;
+        const unsigned char* dyb = reinterpret_cast<const unsigned char*>(a.dy) + ((int64_t)k0 + tap * a.dy_tap_stride) * 4;
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + ((int64_t)c0 + tap * a.x_tap_stride) * 4;
         const int64_t dy_rowb = (int64_t)a.dy_ld * 4, x_rowb = (int64_t)a.x_ld * 4;
         const int* tab = a.ptab != nullptr ? a.ptab + (int64_t)tap * a.M_pad : nullptr;
         // A (dy): 32 pixel rows x 1 KB = 32 instructions, 8 per wave: row 8 lw + j, destination chunk `lane`.
@@ -3134,6 +3136,41 @@ size_t wgrad_slab_bytes(const WgradPlan& p, int64_t Cout, int64_t Cin, int64_t R
     return p.splits > 1 ? (size_t)p.splits * Cout * RS * Cin * sizeof(float) : 0;
 }
 }  // namespace
+
+namespace diga {
+// `batches` independent products dU_b [Cout x Cin] = Z_b^T [Cout x rows] * V_b [rows x Cin] (contraction over the rows) in
+// one launch of conv_wgrad_dma_kernel, the batch riding on the kernel's tap index: Z [batches][rows][Cout],
+// V [batches][rows][Cin], dU [Cout][batches][Cin].  rows % 32 == 0, Cout % 256 == 0, Cin % 128 == 0.  `slab`: scratch of
+// wgrad_batched_slab_bytes() bytes for the split-K partial sums (fixed-order reduce).  Used by winograd.hip.
+size_t wgrad_batched_slab_bytes(int64_t rows, int batches, int64_t Cout, int64_t Cin) {
+    return wgrad_slab_bytes(plan_wgrad_wide(rows, Cout, Cin, batches), Cout, Cin, batches);
+}
+int wgrad_batched_f32_dma(const float* Z, const float* V, float* dU, float* slab, int64_t rows, int batches, int64_t Cout,
+                          int64_t Cin, hipStream_t st) {
+    DIGA_REQUIRE(rows > 0 && rows % 32 == 0 && Cout % 256 == 0 && Cin % 128 == 0 && batches > 0 && rows < (1ll << 31), DIGA_EINVAL,
+                 "wgrad_batched_f32_dma: rows %% 32, Cout %% 256, Cin %% 128 required");
+    const WgradPlan p = plan_wgrad_wide(rows, Cout, Cin, batches);
+    WgradArgs a;
+    a.dy = Z; a.x = V; a.slab = p.splits > 1 ? slab : dU;
+    a.N = 1; a.Hi = 1; a.Wi = (int)rows; a.Cin = (int)Cin; a.x_ld = (int)Cin;
+    a.Ho = 1; a.Wo = (int)rows; a.Cout = (int)Cout; a.dy_ld = (int)Cout;
+    a.R = 1; a.S = batches; a.sy = 1; a.sx = 1; a.oy0 = 0; a.ox0 = 0; a.ody = 1; a.odx = 1;
+    a.M = (int)rows; a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.splits = p.splits; a.steps_per_split = p.steps_per_split;
+    a.ptab = nullptr; a.zeros = nullptr; a.M_pad = (int)rows;
+    a.dy_tap_stride = rows * Cout;
+    a.x_tap_stride = rows * Cin;
+    const unsigned grid = (unsigned)((int64_t)p.tiles_m * p.tiles_n * batches * p.splits);
+    const size_t shd = (size_t)3 * kBK * (256 + 128) * 4;
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shd);
+    hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(grid), dim3(768), shd, st, a);
+    if (p.splits > 1) {
+        const int64_t n4 = Cout * batches * Cin / 4;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, (const float*)slab, dU, n4, p.splits);
+    }
+    return DIGA_OK;
+}
+
+}  // namespace diga
 
 // workspace = [split-K slabs][(tap, pixel) -> input pixel table of the wide split-bf16 kernel][16 zero bytes]; sized
 // for either conv arithmetic so that a query and the call may straddle a diga_set_conv_math()

@@ -22,6 +22,9 @@ namespace diga {
 
 int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, int64_t K, const float* W, int64_t Cout,
                          float* out, hipStream_t st);     // conv.hip
+size_t wgrad_batched_slab_bytes(int64_t rows, int batches, int64_t Cout, int64_t Cin);                                   // conv.hip
+int wgrad_batched_f32_dma(const float* Z, const float* V, float* dU, float* slab, int64_t rows, int batches, int64_t Cout,
+                          int64_t Cin, hipStream_t st);                                                                 // conv.hip
 
 namespace {
 
@@ -322,6 +325,92 @@ __global__ __launch_bounds__(256) void wino_output_epi_kernel(const float* __res
     }
 }
 
+// ---- backward-weight: dL/dg = G^T [ sum over tiles (A dY A^T) (.) (B^T d B) ] G  (the transpose of the forward chain).
+// Z[k][t][co] = (A dY A^T)[i][j] of the 2x2 output-gradient tile t (zero outside the image / for padding tiles)
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int64_t ld, const int4* __restrict__ tab,
+                                                      float* __restrict__ Z, int64_t Tp, int K, int H, int W, int d) {
+    const int k4n = K / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Tp * k4n) return;
+    const int64_t t = idx / k4n;
+    const int k = (int)(idx - t * k4n) * 4;
+    const int4 e = tab[t];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int yy = e.y + i * d, xx = e.z + j * d;
+            const bool ok = e.x >= 0 && yy < H && xx < W;
+            g[i][j] = ok ? *reinterpret_cast<const float4*>(dy + ((int64_t)(e.x * H + yy) * W + xx) * ld + k) : z;
+        }
+    // rows of A = [1 0; 1 1; 1 -1; 0 -1]
+    float4 r[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        r[0][j] = g[0][j];
+        r[1][j] = f4add(g[0][j], g[1][j]);
+        r[2][j] = f4sub(g[0][j], g[1][j]);
+        r[3][j] = f4sub(z, g[1][j]);
+    }
+    float* o = Z + t * K + k;
+    const int64_t plane = Tp * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        nt_store4(o + (4 * i + 0) * plane, r[i][0]);
+        nt_store4(o + (4 * i + 1) * plane, f4add(r[i][0], r[i][1]));
+        nt_store4(o + (4 * i + 2) * plane, f4sub(r[i][0], r[i][1]));
+        nt_store4(o + (4 * i + 3) * plane, f4sub(z, r[i][1]));
+    }
+}
+
+// dw[co][r][s][c] = (G^T dU G)[r][s], dU [co][16][c]
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = Cin / 4;
+    if (idx >= (int64_t)Cout * c4n) return;
+    const int co = (int)(idx / c4n), c = (int)(idx - (int64_t)co * c4n) * 4;
+    const float* src = dU + (int64_t)co * 16 * Cin + c;
+    float4 u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[i][j] = *reinterpret_cast<const float4*>(src + (int64_t)(4 * i + j) * Cin);
+    // G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+    float4 t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 hs = f4half(f4add(u[1][j], u[2][j])), hd = f4half(f4sub(u[1][j], u[2][j]));
+        t[0][j] = f4add(u[0][j], hs);
+        t[1][j] = hd;
+        t[2][j] = f4add(hs, u[3][j]);
+    }
+    float* o = dw + (int64_t)co * 9 * Cin + c;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float4 hs = f4half(f4add(t[r][1], t[r][2])), hd = f4half(f4sub(t[r][1], t[r][2]));
+        *reinterpret_cast<float4*>(o + (int64_t)(3 * r + 0) * Cin) = f4add(t[r][0], hs);
+        *reinterpret_cast<float4*>(o + (int64_t)(3 * r + 1) * Cin) = hd;
+        *reinterpret_cast<float4*>(o + (int64_t)(3 * r + 2) * Cin) = f4add(hs, t[r][3]);
+    }
+}
+
+struct WinoWgradLayout {
+    size_t tab, V, Z, dU, slab, total;
+};
+WinoWgradLayout wino_wgrad_layout(const WinoGeom& g, int64_t Cin, int64_t Cout) {
+    WinoWgradLayout l;
+    size_t o = 0;
+    l.tab = o; o += (size_t)g.Tp * sizeof(int4);
+    l.V = o; o += (size_t)16 * g.Tp * Cin * sizeof(float);
+    l.Z = o; o += (size_t)16 * g.Tp * Cout * sizeof(float);
+    l.dU = o; o += (size_t)16 * Cout * Cin * sizeof(float);
+    l.slab = o; o += wgrad_batched_slab_bytes(g.Tp, 16, Cout, Cin);
+    l.total = o + 64;
+    return l;
+}
+
 struct WinoLayout {
     size_t tab, U, V, M, total;
 };
@@ -419,4 +508,43 @@ extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, f
                  "conv2d_winograd_epi: partials need x, mean and invstd");
     return winograd_impl(in, wgt, nullptr, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, flip, e, prof_tag,
                          stream);
+}
+
+extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                                             int64_t dilation) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || Cout % 256 != 0 || Cin % 128 != 0) return 0;
+    return wino_wgrad_layout(make_wino(N, H, W, dilation), Cin, Cout).total;
+}
+
+extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes,
+                                              int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld, int64_t Cout,
+                                              int64_t dy_ld, int64_t dilation, void* stream) {
+    DIGA_REQUIRE(dy && x && dw && workspace, DIGA_EINVAL, "conv2d_wgrad_winograd: null pointer");
+    DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && N * H * W < (1ll << 31), DIGA_EINVAL,
+                 "conv2d_wgrad_winograd: bad shape");
+    DIGA_REQUIRE(Cout % 256 == 0 && Cin % 128 == 0 && x_ld >= Cin && x_ld % 4 == 0 && dy_ld >= Cout && dy_ld % 4 == 0, DIGA_EINVAL,
+                 "conv2d_wgrad_winograd: Cout %% 256, Cin %% 128 and leading dimensions %% 4 required");
+    DIGA_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw) && aligned16(workspace), DIGA_EALIGN,
+                 "conv2d_wgrad_winograd: pointers must be 16-byte aligned");
+    const WinoGeom g = make_wino(N, H, W, dilation);
+    const WinoWgradLayout l = wino_wgrad_layout(g, Cin, Cout);
+    DIGA_REQUIRE(workspace_bytes >= l.total, DIGA_EWORKSPACE, "conv2d_wgrad_winograd: workspace too small (%zu < %zu)", workspace_bytes,
+                 l.total);
+    char* ws = static_cast<char*>(workspace);
+    int4* tab = reinterpret_cast<int4*>(ws + l.tab);
+    float* V = reinterpret_cast<float*>(ws + l.V);
+    float* Z = reinterpret_cast<float*>(ws + l.Z);
+    float* dU = reinterpret_cast<float*>(ws + l.dU);
+    float* slab = reinterpret_cast<float*>(ws + l.slab);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st, 2.0 * (double)(N * H * W) * (double)Cout * 9.0 * (double)Cin);
+    hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(g.Tp * (Cin / 4), 256)), dim3(256), 0, st, x, x_ld, tab, V, g.Tp,
+                       (int)Cin, (int)H, (int)W, (int)dilation);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)ceil_div(g.Tp * (Cout / 4), 256)), dim3(256), 0, st, dy, dy_ld, tab, Z, g.Tp,
+                       (int)Cout, (int)H, (int)W, (int)dilation);
+    int rc = wgrad_batched_f32_dma(Z, V, dU, slab, g.Tp, 16, Cout, Cin, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, dU, dw, (int)Cout, (int)Cin);
+    return launch_status("diga_conv2d_wgrad_winograd_f32");
 }

@@ -440,6 +440,15 @@ class _Conv2dFn(torch.autograd.Function):
             def run():
                 if use_tw:
                     return run_twin()
+                if (_lib.get_conv_math() == 0 and kp % 256 == 0 and cp % 128 == 0 and gyp.stride(2) % 4 == 0
+                        and _winograd_ok(n, hi, wi, cp, kp, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
+                    nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0])
+                    wsw = _lib.workspace(nb, w.device, "winograd_wgrad")
+                    _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(wsw), wsw.numel(),
+                              n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], _lib.stream())
+                    if not alias:
+                        dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
+                    return
                 nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, cp, r, s)
                 ws = _lib.workspace(nbytes, w.device, "wgrad")
                 _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),

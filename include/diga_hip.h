@@ -339,6 +339,13 @@ int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bia
 int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes, int64_t N,
                                  int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation,
                                  int flip, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
+/* Backward-weight of the same layer through Winograd (dw [Cout][3][3][Cin] = G^T [sum over tiles (A dY A^T) (.) (B^T d B)] G):
+ * transforms of dy and x, 16 products contracted over the tiles in one launch of the fp32 LDS-DMA backward-weight kernel
+ * (fixed-order split-K: bit-reproducible), the 4x4 -> 3x3 transform.  Cout % 256 == 0, Cin % 128 == 0. */
+size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation);
+int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int64_t N,
+                                   int64_t H, int64_t W, int64_t Cin, int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation,
+                                   void* stream);
 
 /* diga_conv2d_nhwc_f32 / _bf16x3 / _twin with a diga_conv_options_t (non-null; inference-only: no statistics output). */
 int diga_conv2d_nhwc_f32_opts(const float* in, const float* wgt, const float* bias, float* out, int64_t N, int64_t Hi, int64_t Wi,

@@ -324,7 +324,7 @@ def test_f32_dma_kernel_bit_identical_to_register_staged_kernel():
     assert len(outs[0]) == 10 and outs[0] == outs[1], (outs[0], outs[1])
 
 
-WINO_CASES = [("d1_ragged", 3, 128, 33, 29, 160, 1), ("d2_97", 2, 256, 97, 97, 256, 2), ("d4_65x129", 1, 512, 65, 129, 128, 4),
+WINO_CASES = [("d1_ragged", 3, 128, 33, 29, 160, 1), ("d1_wide", 2, 384, 31, 37, 512, 1), ("d18_97", 1, 128, 97, 97, 256, 18), ("d2_97", 2, 256, 97, 97, 256, 2), ("d4_65x129", 1, 512, 65, 129, 128, 4),
               ("d6_97", 1, 256, 97, 97, 256, 6), ("d12_97", 1, 128, 97, 97, 128, 12), ("d24_97", 1, 128, 97, 97, 132, 24),
               ("d3_tiny", 2, 128, 5, 7, 128, 3)]
 
@@ -369,6 +369,7 @@ def test_winograd_f32_vs_float64(case, monkeypatch):
     finally:
         _lib.set_conv_math(prev)
     assert calls.count("diga_conv2d_winograd_f32") == 2, calls          # forward + backward-data
+    assert ("diga_conv2d_wgrad_winograd_f32" in calls) == (cout % 256 == 0 and cin % 128 == 0), calls
     for got, want, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (m.weight.grad, wr.grad, "dw")):
         e = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max())
         assert e < 1e-5, (what, e)
