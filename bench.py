@@ -360,12 +360,20 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
             torch.cuda.synchronize()
             _lib.call("diga_prof_reset")
             _lib.call("diga_prof_enable", 1)
+            from diga_amd.model import conv as _dconv
+            _dconv.flop_log = {}
             for _ in range(SERIAL_STEPS):
                 one_step(it)
                 it += 1
             torch.cuda.synchronize()
             _lib.call("diga_prof_enable", 0)
             families = query(SERIAL_STEPS)
+            # what the matrix cores execute next to the FLOPs of the direct convolutions (Winograd layers: 16/36 per 2x2 tile)
+            for tag, (direct, executed) in _dconv.flop_log.items():
+                if tag in families:
+                    families[tag]["direct_flops_per_step"] = direct / SERIAL_STEPS
+                    families[tag]["executed_flops_per_step"] = executed / SERIAL_STEPS
+            _dconv.flop_log = None
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -422,12 +430,13 @@ def rooflines(config, precision, families, counts, geom):
         flops_step = (n_stu + n_tea) * fwd_gflop * 1e9
         n_launch = fam["ms_per_step"] / fam["avg_ms"]                     # launches per step
         ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
-        kname = "conv_fwd_kernel" if precision == "f32" else "conv_fwd_x3w_kernel + conv_fwd_x3t8_kernel"
+        kname = ("conv_fwd_dma_kernel, directly and as the 16 batched products of the Winograd F(2x2,3x3) layers (+ their transform passes)"
+                 if precision == "f32" else "conv_fwd_x3w_kernel + conv_fwd_x3t8_kernel")
         traffic = None
         if pmc and (B, H, W) == (8, 768, 768) and config == "c2":
             # launch-weighted mean over the family's kernels (the 128-column instantiations carry > 95 % of its time;
             # the same kernels also serve backward-data, whose launches are in the PMC averages)
-            names = ("diga::conv_fwd_kernel<2",) if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t8_kernel<2", "diga::conv_fwd_x3t_kernel<2")
+            names = ("diga::conv_fwd_dma_kernel", "diga::conv_fwd_kernel<2") if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t8_kernel<2", "diga::conv_fwd_x3t_kernel<2")
             ent = [v for k, v in pmc.items() if k.startswith(names)]
             nl = sum(v["launches"] for v in ent)
             traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ent) / nl if nl else None
@@ -437,12 +446,25 @@ def rooflines(config, precision, families, counts, geom):
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "algorithmic_flops_per_launch": flops_step / n_launch, "avg_launch_ms": fam["avg_ms"],
                 "launches_per_step": n_launch, "declared_flops_per_step": fam["work_per_step"]}
+
+        def executed(f, out):
+            # `achieved` / `frac` price the ALGORITHMIC work (the direct convolutions) as the contract asks; the
+            # Winograd layers execute 16/36 of their multiplications per 2x2 tile, so the matrix cores' own utilisation is
+            # the executed FLOPs over the same time (it includes the transform passes' time: a lower bound on the GEMM's)
+            if "executed_flops_per_step" in f and f.get("direct_flops_per_step"):
+                ex = f["executed_flops_per_step"] / (f["ms_per_step"] * 1e-3) / 1e12
+                out.update(executed_flops_per_step=f["executed_flops_per_step"], achieved_executed=ex, frac_executed=ex / peak)
+        executed(fam, roof)
+        if "frac_executed" in roof:
+            roof["note"] = ("frac = algorithmic (direct-convolution) FLOPs / time / peak; the stride-1 3x3 layers run as Winograd F(2x2,3x3) "
+                            "(csrc/winograd.hip), which executes fewer multiplications: frac_executed = FLOPs the matrix cores run / the same time / peak")
         for tag in ("conv_bwd_data", "conv_bwd_weight"):
             if tag in families:        # backward: one pass each over the student's images
                 f = n_stu * fwd_gflop * 1e9
                 v = f / (families[tag]["ms_per_step"] * 1e-3) / 1e12
                 other[tag] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": v, "frac": v / peak,
                               "ms_per_step": families[tag]["ms_per_step"]}
+                executed(families[tag], other[tag])
     # per-launch byte counts the host knows (the multi-tensor kernels get device-side size tables)
     known = {"sgd": 20.0 * n_trainable, "ema": 12.0 * n_params}
     for tag, fam in families.items():

@@ -59,6 +59,26 @@ def takes_twin_only_input(conv, pointwise_ok=False):
 
 
 _WINO_CACHE = {}
+# bench.py sets this to a dict to learn what the convolutions of a step multiply: name -> [FLOPs of the direct
+# convolution (the algorithmic work), FLOPs the matrix cores execute (16/36 of it per 2x2 tile on the Winograd path)]
+flop_log = None
+
+
+def _log_flops(name, direct, executed):
+    if flop_log is not None:
+        e = flop_log.setdefault(name, [0.0, 0.0])
+        e[0] += direct
+        e[1] += executed
+
+
+def _wino_ratio(hi, wi, d):
+    key = (hi, wi, d)
+    ratio = _WINO_CACHE.get(key)
+    if ratio is None:
+        def tiles(length):
+            return sum((((length - a + d - 1) // d if length > a else 0) + 1) // 2 for a in range(d))
+        ratio = _WINO_CACHE[key] = 16.0 * tiles(hi) * tiles(wi) / (9.0 * hi * wi)
+    return ratio
 
 
 def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
@@ -73,13 +93,7 @@ def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
     if not (r == 3 and s == 3 and tuple(stride) == (1, 1) and doff[0] == doff[1] and d >= 1 and off0[0] == -doff[0]
             and off0[1] == -doff[1] and hi == ho and wi == wo and cin % 32 == 0 and cin >= 128 and k % 4 == 0 and k >= 128):
         return False
-    key = (hi, wi, d)
-    ratio = _WINO_CACHE.get(key)
-    if ratio is None:
-        def tiles(length):
-            return sum((((length - a + d - 1) // d if length > a else 0) + 1) // 2 for a in range(d))
-        ratio = _WINO_CACHE[key] = 16.0 * tiles(hi) * tiles(wi) / (9.0 * hi * wi)
-    return ratio <= float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62")) and 16 * n * hi * wi < (1 << 31)
+    return _wino_ratio(hi, wi, d) <= float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62")) and 16 * n * hi * wi < (1 << 31)
 
 
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
@@ -147,8 +161,12 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                   n, hi, wi, cin, x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1],
                   doff[0], doff[1], _lib.ptr(stats), tag, _lib.stream())
         return None
-    if (copt is None and stats is None and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):
+    direct = 2.0 * n * ho * wo * k * r * s * cin
+    name = "conv_bwd_data" if tag == _TAG_BWD_DATA else "conv_fwd"
+    if (_lib.get_conv_math() == 0 and copt is None and stats is None
+            and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):
         d = abs(doff[0])
+        _log_flops(name, direct, direct * _wino_ratio(hi, wi, d))
         nbytes = _lib.lib.diga_conv2d_winograd_workspace_bytes(n, hi, wi, cin, k, d)
         ws = _lib.workspace(nbytes, x.device, "winograd")
         if epi is not None:
@@ -158,6 +176,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         _lib.call("diga_conv2d_winograd_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                   n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, tag, _lib.stream())
         return None
+    _log_flops(name, direct, direct)
     if epi is not None:
         _lib.call("diga_conv2d_nhwc_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), n, hi, wi, cin,
                   x.stride(2), ho, wo, k, out.stride(2), r, s, stride[0], stride[1], off0[0], off0[1], doff[0], doff[1],
@@ -442,6 +461,7 @@ class _Conv2dFn(torch.autograd.Function):
                     return run_twin()
                 if (_lib.get_conv_math() == 0 and kp % 256 == 0 and cp % 128 == 0 and gyp.stride(2) % 4 == 0
                         and _winograd_ok(n, hi, wi, cp, kp, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
+                    _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * 9 * cp, 2.0 * n * ho * wo * kp * 9 * cp * _wino_ratio(hi, wi, dilation[0]))
                     nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0])
                     wsw = _lib.workspace(nb, w.device, "winograd_wgrad")
                     _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(wsw), wsw.numel(),
@@ -449,6 +469,7 @@ class _Conv2dFn(torch.autograd.Function):
                     if not alias:
                         dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
                     return
+                _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * r * s * cp, 2.0 * n * ho * wo * kp * r * s * cp)
                 nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, cp, r, s)
                 ws = _lib.workspace(nbytes, w.device, "wgrad")
                 _lib.call("diga_conv2d_wgrad_nhwc_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(ws), ws.numel(),
