@@ -26,7 +26,7 @@ size_t wgrad_batched_slab_bytes(int64_t rows, int batches, int64_t Cout, int64_t
 int wgrad_batched_f32_dma(const float* Z, const float* V, float* dU, float* slab, int64_t rows, int batches, int64_t Cout,
                           int64_t Cin, hipStream_t st);                                                                 // conv.hip
 
-namespace {
+namespace wino {
 
 struct WinoGeom {
     int N, H, W, d;
@@ -425,10 +425,11 @@ WinoLayout wino_layout(const WinoGeom& g, int64_t Cin, int64_t Cout) {
     return l;
 }
 
-}  // namespace
+}  // namespace wino
 }  // namespace diga
 
 using namespace diga;
+using namespace diga::wino;
 
 extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0) return 0;
@@ -438,7 +439,7 @@ extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int
 static int winograd_impl(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                          size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
                          int64_t Cout, int64_t out_ld, int64_t dilation, int flip, const diga_bwd_epilogue_t* epi, int prof_tag,
-                         void* stream) {
+                         void* stream, float* v_keep = nullptr) {
     DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
     DIGA_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 && in_ld >= Cin && in_ld % 4 == 0 && out_ld >= Cout && out_ld % 4 == 0,
@@ -453,7 +454,7 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     char* ws = static_cast<char*>(workspace);
     int4* tab = reinterpret_cast<int4*>(ws + l.tab);
     float* U = reinterpret_cast<float*>(ws + l.U);
-    float* V = reinterpret_cast<float*>(ws + l.V);
+    float* V = v_keep != nullptr ? v_keep : reinterpret_cast<float*>(ws + l.V);
     float* Mb = reinterpret_cast<float*>(ws + l.M);
     hipStream_t st = (hipStream_t)stream;
     // priced as the direct convolution it replaces (the algorithmic FLOPs of the layer)
@@ -491,6 +492,20 @@ extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const
                          prof_tag, stream);
 }
 
+extern "C" size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || dilation <= 0) return 0;
+    return (size_t)16 * make_wino(N, H, W, dilation).Tp * Cin;
+}
+
+extern "C" int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, const float* bias, float* out, float* v_keep,
+                                             void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                                             int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int prof_tag,
+                                             void* stream) {
+    DIGA_REQUIRE(v_keep != nullptr && aligned16(v_keep), DIGA_EINVAL, "conv2d_winograd_keep: v_keep must be a 16-byte aligned buffer");
+    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, 0, nullptr,
+                         prof_tag, stream, v_keep);
+}
+
 extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes,
                                             int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
                                             int64_t out_ld, int64_t dilation, int flip, const diga_bwd_epilogue_t* e, int prof_tag,
@@ -516,15 +531,16 @@ extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t 
     return wino_wgrad_layout(make_wino(N, H, W, dilation), Cin, Cout).total;
 }
 
-extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes,
-                                              int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld, int64_t Cout,
-                                              int64_t dy_ld, int64_t dilation, void* stream) {
-    DIGA_REQUIRE(dy && x && dw && workspace, DIGA_EINVAL, "conv2d_wgrad_winograd: null pointer");
+extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
+                                              size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
+                                              int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream) {
+    DIGA_REQUIRE(dy && (x || v_kept) && dw && workspace, DIGA_EINVAL, "conv2d_wgrad_winograd: null pointer");
+    DIGA_REQUIRE(!v_kept || aligned16(v_kept), DIGA_EALIGN, "conv2d_wgrad_winograd: v_kept must be 16-byte aligned");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && N * H * W < (1ll << 31), DIGA_EINVAL,
                  "conv2d_wgrad_winograd: bad shape");
     DIGA_REQUIRE(Cout % 256 == 0 && Cin % 128 == 0 && x_ld >= Cin && x_ld % 4 == 0 && dy_ld >= Cout && dy_ld % 4 == 0, DIGA_EINVAL,
                  "conv2d_wgrad_winograd: Cout %% 256, Cin %% 128 and leading dimensions %% 4 required");
-    DIGA_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw) && aligned16(workspace), DIGA_EALIGN,
+    DIGA_REQUIRE(aligned16(dy) && (!x || aligned16(x)) && aligned16(dw) && aligned16(workspace), DIGA_EALIGN,
                  "conv2d_wgrad_winograd: pointers must be 16-byte aligned");
     const WinoGeom g = make_wino(N, H, W, dilation);
     const WinoWgradLayout l = wino_wgrad_layout(g, Cin, Cout);
@@ -532,15 +548,16 @@ extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, f
                  l.total);
     char* ws = static_cast<char*>(workspace);
     int4* tab = reinterpret_cast<int4*>(ws + l.tab);
-    float* V = reinterpret_cast<float*>(ws + l.V);
+    const float* V = v_kept != nullptr ? v_kept : reinterpret_cast<float*>(ws + l.V);
     float* Z = reinterpret_cast<float*>(ws + l.Z);
     float* dU = reinterpret_cast<float*>(ws + l.dU);
     float* slab = reinterpret_cast<float*>(ws + l.slab);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st, 2.0 * (double)(N * H * W) * (double)Cout * 9.0 * (double)Cin);
     hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(g.Tp * (Cin / 4), 256)), dim3(256), 0, st, x, x_ld, tab, V, g.Tp,
-                       (int)Cin, (int)H, (int)W, (int)dilation);
+    if (v_kept == nullptr)
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(g.Tp * (Cin / 4), 256)), dim3(256), 0, st, x, x_ld, tab,
+                           reinterpret_cast<float*>(ws + l.V), g.Tp, (int)Cin, (int)H, (int)W, (int)dilation);
     hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)ceil_div(g.Tp * (Cout / 4), 256)), dim3(256), 0, st, dy, dy_ld, tab, Z, g.Tp,
                        (int)Cout, (int)H, (int)W, (int)dilation);
     int rc = wgrad_batched_f32_dma(Z, V, dU, slab, g.Tp, 16, Cout, Cin, st);

@@ -97,7 +97,7 @@ def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
 
 
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
-                 opts=None):
+                 opts=None, keep_v=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x.
     epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue.
@@ -172,6 +172,12 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         if epi is not None:
             _lib.call("diga_conv2d_winograd_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                       n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, ctypes.byref(epi), tag, _lib.stream())
+            return None
+        if keep_v is not None and doff[0] > 0:
+            # keep_v: a one-element list -- the transformed input stays alive for this layer's weight gradient
+            keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d), dtype=torch.float32, device=x.device)
+            _lib.call("diga_conv2d_winograd_f32_keep", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(keep_v[0]),
+                      _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tag, _lib.stream())
             return None
         _lib.call("diga_conv2d_winograd_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                   n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, tag, _lib.stream())
@@ -298,8 +304,16 @@ class _Conv2dFn(torch.autograd.Function):
         wo = ((wi << up) + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
+        # exact-fp32 Winograd layers whose weight gradient is wanted keep their transformed input (4x the input's bytes, HBM
+        # is 288 GB): the backward-weight pass then skips a bandwidth pass of 5x the input (DIGA_WINOGRAD_KEEP_V=0: recompute)
+        keep_v = None
+        if (ctx.needs_input_grad[1] and _lib.get_conv_math() == 0 and k % 256 == 0 and cp % 128 == 0 and stats is None
+                and (opts is None or not any(opts)) and os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
+                and _winograd_ok(n, hi, wi, cp, k, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
+            keep_v = [None]
         x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box,
-                              must_twin=bool(x_is_twin), opts=opts)
+                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v)
+        ctx.wino_v = keep_v[0] if keep_v is not None else None
         ctx.save_for_backward(xn, w)
         # the split twin of the input serves the weight gradient too (multi-tap / shared-input layers, Cout >= 256)
         ctx.x_twin = x_twin if (ctx.needs_input_grad[1] and k >= 256 and k % 8 == 0 and cp == c) else None
@@ -447,6 +461,9 @@ class _Conv2dFn(torch.autograd.Function):
                     dy_twin = torch.empty(n * ho * wo * kp * 4, dtype=torch.uint8, device=w.device)
                     _lib.call("diga_make_twin", _lib.ptr(gyp), kp, _lib.ptr(dy_twin), n * ho * wo, kp, st)
 
+            wino_v = getattr(ctx, "wino_v", None)
+            ctx.wino_v = None
+
             def run_twin():
                 nbytes = _lib.lib.diga_conv2d_wgrad_twin_workspace_bytes(n, ho, wo, kp, cp, r, s)
                 ws = _lib.workspace(nbytes, w.device, "wgrad")
@@ -464,8 +481,8 @@ class _Conv2dFn(torch.autograd.Function):
                     _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * 9 * cp, 2.0 * n * ho * wo * kp * 9 * cp * _wino_ratio(hi, wi, dilation[0]))
                     nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0])
                     wsw = _lib.workspace(nb, w.device, "winograd_wgrad")
-                    _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(dwp), _lib.ptr(wsw), wsw.numel(),
-                              n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], _lib.stream())
+                    _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(wino_v), _lib.ptr(dwp), _lib.ptr(wsw),
+                              wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], _lib.stream())
                     if not alias:
                         dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
                     return
@@ -496,7 +513,7 @@ class _Conv2dFn(torch.autograd.Function):
                 side.wait_stream(torch.cuda.current_stream(w.device))
                 with torch.cuda.stream(side):
                     run()
-                for tns in (gyp, xn, dwp, dw) + ((dy_twin, x_twin) if use_tw else ()):
+                for tns in (gyp, xn, dwp, dw) + ((dy_twin, x_twin) if use_tw else ()) + ((wino_v,) if wino_v is not None else ()):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))

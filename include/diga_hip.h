@@ -343,9 +343,16 @@ int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, 
  * transforms of dy and x, 16 products contracted over the tiles in one launch of the fp32 LDS-DMA backward-weight kernel
  * (fixed-order split-K: bit-reproducible), the 4x4 -> 3x3 transform.  Cout % 256 == 0, Cin % 128 == 0. */
 size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation);
-int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int64_t N,
-                                   int64_t H, int64_t W, int64_t Cin, int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation,
-                                   void* stream);
+int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
+                                   size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld, int64_t Cout,
+                                   int64_t dy_ld, int64_t dilation, void* stream);
+/* Forward that leaves its transformed input V (diga_conv2d_winograd_v_floats floats, 4x the input tensor) in `v_keep` for the
+ * weight gradient of the same layer: pass it as `v_kept` above (x may then be null) and the backward skips the input transform
+ * -- HBM is 288 GB: the transform is a bandwidth pass of 5x the input's bytes per 3x3 layer. */
+size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation);
+int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, const float* bias, float* out, float* v_keep, void* workspace,
+                                  size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
+                                  int64_t out_ld, int64_t dilation, int prof_tag, void* stream);
 
 /* diga_conv2d_nhwc_f32 / _bf16x3 / _twin with a diga_conv_options_t (non-null; inference-only: no statistics output). */
 int diga_conv2d_nhwc_f32_opts(const float* in, const float* wgt, const float* bias, float* out, int64_t N, int64_t Hi, int64_t Wi,

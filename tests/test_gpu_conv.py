@@ -368,8 +368,19 @@ def test_winograd_f32_vs_float64(case, monkeypatch):
         (y * probe.to(DEV)).sum().backward()
     finally:
         _lib.set_conv_math(prev)
-    assert calls.count("diga_conv2d_winograd_f32") == 2, calls          # forward + backward-data
-    assert ("diga_conv2d_wgrad_winograd_f32" in calls) == (cout % 256 == 0 and cin % 128 == 0), calls
+    wide = cout % 256 == 0 and cin % 128 == 0          # weight gradient through Winograd too, on the V the forward kept
+    assert calls.count("diga_conv2d_winograd_f32") + calls.count("diga_conv2d_winograd_f32_keep") == 2, calls   # forward + backward-data
+    assert ("diga_conv2d_wgrad_winograd_f32" in calls) == wide and ("diga_conv2d_winograd_f32_keep" in calls) == wide, calls
     for got, want, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (m.weight.grad, wr.grad, "dw")):
         e = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max())
         assert e < 1e-5, (what, e)
+    if wide:                                           # ... and the same gradient when the backward recomputes V
+        monkeypatch.setenv("DIGA_WINOGRAD_KEEP_V", "0")
+        dw_kept = m.weight.grad.clone()
+        m.weight.grad = None
+        _lib.set_conv_math(0)
+        try:
+            (m(xd.detach()) * probe.to(DEV)).sum().backward()
+        finally:
+            _lib.set_conv_math(prev)
+        assert torch.equal(m.weight.grad, dw_kept)
