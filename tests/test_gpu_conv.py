@@ -316,12 +316,12 @@ def test_f32_dma_kernel_bit_identical_to_register_staged_kernel():
     import subprocess
     import sys
     outs = []
-    for dma in ("0", "2"):
-        env = dict(os.environ, DIGA_CONV_F32_DMA=dma)
+    for dma in ("0", "2", "1"):             # register-staged / LDS-DMA wherever it can run / the dispatch rules (short K: the
+        env = dict(os.environ, DIGA_CONV_F32_DMA=dma, DIGA_CONV_WINOGRAD="0")      # two-blocks-per-CU variant)
         r = subprocess.run([sys.executable, "-c", _DMA_EQ_CODE, ROOT], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.count(" ") == 2])
-    assert len(outs[0]) == 10 and outs[0] == outs[1], (outs[0], outs[1])
+    assert len(outs[0]) == 10 and outs[0] == outs[1] and outs[0] == outs[2], outs
 
 
 WINO_CASES = [("d1_ragged", 3, 128, 33, 29, 160, 1), ("d1_wide", 2, 384, 31, 37, 512, 1), ("d18_97", 1, 128, 97, 97, 256, 18), ("d2_97", 2, 256, 97, 97, 256, 2), ("d4_65x129", 1, 512, 65, 129, 128, 4),
