@@ -40,7 +40,13 @@ using f32x4nt = __attribute__((ext_vector_type(4))) float;
 // channels): epilogue 17.7 k -> 10.7 k cycles per 128 KB tile and the loaders' waits 3.9 k -> 1.0 k (their L2-resident
 // weight panels are no longer evicted by the output stream).
 __device__ __forceinline__ void store4_stream(float* p, float x, float y, float z, float w) {
+#if defined(DIGA_PROBE_NOSTORE)          // diagnostic builds only (tools/diag/build_probe.sh): what the output stream costs a tile
+    if (x == 1.2345e38f) *p = y + z + w;
+#elif defined(DIGA_PROBE_PLAINSTORE)
+    *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w);
+#else
     __builtin_nontemporal_store((f32x4nt){x, y, z, w}, reinterpret_cast<f32x4nt*>(p));
+#endif
 }
 
 constexpr int kBK = 32;
@@ -1536,6 +1542,20 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_x3t8_kernel(ConvArgs a) {
 // the 64 banks exactly once.  Fragment / MFMA order per accumulator is conv_fwd_kernel's (k-group t, element e): results
 // are bit-identical to it (skipped dead taps only ever added exact zeros).
 // ---------------------------------------------------------------------------------------------
+#if defined(DIGA_PROBE_STAMP)      // diagnostic build (tools/diag/f32_tile_stamps.py): phase time stamps of MFMA wave 0 of every block
+__device__ unsigned long long g_probe_stamps[8192 * 6];
+#define DIGA_STAMP(slot_)                                                                                                  \
+    do {                                                                                                                   \
+        if (wv == 0 && lane == 0 && blockIdx.x < 8192) {                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            g_probe_stamps[blockIdx.x * 6 + (slot_)] = __builtin_amdgcn_s_memrealtime();                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+        }                                                                                                                  \
+    } while (0)
+#else
+#define DIGA_STAMP(slot_) do { } while (0)
+#endif
+
 template <bool EPI = false>
 __global__ __launch_bounds__(768, 3) void conv_fwd_dma_kernel(ConvArgs a) {
     constexpr int BM = 256, BN = 128;
@@ -1543,6 +1563,7 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_dma_kernel(ConvArgs a) {
     extern __shared__ __align__(16) unsigned char smem_b[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool loader = wv >= 8;
+    DIGA_STAMP(0);
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -1661,7 +1682,9 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_dma_kernel(ConvArgs a) {
     for (int t = 0; t < 4; ++t) foff[t] = li * 128 + (((2 * t + lh) ^ fsw) << 4);
     const int abase = wm * 64 * 128, bbase = A_BYTES + wn * 64 * 128;
 
+    DIGA_STAMP(1);
     __builtin_amdgcn_s_barrier();                                // stage 0 has landed
+    DIGA_STAMP(2);
     int cur = 0;
     for (int ks = 0; ks < ksteps; ++ks) {
         const unsigned char* As = smem_b + cur * STAGE + abase;
@@ -1698,6 +1721,7 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_dma_kernel(ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         cur = cur == 2 ? 0 : cur + 1;
     }
+    DIGA_STAMP(3);
     __syncthreads();                                             // (8 surviving waves) everyone is out of the ring
 
     // epilogue: thread group h = wv >> 2 (rows 128h .. 128h+127) stages and drains its half
@@ -1712,7 +1736,9 @@ __global__ __launch_bounds__(768, 3) void conv_fwd_dma_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e)
                 stage[((wm & 1) * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDS_LD + wn * 64 + j * 32 + li] = acc[i][j][e];
     __syncthreads();
+    DIGA_STAMP(4);
     drain_stage<2, 2, EPI>(stage, a, m0 + h * 128, n0, t, tile_m * 2 + h, m0 + h * 128 < a.M);
+    DIGA_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3400,3 +3426,9 @@ extern "C" int diga_im2col_nchw(const float* x, float* out, int64_t N, int64_t C
                        (int)R, (int)S, (int)stride, (int)pad, (int)Ho, (int)Wo, (int)Kpad);
     return launch_status("diga_im2col_nchw");
 }
+
+#if defined(DIGA_PROBE_STAMP)
+extern "C" int diga_probe_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(diga::g_probe_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
