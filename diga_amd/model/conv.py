@@ -71,6 +71,19 @@ def _log_flops(name, direct, executed):
         e[1] += executed
 
 
+_TOTAL_MEM = {}
+
+
+def _room_for(nbytes, device):
+    """Keeping a transformed input alive until the backward pass is a memory-for-bandwidth trade: only while live tensors stay
+    under 60 % of the device (288 GB on MI355X; the C2 step peaks at 128 GB with everything kept)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    total = _TOTAL_MEM.get(idx)
+    if total is None:
+        total = _TOTAL_MEM[idx] = torch.cuda.get_device_properties(idx).total_memory
+    return torch.cuda.memory_allocated(idx) + nbytes < 0.6 * total
+
+
 def _wino_ratio(hi, wi, d):
     key = (hi, wi, d)
     ratio = _WINO_CACHE.get(key)
@@ -173,7 +186,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
             _lib.call("diga_conv2d_winograd_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                       n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, ctypes.byref(epi), tag, _lib.stream())
             return None
-        if keep_v is not None and doff[0] > 0:
+        if keep_v is not None and doff[0] > 0 and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d) * 4, x.device):
             # keep_v: a one-element list -- the transformed input stays alive for this layer's weight gradient
             keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d), dtype=torch.float32, device=x.device)
             _lib.call("diga_conv2d_winograd_f32_keep", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(keep_v[0]),
