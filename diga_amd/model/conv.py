@@ -106,7 +106,9 @@ def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
     if not (r == 3 and s == 3 and tuple(stride) == (1, 1) and doff[0] == doff[1] and d >= 1 and off0[0] == -doff[0]
             and off0[1] == -doff[1] and hi == ho and wi == wo and cin % 32 == 0 and cin >= 128 and k % 4 == 0 and k >= 128):
         return False
-    return _wino_ratio(hi, wi, d) <= float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62")) and 16 * n * hi * wi < (1 << 31)
+    ratio = _wino_ratio(hi, wi, d)
+    # (the batched GEMM indexes its 16 * tiles rows as a [rows / 256][256] image with 15-bit row coordinates)
+    return ratio <= float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62")) and n * hi * wi * ratio * 9.0 / 256.0 < 32000
 
 
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,

@@ -288,3 +288,23 @@ def test_split_format_restatement_against_torch_bf16():
     w = torch.randn((70, 3, 64), generator=g).numpy()
     assert osp.weight_image(w).size == 1 * 3 * 2 * 2 * 128 * 64          # 1 tile (128 rows), 3 taps x 2 chunks, 2 planes
     assert [osp.lds_swz(r) for r in range(16)] == [0, 0, 2, 2, 2, 2, 0, 0, 3, 3, 1, 1, 1, 1, 3, 3]
+
+
+def test_winograd_gate_and_tile_ratio():
+    """Host side of the Winograd path (diga_amd/model/conv.py): the multiplication ratio 16 * tiles / (9 * H * W) of the
+    sub-image tiling -- 97x97 maps: 49 x 49 tiles per image at dilation 6, 12 and 24, 54 x 54 at 18 -- and the gate: 3x3,
+    stride 1, padding = dilation in either direction (forward / backward-data offsets), wide enough, not too many tiles."""
+    from diga_amd.model import conv as dc
+    assert dc._wino_ratio(97, 97, 6) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))
+    assert dc._wino_ratio(97, 97, 12) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))
+    assert dc._wino_ratio(97, 97, 24) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))
+    assert dc._wino_ratio(97, 97, 18) == pytest.approx(16 * 54 * 54 / (9 * 97 * 97))
+    assert dc._wino_ratio(4, 4, 1) == pytest.approx(16 * 4 / (9 * 16))
+    ok = dc._winograd_ok
+    assert ok(16, 97, 97, 256, 256, 3, 3, (1, 1), (-2, -2), (2, 2), 97, 97)            # layer3 conv2, forward
+    assert ok(16, 97, 97, 256, 256, 3, 3, (1, 1), (2, 2), (-2, -2), 97, 97)            # ... backward-data (taps reversed)
+    assert not ok(16, 97, 97, 256, 256, 3, 3, (1, 1), (-1, -1), (2, 2), 97, 97)        # padding != dilation
+    assert not ok(16, 97, 97, 256, 256, 3, 3, (2, 2), (-2, -2), (2, 2), 49, 49)        # strided
+    assert not ok(16, 97, 97, 64, 256, 3, 3, (1, 1), (-2, -2), (2, 2), 97, 97)         # narrow input
+    assert not ok(16, 97, 97, 256, 256, 1, 1, (1, 1), (0, 0), (1, 1), 97, 97)          # pointwise
+    assert not ok(64, 385, 385, 256, 256, 3, 3, (1, 1), (-1, -1), (1, 1), 385, 385)    # more tile rows than one launch indexes
