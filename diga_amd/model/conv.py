@@ -71,17 +71,15 @@ def _log_flops(name, direct, executed):
         e[1] += executed
 
 
-_TOTAL_MEM = {}
-
-
 def _room_for(nbytes, device):
-    """Keeping a transformed input alive until the backward pass is a memory-for-bandwidth trade: only while live tensors stay
-    under 60 % of the device (288 GB on MI355X; the C2 step peaks at 128 GB with everything kept)."""
+    """Keeping a transformed input alive until the backward pass is a memory-for-bandwidth trade: only while, after the
+    allocation, a quarter of the device (72 of the MI355X's 288 GB) would still be free -- counting what the driver reports
+    free (other processes on the GPU included: two test ranks may share one) plus this process's cached blocks.  The C2 step
+    peaks at 128 GB with everything kept."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    total = _TOTAL_MEM.get(idx)
-    if total is None:
-        total = _TOTAL_MEM[idx] = torch.cuda.get_device_properties(idx).total_memory
-    return torch.cuda.memory_allocated(idx) + nbytes < 0.6 * total
+    free, total = torch.cuda.mem_get_info(idx)
+    cached = torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx)
+    return free + cached - nbytes > 0.25 * total
 
 
 def _wino_ratio(hi, wi, d):
