@@ -303,7 +303,8 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
         # (here: the same synthetic labels) are fetched on a side stream (DigaTrainer.prefetch_classmix) -- the histogram launch
         # and its D->H copy still happen once per step, they just no longer drain the GPU at the top of the next step
         out_ = inner_step(i)
-        tr.prefetch_classmix(labels)
+        if os.environ.get('DIGA_BENCH_NO_PREFETCH') != '1':
+            tr.prefetch_classmix(labels)
         return out_
 
     it = 0
@@ -384,7 +385,8 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
     if prof:
         _lib.call("diga_prof_reset")
     del tr, student, teacher, batch, one_step, inner_step, labels
-    torch.cuda.empty_cache()
+    if os.environ.get('DIGA_BENCH_NO_EMPTY_CACHE') != '1':
+        torch.cuda.empty_cache()
     return float(t), (families, families_overlapped), losses, counts, (B, H, W, arch_name)
 
 

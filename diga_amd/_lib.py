@@ -76,7 +76,7 @@ SIGNATURES = {
     "diga_conv2d_winograd_workspace_bytes": (SZ, [I64] * 6),
     "diga_conv2d_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 8 + [INT, INT, P]),
     "diga_conv2d_winograd_f32_epi": (INT, [P, P, P, P, SZ] + [I64] * 8 + [INT, P, INT, P]),
-    "diga_conv2d_wgrad_winograd_workspace_bytes": (SZ, [I64] * 6),
+    "diga_conv2d_wgrad_winograd_workspace_bytes": (SZ, [I64] * 6 + [INT]),
     "diga_conv2d_wgrad_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 8 + [P]),
     "diga_conv2d_winograd_v_floats": (SZ, [I64] * 5),
     "diga_conv2d_winograd_f32_keep": (INT, [P, P, P, P, P, P, SZ] + [I64] * 8 + [INT, P]),

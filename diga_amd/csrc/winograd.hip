@@ -399,11 +399,11 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 struct WinoWgradLayout {
     size_t tab, V, Z, dU, slab, total;
 };
-WinoWgradLayout wino_wgrad_layout(const WinoGeom& g, int64_t Cin, int64_t Cout) {
+WinoWgradLayout wino_wgrad_layout(const WinoGeom& g, int64_t Cin, int64_t Cout, bool with_v) {
     WinoWgradLayout l;
     size_t o = 0;
     l.tab = o; o += (size_t)g.Tp * sizeof(int4);
-    l.V = o; o += (size_t)16 * g.Tp * Cin * sizeof(float);
+    l.V = o; o += with_v ? (size_t)16 * g.Tp * Cin * sizeof(float) : 0;        // (not when the forward's V was kept)
     l.Z = o; o += (size_t)16 * g.Tp * Cout * sizeof(float);
     l.dU = o; o += (size_t)16 * Cout * Cin * sizeof(float);
     l.slab = o; o += wgrad_batched_slab_bytes(g.Tp, 16, Cout, Cin);
@@ -526,9 +526,9 @@ extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, f
 }
 
 extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
-                                                             int64_t dilation) {
+                                                             int64_t dilation, int v_kept) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || Cout % 256 != 0 || Cin % 128 != 0) return 0;
-    return wino_wgrad_layout(make_wino(N, H, W, dilation), Cin, Cout).total;
+    return wino_wgrad_layout(make_wino(N, H, W, dilation), Cin, Cout, v_kept == 0).total;
 }
 
 extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
@@ -543,7 +543,7 @@ extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, c
     DIGA_REQUIRE(aligned16(dy) && (!x || aligned16(x)) && aligned16(dw) && aligned16(workspace), DIGA_EALIGN,
                  "conv2d_wgrad_winograd: pointers must be 16-byte aligned");
     const WinoGeom g = make_wino(N, H, W, dilation);
-    const WinoWgradLayout l = wino_wgrad_layout(g, Cin, Cout);
+    const WinoWgradLayout l = wino_wgrad_layout(g, Cin, Cout, v_kept == nullptr);
     DIGA_REQUIRE(workspace_bytes >= l.total, DIGA_EWORKSPACE, "conv2d_wgrad_winograd: workspace too small (%zu < %zu)", workspace_bytes,
                  l.total);
     char* ws = static_cast<char*>(workspace);

@@ -73,13 +73,13 @@ def _log_flops(name, direct, executed):
 
 def _room_for(nbytes, device):
     """Keeping a transformed input alive until the backward pass is a memory-for-bandwidth trade: only while, after the
-    allocation, a quarter of the device (72 of the MI355X's 288 GB) would still be free -- counting what the driver reports
+    allocation, 40 % of the device (115 of the MI355X's 288 GB) would still be free -- counting what the driver reports
     free (other processes on the GPU included: two test ranks may share one) plus this process's cached blocks.  The C2 step
     peaks at 128 GB with everything kept."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     free, total = torch.cuda.mem_get_info(idx)
     cached = torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx)
-    return free + cached - nbytes > 0.25 * total
+    return free + cached - nbytes > 0.4 * total
 
 
 def _wino_ratio(hi, wi, d):
@@ -492,7 +492,7 @@ class _Conv2dFn(torch.autograd.Function):
                 if (_lib.get_conv_math() == 0 and kp % 256 == 0 and cp % 128 == 0 and gyp.stride(2) % 4 == 0
                         and _winograd_ok(n, hi, wi, cp, kp, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
                     _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * 9 * cp, 2.0 * n * ho * wo * kp * 9 * cp * _wino_ratio(hi, wi, dilation[0]))
-                    nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0])
+                    nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0], 1 if wino_v is not None else 0)
                     wsw = _lib.workspace(nb, w.device, "winograd_wgrad")
                     _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(wino_v), _lib.ptr(dwp), _lib.ptr(wsw),
                               wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], _lib.stream())

@@ -20,6 +20,25 @@ from diga_amd.util import loss as L
 from diga_amd.util import utils as U
 
 
+_STREAMS = {}
+
+
+def _shared_stream(device, role):
+    """The step driver's side streams (teacher forward, ClassMix prefetch) exist once per device and process, not once per
+    DigaTrainer: every new HIP stream may become another hardware queue, and a process that had built a second trainer (the
+    bench's second leg) next to another process on the same GPU (the 2-rank gloo test configuration) ran every kernel 25-75x
+    slower once the queues were oversubscribed (tools/diag/two_rank_legs.sh)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _STREAMS.get((idx, role))
+    if st is None:
+        st = _STREAMS[(idx, role)] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _prefetch_stream(device):
+    return _shared_stream(device, "prefetch")
+
+
 class DigaTrainer:
     def __init__(self, student, teacher, base_lr=2.5e-4, max_iter=80000, power=0.9, momentum=0.9,
                  weight_decay=5e-4, rng=random, distill_scale=0.5, centroid_exchange=None, graph=None):
@@ -59,7 +78,7 @@ class DigaTrainer:
         if not labels.is_cuda:
             return
         if getattr(self, "_pf_stream", None) is None:
-            self._pf_stream = torch.cuda.Stream(device=labels.device)
+            self._pf_stream = _prefetch_stream(labels.device)          # one per device and process, not per trainer
             self._pf = {}
         host, ev = U.classmix_present_async(labels, self._pf_stream)
         self._pf[(labels.data_ptr(), labels._version, tuple(labels.shape))] = (host, ev)
@@ -91,7 +110,7 @@ class DigaTrainer:
             with torch.no_grad():
                 return [self.teacher(x)[2:4] for x in inputs]
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+            self._side = _shared_stream(dev, "teacher")
         main = torch.cuda.current_stream(dev)
         self._side.wait_stream(main)                 # EMA update of the teacher and the inputs are ready
         with torch.cuda.stream(self._side), torch.no_grad():

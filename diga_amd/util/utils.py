@@ -213,20 +213,50 @@ def classmix_present(labels):
     return [np.nonzero(present[i])[0].tolist() for i in range(b)]
 
 
+class PinnedRing(object):
+    """A few page-locked host buffers reused round-robin for the step's small asynchronous copies.  Allocating page-locked
+    memory inside the step is not free: every allocation maps pages into the GPU's address space, and with two processes on
+    one GPU (the 2-rank test configuration) a fresh pinned allocation per step slowed every kernel of BOTH processes down
+    25-75x (tools/diag/two_rank_legs.sh).  A slot is handed out again only after the event of its previous use completed."""
+
+    def __init__(self, shape, dtype, slots=4):
+        self.bufs = [torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+
+    def take(self):
+        i = self.i
+        self.i = (i + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        return i, self.bufs[i]
+
+    def mark(self, i, event):
+        self.events[i] = event
+
+
+_PRESENT_RINGS = {}
+
+
 def classmix_present_async(labels, stream):
     """classmix_present started on `stream` (a side stream): returns (pinned host tensor [B,256] of 0/1, event).  The caller
     guarantees that `labels` is complete (its producer has finished); nothing here waits for the current stream, so the D->H copy
-    does not queue behind the training step in flight.  `present_lists(host)` turns the result into the per-image lists."""
+    does not queue behind the training step in flight.  `present_lists(host)` turns the result into the per-image lists (read it
+    before four more calls with the same batch size reuse the buffer)."""
     _lib.require_gpu(labels)
     lab = _lib.contiguous(labels, torch.int64)
     b = lab.shape[0]
+    ring = _PRESENT_RINGS.get(b)
+    if ring is None:
+        ring = _PRESENT_RINGS[b] = PinnedRing((b, 256), torch.bool, slots=8)
     with torch.cuda.stream(stream):
         hist = torch.zeros((b, 256), dtype=torch.int32, device=lab.device)
         _lib.call("diga_label_hist256", _lib.ptr(lab), _lib.ptr(hist), b, lab[0].numel(), _lib.stream())
-        host = torch.empty((b, 256), dtype=torch.bool, pin_memory=True)
+        slot, host = ring.take()
         host.copy_(hist != 0, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(stream)
+        ring.mark(slot, ev)
     lab.record_stream(stream)
     return host, ev
 
@@ -345,6 +375,7 @@ class DigaSGD(torch.optim.Optimizer):
         self._tab = TensorTables([p.numel() for p in self._params], dev)
         self._mult_dev = torch.tensor(self._mult, dtype=torch.int32, device=dev)
         self._lr_host = None
+        self._lr_ring = None
         self._lr_dev = torch.empty(len(self._params), dtype=torch.float32, device=dev)
 
     @torch.no_grad()
@@ -362,10 +393,16 @@ class DigaSGD(torch.optim.Optimizer):
             grads.append(g)
         lrs = [float(self.param_groups[gi]["lr"]) for gi in self._group_of]
         if lrs != self._lr_host:
-            # (the poly schedule changes the rates every step.)  Asynchronous copy from a fresh PINNED buffer: a blocking copy
-            # from pageable memory here drained the stream once per step -- the host could never run ahead of the GPU; the
-            # caching host allocator keeps the buffer alive until the copy has executed
-            self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32).pin_memory(), non_blocking=True)
+            # (the poly schedule changes the rates every step.)  Asynchronous copy from a page-locked ring slot: a blocking
+            # copy from pageable memory here drained the stream once per step -- the host could never run ahead of the GPU
+            if self._lr_ring is None:
+                self._lr_ring = PinnedRing((len(lrs),), torch.float32, slots=4)
+            slot, pin = self._lr_ring.take()
+            pin.copy_(torch.tensor(lrs, dtype=torch.float32))
+            self._lr_dev.copy_(pin, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._lr_ring.mark(slot, ev)
             self._lr_host = lrs
         tab = self._tab
         pp = tab.pointers("p", [p.data for p in self._params])

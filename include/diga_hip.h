@@ -342,7 +342,8 @@ int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, 
 /* Backward-weight of the same layer through Winograd (dw [Cout][3][3][Cin] = G^T [sum over tiles (A dY A^T) (.) (B^T d B)] G):
  * transforms of dy and x, 16 products contracted over the tiles in one launch of the fp32 LDS-DMA backward-weight kernel
  * (fixed-order split-K: bit-reproducible), the 4x4 -> 3x3 transform.  Cout % 256 == 0, Cin % 128 == 0. */
-size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation);
+size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation,
+                                                  int v_kept /* 1: the call will pass the forward's kept V */);
 int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
                                    size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld, int64_t Cout,
                                    int64_t dy_ld, int64_t dilation, void* stream);
