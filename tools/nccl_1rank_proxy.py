@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-GPU proxy for the N>1 RCCL path:  python tools/nccl_1rank_proxy.py <B> <crop>   (e.g. 8 768)."""
+"""One-GPU proxy for the N>1 RCCL path:  python tools/nccl_1rank_proxy.py <B> <crop> [f32|bf16x3]   (e.g. 8 768 f32)."""
 # Proxy for the N>1 RCCL path on one GPU: a 1-rank "nccl" process group with the gradient reducer forced on, so that every
 # step runs hook-driven RCCL all-reduces (RCCL stream + events) next to the teacher / weight-gradient side streams.
 import os, sys, time, random
@@ -13,7 +13,7 @@ ddp.world_size = lambda: 2            # make the reducer (and its hooks) believe
 from diga_amd.model import seg_model_noaux as sm
 from diga_amd.model.model_noaux import SegModel
 from diga_amd.train_step import DigaTrainer
-_lib.set_conv_math(1)
+_lib.set_conv_math(0 if (len(sys.argv) > 3 and sys.argv[3] == 'f32') else 1)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 student, teacher = SegModel(arch=sm.RESNET101).to(dev), SegModel(arch=sm.RESNET101).to(dev)
