@@ -2738,6 +2738,163 @@ static int set_bwd_epilogue(ConvArgs& a, const diga_bwd_epilogue_t* e, const cha
     return DIGA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Plain fp32 GEMM out [M x Cout] = A [M x K] * W^T (W [Cout][K], one panel per `wb_tiles` 256-row tiles) as a PERSISTENT
+// version of conv_fwd_dma_kernel: 256 blocks (one per CU), each walking its share of the 256 x 128 tiles in one continuous
+// stream of K-steps through the three-stage LDS-DMA ring.  The loader waves run two steps ahead ACROSS tile boundaries, so
+// the next tile's first stages land under the current tile's last steps (a fresh block waits 3.3-3.9 us for them, sets up for
+// 0.6 us and follows its predecessor by 1.7 us: 13 % of a K = 256 tile); a finished tile leaves the accumulators by
+// non-temporal stores straight from the registers (128-byte row pieces: a 32x32 accumulator tile holds 32 consecutive
+// columns over the lanes) -- no LDS staging, no extra barrier, the stores drain under the next tile's MFMAs.  XCD x owns a
+// contiguous range of tiles (as xcd_remap gives it); its 32 blocks take them round-robin.  Same MFMA order per accumulator
+// as conv_fwd_dma_kernel: bit-identical results.  M % 256 == 0, K % 32 == 0, Cout % 128 == 0.
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* A;
+    const float* W;
+    float* out;
+    int M, K, Cout, tiles_m, tiles_n, wb_tiles;
+    int64_t wb_stride;
+};
+
+__global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g) {
+    constexpr int A_BYTES = 256 * 128, B_BYTES = 128 * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool loader = wv >= 8;
+    const int total = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, len = q + (xcd < r ? 1 : 0);
+    const int nmine = slot < len ? (len - slot + nslots - 1) / nslots : 0;
+    if (nmine == 0) return;                                      // (uniform over the block)
+    const int ksteps = g.K / 32;
+    const int total_steps = nmine * ksteps;
+    const int64_t rowb = (int64_t)g.K * 4;
+
+    if (loader) {
+        const int lw = wv - 8;
+        const int lrow = lane >> 3;
+        const unsigned char* pa[8];
+        const unsigned char* pb[4];
+        int l_it = 0, l_cc = 0, issued = 0;
+        auto set_tile = [&](int it) {
+            const int t = start + slot + nslots * it;
+            const int tile_n = t % g.tiles_n, tile_m = t / g.tiles_n;
+            const unsigned char* ab = reinterpret_cast<const unsigned char*>(g.A) + (int64_t)(tile_m * 256 + lw * 64 + lrow) * rowb;
+            const unsigned char* wb = reinterpret_cast<const unsigned char*>(g.W + (int64_t)(tile_m / g.wb_tiles) * g.wb_stride) +
+                                      (int64_t)(tile_n * 128 + lw * 32 + lrow) * rowb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] = ab + (int64_t)(8 * j) * rowb + (((lane & 7) ^ (((8 * j + lrow) >> 1) & 7)) << 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pb[c] = wb + (int64_t)(8 * c) * rowb + (((lane & 7) ^ (((8 * c + lrow) >> 1) & 7)) << 4);
+        };
+        auto issue = [&](int buf) {
+            unsigned char* stage = smem_b + buf * STAGE;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + l_cc * 128),
+                                                 (__attribute__((address_space(3))) void*)(stage + (lw * 64 + 8 * j) * 128), 16, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[c] + l_cc * 128),
+                                                 (__attribute__((address_space(3))) void*)(stage + A_BYTES + (lw * 32 + 8 * c) * 128), 16, 0, 0);
+            ++issued;
+            if (++l_cc == ksteps) {
+                l_cc = 0;
+                if (++l_it < nmine) set_tile(l_it);
+            }
+        };
+        auto wait_next = [&](bool newest_in_flight) {            // 12 loads per stage and loader wave
+            if (newest_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        set_tile(0);
+        issue(0);
+        if (total_steps > 1) issue(1);
+        wait_next(total_steps > 1);
+        int nx = 2;
+        for (int gs = 0; gs < total_steps; ++gs) {
+            const bool ahead = gs + 2 < total_steps;
+            if (ahead) issue(nx);
+            wait_next(ahead);
+            nx = nx == 2 ? 0 : nx + 1;
+        }
+        return;
+    }
+
+    const int wm = wv >> 1, wn = wv & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    const int fsw = (li >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) foff[t] = li * 128 + (((2 * t + lh) ^ fsw) << 4);
+    const int abase = wm * 64 * 128, bbase = A_BYTES + wn * 64 * 128;
+
+    __builtin_amdgcn_s_barrier();                                // stage 0 has landed
+    int cur = 0, it = 0, ks_in_tile = 0;
+    for (int gs = 0; gs < total_steps; ++gs) {
+        const unsigned char* As = smem_b + cur * STAGE + abase;
+        const unsigned char* Bs = smem_b + cur * STAGE + bbase;
+        float4 fa[2][2], fb[2][2];
+        fa[0][0] = *reinterpret_cast<const float4*>(As + foff[0]);
+        fa[0][1] = *reinterpret_cast<const float4*>(As + foff[0] + 32 * 128);
+        fb[0][0] = *reinterpret_cast<const float4*>(Bs + foff[0]);
+        fb[0][1] = *reinterpret_cast<const float4*>(Bs + foff[0] + 32 * 128);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p = t & 1;
+            if (t + 1 < 4) {
+                fa[p ^ 1][0] = *reinterpret_cast<const float4*>(As + foff[t + 1]);
+                fa[p ^ 1][1] = *reinterpret_cast<const float4*>(As + foff[t + 1] + 32 * 128);
+                fb[p ^ 1][0] = *reinterpret_cast<const float4*>(Bs + foff[t + 1]);
+                fb[p ^ 1][1] = *reinterpret_cast<const float4*>(Bs + foff[t + 1] + 32 * 128);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float av = e == 0 ? fa[p][i].x : e == 1 ? fa[p][i].y : e == 2 ? fa[p][i].z : fa[p][i].w;
+                        const float bv = e == 0 ? fb[p][j].x : e == 1 ? fb[p][j].y : e == 2 ? fb[p][j].z : fb[p][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+        if (++ks_in_tile == ksteps) {
+            // tile finished: accumulator register e of a 32x32 tile is row (e & 3) + 8 (e >> 2) + 4 lh, column li
+            const int t = start + slot + nslots * it;
+            const int tile_n = t % g.tiles_n, tile_m = t / g.tiles_n;
+            float* o = g.out + (int64_t)(tile_m * 256 + wm * 64 + 4 * lh) * g.Cout + tile_n * 128 + wn * 64 + li;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        __builtin_nontemporal_store(acc[i][j][e], o + (int64_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * g.Cout + j * 32);
+                        acc[i][j][e] = 0.f;
+                    }
+            ks_in_tile = 0;
+            ++it;
+        }
+    }
+}
+
 // `batches` independent products out_b [rows x Cout] = A_b [rows x K] * W_b^T (W_b [Cout][K]) in one launch of
 // conv_fwd_dma_kernel: the operands of all batches are stacked row-wise (A [batches * rows][K], out likewise,
 // W [batches][Cout][K]); rows % 256 == 0 so that no 256-row tile straddles two batches.  Used by winograd.hip.
@@ -2761,6 +2918,15 @@ int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, in
     a.wb_stride = Cout * K;
     const unsigned grid = (unsigned)((M / 256) * a.tiles_n);
     const size_t sh = 3 * (256 + 128) * 128;
+    static const int persist = [] { const char* e = getenv("DIGA_CONV_F32_PERSIST"); return e ? atoi(e) : 1; }();
+    if (persist && Cout % 128 == 0 && grid >= 512) {
+        GemmArgs g;
+        g.A = A; g.W = W; g.out = out; g.M = (int)M; g.K = (int)K; g.Cout = (int)Cout;
+        g.tiles_m = (int)(M / 256); g.tiles_n = a.tiles_n; g.wb_tiles = a.wb_tiles; g.wb_stride = a.wb_stride;
+        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(gemm_f32_persistent_kernel, dim3(256), dim3(768), sh, st, g);
+        return DIGA_OK;
+    }
     (void)hipFuncSetAttribute((const void*)conv_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(conv_fwd_dma_kernel<false>, dim3(grid), dim3(768), sh, st, a);
     return DIGA_OK;

@@ -384,3 +384,35 @@ def test_winograd_f32_vs_float64(case, monkeypatch):
         finally:
             _lib.set_conv_math(prev)
         assert torch.equal(m.weight.grad, dw_kept)
+
+
+_PERSIST_EQ_CODE = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+from diga_amd import _lib
+from diga_amd.model.conv import DigaConv2d
+_lib.set_conv_math(0)
+torch.manual_seed(5)
+g = torch.Generator().manual_seed(99)
+for name, n, cin, h, w, cout, d in [("d2", 2, 128, 97, 97, 256, 2), ("d6", 3, 256, 65, 129, 128, 6)]:
+    x = torch.randn((n, cin, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    m = DigaConv2d(cin, cout, 3, padding=d, dilation=d, bias=False).cuda()
+    y = m(x)
+    (y * torch.randn(y.shape, generator=g).cuda()).sum().backward()
+    for what, v in (("y", y), ("dx", x.grad)):
+        print(name, what, hashlib.sha256(v.detach().contiguous().cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_persistent_gemm_bit_identical_to_per_tile_launch():
+    """The 16 Winograd products on gemm_f32_persistent_kernel (256 blocks walking the tiles, next tile's stages prefetched under
+    the current one, accumulators stored from registers) equal the per-tile launch of conv_fwd_dma_kernel bit for bit."""
+    import subprocess
+    import sys
+    outs = []
+    for persist in ("0", "1"):
+        env = dict(os.environ, DIGA_CONV_F32_PERSIST=persist, DIGA_CONV_WINOGRAD="1", DIGA_CONV_WINOGRAD_RATIO="10")
+        r = subprocess.run([sys.executable, "-c", _PERSIST_EQ_CODE, ROOT], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.count(" ") == 2])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], outs
