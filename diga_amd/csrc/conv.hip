@@ -2753,8 +2753,11 @@ struct GemmArgs {
     const float* A;
     const float* W;
     float* out;
-    int M, K, Cout, tiles_m, tiles_n, wb_tiles;
+    int M, K, Cout, tiles_m, tiles_n, wb_tiles;      // M: valid rows (tiles_m = ceil(M / 256); rows beyond M load zeros, store nothing)
     int64_t wb_stride;
+    int64_t a_ld, out_ld;                            // floats between rows of A / out
+    const float* bias;                               // nullable [Cout]
+    float* stats;                                    // nullable [ceil(M / 64)][3][Cout]: {sum (y - s), sum (y - s)^2, s = first row} per 64-row chunk
 };
 
 __global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g) {
@@ -2770,7 +2773,7 @@ __global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g)
     if (nmine == 0) return;                                      // (uniform over the block)
     const int ksteps = g.K / 32;
     const int total_steps = nmine * ksteps;
-    const int64_t rowb = (int64_t)g.K * 4;
+    const int64_t rowb = g.a_ld * 4, wrowb = (int64_t)g.K * 4;
 
     if (loader) {
         const int lw = wv - 8;
@@ -2781,20 +2784,24 @@ __global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g)
         auto set_tile = [&](int it) {
             const int t = start + slot + nslots * it;
             const int tile_n = t % g.tiles_n, tile_m = t / g.tiles_n;
-            const unsigned char* ab = reinterpret_cast<const unsigned char*>(g.A) + (int64_t)(tile_m * 256 + lw * 64 + lrow) * rowb;
-            const unsigned char* wb = reinterpret_cast<const unsigned char*>(g.W + (int64_t)(tile_m / g.wb_tiles) * g.wb_stride) +
-                                      (int64_t)(tile_n * 128 + lw * 32 + lrow) * rowb;
+            const int row0 = tile_m * 256 + lw * 64 + lrow;
+            const unsigned char* ab = reinterpret_cast<const unsigned char*>(g.A) + (int64_t)row0 * rowb;
+            const unsigned char* wb = reinterpret_cast<const unsigned char*>(g.W + (g.wb_tiles > 0 ? (int64_t)(tile_m / g.wb_tiles) * g.wb_stride : 0)) +
+                                      (int64_t)(tile_n * 128 + lw * 32 + lrow) * wrowb;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pa[j] = ab + (int64_t)(8 * j) * rowb + (((lane & 7) ^ (((8 * j + lrow) >> 1) & 7)) << 4);
+            for (int j = 0; j < 8; ++j)
+                pa[j] = row0 + 8 * j < g.M ? ab + (int64_t)(8 * j) * rowb + (((lane & 7) ^ (((8 * j + lrow) >> 1) & 7)) << 4) : nullptr;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) pb[c] = wb + (int64_t)(8 * c) * rowb + (((lane & 7) ^ (((8 * c + lrow) >> 1) & 7)) << 4);
+            for (int c = 0; c < 4; ++c) pb[c] = wb + (int64_t)(8 * c) * wrowb + (((lane & 7) ^ (((8 * c + lrow) >> 1) & 7)) << 4);
         };
         auto issue = [&](int buf) {
             unsigned char* stage = smem_b + buf * STAGE;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + l_cc * 128),
+            for (int j = 0; j < 8; ++j) {
+                const unsigned char* src = pa[j] != nullptr ? pa[j] + l_cc * 128 : g_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(stage + (lw * 64 + 8 * j) * 128), 16, 0, 0);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[c] + l_cc * 128),
@@ -2879,16 +2886,42 @@ __global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g)
             // tile finished: accumulator register e of a 32x32 tile is row (e & 3) + 8 (e >> 2) + 4 lh, column li
             const int t = start + slot + nslots * it;
             const int tile_n = t % g.tiles_n, tile_m = t / g.tiles_n;
-            float* o = g.out + (int64_t)(tile_m * 256 + wm * 64 + 4 * lh) * g.Cout + tile_n * 128 + wn * 64 + li;
+            const int row_w = tile_m * 256 + wm * 64;                          // first row of this wave's 64 x 64 piece
+            const int col_w = tile_n * 128 + wn * 64 + li;
+            float* o = g.out + (int64_t)(row_w + 4 * lh) * g.out_ld + col_w;
+            const int rows_left = g.M - (row_w + 4 * lh);                      // row offset r is valid iff r < rows_left
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const float bv = g.bias != nullptr ? g.bias[col_w + j * 32] : 0.f;
+                // what the BatchNorm after the conv needs, per 64-row chunk (= this wave's rows) and column: shift s = the chunk's
+                // first row (register 0 of the lower lane half), sum (y - s), sum (y - s)^2 over the valid rows
+                const float sh = __shfl(acc[0][j][0] + bv, li, 64);
+                float sd = 0.f, sd2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        __builtin_nontemporal_store(acc[i][j][e], o + (int64_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * g.Cout + j * 32);
+                        const int r = i * 32 + (e & 3) + 8 * (e >> 2);
+                        const float v = acc[i][j][e] + bv;
+                        if (r < rows_left) {
+                            __builtin_nontemporal_store(v, o + (int64_t)r * g.out_ld + j * 32);
+                            const float d = v - sh;
+                            sd += d;
+                            sd2 += d * d;
+                        }
                         acc[i][j][e] = 0.f;
                     }
+                if (g.stats != nullptr && row_w < g.M) {
+                    sd += __shfl_xor(sd, 32, 64);
+                    sd2 += __shfl_xor(sd2, 32, 64);
+                    if (lh == 0) {
+                        float* sp = g.stats + (int64_t)(row_w >> 6) * 3 * g.Cout + col_w + j * 32;
+                        sp[0] = sd;
+                        sp[g.Cout] = sd2;
+                        sp[2 * g.Cout] = sh;
+                    }
+                }
+            }
             ks_in_tile = 0;
             ++it;
         }
@@ -2923,6 +2956,7 @@ int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, in
         GemmArgs g;
         g.A = A; g.W = W; g.out = out; g.M = (int)M; g.K = (int)K; g.Cout = (int)Cout;
         g.tiles_m = (int)(M / 256); g.tiles_n = a.tiles_n; g.wb_tiles = a.wb_tiles; g.wb_stride = a.wb_stride;
+        g.a_ld = K; g.out_ld = Cout; g.bias = nullptr; g.stats = nullptr;
         (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL(gemm_f32_persistent_kernel, dim3(256), dim3(768), sh, st, g);
         return DIGA_OK;
@@ -2930,6 +2964,15 @@ int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, in
     (void)hipFuncSetAttribute((const void*)conv_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(conv_fwd_dma_kernel<false>, dim3(grid), dim3(768), sh, st, a);
     return DIGA_OK;
+}
+
+// A stride-1 pointwise convolution in fp32 with enough tiles for two rounds goes to gemm_f32_persistent_kernel (shape rule
+// only: the statistics buffer's chunk size must be known to the caller, diga_conv2d_stats_chunk_rows).
+bool pointwise_persistent_ok(int64_t M, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t R,
+                             int64_t S, int64_t sy, int64_t sx, int64_t oy0, int64_t ox0) {
+    static const int persist = [] { const char* e = getenv("DIGA_CONV_F32_PERSIST"); return e ? atoi(e) : 1; }();
+    return persist != 0 && R == 1 && S == 1 && sy == 1 && sx == 1 && oy0 == 0 && ox0 == 0 && Hi == Ho && Wi == Wo && Cin % 32 == 0 &&
+           Cout % 128 == 0 && ceil_div(M, 256) * (Cout / 128) >= 512;
 }
 
 }  // namespace diga
@@ -2982,6 +3025,18 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
     // measured on the C2 shapes (tools/bench_conv.py, same box) it wins 5-12 % (22 % with dead taps) from K >= 256 into
     // >= 256 channels and loses 5-10 % on the 128-channel / K = 64 layers, which stay on the 128 x 128 kernel at two
     // blocks per CU.  DIGA_CONV_F32_DMA=0 / 2: never / wherever it can run.
+    if (pointwise_persistent_ok(N * Ho * Wo, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride_y, stride_x, off_y0, off_x0) && epi == nullptr &&
+        !(opts && (opts->reflect_pad || opts->upsample_shift || opts->activation)) ) {
+        // 1x1, stride 1: the persistent GEMM (statistics per 64-row chunk: diga_conv2d_stats_chunk_rows)
+        GemmArgs g;
+        g.A = in; g.W = wgt; g.out = out; g.M = a.M; g.K = (int)Cin; g.Cout = (int)Cout;
+        g.tiles_m = (int)ceil_div(a.M, 256); g.tiles_n = (int)(Cout / 128); g.wb_tiles = 0; g.wb_stride = 0;
+        g.a_ld = in_ld; g.out_ld = out_ld; g.bias = bias; g.stats = stats_partial;
+        const size_t shp = 3 * (256 + 128) * 128;
+        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp);
+        hipLaunchKernelGGL(gemm_f32_persistent_kernel, dim3(256), dim3(768), shp, st, g);
+        return launch_status("diga_conv2d_nhwc_f32");
+    }
     const bool dma_ok = Cout > 64 && bk == 32 && a.M >= 256;
     if (dma_ok && (dma_env == 2 || (dma_env == 1 && Cout >= 256 && R * S * Cin >= 256))) {
         // (the BatchNorm partials keep their 128-row chunks)
@@ -3266,7 +3321,14 @@ extern "C" int diga_conv2d_nhwc_twin_opts(const void* in_twin, const void* wgt_i
 }
 
 extern "C" size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout) {
-    return (size_t)ceil_div(N * Ho * Wo, 128) * 3 * (size_t)Cout;
+    return (size_t)ceil_div(N * Ho * Wo, 64) * 3 * (size_t)Cout;       // (room for 64-row chunks)
+}
+
+extern "C" int diga_conv2d_stats_chunk_rows(int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout,
+                                            int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
+                                            int math) {
+    return (math == DIGA_CONV_MATH_F32 && pointwise_persistent_ok(N * Ho * Wo, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride_y, stride_x, off_y0, off_x0))
+               ? 64 : 128;
 }
 
 

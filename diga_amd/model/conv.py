@@ -605,5 +605,8 @@ class DigaConv2d(nn.Conv2d):
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
                          twin_box)
         if stats is not None:
-            y._diga_bn_partials = (stats, 128)       # picked up by the DigaBatchNorm2d that consumes y
+            chunk = _lib.lib.diga_conv2d_stats_chunk_rows(n, h, w, _pad_to(self.in_channels), ho, wo, self.out_channels,
+                                                          self.kernel_size[0], self.kernel_size[1], self.stride[0], self.stride[1],
+                                                          -self.padding[0], -self.padding[1], _lib.get_conv_math())
+            y._diga_bn_partials = (stats, chunk)     # picked up by the DigaBatchNorm2d that consumes y
         return y

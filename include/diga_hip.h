@@ -225,6 +225,11 @@ int diga_conv2d_nhwc_f32(const float* in, const float* wgt, const float* bias, f
  * tile and channel, sum(y - s), sum((y - s)^2), s -- the column-statistics partials of the BatchNorm that follows the
  * conv (diga_bn_fwd_partials), which then needs no statistics pass of its own over y. */
 size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout);
+/* Rows per statistics chunk the forward entry point will use for this layer: 128, or 64 where an fp32 stride-1 pointwise layer
+ * runs on the persistent GEMM (each wave reduces its own 64 rows in registers).  Pass it to diga_bn_fwd_partials as chunk_rows;
+ * diga_conv2d_stats_floats sizes the buffer for either. */
+int diga_conv2d_stats_chunk_rows(int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t R,
+                                 int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int math);
 
 /* ------------------------------------------------------------------------------------
  * Backward-data with a fused epilogue.  The gradient a backward-data convolution produces is the input gradient of the

@@ -163,7 +163,8 @@ def test_conv_rejects_cpu():
 
 @pytest.mark.parametrize("math", [0, 1], ids=["f32", "bf16x3"])
 @pytest.mark.parametrize("case", [c for c in CASES if c[5] % 4 == 0 and not c[10]] +
-                         [("stats_merge", 2, 32, 192, 193, 64, 1, 1, 0, 1, False)],     # > 512 tiles: merge stage
+                         [("stats_merge", 2, 32, 192, 193, 64, 1, 1, 0, 1, False),      # > 512 tiles: merge stage
+                          ("pw_persist", 4, 64, 193, 193, 256, 1, 1, 0, 1, False)],     # f32: persistent GEMM, 64-row chunks
                          ids=lambda c: c[0])
 def test_conv_epilogue_bn_statistics(case, math, monkeypatch):
     """Train-mode BN fed by the per-tile {sum d, sum d^2, shift} partials the conv epilogue emits equals BN that
@@ -294,7 +295,7 @@ _lib.set_conv_math(0)
 torch.manual_seed(11)                                   # (default initialisers of weight / bias)
 g = torch.Generator().manual_seed(4321)
 # name, N, Cin, H, W, Cout, k, stride, pad, dil
-cases = [("aspp_d24", 1, 256, 97, 97, 256, 3, 1, 24, 24), ("pw_tail", 2, 64, 37, 41, 192, 1, 1, 0, 1),
+cases = [("aspp_d24", 1, 256, 97, 97, 256, 3, 1, 24, 24), ("pw_tail", 2, 64, 37, 41, 192, 1, 1, 0, 1), ("pw_big", 3, 128, 193, 161, 256, 1, 1, 0, 1),
          ("stride2", 2, 128, 65, 65, 128, 1, 2, 0, 1), ("d2_3x3", 3, 96, 33, 29, 160, 3, 1, 2, 2), ("d12", 1, 288, 97, 97, 256, 3, 1, 12, 12)]
 for name, n, cin, h, w, cout, k, s, p, d in cases:
     x = torch.randn((n, cin, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
@@ -316,12 +317,13 @@ def test_f32_dma_kernel_bit_identical_to_register_staged_kernel():
     import subprocess
     import sys
     outs = []
-    for dma in ("0", "2", "1"):             # register-staged / LDS-DMA wherever it can run / the dispatch rules (short K: the
-        env = dict(os.environ, DIGA_CONV_F32_DMA=dma, DIGA_CONV_WINOGRAD="0")      # two-blocks-per-CU variant)
+    for dma, persist in (("0", "0"), ("2", "0"), ("1", "1")):   # register-staged / LDS-DMA wherever it can run / the dispatch
+        # rules incl. the persistent GEMM for the big pointwise layer (pw_big: 730 tiles)
+        env = dict(os.environ, DIGA_CONV_F32_DMA=dma, DIGA_CONV_F32_PERSIST=persist, DIGA_CONV_WINOGRAD="0")
         r = subprocess.run([sys.executable, "-c", _DMA_EQ_CODE, ROOT], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.count(" ") == 2])
-    assert len(outs[0]) == 10 and outs[0] == outs[1] and outs[0] == outs[2], outs
+    assert len(outs[0]) == 12 and outs[0] == outs[1] and outs[0] == outs[2], outs
 
 
 WINO_CASES = [("d1_ragged", 3, 128, 33, 29, 160, 1), ("d1_wide", 2, 384, 31, 37, 512, 1), ("d18_97", 1, 128, 97, 97, 256, 18), ("d2_97", 2, 256, 97, 97, 256, 2), ("d4_65x129", 1, 512, 65, 129, 128, 4),
