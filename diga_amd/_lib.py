@@ -53,6 +53,7 @@ SIGNATURES = {
     "diga_conv2d_nhwc_f32": (INT, [P, P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_conv2d_stats_floats": (SZ, [I64, I64, I64, I64]),
     "diga_conv2d_stats_chunk_rows": (INT, [I64] * 13 + [INT]),
+    "diga_conv2d_epi_chunk_rows": (INT, [I64] * 13 + [INT]),
     "diga_split_bf16": (INT, [P, P, P, I64, P]),
     "diga_conv2d_nhwc_bf16x3": (INT, [P, P, P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_make_twin": (INT, [P, I64, P, I64, I64, P]),

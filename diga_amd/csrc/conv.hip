@@ -2758,8 +2758,19 @@ struct GemmArgs {
     int64_t a_ld, out_ld;                            // floats between rows of A / out
     const float* bias;                               // nullable [Cout]
     float* stats;                                    // nullable [ceil(M / 64)][3][Cout]: {sum (y - s), sum (y - s)^2, s = first row} per 64-row chunk
+    // backward-data epilogue (diga_bwd_epilogue_t; EPI instantiation): out = mask(acc + addend), partials[ceil(M / 64)][2][Cout]
+    const float* e_add;
+    const float* e_masky;
+    const unsigned char* e_maskbits;
+    const float* e_x;
+    const float* e_relu_ab;
+    const float* e_mean;
+    const float* e_invstd;
+    float* e_partials;
+    int64_t e_add_ld, e_masky_ld, e_x_ld, e_maskbits_ld;
 };
 
+template <bool EPI = false>
 __global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g) {
     constexpr int A_BYTES = 256 * 128, B_BYTES = 128 * 128, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __align__(16) unsigned char smem_b[];
@@ -2890,6 +2901,69 @@ __global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g)
             const int col_w = tile_n * 128 + wn * 64 + li;
             float* o = g.out + (int64_t)(row_w + 4 * lh) * g.out_ld + col_w;
             const int rows_left = g.M - (row_w + 4 * lh);                      // row offset r is valid iff r < rows_left
+            if constexpr (EPI) {
+                // the backward-data epilogue of diga_bwd_epilogue_t, element for element as drain_stage<EPI> applies it, on the
+                // accumulator layout: per 32x32 tile 16 rows per lane of one column; the loads of a tile (addend, x, mask) are all
+                // issued before their first use; sum g / sum g * xhat per 64-row chunk = this wave's rows
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = col_w + j * 32;
+                    float ra = 0.f, rb = 0.f, mu = 0.f, is = 0.f;
+                    if (g.e_relu_ab != nullptr) {
+                        ra = g.e_relu_ab[col];
+                        rb = g.e_relu_ab[g.Cout + col];
+                    }
+                    if (g.e_partials != nullptr) {
+                        mu = g.e_mean[col];
+                        is = g.e_invstd[col];
+                    }
+                    float sd = 0.f, sd2 = 0.f;
+#pragma unroll
+                    for (int ih = 0; ih < 4; ++ih) {                        // half an accumulator tile at a time (register budget)
+                        const int i = ih >> 1, e0 = (ih & 1) * 8;
+                        float va[8], vx[8], vy[8];
+                        unsigned vb[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + u;
+                            const int r = i * 32 + (e & 3) + 8 * (e >> 2);
+                            const unsigned row = (unsigned)min(row_w + 4 * lh + r, g.M - 1);      // (32-bit element offsets: host checks)
+                            va[u] = g.e_add != nullptr ? g.e_add[row * (unsigned)g.e_add_ld + (unsigned)col] : 0.f;
+                            vx[u] = g.e_x != nullptr ? g.e_x[row * (unsigned)g.e_x_ld + (unsigned)col] : 0.f;
+                            vy[u] = g.e_masky != nullptr ? g.e_masky[row * (unsigned)g.e_masky_ld + (unsigned)col] : 0.f;
+                            vb[u] = g.e_maskbits != nullptr ? g.e_maskbits[row * (unsigned)g.e_maskbits_ld + (unsigned)(col >> 3)] : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + u;
+                            const int r = i * 32 + (e & 3) + 8 * (e >> 2);
+                            float v = acc[i][j][e] + va[u];
+                            if (g.e_masky != nullptr) v = vy[u] > 0.f ? v : 0.f;
+                            else if (g.e_maskbits != nullptr) v = ((vb[u] >> (col & 7)) & 1u) ? v : 0.f;
+                            else if (g.e_relu_ab != nullptr) v = __builtin_fmaf(vx[u], ra, rb) > 0.f ? v : 0.f;
+                            if (r < rows_left) {
+                                __builtin_nontemporal_store(v, o + (int64_t)r * g.out_ld + j * 32);
+                                sd += v;
+                                sd2 += v * ((vx[u] - mu) * is);
+                            }
+                            acc[i][j][e] = 0.f;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);                  // (keep the next half's 32 loads from being hoisted up here)
+                    }
+                    if (g.e_partials != nullptr && row_w < g.M) {
+                        sd += __shfl_xor(sd, 32, 64);
+                        sd2 += __shfl_xor(sd2, 32, 64);
+                        if (lh == 0) {
+                            float* sp = g.e_partials + (int64_t)(row_w >> 6) * 2 * g.Cout + col;
+                            sp[0] = sd;
+                            sp[g.Cout] = sd2;
+                        }
+                    }
+                }
+                ks_in_tile = 0;
+                ++it;
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float bv = g.bias != nullptr ? g.bias[col_w + j * 32] : 0.f;
@@ -2957,8 +3031,10 @@ int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, in
         g.A = A; g.W = W; g.out = out; g.M = (int)M; g.K = (int)K; g.Cout = (int)Cout;
         g.tiles_m = (int)(M / 256); g.tiles_n = a.tiles_n; g.wb_tiles = a.wb_tiles; g.wb_stride = a.wb_stride;
         g.a_ld = K; g.out_ld = Cout; g.bias = nullptr; g.stats = nullptr;
-        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(gemm_f32_persistent_kernel, dim3(256), dim3(768), sh, st, g);
+        g.e_add = g.e_masky = g.e_x = g.e_relu_ab = g.e_mean = g.e_invstd = nullptr;
+        g.e_maskbits = nullptr; g.e_partials = nullptr; g.e_add_ld = g.e_masky_ld = g.e_x_ld = g.e_maskbits_ld = 0;
+        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(gemm_f32_persistent_kernel<false>, dim3(256), dim3(768), sh, st, g);
         return DIGA_OK;
     }
     (void)hipFuncSetAttribute((const void*)conv_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -2968,10 +3044,13 @@ int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, in
 
 // A stride-1 pointwise convolution in fp32 with enough tiles for two rounds goes to gemm_f32_persistent_kernel (shape rule
 // only: the statistics buffer's chunk size must be known to the caller, diga_conv2d_stats_chunk_rows).
+int persist_mode() {
+    static const int persist = [] { const char* e = getenv("DIGA_CONV_F32_PERSIST"); return e ? atoi(e) : 1; }();
+    return persist;          // 0: off, 1: forward / plain backward-data, 2: also the backward-data epilogue (measured slower)
+}
 bool pointwise_persistent_ok(int64_t M, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t R,
                              int64_t S, int64_t sy, int64_t sx, int64_t oy0, int64_t ox0) {
-    static const int persist = [] { const char* e = getenv("DIGA_CONV_F32_PERSIST"); return e ? atoi(e) : 1; }();
-    return persist != 0 && R == 1 && S == 1 && sy == 1 && sx == 1 && oy0 == 0 && ox0 == 0 && Hi == Ho && Wi == Wo && Cin % 32 == 0 &&
+    return persist_mode() != 0 && R == 1 && S == 1 && sy == 1 && sx == 1 && oy0 == 0 && ox0 == 0 && Hi == Ho && Wi == Wo && Cin % 32 == 0 &&
            Cout % 128 == 0 && ceil_div(M, 256) * (Cout / 128) >= 512;
 }
 
@@ -3025,16 +3104,26 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
     // measured on the C2 shapes (tools/bench_conv.py, same box) it wins 5-12 % (22 % with dead taps) from K >= 256 into
     // >= 256 channels and loses 5-10 % on the 128-channel / K = 64 layers, which stay on the 128 x 128 kernel at two
     // blocks per CU.  DIGA_CONV_F32_DMA=0 / 2: never / wherever it can run.
-    if (pointwise_persistent_ok(N * Ho * Wo, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride_y, stride_x, off_y0, off_x0) && epi == nullptr &&
-        !(opts && (opts->reflect_pad || opts->upsample_shift || opts->activation)) ) {
+    if (pointwise_persistent_ok(N * Ho * Wo, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride_y, stride_x, off_y0, off_x0) &&
+        (epi == nullptr || persist_mode() == 2) && !(opts && (opts->reflect_pad || opts->upsample_shift || opts->activation))) {
         // 1x1, stride 1: the persistent GEMM (statistics per 64-row chunk: diga_conv2d_stats_chunk_rows)
         GemmArgs g;
         g.A = in; g.W = wgt; g.out = out; g.M = a.M; g.K = (int)Cin; g.Cout = (int)Cout;
         g.tiles_m = (int)ceil_div(a.M, 256); g.tiles_n = (int)(Cout / 128); g.wb_tiles = 0; g.wb_stride = 0;
         g.a_ld = in_ld; g.out_ld = out_ld; g.bias = bias; g.stats = stats_partial;
+        g.e_add = a.e_add; g.e_masky = a.e_masky; g.e_maskbits = a.e_maskbits; g.e_x = a.e_x; g.e_relu_ab = a.e_relu_ab;
+        g.e_mean = a.e_mean; g.e_invstd = a.e_invstd; g.e_partials = a.e_partials;
+        g.e_add_ld = a.e_add_ld; g.e_masky_ld = a.e_masky_ld; g.e_x_ld = a.e_x_ld; g.e_maskbits_ld = a.e_maskbits_ld;
         const size_t shp = 3 * (256 + 128) * 128;
-        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp);
-        hipLaunchKernelGGL(gemm_f32_persistent_kernel, dim3(256), dim3(768), shp, st, g);
+        if (epi != nullptr) {          // (partials per 64-row chunk: diga_conv2d_stats_chunk_rows tells the caller)
+            DIGA_REQUIRE((int64_t)a.M * std::max({(int64_t)a.e_add_ld, (int64_t)a.e_x_ld, (int64_t)a.e_masky_ld, (int64_t)1}) < (1ll << 32),
+                         DIGA_EINVAL, "conv2d_epi: epilogue tensors beyond 2^32 elements");
+            (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp);
+            hipLaunchKernelGGL(gemm_f32_persistent_kernel<true>, dim3(256), dim3(768), shp, st, g);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp);
+            hipLaunchKernelGGL(gemm_f32_persistent_kernel<false>, dim3(256), dim3(768), shp, st, g);
+        }
         return launch_status("diga_conv2d_nhwc_f32");
     }
     const bool dma_ok = Cout > 64 && bk == 32 && a.M >= 256;
@@ -3322,6 +3411,13 @@ extern "C" int diga_conv2d_nhwc_twin_opts(const void* in_twin, const void* wgt_i
 
 extern "C" size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout) {
     return (size_t)ceil_div(N * Ho * Wo, 64) * 3 * (size_t)Cout;       // (room for 64-row chunks)
+}
+
+extern "C" int diga_conv2d_epi_chunk_rows(int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout,
+                                          int64_t R, int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0,
+                                          int math) {
+    return (math == DIGA_CONV_MATH_F32 && persist_mode() == 2 &&
+            pointwise_persistent_ok(N * Ho * Wo, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride_y, stride_x, off_y0, off_x0)) ? 64 : 128;
 }
 
 extern "C" int diga_conv2d_stats_chunk_rows(int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout,

@@ -400,6 +400,10 @@ class _Conv2dFn(torch.autograd.Function):
             if stride == (1, 1):
                 dxn = torch.empty((n, hi, wi, cp), dtype=torch.float32, device=w.device)
                 epi, box = None, ctx.bn_box
+                # rows per partial-sum record of the backward-data epilogue this call will run (the Winograd form writes one
+                # record per tile group: any divisor of the row count the finaliser is told works, 128 as before)
+                epi_chunk = _lib.lib.diga_conv2d_epi_chunk_rows(n, ho, wo, kp, hi, wi, cp, r, s, 1, 1, padding[0], padding[1],
+                                                                  _lib.get_conv_math())
                 chain = ctx.chain if (ctx.chain is not None and not ctx.chain.get("disabled")) else None
                 last_of_chain = False
                 if chain is not None:
@@ -423,19 +427,19 @@ class _Conv2dFn(torch.autograd.Function):
                         epi.addend, epi.addend_ld = _lib.ptr(prev), cp
                         if cbox is not None:
                             m_rows = n * hi * wi
-                            part = torch.empty(((m_rows + 127) // 128) * 2 * cp, dtype=torch.float32, device=w.device)
+                            part = torch.empty(((m_rows + 63) // 64) * 2 * cp, dtype=torch.float32, device=w.device)      # (room for 64-row chunks)
                             _set_mask(epi, cbox, xn, cp)
                             epi.x, epi.x_ld = _lib.ptr(cbox["x"]), cp
                             epi.relu_ab = _lib.ptr(cbox["relu_ab"]) if not cbox["has_res"] else None
                             epi.mean, epi.invstd, epi.partials = _lib.ptr(cbox["mean"]), _lib.ptr(cbox["invstd"]), _lib.ptr(part)
                             cbox["claimed"] = True
-                            cbox["premasked"] = (dxn.data_ptr(), part, dxn, prev, dxn._version)
+                            cbox["premasked"] = (dxn.data_ptr(), part, dxn, prev, dxn._version, epi_chunk)
                     chain["acc"] = dxn
                 elif box is not None:
                     # finish the gradient of the BatchNorm in front of this conv in the epilogue: + residual-branch
                     # gradient, ReLU mask, sum g / sum g*xhat per 128-row chunk (include/diga_hip.h, diga_bwd_epilogue_t)
                     m_rows = n * hi * wi
-                    part = torch.empty(((m_rows + 127) // 128) * 2 * cp, dtype=torch.float32, device=w.device)
+                    part = torch.empty(((m_rows + 63) // 64) * 2 * cp, dtype=torch.float32, device=w.device)      # (room for 64-row chunks)
                     # the residual-branch gradient of the tensor this conv reads, left by the BatchNorm that took it as
                     # residual -- whether or not the producing BN itself had a residual (the epilogue combines `addend`
                     # with either mask form)
@@ -447,7 +451,7 @@ class _Conv2dFn(torch.autograd.Function):
                     epi.x, epi.x_ld = _lib.ptr(box["x"]), cp
                     epi.relu_ab = _lib.ptr(box["relu_ab"]) if not box["has_res"] else None
                     epi.mean, epi.invstd, epi.partials = _lib.ptr(box["mean"]), _lib.ptr(box["invstd"]), _lib.ptr(part)
-                    box["premasked"] = (dxn.data_ptr(), part, dxn, add, dxn._version)
+                    box["premasked"] = (dxn.data_ptr(), part, dxn, add, dxn._version, epi_chunk)
                 _conv_launch(gyp, wt, None, dxn, (1, 1), (padding[0], padding[1]), (-dilation[0], -dilation[1]),
                              _TAG_BWD_DATA, None, dy_box if ((use_tw or ctx.dy_is_twin) and cp > 64) else None,
                              must_twin=ctx.dy_is_twin, epi=epi)

@@ -230,6 +230,9 @@ size_t diga_conv2d_stats_floats(int64_t N, int64_t Ho, int64_t Wo, int64_t Cout)
  * diga_conv2d_stats_floats sizes the buffer for either. */
 int diga_conv2d_stats_chunk_rows(int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t R,
                                  int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int math);
+/* ... and of the `partials` records a backward-data epilogue (`_epi` entry points) will write for this geometry. */
+int diga_conv2d_epi_chunk_rows(int64_t N, int64_t Hi, int64_t Wi, int64_t Cin, int64_t Ho, int64_t Wo, int64_t Cout, int64_t R,
+                               int64_t S, int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int math);
 
 /* ------------------------------------------------------------------------------------
  * Backward-data with a fused epilogue.  The gradient a backward-data convolution produces is the input gradient of the
@@ -244,7 +247,9 @@ int diga_conv2d_stats_chunk_rows(int64_t N, int64_t Hi, int64_t Wi, int64_t Cin,
  *     partials[chunk] = { sum out, sum out*xhat } per 128-row chunk and channel, xhat = (x - mean) * invstd
  * `out` is then the MASKED gradient g of that BatchNorm and `partials` what diga_bn_bwd_partials finalises -- its
  * reduce pass over (g, x), the separate add and the residual-gradient copy are gone.  All tensors [M][ld] fp32 with
- * M = N*Ho*Wo rows, ld % 4 == 0, 16-byte aligned; Cout % 4 == 0; partials holds ceil(M/128)*2*Cout floats.
+ * M = N*Ho*Wo rows, ld % 4 == 0, 16-byte aligned; Cout % 4 == 0; partials holds ceil(M/64)*2*Cout floats: one {sum, sum*xhat}
+ * record per chunk of diga_conv2d_epi_chunk_rows(...) rows (128; 64 on the persistent fp32 GEMM) -- pass that chunk size
+ * to diga_bn_bwd_partials.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
     const float* addend;   /* nullable */
