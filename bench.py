@@ -432,13 +432,13 @@ def rooflines(config, precision, families, counts, geom):
         flops_step = (n_stu + n_tea) * fwd_gflop * 1e9
         n_launch = fam["ms_per_step"] / fam["avg_ms"]                     # launches per step
         ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
-        kname = ("conv_fwd_dma_kernel, directly and as the 16 batched products of the Winograd F(2x2,3x3) layers (+ their transform passes)"
+        kname = ("gemm_f32_persistent_kernel (pointwise layers and the 16 batched products of the Winograd F(2x2,3x3) layers, + their transform passes) / conv_fwd_dma_kernel"
                  if precision == "f32" else "conv_fwd_x3w_kernel + conv_fwd_x3t8_kernel")
         traffic = None
         if pmc and (B, H, W) == (8, 768, 768) and config == "c2":
             # launch-weighted mean over the family's kernels (the 128-column instantiations carry > 95 % of its time;
             # the same kernels also serve backward-data, whose launches are in the PMC averages)
-            names = ("diga::conv_fwd_dma_kernel", "diga::conv_fwd_kernel<2") if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t8_kernel<2", "diga::conv_fwd_x3t_kernel<2")
+            names = ("diga::gemm_f32_persistent_kernel", "diga::conv_fwd_dma_kernel", "diga::conv_fwd_kernel<2") if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t8_kernel<2", "diga::conv_fwd_x3t_kernel<2")
             ent = [v for k, v in pmc.items() if k.startswith(names)]
             nl = sum(v["launches"] for v in ent)
             traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ent) / nl if nl else None
