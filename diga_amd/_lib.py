@@ -81,6 +81,8 @@ SIGNATURES = {
     "diga_conv2d_wgrad_winograd_workspace_bytes": (SZ, [I64] * 6 + [INT]),
     "diga_conv2d_wgrad_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 8 + [P]),
     "diga_conv2d_winograd_v_floats": (SZ, [I64] * 5),
+    "diga_conv2d_winograd_f32_ab": (INT, [P, P, P, P, P, P, P, SZ] + [I64] * 8 + [INT, P]),
+    "diga_conv2d_wgrad_winograd_f32_ab": (INT, [P, P, P, P, P, P, SZ] + [I64] * 8 + [P]),
     "diga_conv2d_winograd_f32_keep": (INT, [P, P, P, P, P, P, SZ] + [I64] * 8 + [INT, P]),
     "diga_conv2d_nhwc_bf16x3_epi": (INT, [P, P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_conv2d_nhwc_twin_epi": (INT, [P, P, P] + [I64] * 16 + [P, INT, P]),

@@ -852,9 +852,10 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
                            size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "bn_fwd: relu_bits needs relu and C % 32 == 0");
     DIGA_REQUIRE(!y_twin || (C % 8 == 0 && ld_y == C), DIGA_EINVAL, "bn_fwd: twin output needs C % 8 == 0 and a dense y");
-    DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && workspace && M > 0, DIGA_EINVAL, "bn_fwd: bad argument");
+    DIGA_REQUIRE(x && gamma && beta && save_mean && save_invstd && workspace && M > 0, DIGA_EINVAL, "bn_fwd: bad argument");
+    DIGA_REQUIRE(y || (save_ab && !residual && !relu_bits && !y_twin), DIGA_EINVAL, "bn_fwd: y = null (coefficients only) needs save_ab and no residual / bits / twin");
     DIGA_REQUIRE(training || (running_mean && running_var), DIGA_EINVAL, "bn_fwd: eval mode needs running statistics");
-    int rc = check_norm("bn_fwd", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
+    int rc = check_norm("bn_fwd", C, {ld_x, y ? ld_y : C, residual ? ld_r : C}, {x, y ? (const void*)y : (const void*)x, residual});
     if (rc) return rc;
     DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(M, 1, C), DIGA_EWORKSPACE, "bn_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -871,8 +872,9 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
         hipLaunchKernelGGL(bn_eval_ab_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, gamma, beta, running_mean,
                            running_var, save_mean, save_invstd, ab, (int)C, eps);
     }
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
-                       ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
+    if (y != nullptr)
+        hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
+                           ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
     return launch_status("diga_bn_fwd");
 }
 
@@ -883,9 +885,11 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
                                     const float* partial, int64_t chunk_rows,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "bn_fwd_partials: relu_bits needs relu and C % 32 == 0");
-    DIGA_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0 && chunk_rows > 0,
+    DIGA_REQUIRE(x && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0 && chunk_rows > 0,
                  DIGA_EINVAL, "bn_fwd_partials: bad argument");
-    int rc = check_norm("bn_fwd_partials", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
+    // y == nullptr: statistics and coefficients only (save_ab required) -- the consumer applies relu(fma(x, a, b)) on load
+    DIGA_REQUIRE(y || (save_ab && !residual && !relu_bits && !y_twin), DIGA_EINVAL, "bn_fwd_partials: y = null needs save_ab and no residual / bits / twin");
+    int rc = check_norm("bn_fwd_partials", C, {ld_x, y ? ld_y : C, residual ? ld_r : C}, {x, y ? (const void*)y : (const void*)x, residual});
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * (8.0 + (residual ? 4.0 : 0.0)));   // read x [+ residual], write y
@@ -914,8 +918,9 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
     }
     hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
                        running_mean, running_var, save_mean, save_invstd, ab, momentum, eps);
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
-                       ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
+    if (y != nullptr)
+        hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
+                           ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
     return launch_status("diga_bn_fwd_partials");
 }
 

@@ -131,8 +131,12 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 }
 
 // V[k][t][c] = (B^T d B)[i][j] of the 4x4 patch of tile t, channel c (zero outside the image / for padding tiles)
+// ab != nullptr: the input is the PRE-activation tensor of a train-mode BatchNorm + ReLU without residual; the transform reads
+// relu(fma(x, a[c], b[c])) (ab = [2][C], the BatchNorm's forward coefficients, the expression affine_apply_kernel evaluates) --
+// the activated tensor is never written or re-read (out-of-image taps stay exact zeros).
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
-                                                         float* __restrict__ V, int64_t Tp, int C, int H, int W, int d) {
+                                                         float* __restrict__ V, int64_t Tp, int C, int H, int W, int d,
+                                                         const float* __restrict__ ab) {
     const int c4n = C / 4;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= Tp * c4n) return;
@@ -140,6 +144,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const int c = (int)(idx - t * c4n) * 4;
     const int4 e = tab[t];
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = z;
+    if (ab != nullptr) {
+        av = *reinterpret_cast<const float4*>(ab + c);
+        bv = *reinterpret_cast<const float4*>(ab + C + c);
+    }
     float4 p[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -149,7 +158,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) {
             const int xx = e.z + (j - 1) * d;
             const bool ok = yok && (unsigned)xx < (unsigned)W;
-            p[i][j] = ok ? *reinterpret_cast<const float4*>(x + ((int64_t)(e.x * H + y) * W + xx) * ld + c) : z;
+            float4 v = ok ? *reinterpret_cast<const float4*>(x + ((int64_t)(e.x * H + y) * W + xx) * ld + c) : z;
+            if (ab != nullptr && ok) {
+                v.x = fmaxf(__builtin_fmaf(v.x, av.x, bv.x), 0.f); v.y = fmaxf(__builtin_fmaf(v.y, av.y, bv.y), 0.f);
+                v.z = fmaxf(__builtin_fmaf(v.z, av.z, bv.z), 0.f); v.w = fmaxf(__builtin_fmaf(v.w, av.w, bv.w), 0.f);
+            }
+            p[i][j] = v;
         }
     }
     float4 m[4][4];
@@ -439,7 +453,7 @@ extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int
 static int winograd_impl(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                          size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
                          int64_t Cout, int64_t out_ld, int64_t dilation, int flip, const diga_bwd_epilogue_t* epi, int prof_tag,
-                         void* stream, float* v_keep = nullptr) {
+                         void* stream, float* v_keep = nullptr, const float* in_ab = nullptr) {
     DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
     DIGA_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 && in_ld >= Cin && in_ld % 4 == 0 && out_ld >= Cout && out_ld % 4 == 0,
@@ -463,8 +477,9 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, wgt, U, (int)Cout,
                        (int)Cin, flip);
+    DIGA_REQUIRE(!in_ab || aligned16(in_ab), DIGA_EALIGN, "conv2d_winograd: in_ab must be 16-byte aligned");
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(g.Tp * (Cin / 4), 256)), dim3(256), 0, st, in, in_ld, tab, V, g.Tp,
-                       (int)Cin, (int)H, (int)W, (int)dilation);
+                       (int)Cin, (int)H, (int)W, (int)dilation, in_ab);
     int rc = gemm_batched_f32_dma(V, g.Tp, 16, Cin, U, Cout, Mb, st);
     if (rc) return rc;
     if (epi == nullptr) {
@@ -490,6 +505,16 @@ extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const
                                         int64_t Cout, int64_t out_ld, int64_t dilation, int flip, int prof_tag, void* stream) {
     return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, flip, nullptr,
                          prof_tag, stream);
+}
+
+extern "C" int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out,
+                                           float* v_keep, void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W,
+                                           int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int prof_tag,
+                                           void* stream) {
+    DIGA_REQUIRE(in_ab != nullptr, DIGA_EINVAL, "conv2d_winograd_ab: null coefficients");
+    DIGA_REQUIRE(!v_keep || aligned16(v_keep), DIGA_EALIGN, "conv2d_winograd_ab: v_keep must be 16-byte aligned");
+    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, 0, nullptr,
+                         prof_tag, stream, v_keep, in_ab);
 }
 
 extern "C" size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation) {
@@ -531,9 +556,9 @@ extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t 
     return wino_wgrad_layout(make_wino(N, H, W, dilation), Cin, Cout, v_kept == 0).total;
 }
 
-extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
-                                              size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
-                                              int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream) {
+static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw, void* workspace,
+                               size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
+                               int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream) {
     DIGA_REQUIRE(dy && (x || v_kept) && dw && workspace, DIGA_EINVAL, "conv2d_wgrad_winograd: null pointer");
     DIGA_REQUIRE(!v_kept || aligned16(v_kept), DIGA_EALIGN, "conv2d_wgrad_winograd: v_kept must be 16-byte aligned");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && N * H * W < (1ll << 31), DIGA_EINVAL,
@@ -557,11 +582,24 @@ extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, c
     hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
     if (v_kept == nullptr)
         hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(g.Tp * (Cin / 4), 256)), dim3(256), 0, st, x, x_ld, tab,
-                           reinterpret_cast<float*>(ws + l.V), g.Tp, (int)Cin, (int)H, (int)W, (int)dilation);
+                           reinterpret_cast<float*>(ws + l.V), g.Tp, (int)Cin, (int)H, (int)W, (int)dilation, x_ab);
     hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)ceil_div(g.Tp * (Cout / 4), 256)), dim3(256), 0, st, dy, dy_ld, tab, Z, g.Tp,
                        (int)Cout, (int)H, (int)W, (int)dilation);
     int rc = wgrad_batched_f32_dma(Z, V, dU, slab, g.Tp, 16, Cout, Cin, st);
     if (rc) return rc;
     hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, dU, dw, (int)Cout, (int)Cin);
     return launch_status("diga_conv2d_wgrad_winograd_f32");
+}
+
+extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
+                                              size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
+                                              int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream) {
+    return wgrad_winograd_impl(dy, x, nullptr, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, stream);
+}
+
+extern "C" int diga_conv2d_wgrad_winograd_f32_ab(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw,
+                                                 void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                                                 int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream) {
+    DIGA_REQUIRE(x_ab != nullptr && aligned16(x_ab), DIGA_EINVAL, "conv2d_wgrad_winograd_ab: null / unaligned coefficients");
+    return wgrad_winograd_impl(dy, x, x_ab, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, stream);
 }

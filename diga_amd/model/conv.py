@@ -46,6 +46,23 @@ def _use_twin(cin, k, taps, shared):
     return mode == "1" or taps > 1 or shared
 
 
+def bn1_defer_ok(conv, x, need_wgrad):
+    """True when the BatchNorm + ReLU in front of `conv` (a DigaConv2d, the 3x3 conv2 of a bottleneck reading x [N,C,H,W]) may
+    skip its apply pass: fp32 arithmetic, the forward on the Winograd path and -- if the weight gradient is wanted -- that one
+    too (it reads the kept transform, or re-applies the coefficients).  Off by default (DIGA_FUSE_BN1=1 enables it): bit-identical
+    and 3 ms of BatchNorm passes less per serialised step, but the two-stream step did not get faster (same-box A/B 542.0 / 538.4 ms
+    with, 538.5 / 540.1 ms without: the pass it removes was already hidden, the transform pays the coefficients' loads)."""
+    if os.environ.get("DIGA_FUSE_BN1", "0") != "1" or _lib.get_conv_math() != 0 or conv.bias is not None:
+        return False
+    n, c, h, w = x.shape
+    k = conv.out_channels
+    if c != conv.in_channels or c % 32 != 0 or tuple(conv.kernel_size) != (3, 3) or conv.groups != 1:
+        return False
+    if need_wgrad and not (k % 256 == 0 and c % 128 == 0):
+        return False
+    return _winograd_ok(n, h, w, c, k, 3, 3, tuple(conv.stride), (-conv.padding[0], -conv.padding[1]), tuple(conv.dilation), h, w)
+
+
 def takes_twin_only_input(conv, pointwise_ok=False):
     """True when `conv` (a DigaConv2d) reads its input exclusively through split twins -- forward on the twin kernel and
     backward-weight on the twin kernel -- so that its producer may write the twin instead of the fp32 tensor.
@@ -110,7 +127,7 @@ def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
 
 
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
-                 opts=None, keep_v=None):
+                 opts=None, keep_v=None, in_ab=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x.
     epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue.
@@ -126,6 +143,8 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
     n, hi, wi, cin = x.shape
     _, ho, wo, k = out.shape
     _, r, s, _ = w_krsc.shape
+    if in_ab is not None and _lib.get_conv_math() != 0:
+        raise RuntimeError("DigaConv2d: a deferred BatchNorm input needs the fp32 arithmetic")
     if (_lib.get_conv_math() == 1 and _use_twin(cin, k, r * s, twin_box is not None)
             and n * hi * wi * cin * 4 < (1 << 40)):
         # split-bf16 arithmetic without register staging: both operands pre-split, copied global -> LDS by LDS-DMA
@@ -186,6 +205,16 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
             _lib.call("diga_conv2d_winograd_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                       n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, ctypes.byref(epi), tag, _lib.stream())
             return None
+        if in_ab is not None:
+            # x holds the pre-activation values of a BatchNorm + ReLU: the input transform applies relu(fma(x, a, b)) on load
+            if epi is not None or doff[0] < 0:
+                raise RuntimeError("DigaConv2d: a deferred BatchNorm input only feeds a forward convolution")
+            if keep_v is not None and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d) * 4, x.device):
+                keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d), dtype=torch.float32, device=x.device)
+            _lib.call("diga_conv2d_winograd_f32_ab", _lib.ptr(x), _lib.ptr(in_ab), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out),
+                      _lib.ptr(keep_v[0]) if keep_v is not None else None, _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k,
+                      out.stride(2), d, tag, _lib.stream())
+            return None
         if keep_v is not None and doff[0] > 0 and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d) * 4, x.device):
             # keep_v: a one-element list -- the transformed input stays alive for this layer's weight gradient
             keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d), dtype=torch.float32, device=x.device)
@@ -195,6 +224,9 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         _lib.call("diga_conv2d_winograd_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                   n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, tag, _lib.stream())
         return None
+    if in_ab is not None:
+        raise RuntimeError("DigaConv2d: the input carries a deferred BatchNorm apply (_diga_lazy_ab) but this call is not on the "
+                           "fp32 Winograd path that can apply it (check bn1_defer_ok before deferring)")
     _log_flops(name, direct, direct)
     if epi is not None:
         _lib.call("diga_conv2d_nhwc_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), n, hi, wi, cin,
@@ -291,7 +323,7 @@ def _set_mask(epi, box, xn, cp):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None, x_is_twin=False,
-                dy_is_twin=False, bn_box=None, opts=None, chain=None):
+                dy_is_twin=False, bn_box=None, opts=None, chain=None, lazy_ab=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         if x_is_twin:          # the producer wrote the split twin instead of fp32 (same bytes per element): hand it on
@@ -324,9 +356,12 @@ class _Conv2dFn(torch.autograd.Function):
                 and (opts is None or not any(opts)) and os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
                 and _winograd_ok(n, hi, wi, cp, k, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
             keep_v = [None]
+        if lazy_ab is not None and cp != c:
+            raise RuntimeError("DigaConv2d: a deferred BatchNorm input needs Cin % 32 == 0")
         x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box,
-                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v)
+                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v, in_ab=lazy_ab)
         ctx.wino_v = keep_v[0] if keep_v is not None else None
+        ctx.in_ab = lazy_ab                 # (the saved xn then holds pre-activation values: the weight gradient applies them too)
         ctx.save_for_backward(xn, w)
         # the split twin of the input serves the weight gradient too (multi-tap / shared-input layers, Cout >= 256)
         ctx.x_twin = x_twin if (ctx.needs_input_grad[1] and k >= 256 and k % 8 == 0 and cp == c) else None
@@ -480,6 +515,7 @@ class _Conv2dFn(torch.autograd.Function):
 
             wino_v = getattr(ctx, "wino_v", None)
             ctx.wino_v = None
+            in_ab = getattr(ctx, "in_ab", None)
 
             def run_twin():
                 nbytes = _lib.lib.diga_conv2d_wgrad_twin_workspace_bytes(n, ho, wo, kp, cp, r, s)
@@ -498,11 +534,18 @@ class _Conv2dFn(torch.autograd.Function):
                     _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * 9 * cp, 2.0 * n * ho * wo * kp * 9 * cp * _wino_ratio(hi, wi, dilation[0]))
                     nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0], 1 if wino_v is not None else 0)
                     wsw = _lib.workspace(nb, w.device, "winograd_wgrad")
-                    _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(wino_v), _lib.ptr(dwp), _lib.ptr(wsw),
-                              wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], _lib.stream())
+                    if in_ab is not None:
+                        _lib.call("diga_conv2d_wgrad_winograd_f32_ab", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(in_ab), _lib.ptr(wino_v),
+                                  _lib.ptr(dwp), _lib.ptr(wsw), wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0],
+                                  _lib.stream())
+                    else:
+                        _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(wino_v), _lib.ptr(dwp), _lib.ptr(wsw),
+                                  wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], _lib.stream())
                     if not alias:
                         dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
                     return
+                if in_ab is not None:
+                    raise RuntimeError("DigaConv2d: weight gradient of a layer with a deferred BatchNorm input off the Winograd path")
                 _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * r * s * cp, 2.0 * n * ho * wo * kp * r * s * cp)
                 nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, cp, r, s)
                 ws = _lib.workspace(nbytes, w.device, "wgrad")
@@ -534,7 +577,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1, 2))
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -588,6 +631,9 @@ class DigaConv2d(nn.Conv2d):
         x_is_twin = bool(getattr(x, "_diga_is_twin", False))
         if x_is_twin and fn is not _Conv2dFn:
             raise RuntimeError("DigaConv2d: twin-only input on the stem path")
+        lazy_ab = getattr(x, "_diga_lazy_ab", None)       # the BatchNorm in front deferred its apply to this conv's input transform
+        if lazy_ab is not None and (fn is not _Conv2dFn or x_is_twin or twin_grad or chain is not None or (opts is not None and any(opts))):
+            raise RuntimeError("DigaConv2d: a deferred BatchNorm input (_diga_lazy_ab) reached a call that cannot apply it")
         bn_box = getattr(x, "_diga_bn_box", None)
         if bn_box is not None and (self.share_twin or chain is not None or fn is not _Conv2dFn or not torch.is_grad_enabled()):
             bn_box = None                     # several convs read this tensor (the chain carries the box) / no backward
@@ -596,14 +642,14 @@ class DigaConv2d(nn.Conv2d):
                 raise RuntimeError("DigaConv2d: folded padding / upsampling / activation need the implicit-GEMM path without BN statistics")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), None, uses,
                          twin_box, False, False, None, tuple(int(v) for v in opts))
-        elif x_is_twin or twin_grad or bn_box is not None or chain is not None:
+        elif x_is_twin or twin_grad or bn_box is not None or chain is not None or lazy_ab is not None:
             if fn is not _Conv2dFn or (self.bias is not None and twin_grad):
                 if chain is not None:
                     chain["disabled"] = True
                 else:
                     raise RuntimeError("DigaConv2d: twin gradient needs a bias-free conv on the implicit-GEMM path")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
-                         twin_box, x_is_twin, bool(twin_grad), bn_box, None, chain) if fn is _Conv2dFn else \
+                         twin_box, x_is_twin, bool(twin_grad), bn_box, None, chain, lazy_ab) if fn is _Conv2dFn else \
                 fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses, twin_box)
         else:
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,

@@ -61,13 +61,18 @@ class _BnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, relu, momentum, eps,
-                partials=None, twin_out=False, dx_twin=False, box=None, res_box=None):
+                partials=None, twin_out=False, dx_twin=False, box=None, res_box=None, lazy=None):
         _lib.require_gpu(x)
         xn = nhwc(x.detach())
         n, h, w, c = xn.shape
         m = n * h * w
         rn = None if residual is None else nhwc(residual.detach())
-        y = torch.empty_like(xn)
+        # lazy (a dict, ReLU without residual only): statistics and coefficients only -- the consumer (the Winograd input
+        # transform of the 3x3 conv behind this BN) applies relu(fma(x, a, b)) on load; the "output" aliases x
+        defer = lazy is not None
+        if defer and not (relu and residual is None and not twin_out):
+            raise RuntimeError("DigaBatchNorm2d: a deferred apply needs ReLU, no residual and an fp32 output")
+        y = xn if defer else torch.empty_like(xn)
         save_mean = torch.empty(c, dtype=torch.float32, device=xn.device)
         save_invstd = torch.empty_like(save_mean)
         # ReLU without residual: the backward re-derives the mask from x and the forward coefficients (no y read)
@@ -80,16 +85,18 @@ class _BnFn(torch.autograd.Function):
             bits = torch.empty((m, c // 8), dtype=torch.uint8, device=xn.device)
         if partials is not None and training:
             # the producing conv already reduced its output tile by tile: finalise + apply only
-            _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
+            _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, None if defer else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
                       _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0, _lib.ptr(bits),
                       float(momentum), float(eps), _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(),
                       _lib.stream())
         else:
-            _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
+            _lib.call("diga_bn_fwd", _lib.ptr(xn), c, None if defer else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
                       _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd),
                       _lib.ptr(save_ab), m, c, 1 if training else 0, 1 if relu else 0, 1 if twin_out else 0, _lib.ptr(bits),
                       float(momentum), float(eps), _lib.ptr(ws), ws.numel(), _lib.stream())
+        if defer:
+            lazy["ab"] = save_ab
         ctx.save_for_backward(xn, y if (relu and save_ab is None) else None, weight, save_mean, save_invstd, save_ab)
         ctx.flags = (training, residual is not None)
         ctx.dx_twin = bool(dx_twin and c % 8 == 0)
@@ -130,7 +137,7 @@ class _BnFn(torch.autograd.Function):
             ctx.res_box["dres"] = dres
             dres = None
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
-                None, None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class DigaBatchNorm2d(nn.BatchNorm2d):
@@ -138,7 +145,7 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
     G5/model/seg_model_noaux.py:64-76) -- gradients flow to the input only.  forward(x, residual, relu)
     computes relu(bn(x) + residual) in one pass."""
 
-    def forward(self, x, residual=None, relu=False, twin_out=False, dx_twin=False):
+    def forward(self, x, residual=None, relu=False, twin_out=False, dx_twin=False, defer_apply=False):
         """twin_out (ReLU, no residual, C % 8 == 0): the result is written as the split twin the staging-free conv
         kernels read (same 4 bytes per element, diga_make_twin's format) INSTEAD of fp32; the returned tensor has the
         usual shape and dtype but holds twin bytes (`_diga_is_twin`) -- only a DigaConv2d on the twin path may read it."""
@@ -159,8 +166,14 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
                 if rb is not None and rb.get("consumer_ready") and "res_claimed" not in rb:
                     rb["res_claimed"] = True
                     res_box = rb
+        # defer_apply (ReLU, no residual): statistics and coefficients only; the returned tensor holds the PRE-activation values
+        # and carries the coefficients (`_diga_lazy_ab`) -- only a DigaConv2d on the Winograd path may read it (it applies
+        # relu(fma(x, a, b)) in its input transform, diga_conv2d_winograd_f32_ab)
+        lazy = {} if (defer_apply and relu and residual is None and not twin_out) else None
         y = _BnFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, training, relu,
-                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin), box, res_box)
+                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin), box, res_box, lazy)
+        if lazy is not None:
+            y._diga_lazy_ab = lazy["ab"]
         if twin_out:
             y._diga_is_twin = True
         if box is not None:

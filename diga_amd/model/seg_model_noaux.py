@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from diga_amd.model import norm as dn
-from diga_amd.model.conv import DigaConv2d, takes_twin_only_input
+from diga_amd.model.conv import DigaConv2d, bn1_defer_ok, takes_twin_only_input
 
 
 @dataclass(frozen=True)
@@ -92,7 +92,12 @@ class Bottleneck(nn.Module):
         #  weight gradient -- the no-grad teacher takes it too; DIGA_TWIN_CONV3=2 restricts it to autograd passes as in round 1)
         c3 = os.environ.get("DIGA_TWIN_CONV3", "1")
         tw3 = (grad or c3 != "2") and c3 != "0" and takes_twin_only_input(self.conv3, pointwise_ok=True)
-        y = self.bn1(self.conv1(x, chain=chain), relu=True, twin_out=tw2)
+        y1 = self.conv1(x, chain=chain)
+        # fp32: bn1's activated output would be read only by conv2's Winograd input transform (and, through the transform the
+        # forward keeps, by its weight gradient): bn1 then computes statistics and coefficients only and the transform applies
+        # relu(fma(y1, a, b)) on load -- one BatchNorm apply pass per bottleneck less (model/conv.py: bn1_defer_ok)
+        defer1 = (not tw2) and bn1_defer_ok(self.conv2, y1, grad and self.conv2.weight.requires_grad)
+        y = self.bn1(y1, relu=True, twin_out=tw2, defer_apply=defer1)
         y = self.bn2(self.conv2(y, twin_grad=tw2 and grad), relu=True, twin_out=tw3, dx_twin=tw2 and grad)
         if self.downsample is None:
             skip = x

@@ -361,6 +361,16 @@ int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float*
  * weight gradient of the same layer: pass it as `v_kept` above (x may then be null) and the backward skips the input transform
  * -- HBM is 288 GB: the transform is a bandwidth pass of 5x the input's bytes per 3x3 layer. */
 size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation);
+/* Forward / backward-weight whose input is the PRE-activation tensor of a train-mode BatchNorm + ReLU without residual
+ * (bn1 of a bottleneck in front of its 3x3 conv2, G5/model/seg_model_noaux.py:89-93): the input transform reads
+ * relu(fma(in, a[c], b[c])) with in_ab = [2][Cin] = the coefficients diga_bn_fwd* leaves in save_ab (call it with y = NULL:
+ * statistics and coefficients only) -- the activated tensor is never written.  v_keep nullable. */
+int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out, float* v_keep,
+                                void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
+                                int64_t Cout, int64_t out_ld, int64_t dilation, int prof_tag, void* stream);
+int diga_conv2d_wgrad_winograd_f32_ab(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw,
+                                      void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                                      int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream);
 int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, const float* bias, float* out, float* v_keep, void* workspace,
                                   size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
                                   int64_t out_ld, int64_t dilation, int prof_tag, void* stream);

@@ -91,3 +91,42 @@ def test_second_backward_through_a_gradient_chain_raises():
     assert x.grad is not None and float(x.grad.abs().sum()) > 0
     with pytest.raises(RuntimeError, match="second backward"):
         loss.backward()
+
+
+def test_deferred_bn1_apply_is_bit_identical(monkeypatch):
+    """fp32: bn1 of a bottleneck computes statistics and coefficients only and conv2's Winograd input transform applies
+    relu(fma(y1, a, b)) on load (diga_conv2d_winograd_f32_ab; the weight gradient reads the kept transform or re-applies the
+    coefficients): output, input gradient and every weight gradient equal the run with the stand-alone apply pass bit for bit."""
+    from diga_amd import _lib
+    from diga_amd.model import seg_model_noaux as sm
+    torch.manual_seed(3)
+    blk = sm.Bottleneck(1024, 256, 1, dilation=2).to(DEV).train()
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.randn((2, 1024, 19, 17), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    probe = torch.randn((2, 1024, 19, 17), generator=g).to(DEV)
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(0)
+    calls, real = [], _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    try:
+        res = []
+        for fuse, keep in (("0", "1"), ("1", "1"), ("1", "0")):
+            monkeypatch.setenv("DIGA_FUSE_BN1", fuse)
+            monkeypatch.setenv("DIGA_WINOGRAD_KEEP_V", keep)
+            for p_ in blk.parameters():
+                p_.grad = None
+            sd = {k: v.clone() for k, v in blk.state_dict().items()}
+            calls.clear()
+            x = x0.clone().requires_grad_()
+            y = blk(x)
+            (y * probe).sum().backward()
+            assert ("diga_conv2d_winograd_f32_ab" in calls) == (fuse == "1"), calls
+            assert ("diga_conv2d_wgrad_winograd_f32_ab" in calls) == (fuse == "1"), calls
+            res.append([y.detach().clone(), x.grad.clone()] + [getattr(blk, c).weight.grad.clone() for c in ("conv1", "conv2", "conv3")]
+                       + [blk.bn1.running_mean.clone(), blk.bn1.running_var.clone()])
+            blk.load_state_dict(sd)              # (running statistics back to where they were)
+    finally:
+        _lib.set_conv_math(prev)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
