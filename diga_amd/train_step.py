@@ -120,6 +120,34 @@ class DigaTrainer:
         self._pending_join = True
         return outs
 
+    def _student_and_teacher(self, student_in, *teacher_in):
+        """Student forward on the current stream, teacher forward(s) on the side stream -- the teacher enqueued from a hook
+        behind the student's first stage (`DIGA_TEACHER_OFFSET`, default `layer1`; `0` = both at once, as before).  Why the
+        offset: student and teacher run the SAME kernel sequence, and two matrix-core kernels launched together share the
+        CUs half and half, finish together and leave the BatchNorm / transform passes of both streams to run together with no
+        matrix-core kernel in flight (tools/diag/overlap_timeline.py: 52 ms of the forward).  Started one stage apart, a
+        persistent GEMM of one stream holds every CU while the other stream's bandwidth passes run under it, and the two
+        alternate from then on.  Returns (student outputs, pending teacher outputs for `_teacher_join`)."""
+        where = os.environ.get("DIGA_TEACHER_OFFSET", "layer1")
+        stage = getattr(self.student, where, None) if where not in ("", "0") else None
+        if not isinstance(stage, torch.nn.Module) or os.environ.get("DIGA_TEACHER_STREAM", "1") == "0" or not student_in.is_cuda:
+            pending = self._teacher_async(*teacher_in)
+            return self.student(student_in), pending
+        box = {}
+
+        def launch(mod, inp, out):
+            if "p" not in box:
+                box["p"] = self._teacher_async(*teacher_in)
+
+        handle = stage.register_forward_hook(launch)
+        try:
+            s_out = self.student(student_in)
+        finally:
+            handle.remove()
+        if "p" not in box:                                     # (the stage did not run in this forward)
+            box["p"] = self._teacher_async(*teacher_in)
+        return s_out, box["p"]
+
     def _teacher_join(self, outs):
         if getattr(self, "_pending_join", False):
             main = torch.cuda.current_stream(outs[0][0].device)
@@ -208,8 +236,7 @@ class DigaTrainer:
         with torch.no_grad():
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng, present=self._present(labels))
             cat = torch.cat([x, mix])
-        pending = self._teacher_async(cat)
-        _, _, s_lr, _ = self.student(cat)
+        (_, _, s_lr, _), pending = self._student_and_teacher(cat, cat)
         (t_lr, _), = self._teacher_join(pending)
         total, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
         self._finish(total)
@@ -228,8 +255,7 @@ class DigaTrainer:
                 present = U.classmix_present(labels)          # both ClassMix blocks of the step draw from the same label lists
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng, present=present)
             cat = torch.cat([x, mix])
-        pending = self._teacher_async(cat, t_img)
-        _, _, s_lr, _ = self.student(cat)
+        (_, _, s_lr, _), pending = self._student_and_teacher(cat, cat, t_img)
         (t_lr, t_feat), (tt_lr, tt_feat) = self._teacher_join(pending)
         with torch.no_grad():
             # bilateral consensus: keep the offline pseudo-label where the centroid label agrees
