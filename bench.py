@@ -81,8 +81,11 @@ def parse():
     ap.add_argument("--other-steps", type=int, default=None, help="steps of the other arithmetic (default: --steps)")
     ap.add_argument("--other-warmup", type=int, default=None, help="warm-ups of the other arithmetic (default: --warmup)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the c4 / c1 legs")
-    ap.add_argument("--c4-steps", type=int, default=3)
-    ap.add_argument("--c5-steps", type=int, default=5)
+    ap.add_argument("--c4-steps", type=int, default=None, help="steps of the self-training leg (default: --steps)")
+    ap.add_argument("--c4-warmup", type=int, default=None, help="warm-ups of the self-training leg (default: --warmup)")
+    ap.add_argument("--c5-steps", type=int, default=None, help="steps of the SegFormer leg (default: --steps)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file the full tables go to (kernel families, every roofline, bandwidth kernels, mIoU parity)")
     ap.add_argument("--no-graph", action="store_true", help="run the launch-bound legs (c1, c5) eagerly instead of from a HIP graph")
     ap.add_argument("--no-bandwidth-kernels", action="store_true")
     ap.add_argument("--no-miou", action="store_true", help="skip the fixed-seed validation-mIoU parity leg")
@@ -102,6 +105,12 @@ def parse():
         a.other_steps = a.steps
     if a.other_warmup is None:
         a.other_warmup = a.warmup
+    if a.c4_steps is None:
+        a.c4_steps = a.steps
+    if a.c4_warmup is None:
+        a.c4_warmup = a.warmup
+    if a.c5_steps is None:
+        a.c5_steps = a.steps
     if a.lean:
         a.no_other_precision = a.no_other_configs = a.no_bandwidth_kernels = a.no_cpu_baseline = a.no_miou = True
     return a
@@ -390,9 +399,35 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
     return float(t), (families, families_overlapped), losses, counts, (B, H, W, arch_name)
 
 
+def target_statement(config, precision, families, B, H, W, n_stu, n_tea):
+    """north_star asks for >= 40 crops/s/GPU; in exact fp32 the step is capped by the fp32 matrix pipe: the FLOPs the step's
+    convolutions execute (after Winograd) / 157.3 TFLOP/s."""
+    if config != "c2" or precision != "f32":
+        return None
+    ex = sum(f.get("executed_flops_per_step", 0.0) for t, f in families.items() if t.startswith("conv_"))
+    if not ex:
+        return None
+    floor_ms = ex / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+    return {"north_star_crops_per_s_per_gpu": 40.0, "fp32_ceiling_crops_per_s": float(f"{B / (floor_ms * 1e-3):.4g}"),
+            "executed_conv_tflop_per_step": float(f"{ex / 1e12:.4g}"),
+            "note": "40 crops/s needs ~400 TFLOP/s: beyond the fp32 matrix peak (157.3); ceiling = executed conv FLOPs / peak"}
+
+
 def images_per_step(config, B):
     """Images through the student (forward + backward) and through the teacher (forward) per step and GPU."""
     return (3 * B, 3 * B) if config == "c4" else (2 * B, 2 * B)
+
+
+def executed_fraction(fam, out, peak):
+    """`achieved` / `frac` of an MFMA-bound family = the FLOPs its kernels EXECUTE on the matrix cores / the summed launch
+    durations (/ peak): a utilisation, always <= 1.  The stride-1 3x3 layers run as Winograd (csrc/winograd.hip) and execute
+    fewer multiplications than the direct convolution SURVEY section 8d prices (16/36 per 2x2 tile, 36/144 per 4x4 tile), so
+    the algorithmic figure (direct-convolution FLOPs / the same time, which can exceed the peak) is kept next to it as
+    `achieved_algorithmic` / `frac_algorithmic`.  The family's time includes its transform passes."""
+    if "executed_flops_per_step" in fam and fam.get("direct_flops_per_step"):
+        ex = fam["executed_flops_per_step"] / (fam["ms_per_step"] * 1e-3) / 1e12
+        out.update(achieved_algorithmic=out["achieved"], frac_algorithmic=out["frac"],
+                   executed_flops_per_step=fam["executed_flops_per_step"], achieved=ex, frac=ex / peak)
 
 
 def rooflines(config, precision, families, counts, geom):
@@ -432,8 +467,8 @@ def rooflines(config, precision, families, counts, geom):
         flops_step = (n_stu + n_tea) * fwd_gflop * 1e9
         n_launch = fam["ms_per_step"] / fam["avg_ms"]                     # launches per step
         ach = flops_step / (fam["ms_per_step"] * 1e-3) / 1e12
-        kname = ("gemm_f32_persistent_kernel (pointwise layers and the 16 batched products of the Winograd F(2x2,3x3) layers, + their transform passes) / conv_fwd_dma_kernel"
-                 if precision == "f32" else "conv_fwd_x3w_kernel + conv_fwd_x3t8_kernel")
+        kname = ("gemm_f32_persistent_kernel + conv_fwd_dma_kernel + Winograd transforms" if precision == "f32"
+                 else "conv_fwd_x3w_kernel + conv_fwd_x3t8_kernel")
         traffic = None
         if pmc and (B, H, W) == (8, 768, 768) and config == "c2":
             # launch-weighted mean over the family's kernels (the 128-column instantiations carry > 95 % of its time;
@@ -442,31 +477,18 @@ def rooflines(config, precision, families, counts, geom):
             ent = [v for k, v in pmc.items() if k.startswith(names)]
             nl = sum(v["launches"] for v in ent)
             traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ent) / nl if nl else None
-        roof = {"kernel": f"{kname} (implicit-GEMM convolution on the "
-                          f"{'fp32' if precision == 'f32' else 'bf16'} matrix cores; all forward-conv launches of a step"
-                          f"{'' if precision == 'f32' else ', split-twin conversions of their inputs counted in elementwise'})",
+        roof = {"kernel": f"{kname} (all forward-convolution launches of a step, {'fp32' if precision == 'f32' else 'bf16'} MFMA)",
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "algorithmic_flops_per_launch": flops_step / n_launch, "avg_launch_ms": fam["avg_ms"],
                 "launches_per_step": n_launch, "declared_flops_per_step": fam["work_per_step"]}
-
-        def executed(f, out):
-            # `achieved` / `frac` price the ALGORITHMIC work (the direct convolutions) as the contract asks; the
-            # Winograd layers execute 16/36 of their multiplications per 2x2 tile, so the matrix cores' own utilisation is
-            # the executed FLOPs over the same time (it includes the transform passes' time: a lower bound on the GEMM's)
-            if "executed_flops_per_step" in f and f.get("direct_flops_per_step"):
-                ex = f["executed_flops_per_step"] / (f["ms_per_step"] * 1e-3) / 1e12
-                out.update(executed_flops_per_step=f["executed_flops_per_step"], achieved_executed=ex, frac_executed=ex / peak)
-        executed(fam, roof)
-        if "frac_executed" in roof:
-            roof["note"] = ("frac = algorithmic (direct-convolution) FLOPs / time / peak; the stride-1 3x3 layers run as Winograd F(2x2,3x3) "
-                            "(csrc/winograd.hip), which executes fewer multiplications: frac_executed = FLOPs the matrix cores run / the same time / peak")
+        executed_fraction(fam, roof, peak)
         for tag in ("conv_bwd_data", "conv_bwd_weight"):
             if tag in families:        # backward: one pass each over the student's images
                 f = n_stu * fwd_gflop * 1e9
                 v = f / (families[tag]["ms_per_step"] * 1e-3) / 1e12
                 other[tag] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": v, "frac": v / peak,
                               "ms_per_step": families[tag]["ms_per_step"]}
-                executed(families[tag], other[tag])
+                executed_fraction(families[tag], other[tag], peak)
     # per-launch byte counts the host knows (the multi-tensor kernels get device-side size tables)
     known = {"sgd": 20.0 * n_trainable, "ema": 12.0 * n_params}
     for tag, fam in families.items():
@@ -620,13 +642,13 @@ def main():
                       "kernel_families": ofam, "losses_last_step": olosses}
     other_cfg = {}
     if not a.no_other_configs:
-        for cfg, (st, wu) in (("c5", (a.c5_steps, 2)), ("c4", (a.c4_steps, 1)), ("c1", (5, 2))):
+        for cfg, (st, wu) in (("c5", (a.c5_steps, max(a.warmup, 2))), ("c4", (a.c4_steps, a.c4_warmup)), ("c1", (5, 2))):
             if cfg == a.config or (cfg == "c1" and world > 1):
                 continue
             use_graph = cfg in ("c1", "c5") and not a.no_graph and world == 1
             cdt, (cfam, _), closs, ccounts, cgeom = run_steps(a, cfg, a.precision, st, wu, rank, world, dev, prof, graph=use_graph)
             cB, cH, cW, carch = cgeom
-            croof, _ = rooflines(cfg, a.precision, cfam, ccounts, cgeom)
+            croof, cother = rooflines(cfg, a.precision, cfam, ccounts, cgeom)
             n_stu, n_tea = images_per_step(cfg, cB)
             other_cfg[cfg] = {
                 "workload": f"{CONFIGS[cfg][5]}: {CONFIGS[cfg][6]}, {cH}x{cW}, batch {cB} per GPU",
@@ -635,10 +657,11 @@ def main():
                 "value": world * cB * st / cdt, "unit": "pairs/s" if cfg == "c4" else "crops/s", "steps": st, "warmup": wu,
                 "ms_per_step": 1e3 * cdt / st, "n_gpus": world,
                 "dtype": ("fp16 storage / fp32 accumulate (MiT encoder); head convs " + a.precision) if cfg == "c5" else a.precision,
-                "kernel_families": cfam if cfg == "c5" else None,
+                "kernel_families": cfam if cfg in ("c5", "c4") else None,
                 "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea},
                 "hip_graph": bool(use_graph),
-                "roofline_conv_fwd": None if croof is None else {k: croof[k] for k in ("achieved", "peak", "unit", "frac")},
+                "roofline_conv_fwd": None if croof is None else {k: croof.get(k) for k in ("achieved", "peak", "unit", "frac", "frac_algorithmic")},
+                "roofline_other_kernels": cother if cfg == "c4" else None,
                 "losses_last_step": closs}
             if cfg == "c5":
                 # MFMA-bound families of the encoder: declared algorithmic FLOPs / summed HIP-event durations, against the
@@ -679,6 +702,8 @@ def main():
             "value": world * B * a.steps / dt, "unit": "crops/s" if a.config != "c4" else "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[a.precision], "data": "synthetic",
+            # BASELINE.md publishes no number for this metric (vs_baseline stays null); north_star's target next to what exact fp32 allows
+            "target": target_statement(a.config, a.precision, families, B, H, W, n_stu, n_tea),
             "config": {"workload": f"{CONFIGS[a.config][5]}: {CONFIGS[a.config][6]} {H}x{W}, batch {B} per GPU",
                        "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
                        "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea}},
@@ -689,11 +714,69 @@ def main():
             # student: forward + backward-data + backward-weight (3 passes) ; teacher: forward
             "model_tflop_per_step_per_gpu": (3 * n_stu + n_tea) * fwd_tflop,
         }
-        print(json.dumps(line), flush=True)
+        emit(line, a.detail)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     return 0
+
+
+COMPACT_LIMIT = 4000    # bytes: the driver reads the tail of stdout; a line it cannot hold whole is a line it cannot parse
+
+
+def compact(line):
+    """The ONE stdout line: the contract's fields, the dominant kernel's roofline, the CPU baseline, and one-line summaries of the
+    other arithmetic / the self-training (c4) and SegFormer (c5) legs.  Every table stays in the detail file."""
+    def num(v, nd=4):
+        return None if v is None else float(f"{v:.{nd}g}") if isinstance(v, float) else v
+
+    def pick(d, keys, nd=4):
+        return None if not d else {k: (num(d[k], nd) if not isinstance(d[k], str) else d[k][:200]) for k in keys if k in d}
+
+    roof = pick(line.get("roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "traffic",
+                                       "algorithmic_flops_per_launch", "avg_launch_ms", "launches_per_step"), 5)
+    cpu = pick(line.get("cpu_baseline"), ("value", "unit", "cores", "kind", "sample"), 4)
+    if cpu and "sample" in cpu:
+        cpu["sample"] = cpu["sample"][:200]
+
+    def leg(d):
+        if not d:
+            return None
+        r = d.get("roofline") or d.get("roofline_conv_fwd") or {}
+        return {"value": num(d["value"]), "unit": d["unit"], "ms_per_step": num(d["ms_per_step"]), "steps": d["steps"],
+                "warmup": d["warmup"], "dtype": d["dtype"].split(" (")[0], "frac": num(r.get("frac"))}
+
+    oc = line.get("other_configs") or {}
+    out = {k: (num(line[k], 6) if isinstance(line[k], float) else line[k]) for k in
+           ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_region_s", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")}
+    out["dtype"] = out["dtype"].split(" (")[0]
+    cfg = line["config"]
+    out["config"] = {"workload": cfg["workload"][:220], "global_batch": cfg["global_batch"], "crop": cfg["crop"],
+                     "parallelism": cfg["parallelism"]}
+    out.update(rccl_ranks=line["rccl_ranks"], roofline=roof, cpu_baseline=cpu, target=line.get("target"),
+               second_precision=leg(line.get("second_precision")), c4_selftrain=leg(oc.get("c4")), c5_segformer=leg(oc.get("c5")),
+               detail=line.get("detail_file"))
+    return out
+
+
+def emit(line, detail_path):
+    """Write the full record to `detail_path` (and a copy under gpurun_out/ so that it comes home from a GPU box), then print the
+    compact line -- strict JSON, re-parsed and length-checked before it goes out -- as the last thing on stdout."""
+    for path in (detail_path, os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as fh:
+                json.dump(line, fh, indent=1)
+            line.setdefault("detail_file", os.path.relpath(detail_path, ROOT))
+        except OSError as e:
+            print(f"bench.py: cannot write {path}: {e}", file=sys.stderr)
+    text = json.dumps(compact(line), allow_nan=False, separators=(",", ":"))
+    back = json.loads(text)
+    if len(text.encode()) > COMPACT_LIMIT or "\n" in text or back["value"] is None:
+        raise SystemExit(f"bench.py: compact line is {len(text.encode())} bytes (limit {COMPACT_LIMIT}) or malformed")
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 if __name__ == "__main__":

@@ -1,8 +1,9 @@
-"""A warm-up step driven through the DROP-IN surface exactly as the unmodified reference script drives it
-(G5/train_DiGA_gta2city_warm_up.py:22-28 import lines, :145-185 set-up, :197-305 loop body): `SegModel`, stock
+"""A warm-up step driven through the DROP-IN surface a user of the reference keeps (the symbols
+G5/train_DiGA_gta2city_warm_up.py:22-28 imports and the calls its loop :197-305 makes on them): `SegModel`, stock
 `nn.Upsample(bilinear, align_corners=True)` to label size, full-resolution `cross_entropy2d` / `distillation_loss`,
-`create/update_teacher_params`, the inline ClassMix block with torch ops, and stock `torch.optim.SGD` over
-`student.optim_parameters(lr)` -- no DigaTrainer, no fused low-res loss block, no DigaSGD.  Runs in a child process with
+`create/update_teacher_params`, a ClassMix written with plain torch ops, and stock `torch.optim.SGD` over
+`student.optim_parameters(lr)` -- no DigaTrainer, no fused low-res loss block, no DigaSGD.  The caller is this test's own
+code; the numbers it must reproduce are the capture of the reference.  Runs in a child process with
 diga_amd/ in front of sys.path (the way a user of the reference would switch), three steps against the capture of the
 reference (tests/golden/step.npz).  Stock SGD needs foreach=False: see INTEGRATION.md section 2."""
 import json
@@ -19,9 +20,7 @@ pytestmark = pytest.mark.gpu
 SCRIPT = r"""
 import json, random, sys
 import torch
-import torch.nn as nn
-import torch.optim as optim
-# ---- the reference script's own import lines (warm_up.py:22-28)
+# ---- the import surface a user of the reference keeps (module and symbol names of warm_up.py:22-28)
 from model.model_noaux import SegModel
 from util.loss import cross_entropy2d, distillation_loss
 from util.utils import adjust_learning_rate, create_teacher_params, update_teacher_params
@@ -33,65 +32,58 @@ from diga_amd import _lib
 _lib.set_conv_math(int(sys.argv[3]))
 foreach = {"0": False, "1": True, "none": None}[sys.argv[4]]
 
-batch_size, H, W = 2, 128, 128
-learning_rate_seg, num_steps, power = 2.5e-4, 80000, 0.9
-lambda_seg, lambda_distil = 1.0, 0.5
-student, teacher = SegModel().cuda(), SegModel().cuda()
-for mdl in (student, teacher):
-    mdl.load_state_dict(detweights.state_dict(od.RESNET101))
-    mdl.final.head[0].p = 0.0                                  # Dropout2d off, as in the capture
-kw = {} if foreach is None else {"foreach": foreach}
-student_opt = optim.SGD(student.optim_parameters(learning_rate_seg), lr=learning_rate_seg, momentum=0.9,
-                        weight_decay=0.0005, **kw)
-seg_opt_list = [student_opt]
-seg_loss = cross_entropy2d
-upsample_src = nn.Upsample(size=[H, W], mode='bilinear', align_corners=True)
-teacher = create_teacher_params(teacher, student)
+B, H, W = 2, 128, 128
+BASE_LR, MAX_IT = 2.5e-4, 80000
+dev = torch.device("cuda")
+nets = {"stu": SegModel().to(dev), "tea": SegModel().to(dev)}
+for net in nets.values():
+    net.load_state_dict(detweights.state_dict(od.RESNET101))
+    net.final.head[0].p = 0.0                                  # Dropout2d off, as in the capture
+sgd = torch.optim.SGD(nets["stu"].optim_parameters(BASE_LR), lr=BASE_LR, momentum=0.9, weight_decay=5e-4,
+                      **({} if foreach is None else {"foreach": foreach}))
+to_label_size = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+nets["tea"] = create_teacher_params(nets["tea"], nets["stu"])
 random.seed(77)
 log = {"ce": [], "distil": [], "lr": []}
-for i_iter in range(3):
-    student.train()
-    adjust_learning_rate(seg_opt_list, base_lr=learning_rate_seg, i_iter=i_iter, max_iter=num_steps, power=power)
+
+
+def classmix_mask(labels):
+    # per image: half of the classes present (python `random`, the draw order of the capture), plus the ignore label
+    m = torch.zeros_like(labels, dtype=torch.float32)
+    for n in range(labels.shape[0]):
+        present = torch.unique(labels[n]).tolist()
+        chosen = set(random.sample(present, len(present) // 2)) | {255}
+        m[n] = torch.isin(labels[n], torch.tensor(sorted(chosen), device=labels.device)).float()
+    return m.unsqueeze(1)
+
+
+for step in range(3):
+    nets["stu"].train()
+    adjust_learning_rate([sgd], base_lr=BASE_LR, i_iter=step, max_iter=MAX_IT, power=0.9)
     with torch.no_grad():
-        teacher = update_teacher_params(teacher, student, i_iter)
-    sdatav, sdatav_aug, rec_s2t, slabelv = (t.cuda() for t in synth.warmup_batch(1000 + i_iter, batch_size, H, W, block=16))
-    # Cross-domain Mixture Data Augmentation (warm_up.py:240-259, verbatim semantics)
-    rec_s2t_clone = rec_s2t.detach().clone()
-    sdatav_aug_clone = sdatav_aug.detach().clone()
-    mask = torch.zeros(slabelv.size()).cuda()
-    for idx in range(slabelv.size()[0]):
-        label_list = torch.unique(slabelv[idx]).tolist()
-        classes_select = random.sample(label_list, len(label_list) // 2)
-        if 255 not in classes_select:
-            classes_select.append(255)
-        for cls_m in classes_select:
-            mask[idx][slabelv[idx] == cls_m] = 1
-    sdatav_aug_crdomix = torch.zeros(rec_s2t_clone.size()).cuda()
-    for idx in range(rec_s2t_clone.size()[0]):
-        sdatav_aug_crdomix[idx] = torch.mul(rec_s2t_clone[idx], 1 - mask[idx]) + torch.mul(sdatav_aug_clone[idx], mask[idx])
-    sdatav_cat = torch.cat([sdatav, sdatav_aug_crdomix])
-    _, _, s_pred_cat_stu, s_feat_cat_stu = student(sdatav_cat)
-    s_pred_cat_stu = upsample_src(s_pred_cat_stu)
-    s_pred_stu = s_pred_cat_stu[:batch_size]
-    _, _, s_pred_cat_tea, s_feat_cat_tea = teacher(sdatav_cat)
-    s_pred_cat_tea = upsample_src(s_pred_cat_tea)
-    loss_semseg = seg_loss(s_pred_stu, slabelv)
-    loss_s_distil = distillation_loss(s_pred_cat_tea, s_pred_cat_stu)
-    total_loss = lambda_seg * loss_semseg + lambda_distil * loss_s_distil
-    student_opt.zero_grad()
-    total_loss.backward()
-    student_opt.step()
-    log["ce"].append(float(loss_semseg)); log["distil"].append(float(loss_s_distil))
-    log["lr"].append(student_opt.param_groups[0]["lr"])
-sd, td = student.state_dict(), teacher.state_dict()
+        nets["tea"] = update_teacher_params(nets["tea"], nets["stu"], step)
+    img, img_aug, img_translated, lab = (t.to(dev) for t in synth.warmup_batch(1000 + step, B, H, W, block=16))
+    m = classmix_mask(lab)
+    mixed = img_translated * (1.0 - m) + img_aug * m           # selected classes come from the augmented source view
+    both = torch.cat([img, mixed])
+    stu_logits = to_label_size(nets["stu"](both)[2])
+    tea_logits = to_label_size(nets["tea"](both)[2])
+    ce = cross_entropy2d(stu_logits[:B], lab)
+    kd = distillation_loss(tea_logits, stu_logits)
+    sgd.zero_grad()
+    (1.0 * ce + 0.5 * kd).backward()
+    sgd.step()
+    log["ce"].append(float(ce)); log["distil"].append(float(kd))
+    log["lr"].append(sgd.param_groups[0]["lr"])
+sd, td = nets["stu"].state_dict(), nets["tea"].state_dict()
 log["student_head"] = sd["final.head.1.weight"].cpu().reshape(-1).tolist()
 log["teacher_head"] = td["final.head.1.weight"].cpu().reshape(-1).tolist()
 log["stem_sum"] = synth.checksum(sd["layer0.0.weight"].cpu())
 log["stu_rm"] = sd["layer1.0.bn1.running_mean"].cpu().tolist()
-student.eval()
-xp = synth.warmup_batch(2000, 1, H, W, block=16)[0].cuda()
+nets["stu"].eval()
+xp = synth.warmup_batch(2000, 1, H, W, block=16)[0].to(dev)
 with torch.no_grad():
-    log["probe_student"] = student(xp)[2].cpu().reshape(-1).tolist()
+    log["probe_student"] = nets["stu"](xp)[2].cpu().reshape(-1).tolist()
 print("DROPIN " + json.dumps(log))
 """
 
@@ -108,7 +100,7 @@ def _run(conv_math, foreach):
 
 
 @pytest.mark.parametrize("conv_math", [0, 1], ids=["f32", "bf16x3"])
-def test_unmodified_script_body_matches_reference_capture(golden, conv_math):
+def test_dropin_surface_step_matches_reference_capture(golden, conv_math):
     import numpy as np
     g = golden("step")
     log = _run(conv_math, "0")
