@@ -19,7 +19,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdiga_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-DNDEBUG"]
+         "-fno-gpu-rdc", "-DNDEBUG", "-fvisibility=hidden"]
 
 
 def hipcc():
@@ -66,7 +66,12 @@ def build(force=False, jobs=None, verbose=True, extra=()):
                     if warn.strip():
                         print(warn)
     if todo or force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        # the dynamic symbol table is the C ABI and nothing else: -fvisibility=hidden leaves hipcc's kernel-handle objects
+        # exported, the version script makes them local too
+        vs = os.path.join(OBJ, "exports.map")
+        with open(vs, "w") as fh:
+            fh.write("{ global: diga_*; local: *; };\n")
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,--version-script={vs}", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -30,6 +30,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libdiga_hip.so is built with -fvisibility=hidden: the functions declared in this header are its whole dynamic symbol table */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define DIGA_ABI_VERSION 1
 
@@ -545,6 +549,9 @@ int diga_prof_query(int tag, int64_t* h_count, double* h_total_ms);
  * 2*M*Cout*R*S*Cin). */
 int diga_prof_query_work(int tag, double* h_work);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libdiga_hip.so is built with -fvisibility=hidden: the functions declared in this header are its whole dynamic symbol table */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* nn.Linear forward and backward-data (MixTransfomer.py:52-55,72-79 Mlp.fc1/fc2; :97-99,122,130,135 Attention.q/kv/proj),
  * and -- on rows gathered by diga_mit_im2col -- the patch-embedding / spatial-reduction convolutions (:200,105).
@@ -121,6 +125,9 @@ int diga_mit_attention_bwd(const void* q, int64_t ldq, const void* kv, int64_t l
                            const float* lse, void* dq, void* dkv, void* workspace, size_t workspace_bytes, int64_t B, int64_t heads,
                            int64_t N, int64_t Nk, float scale, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

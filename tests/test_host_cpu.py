@@ -41,6 +41,16 @@ def test_library_exports_every_declared_symbol():
     assert len(_lib.PROF_TAGS) == 23
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden + the link's version script (diga_amd/build.py): the dynamic symbol table of libdiga_hip.so is the set
+    of functions include/*.h declares -- no C++ internals, no kernel handles."""
+    import subprocess
+    from diga_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == _header_symbols(), sorted(set(exported) ^ set(_header_symbols()))
+
+
 def test_abi_argument_errors_without_gpu():
     """Argument validation happens before any launch, so it can be exercised without a device."""
     from diga_amd import _lib
