@@ -75,15 +75,15 @@ SIGNATURES = {
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
     "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
     "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
-    "diga_conv2d_winograd_workspace_bytes": (SZ, [I64] * 6),
-    "diga_conv2d_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 8 + [INT, INT, P]),
-    "diga_conv2d_winograd_f32_epi": (INT, [P, P, P, P, SZ] + [I64] * 8 + [INT, P, INT, P]),
-    "diga_conv2d_wgrad_winograd_workspace_bytes": (SZ, [I64] * 6 + [INT]),
-    "diga_conv2d_wgrad_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 8 + [P]),
-    "diga_conv2d_winograd_v_floats": (SZ, [I64] * 5),
-    "diga_conv2d_winograd_f32_ab": (INT, [P, P, P, P, P, P, P, SZ] + [I64] * 8 + [INT, P]),
-    "diga_conv2d_wgrad_winograd_f32_ab": (INT, [P, P, P, P, P, P, SZ] + [I64] * 8 + [P]),
-    "diga_conv2d_winograd_f32_keep": (INT, [P, P, P, P, P, P, SZ] + [I64] * 8 + [INT, P]),
+    "diga_conv2d_winograd_workspace_bytes": (SZ, [I64] * 7),
+    "diga_conv2d_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [INT, INT, P]),
+    "diga_conv2d_winograd_f32_epi": (INT, [P, P, P, P, SZ] + [I64] * 9 + [INT, P, INT, P]),
+    "diga_conv2d_wgrad_winograd_workspace_bytes": (SZ, [I64] * 7 + [INT]),
+    "diga_conv2d_wgrad_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [P]),
+    "diga_conv2d_winograd_v_floats": (SZ, [I64] * 6),
+    "diga_conv2d_winograd_f32_ab": (INT, [P, P, P, P, P, P, P, SZ] + [I64] * 9 + [INT, P]),
+    "diga_conv2d_wgrad_winograd_f32_ab": (INT, [P, P, P, P, P, P, SZ] + [I64] * 9 + [P]),
+    "diga_conv2d_winograd_f32_keep": (INT, [P, P, P, P, P, P, SZ] + [I64] * 9 + [INT, P]),
     "diga_conv2d_nhwc_bf16x3_epi": (INT, [P, P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_conv2d_nhwc_twin_epi": (INT, [P, P, P] + [I64] * 16 + [P, INT, P]),
     "diga_gn_fwd": (INT, [P, I64, P, I64, P, P, P, P, P, I64, I64, I64, I64, INT, F32, P, SZ, P]),

@@ -30,31 +30,33 @@ namespace wino {
 
 struct WinoGeom {
     int N, H, W, d;
+    int m;                 // output tile edge: 2 = F(2x2,3x3) (16 products), 4 = F(4x4,3x3) (36 products)
     int tys, txs;          // tile rows / columns summed over the d phases
     int64_t T, Tp;
 };
 
-int phase_tiles(int len, int d) {
+int phase_tiles(int len, int d, int m) {
     int s = 0;
     for (int a = 0; a < d; ++a) {
         const int n = len > a ? (len - a + d - 1) / d : 0;
-        s += (n + 1) / 2;
+        s += (n + m - 1) / m;
     }
     return s;
 }
 
-WinoGeom make_wino(int64_t N, int64_t H, int64_t W, int64_t d) {
+WinoGeom make_wino(int64_t N, int64_t H, int64_t W, int64_t d, int64_t m) {
     WinoGeom g;
-    g.N = (int)N; g.H = (int)H; g.W = (int)W; g.d = (int)d;
-    g.tys = phase_tiles((int)H, (int)d);
-    g.txs = phase_tiles((int)W, (int)d);
+    g.N = (int)N; g.H = (int)H; g.W = (int)W; g.d = (int)d; g.m = (int)m;
+    g.tys = phase_tiles((int)H, (int)d, (int)m);
+    g.txs = phase_tiles((int)W, (int)d, (int)m);
     g.T = N * g.tys * g.txs;
     g.Tp = ceil_div(g.T, 256) * 256;
     return g;
 }
+static inline int products(int64_t m) { return (int)((m + 2) * (m + 2)); }
 
-// tab[t] = {image, oy, ox, 0}: top-left OUTPUT pixel of tile t (its 2x2 outputs are (oy + d i, ox + d j), its 4x4 input
-// patch (oy + d (i - 1), ox + d (j - 1))); image = -1 for the padding tiles
+// tab[t] = {image, oy, ox, 0}: top-left OUTPUT pixel of tile t (its m x m outputs are (oy + d i, ox + d j), its (m+2) x (m+2)
+// input patch (oy + d (i - 1), ox + d (j - 1))); image = -1 for the padding tiles
 __global__ __launch_bounds__(256) void wino_tiles_kernel(int4* __restrict__ tab, WinoGeom g) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= g.Tp) return;
@@ -68,17 +70,17 @@ __global__ __launch_bounds__(256) void wino_tiles_kernel(int4* __restrict__ tab,
     int a = 0, b = 0;
     for (; a < g.d; ++a) {
         const int cnt = g.H > a ? (g.H - a + g.d - 1) / g.d : 0;
-        const int tl = (cnt + 1) / 2;
+        const int tl = (cnt + g.m - 1) / g.m;
         if (R < tl) break;
         R -= tl;
     }
     for (; b < g.d; ++b) {
         const int cnt = g.W > b ? (g.W - b + g.d - 1) / g.d : 0;
-        const int tl = (cnt + 1) / 2;
+        const int tl = (cnt + g.m - 1) / g.m;
         if (Cc < tl) break;
         Cc -= tl;
     }
-    tab[t] = make_int4(n, a + 2 * R * g.d, b + 2 * Cc * g.d, 0);
+    tab[t] = make_int4(n, a + g.m * R * g.d, b + g.m * Cc * g.d, 0);
 }
 
 using f32x4nt = __attribute__((ext_vector_type(4))) float;
@@ -149,21 +151,25 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         av = *reinterpret_cast<const float4*>(ab + c);
         bv = *reinterpret_cast<const float4*>(ab + C + c);
     }
+    // branch-free: every tap is loaded from a clamped (valid) address and zeroed afterwards when it lies outside the image, so the
+    // 16 loads of a thread issue back to back (measured on the 4x4-tile twin of this kernel: 151 -> 109 us)
+    const int img = max(e.x, 0);
     float4 p[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int y = e.y + (i - 1) * d;
         const bool yok = e.x >= 0 && (unsigned)y < (unsigned)H;
+        const int yc = min(max(y, 0), H - 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int xx = e.z + (j - 1) * d;
             const bool ok = yok && (unsigned)xx < (unsigned)W;
-            float4 v = ok ? *reinterpret_cast<const float4*>(x + ((int64_t)(e.x * H + y) * W + xx) * ld + c) : z;
-            if (ab != nullptr && ok) {
+            float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(img * H + yc) * W + min(max(xx, 0), W - 1)) * ld + c);
+            if (ab != nullptr) {
                 v.x = fmaxf(__builtin_fmaf(v.x, av.x, bv.x), 0.f); v.y = fmaxf(__builtin_fmaf(v.y, av.y, bv.y), 0.f);
                 v.z = fmaxf(__builtin_fmaf(v.z, av.z, bv.z), 0.f); v.w = fmaxf(__builtin_fmaf(v.w, av.w, bv.w), 0.f);
             }
-            p[i][j] = v;
+            p[i][j] = ok ? v : z;
         }
     }
     float4 m[4][4];
@@ -357,7 +363,8 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
         for (int j = 0; j < 2; ++j) {
             const int yy = e.y + i * d, xx = e.z + j * d;
             const bool ok = e.x >= 0 && yy < H && xx < W;
-            g[i][j] = ok ? *reinterpret_cast<const float4*>(dy + ((int64_t)(e.x * H + yy) * W + xx) * ld + k) : z;
+            const float4 v = *reinterpret_cast<const float4*>(dy + ((int64_t)(max(e.x, 0) * H + min(yy, H - 1)) * W + min(xx, W - 1)) * ld + k);
+            g[i][j] = ok ? v : z;
         }
     // rows of A = [1 0; 1 1; 1 -1; 0 -1]
     float4 r[4][2];
@@ -410,6 +417,416 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
     }
 }
 
+// ======================================================================================================================
+// F(4x4, 3x3): 36 products per 4x4 outputs (2.25 multiplications per output instead of 9 direct / 4 with F(2x2)); V is
+// 2.25x the input instead of 4x, M 2.25x the output.  Interpolation points 0, +-1, +-2, inf (Lavin & Gray 2016):
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// fp32 rounding error of a 256-channel layer against float64: max 8e-6 of the output scale (F(2x2): 6e-7, the direct fmaf
+// chain 3e-7; measured) -- taken for the dilation 1 / 2 / 4 layers, whose sub-images are large enough
+// for 4x4 tiles; tests hold it to 3e-5 of scale per layer, the full-size captures to north_star's 1e-3.
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
+    return make_float4(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y), __builtin_fmaf(s, a.z, b.z), __builtin_fmaf(s, a.w, b.w));
+}
+__device__ __forceinline__ float4 f4scale(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+// the same helpers on channel pairs: the F(4x4) transforms hold 36 vectors per thread, float2 halves the registers (twice the waves)
+__device__ __forceinline__ float2 f4add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 f4sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 f4fma(float s, float2 a, float2 b) { return make_float2(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y)); }
+__device__ __forceinline__ float2 f4scale(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
+using f32x2nt = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ void nt_store4(float* p, float2 v) {
+    __builtin_nontemporal_store((f32x2nt){v.x, v.y}, reinterpret_cast<f32x2nt*>(p));
+}
+template <typename V> __device__ __forceinline__ V nt_loadv(const float* p);
+template <> __device__ __forceinline__ float4 nt_loadv<float4>(const float* p) { return nt_load4(p); }
+template <> __device__ __forceinline__ float2 nt_loadv<float2>(const float* p) {
+    const f32x2nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x2nt*>(p));
+    return make_float2(v.x, v.y);
+}
+template <typename V> __device__ __forceinline__ V vzero();
+template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ float2 vzero<float2>() { return make_float2(0.f, 0.f); }
+__device__ __forceinline__ float4 relu_fma(float4 v, float4 a, float4 b) {
+    return make_float4(fmaxf(__builtin_fmaf(v.x, a.x, b.x), 0.f), fmaxf(__builtin_fmaf(v.y, a.y, b.y), 0.f),
+                       fmaxf(__builtin_fmaf(v.z, a.z, b.z), 0.f), fmaxf(__builtin_fmaf(v.w, a.w, b.w), 0.f));
+}
+__device__ __forceinline__ float2 relu_fma(float2 v, float2 a, float2 b) {
+    return make_float2(fmaxf(__builtin_fmaf(v.x, a.x, b.x), 0.f), fmaxf(__builtin_fmaf(v.y, a.y, b.y), 0.f));
+}
+#ifndef DIGA_WINO4_IN_VEC
+#define DIGA_WINO4_IN_VEC float4
+#endif
+#ifndef DIGA_WINO4_OUT_VEC
+#define DIGA_WINO4_OUT_VEC float2     /* measured on l3.conv2: 82 vs 94 us (113 instead of 215 VGPRs); input / dy: no difference */
+#endif
+#ifndef DIGA_WINO4_DY_VEC
+#define DIGA_WINO4_DY_VEC float4
+#endif
+// one column / row of B^T d (in place on six values)
+template <typename V>
+__device__ __forceinline__ void bt6(V d0, V d1, V d2, V d3, V d4, V d5, V* r) {
+    const V t0 = f4fma(-4.f, d2, d4), t1 = f4fma(-4.f, d1, d3), t2 = f4sub(d4, d2), t3 = f4sub(d3, d1);
+    r[0] = f4fma(4.f, d0, f4fma(-5.f, d2, d4));
+    r[1] = f4add(t0, t1);
+    r[2] = f4sub(t0, t1);
+    r[3] = f4fma(2.f, t3, t2);
+    r[4] = f4fma(-2.f, t3, t2);
+    r[5] = f4fma(4.f, d1, f4fma(-5.f, d3, d5));
+}
+// G g (three values -> six)
+template <typename V>
+__device__ __forceinline__ void g6(V g0, V g1, V g2, V* r) {
+    const V s = f4add(g0, g2);
+    const V e = f4fma(1.f / 6.f, g2, f4scale(1.f / 24.f, g0));
+    r[0] = f4scale(0.25f, g0);
+    r[1] = f4scale(-1.f / 6.f, f4add(s, g1));
+    r[2] = f4scale(-1.f / 6.f, f4sub(s, g1));
+    r[3] = f4fma(1.f / 12.f, g1, e);
+    r[4] = f4fma(-1.f / 12.f, g1, e);
+    r[5] = g2;
+}
+// A^T m (six values -> four)
+template <typename V>
+__device__ __forceinline__ void at4(V m0, V m1, V m2, V m3, V m4, V m5, V* r) {
+    const V s12 = f4add(m1, m2), d12 = f4sub(m1, m2), s34 = f4add(m3, m4), d34 = f4sub(m3, m4);
+    r[0] = f4add(f4add(m0, s12), s34);
+    r[1] = f4fma(2.f, d34, d12);
+    r[2] = f4fma(4.f, s34, s12);
+    r[3] = f4add(f4fma(8.f, d34, d12), m5);
+}
+// A g (four values -> six)
+template <typename V>
+__device__ __forceinline__ void a6(V g0, V g1, V g2, V g3, V* r) {
+    const V e = f4add(g0, g2), o = f4add(g1, g3);
+    const V e4 = f4fma(4.f, g2, g0), o4 = f4fma(8.f, g3, f4add(g1, g1));
+    r[0] = g0;
+    r[1] = f4add(e, o);
+    r[2] = f4sub(e, o);
+    r[3] = f4add(e4, o4);
+    r[4] = f4sub(e4, o4);
+    r[5] = g3;
+}
+// G^T u (six values -> three)
+template <typename V>
+__device__ __forceinline__ void gt3(V u0, V u1, V u2, V u3, V u4, V u5, V* r) {
+    const V s12 = f4add(u1, u2), d12 = f4sub(u1, u2), s34 = f4add(u3, u4), d34 = f4sub(u3, u4);
+    r[0] = f4fma(0.25f, u0, f4fma(-1.f / 6.f, s12, f4scale(1.f / 24.f, s34)));
+    r[1] = f4fma(-1.f / 6.f, d12, f4scale(1.f / 12.f, d34));
+    r[2] = f4add(f4fma(-1.f / 6.f, s12, f4scale(1.f / 6.f, s34)), u5);
+}
+
+// U[k = 6 i + j][co][c] = (G g G^T)[i][j]
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
+                                                           int flip) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = Cin / 4;
+    if (idx >= (int64_t)Cout * c4n) return;
+    const int co = (int)(idx / c4n), c = (int)(idx - (int64_t)co * c4n) * 4;
+    float4 t[6][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        float4 g[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
+            g[r] = *reinterpret_cast<const float4*>(w + ((int64_t)co * 9 + rr * 3 + ss) * Cin + c);
+        }
+        float4 col[6];
+        g6(g[0], g[1], g[2], col);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i][s] = col[i];
+    }
+    const int64_t plane = (int64_t)Cout * Cin;
+    float* o = U + (int64_t)co * Cin + c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float4 row[6];
+        g6(t[i][0], t[i][1], t[i][2], row);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(o + (6 * i + j) * plane) = row[j];
+    }
+}
+
+// V[k = 6 i + j][t][c] = (B^T d B)[i][j] of the 6x6 patch of tile t (zero outside the image / for padding tiles); `ab` as in
+// wino_input_kernel
+template <typename V>
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
+                                                          float* __restrict__ Vo, int64_t Tp, int C, int H, int W, int d,
+                                                          const float* __restrict__ ab) {
+    constexpr int VW = sizeof(V) / 4;
+    const int c4n = C / VW;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Tp * c4n) return;
+    const int64_t t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * VW;
+    const int4 e = tab[t];
+    const V z = vzero<V>();
+    V av = z, bv = z;
+    if (ab != nullptr) {
+        av = *reinterpret_cast<const V*>(ab + c);
+        bv = *reinterpret_cast<const V*>(ab + C + c);
+    }
+    const int img = max(e.x, 0);
+    V m[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        // branch-free: every tap is loaded from a clamped (valid) address and zeroed afterwards when it lies outside the image,
+        // so the 36 loads of a thread issue back to back
+        const int xx = e.z + (j - 1) * d;
+        const bool xok = e.x >= 0 && (unsigned)xx < (unsigned)W;
+        const int xc = min(max(xx, 0), W - 1);
+        V p[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int y = e.y + (i - 1) * d;
+            const bool ok = xok && (unsigned)y < (unsigned)H;
+            const int yc = min(max(y, 0), H - 1);
+            V v = *reinterpret_cast<const V*>(x + ((int64_t)(img * H + yc) * W + xc) * ld + c);
+            if (ab != nullptr) v = relu_fma(v, av, bv);
+            p[i] = ok ? v : z;
+        }
+        V col[6];
+        bt6(p[0], p[1], p[2], p[3], p[4], p[5], col);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i][j] = col[i];
+    }
+    float* o = Vo + t * C + c;
+    const int64_t plane = Tp * C;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        V row[6];
+        bt6(m[i][0], m[i][1], m[i][2], m[i][3], m[i][4], m[i][5], row);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) nt_store4(o + (6 * i + j) * plane, row[j]);
+    }
+}
+
+// s[i][j] = (A^T M)[i][j] of tile t, channels k..k+3: 4 x 6 values from the 36 product planes
+template <typename V>
+__device__ __forceinline__ void wino4_load_rows(const float* __restrict__ src, int64_t plane, V (*s)[6]) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        V m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = nt_loadv<V>(src + (6 * i + j) * plane);
+        V col[4];
+        at4(m[0], m[1], m[2], m[3], m[4], m[5], col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = col[i];
+    }
+}
+
+// y[4x4 of tile t][co] = A^T M A + bias
+template <typename V>
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int64_t ld,
+                                                           int64_t T, int64_t Tp, int K, int H, int W, int d) {
+    constexpr int VW = sizeof(V) / 4;
+    const int k4n = K / VW;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * k4n) return;
+    const int64_t t = idx / k4n;
+    const int k = (int)(idx - t * k4n) * VW;
+    const int4 e = tab[t];
+    V s[4][6];
+    wino4_load_rows(Mb + t * K + k, Tp * K, s);
+    const V b = bias != nullptr ? *reinterpret_cast<const V*>(bias + k) : vzero<V>();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = e.y + i * d;
+        if (yy >= H) continue;
+        V o[4];
+        at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
+        float* row = y + ((int64_t)(e.x * H + yy) * W) * ld + k;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (e.z + j * d < W) *reinterpret_cast<V*>(row + (int64_t)(e.z + j * d) * ld) = f4add(o[j], b);
+    }
+}
+
+// one output pixel of a backward-data convolution through the epilogue of diga_bwd_epilogue_t (the arithmetic of
+// wino_output_epi_kernel / drain_stage<EPI>, element for element)
+__device__ __forceinline__ void wino_epi_pixel(float4 o, int64_t row, int k, float* __restrict__ y, int64_t ld, const WinoEpi& ep,
+                                               const float* ra, const float* rb, const float* mu, const float* is, float* sd,
+                                               float* sd2) {
+    float v[4] = {o.x, o.y, o.z, o.w};
+    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ep.add != nullptr) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ep.add + row * ep.add_ld + k);
+        v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+    }
+    if (ep.x != nullptr) {
+        const float4 x4 = *reinterpret_cast<const float4*>(ep.x + row * ep.x_ld + k);
+        xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+    }
+    if (ep.masky != nullptr) {
+        const float4 y4 = *reinterpret_cast<const float4*>(ep.masky + row * ep.masky_ld + k);
+        v[0] = y4.x > 0.f ? v[0] : 0.f; v[1] = y4.y > 0.f ? v[1] : 0.f;
+        v[2] = y4.z > 0.f ? v[2] : 0.f; v[3] = y4.w > 0.f ? v[3] : 0.f;
+    } else if (ep.maskbits != nullptr) {
+        const unsigned b = ep.maskbits[row * ep.maskbits_ld + (k >> 3)] >> (k & 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = ((b >> c) & 1u) ? v[c] : 0.f;
+    } else if (ep.relu_ab != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaf(xv[c], ra[c], rb[c]) > 0.f ? v[c] : 0.f;
+    }
+    *reinterpret_cast<float4*>(y + row * ld + k) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        sd[c] += v[c];
+        sd2[c] += v[c] * ((xv[c] - mu[c]) * is[c]);
+    }
+}
+
+// wino4_output_kernel with the backward-data epilogue: block / partial-row layout of wino_output_epi_kernel
+__global__ __launch_bounds__(256) void wino4_output_epi_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+                                                               float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
+                                                               int H, int W, int d, int tpb, WinoEpi ep) {
+    __shared__ float red[2][4][256];
+    const int q = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const int k = (blockIdx.y * 64 + q) * 4;
+    const bool kok = k < K;
+    const int64_t t0 = (int64_t)blockIdx.x * tpb;
+    int64_t t1 = t0 + tpb;
+    if (t1 > T) t1 = T;
+    const int64_t plane = Tp * K;
+    float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kok && ep.relu_ab != nullptr) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ep.relu_ab + k), a1 = *reinterpret_cast<const float4*>(ep.relu_ab + K + k);
+        ra[0] = a0.x; ra[1] = a0.y; ra[2] = a0.z; ra[3] = a0.w;
+        rb[0] = a1.x; rb[1] = a1.y; rb[2] = a1.z; rb[3] = a1.w;
+    }
+    if (kok && ep.partials != nullptr) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ep.mean + k), a1 = *reinterpret_cast<const float4*>(ep.invstd + k);
+        mu[0] = a0.x; mu[1] = a0.y; mu[2] = a0.z; mu[3] = a0.w;
+        is[0] = a1.x; is[1] = a1.y; is[2] = a1.z; is[3] = a1.w;
+    }
+    float sd[4] = {0.f, 0.f, 0.f, 0.f}, sd2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kok) {
+        for (int64_t t = t0 + tl; t < t1; t += 4) {
+            const int4 e = tab[t];
+            float4 s[4][6];
+            wino4_load_rows(Mb + t * K + k, plane, s);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yy = e.y + i * d;
+                if (yy >= H) continue;
+                float4 o[4];
+                at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xx = e.z + j * d;
+                    if (xx >= W) continue;
+                    wino_epi_pixel(o[j], (int64_t)(e.x * H + yy) * W + xx, k, y, ld, ep, ra, rb, mu, is, sd, sd2);
+                }
+            }
+        }
+    }
+    if (ep.partials == nullptr) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        red[0][tl][q * 4 + c] = sd[c];
+        red[1][tl][q * 4 + c] = sd2[c];
+    }
+    __syncthreads();
+    const int ch = blockIdx.y * 256 + threadIdx.x;
+    if (ch < K) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            a0 += red[0][l][threadIdx.x];
+            a1 += red[1][l][threadIdx.x];
+        }
+        float* sp = ep.partials + (int64_t)blockIdx.x * 2 * K + ch;
+        sp[0] = a0;
+        sp[K] = a1;
+    }
+}
+
+// Z[k = 6 i + j][t][co] = (A dY A^T)[i][j] of the 4x4 output-gradient tile t
+template <typename V>
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int64_t ld, const int4* __restrict__ tab,
+                                                       float* __restrict__ Z, int64_t Tp, int K, int H, int W, int d) {
+    constexpr int VW = sizeof(V) / 4;
+    const int k4n = K / VW;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Tp * k4n) return;
+    const int64_t t = idx / k4n;
+    const int k = (int)(idx - t * k4n) * VW;
+    const int4 e = tab[t];
+    const V z = vzero<V>();
+    const int img = max(e.x, 0);
+    V r[6][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = e.z + j * d, xc = min(xx, W - 1);
+        V g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = e.y + i * d;
+            const bool ok = e.x >= 0 && yy < H && xx < W;
+            const V v = *reinterpret_cast<const V*>(dy + ((int64_t)(img * H + min(yy, H - 1)) * W + xc) * ld + k);     // (clamped address)
+            g[i] = ok ? v : z;
+        }
+        V col[6];
+        a6(g[0], g[1], g[2], g[3], col);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i][j] = col[i];
+    }
+    float* o = Z + t * K + k;
+    const int64_t plane = Tp * K;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        V row[6];
+        a6(r[i][0], r[i][1], r[i][2], r[i][3], row);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) nt_store4(o + (6 * i + j) * plane, row[j]);
+    }
+}
+
+// dw[co][r][s][c] = (G^T dU G)[r][s], dU [co][36][c]
+__global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = Cin / 4;
+    if (idx >= (int64_t)Cout * c4n) return;
+    const int co = (int)(idx / c4n), c = (int)(idx - (int64_t)co * c4n) * 4;
+    const float* src = dU + (int64_t)co * 36 * Cin + c;
+    float4 t[3][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float4 u[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) u[i] = *reinterpret_cast<const float4*>(src + (int64_t)(6 * i + j) * Cin);
+        float4 col[3];
+        gt3(u[0], u[1], u[2], u[3], u[4], u[5], col);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t[r][j] = col[r];
+    }
+    float* o = dw + (int64_t)co * 9 * Cin + c;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float4 row[3];
+        gt3(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], row);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(o + (int64_t)(3 * r + q) * Cin) = row[q];
+    }
+}
+
+static void launch_input(int64_t tile, const float* x, int64_t ld, const int4* tab, float* V, int64_t Tp, int64_t C, int64_t H, int64_t W,
+                         int64_t d, const float* ab, hipStream_t st) {
+    if (tile == 4) {
+        constexpr int VW = sizeof(DIGA_WINO4_IN_VEC) / 4;
+        hipLaunchKernelGGL(wino4_input_kernel<DIGA_WINO4_IN_VEC>, dim3((unsigned)ceil_div(Tp * (C / VW), 256)), dim3(256), 0, st, x, ld, tab, V,
+                           Tp, (int)C, (int)H, (int)W, (int)d, ab);
+    } else {
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(Tp * (C / 4), 256)), dim3(256), 0, st, x, ld, tab, V, Tp, (int)C,
+                           (int)H, (int)W, (int)d, ab);
+    }
+}
+
 struct WinoWgradLayout {
     size_t tab, V, Z, dU, slab, total;
 };
@@ -417,10 +834,10 @@ WinoWgradLayout wino_wgrad_layout(const WinoGeom& g, int64_t Cin, int64_t Cout, 
     WinoWgradLayout l;
     size_t o = 0;
     l.tab = o; o += (size_t)g.Tp * sizeof(int4);
-    l.V = o; o += with_v ? (size_t)16 * g.Tp * Cin * sizeof(float) : 0;        // (not when the forward's V was kept)
-    l.Z = o; o += (size_t)16 * g.Tp * Cout * sizeof(float);
-    l.dU = o; o += (size_t)16 * Cout * Cin * sizeof(float);
-    l.slab = o; o += wgrad_batched_slab_bytes(g.Tp, 16, Cout, Cin);
+    l.V = o; o += with_v ? (size_t)products(g.m) * g.Tp * Cin * sizeof(float) : 0;        // (not when the forward's V was kept)
+    l.Z = o; o += (size_t)products(g.m) * g.Tp * Cout * sizeof(float);
+    l.dU = o; o += (size_t)products(g.m) * Cout * Cin * sizeof(float);
+    l.slab = o; o += wgrad_batched_slab_bytes(g.Tp, products(g.m), Cout, Cin);
     l.total = o + 64;
     return l;
 }
@@ -432,9 +849,9 @@ WinoLayout wino_layout(const WinoGeom& g, int64_t Cin, int64_t Cout) {
     WinoLayout l;
     size_t o = 0;
     l.tab = o; o += (size_t)g.Tp * sizeof(int4);
-    l.U = o; o += (size_t)16 * Cout * Cin * sizeof(float);
-    l.V = o; o += (size_t)16 * g.Tp * Cin * sizeof(float);
-    l.M = o; o += (size_t)16 * g.Tp * Cout * sizeof(float);
+    l.U = o; o += (size_t)products(g.m) * Cout * Cin * sizeof(float);
+    l.V = o; o += (size_t)products(g.m) * g.Tp * Cin * sizeof(float);
+    l.M = o; o += (size_t)products(g.m) * g.Tp * Cout * sizeof(float);
     l.total = o + 64;
     return l;
 }
@@ -445,24 +862,26 @@ WinoLayout wino_layout(const WinoGeom& g, int64_t Cin, int64_t Cout) {
 using namespace diga;
 using namespace diga::wino;
 
-extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0) return 0;
-    return wino_layout(make_wino(N, H, W, dilation), Cin, Cout).total;
+extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation, int64_t tile) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || (tile != 2 && tile != 4)) return 0;
+    return wino_layout(make_wino(N, H, W, dilation, tile), Cin, Cout).total;
 }
 
 static int winograd_impl(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                          size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
-                         int64_t Cout, int64_t out_ld, int64_t dilation, int flip, const diga_bwd_epilogue_t* epi, int prof_tag,
+                         int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int flip, const diga_bwd_epilogue_t* epi, int prof_tag,
                          void* stream, float* v_keep = nullptr, const float* in_ab = nullptr) {
     DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
+    DIGA_REQUIRE(tile == 2 || tile == 4, DIGA_EINVAL, "conv2d_winograd: tile must be 2 (F(2x2,3x3)) or 4 (F(4x4,3x3))");
     DIGA_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 && in_ld >= Cin && in_ld % 4 == 0 && out_ld >= Cout && out_ld % 4 == 0,
                  DIGA_EINVAL, "conv2d_winograd: Cin %% 32, Cout %% 4 (> 64) and leading dimensions %% 4 required");
     DIGA_REQUIRE(aligned16(in) && aligned16(wgt) && aligned16(out) && aligned16(workspace) && (!bias || aligned16(bias)), DIGA_EALIGN,
                  "conv2d_winograd: pointers must be 16-byte aligned");
     DIGA_REQUIRE(N * H * W < (1ll << 31), DIGA_EINVAL, "conv2d_winograd: too many pixels");
-    const WinoGeom g = make_wino(N, H, W, dilation);
-    DIGA_REQUIRE(16 * g.Tp / 256 < 32768, DIGA_EINVAL, "conv2d_winograd: too many tiles for one launch");
+    const WinoGeom g = make_wino(N, H, W, dilation, tile);
+    const int P = products(tile);
+    DIGA_REQUIRE(P * g.Tp / 256 < 32768, DIGA_EINVAL, "conv2d_winograd: too many tiles for one launch");
     const WinoLayout l = wino_layout(g, Cin, Cout);
     DIGA_REQUIRE(workspace_bytes >= l.total, DIGA_EWORKSPACE, "conv2d_winograd: workspace too small (%zu < %zu)", workspace_bytes, l.total);
     char* ws = static_cast<char*>(workspace);
@@ -475,16 +894,21 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
                    2.0 * (double)(N * H * W) * (double)Cout * 9.0 * (double)Cin);
     hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, wgt, U, (int)Cout,
-                       (int)Cin, flip);
+    hipLaunchKernelGGL(tile == 4 ? wino4_weight_kernel : wino_weight_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0,
+                       st, wgt, U, (int)Cout, (int)Cin, flip);
     DIGA_REQUIRE(!in_ab || aligned16(in_ab), DIGA_EALIGN, "conv2d_winograd: in_ab must be 16-byte aligned");
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(g.Tp * (Cin / 4), 256)), dim3(256), 0, st, in, in_ld, tab, V, g.Tp,
-                       (int)Cin, (int)H, (int)W, (int)dilation, in_ab);
-    int rc = gemm_batched_f32_dma(V, g.Tp, 16, Cin, U, Cout, Mb, st);
+    launch_input(tile, in, in_ld, tab, V, g.Tp, Cin, H, W, dilation, in_ab, st);
+    int rc = gemm_batched_f32_dma(V, g.Tp, P, Cin, U, Cout, Mb, st);
     if (rc) return rc;
     if (epi == nullptr) {
-        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(g.T * (Cout / 4), 256)), dim3(256), 0, st, Mb, tab, bias, out,
-                           out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
+        if (tile == 4) {
+            constexpr int VW = sizeof(DIGA_WINO4_OUT_VEC) / 4;
+            hipLaunchKernelGGL(wino4_output_kernel<DIGA_WINO4_OUT_VEC>, dim3((unsigned)ceil_div(g.T * (Cout / VW), 256)), dim3(256), 0, st, Mb, tab,
+                               bias, out, out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
+        } else {
+            hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(g.T * (Cout / 4), 256)), dim3(256), 0, st, Mb, tab, bias, out,
+                               out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
+        }
     } else {
         WinoEpi ep;
         ep.add = epi->addend; ep.add_ld = epi->addend_ld;
@@ -494,46 +918,46 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
         ep.relu_ab = epi->relu_ab; ep.mean = epi->mean; ep.invstd = epi->invstd; ep.partials = epi->partials;
         const int64_t G = ceil_div(N * H * W, 128);
         const int tpb = (int)ceil_div(g.T, G);
-        hipLaunchKernelGGL(wino_output_epi_kernel, dim3((unsigned)G, (unsigned)ceil_div(Cout, 256)), dim3(256), 0, st, Mb, tab, out,
-                           out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
+        hipLaunchKernelGGL(tile == 4 ? wino4_output_epi_kernel : wino_output_epi_kernel, dim3((unsigned)G, (unsigned)ceil_div(Cout, 256)),
+                           dim3(256), 0, st, Mb, tab, out, out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
     }
     return launch_status("diga_conv2d_winograd_f32");
 }
 
 extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                                         size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
-                                        int64_t Cout, int64_t out_ld, int64_t dilation, int flip, int prof_tag, void* stream) {
-    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, flip, nullptr,
+                                        int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int flip, int prof_tag, void* stream) {
+    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, flip, nullptr,
                          prof_tag, stream);
 }
 
 extern "C" int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out,
                                            float* v_keep, void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W,
-                                           int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int prof_tag,
+                                           int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int prof_tag,
                                            void* stream) {
     DIGA_REQUIRE(in_ab != nullptr, DIGA_EINVAL, "conv2d_winograd_ab: null coefficients");
     DIGA_REQUIRE(!v_keep || aligned16(v_keep), DIGA_EALIGN, "conv2d_winograd_ab: v_keep must be 16-byte aligned");
-    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, 0, nullptr,
+    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, 0, nullptr,
                          prof_tag, stream, v_keep, in_ab);
 }
 
-extern "C" size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || dilation <= 0) return 0;
-    return (size_t)16 * make_wino(N, H, W, dilation).Tp * Cin;
+extern "C" size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation, int64_t tile) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || dilation <= 0 || (tile != 2 && tile != 4)) return 0;
+    return (size_t)products(tile) * make_wino(N, H, W, dilation, tile).Tp * Cin;
 }
 
 extern "C" int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, const float* bias, float* out, float* v_keep,
                                              void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                             int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int prof_tag,
+                                             int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int prof_tag,
                                              void* stream) {
     DIGA_REQUIRE(v_keep != nullptr && aligned16(v_keep), DIGA_EINVAL, "conv2d_winograd_keep: v_keep must be a 16-byte aligned buffer");
-    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, 0, nullptr,
+    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, 0, nullptr,
                          prof_tag, stream, v_keep);
 }
 
 extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes,
                                             int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
-                                            int64_t out_ld, int64_t dilation, int flip, const diga_bwd_epilogue_t* e, int prof_tag,
+                                            int64_t out_ld, int64_t dilation, int64_t tile, int flip, const diga_bwd_epilogue_t* e, int prof_tag,
                                             void* stream) {
     DIGA_REQUIRE(e != nullptr, DIGA_EINVAL, "conv2d_winograd_epi: null epilogue descriptor");
     DIGA_REQUIRE(e->addend || e->mask_y || e->mask_bits || e->x, DIGA_EINVAL, "conv2d_winograd_epi: empty epilogue descriptor");
@@ -546,28 +970,28 @@ extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, f
     DIGA_REQUIRE(!e->relu_ab || (e->x && aligned16(e->relu_ab)), DIGA_EINVAL, "conv2d_winograd_epi: relu_ab needs x");
     DIGA_REQUIRE(!e->partials || (e->x && e->mean && e->invstd && aligned16(e->mean) && aligned16(e->invstd)), DIGA_EINVAL,
                  "conv2d_winograd_epi: partials need x, mean and invstd");
-    return winograd_impl(in, wgt, nullptr, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, flip, e, prof_tag,
+    return winograd_impl(in, wgt, nullptr, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, flip, e, prof_tag,
                          stream);
 }
 
 extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
-                                                             int64_t dilation, int v_kept) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || Cout % 256 != 0 || Cin % 128 != 0) return 0;
-    return wino_wgrad_layout(make_wino(N, H, W, dilation), Cin, Cout, v_kept == 0).total;
+                                                             int64_t dilation, int64_t tile, int v_kept) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || Cout % 256 != 0 || Cin % 128 != 0 || (tile != 2 && tile != 4)) return 0;
+    return wino_wgrad_layout(make_wino(N, H, W, dilation, tile), Cin, Cout, v_kept == 0).total;
 }
 
 static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw, void* workspace,
                                size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
-                               int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream) {
+                               int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream) {
     DIGA_REQUIRE(dy && (x || v_kept) && dw && workspace, DIGA_EINVAL, "conv2d_wgrad_winograd: null pointer");
     DIGA_REQUIRE(!v_kept || aligned16(v_kept), DIGA_EALIGN, "conv2d_wgrad_winograd: v_kept must be 16-byte aligned");
-    DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && N * H * W < (1ll << 31), DIGA_EINVAL,
-                 "conv2d_wgrad_winograd: bad shape");
+    DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && N * H * W < (1ll << 31) && (tile == 2 || tile == 4),
+                 DIGA_EINVAL, "conv2d_wgrad_winograd: bad shape / tile");
     DIGA_REQUIRE(Cout % 256 == 0 && Cin % 128 == 0 && x_ld >= Cin && x_ld % 4 == 0 && dy_ld >= Cout && dy_ld % 4 == 0, DIGA_EINVAL,
                  "conv2d_wgrad_winograd: Cout %% 256, Cin %% 128 and leading dimensions %% 4 required");
     DIGA_REQUIRE(aligned16(dy) && (!x || aligned16(x)) && aligned16(dw) && aligned16(workspace), DIGA_EALIGN,
                  "conv2d_wgrad_winograd: pointers must be 16-byte aligned");
-    const WinoGeom g = make_wino(N, H, W, dilation);
+    const WinoGeom g = make_wino(N, H, W, dilation, tile);
     const WinoWgradLayout l = wino_wgrad_layout(g, Cin, Cout, v_kept == nullptr);
     DIGA_REQUIRE(workspace_bytes >= l.total, DIGA_EWORKSPACE, "conv2d_wgrad_winograd: workspace too small (%zu < %zu)", workspace_bytes,
                  l.total);
@@ -581,25 +1005,31 @@ static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_a
     ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st, 2.0 * (double)(N * H * W) * (double)Cout * 9.0 * (double)Cin);
     hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
     if (v_kept == nullptr)
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(g.Tp * (Cin / 4), 256)), dim3(256), 0, st, x, x_ld, tab,
-                           reinterpret_cast<float*>(ws + l.V), g.Tp, (int)Cin, (int)H, (int)W, (int)dilation, x_ab);
-    hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)ceil_div(g.Tp * (Cout / 4), 256)), dim3(256), 0, st, dy, dy_ld, tab, Z, g.Tp,
-                       (int)Cout, (int)H, (int)W, (int)dilation);
-    int rc = wgrad_batched_f32_dma(Z, V, dU, slab, g.Tp, 16, Cout, Cin, st);
+        launch_input(tile, x, x_ld, tab, reinterpret_cast<float*>(ws + l.V), g.Tp, Cin, H, W, dilation, x_ab, st);
+    if (tile == 4) {
+        constexpr int VW = sizeof(DIGA_WINO4_DY_VEC) / 4;
+        hipLaunchKernelGGL(wino4_dy_kernel<DIGA_WINO4_DY_VEC>, dim3((unsigned)ceil_div(g.Tp * (Cout / VW), 256)), dim3(256), 0, st, dy, dy_ld, tab,
+                           Z, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
+    } else {
+        hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)ceil_div(g.Tp * (Cout / 4), 256)), dim3(256), 0, st, dy, dy_ld, tab, Z, g.Tp,
+                           (int)Cout, (int)H, (int)W, (int)dilation);
+    }
+    int rc = wgrad_batched_f32_dma(Z, V, dU, slab, g.Tp, products(tile), Cout, Cin, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, dU, dw, (int)Cout, (int)Cin);
+    hipLaunchKernelGGL(tile == 4 ? wino4_dw_kernel : wino_dw_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st,
+                       dU, dw, (int)Cout, (int)Cin);
     return launch_status("diga_conv2d_wgrad_winograd_f32");
 }
 
 extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
                                               size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
-                                              int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream) {
-    return wgrad_winograd_impl(dy, x, nullptr, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, stream);
+                                              int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream) {
+    return wgrad_winograd_impl(dy, x, nullptr, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile, stream);
 }
 
 extern "C" int diga_conv2d_wgrad_winograd_f32_ab(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw,
                                                  void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                                 int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream) {
+                                                 int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream) {
     DIGA_REQUIRE(x_ab != nullptr && aligned16(x_ab), DIGA_EINVAL, "conv2d_wgrad_winograd_ab: null / unaligned coefficients");
-    return wgrad_winograd_impl(dy, x, x_ab, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, stream);
+    return wgrad_winograd_impl(dy, x, x_ab, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile, stream);
 }

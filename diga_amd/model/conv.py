@@ -88,42 +88,71 @@ def _log_flops(name, direct, executed):
         e[1] += executed
 
 
-def _room_for(nbytes, device):
+# Path switches, read ONCE at import (not per call: a convolution call makes no environment or driver query); tests and
+# A/B runs set the module attributes.  WINOGRAD_MAX_TILE 2 keeps every layer on F(2x2,3x3).
+WINOGRAD = os.environ.get("DIGA_CONV_WINOGRAD", "1") != "0"
+WINOGRAD_RATIO = float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62"))
+WINOGRAD_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "4"))
+WINOGRAD_KEEP_V = os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
+_KEEP_DECISION = {}
+
+
+def _room_for(nbytes, device, key):
     """Keeping a transformed input alive until the backward pass is a memory-for-bandwidth trade: only while, after the
     allocation, 40 % of the device (115 of the MI355X's 288 GB) would still be free -- counting what the driver reports
     free (other processes on the GPU included: two test ranks may share one) plus this process's cached blocks.  The C2 step
-    peaks at 128 GB with everything kept."""
+    peaks at 128 GB with everything kept.  Decided ONCE per layer and shape (`key`), at its first forward -- when the kept
+    tensors of the layers in front of it are already allocated -- and cached: later steps (and a captured HIP graph) repeat the
+    first step's choices without a driver query."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    free, total = torch.cuda.mem_get_info(idx)
-    cached = torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx)
-    return free + cached - nbytes > 0.4 * total
+    key = (idx, nbytes) + tuple(key)
+    ok = _KEEP_DECISION.get(key)
+    if ok is None:
+        free, total = torch.cuda.mem_get_info(idx)
+        cached = torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx)
+        ok = _KEEP_DECISION[key] = bool(free + cached - nbytes > 0.4 * total)
+    return ok
+
+
+def _wino_plan(hi, wi, d):
+    """(tile, ratio): the Winograd output-tile edge for a stride-1 3x3 layer with dilation d on an hi x wi map and the share of the
+    direct convolution's multiplications it executes.  The d*d sub-images {(a + d i, b + d j)} are cut into m x m tiles of
+    (m + 2)^2 products each: F(2x2,3x3) 16 per 4 outputs, F(4x4,3x3) 36 per 16 outputs; the smaller count wins (97 x 97:
+    d = 1 / 2 / 4 -> 0.27 / 0.27 / 0.33 with 4x4 tiles against 0.45 / 0.45 / 0.48; d = 18 ties at 0.55 and stays on 2x2)."""
+    key = (hi, wi, d, WINOGRAD_MAX_TILE)
+    plan = _WINO_CACHE.get(key)
+    if plan is None:
+        def tiles(length, m):
+            return sum((((length - a + d - 1) // d if length > a else 0) + m - 1) // m for a in range(d))
+        plan = None
+        for m in (2, 4):
+            if m > WINOGRAD_MAX_TILE:
+                continue
+            ratio = float((m + 2) ** 2) * tiles(hi, m) * tiles(wi, m) / (9.0 * hi * wi)
+            if plan is None or ratio < plan[1] - 1e-9:
+                plan = (m, ratio)
+        _WINO_CACHE[key] = plan
+    return plan
 
 
 def _wino_ratio(hi, wi, d):
-    key = (hi, wi, d)
-    ratio = _WINO_CACHE.get(key)
-    if ratio is None:
-        def tiles(length):
-            return sum((((length - a + d - 1) // d if length > a else 0) + 1) // 2 for a in range(d))
-        ratio = _WINO_CACHE[key] = 16.0 * tiles(hi) * tiles(wi) / (9.0 * hi * wi)
-    return ratio
+    return _wino_plan(hi, wi, d)[1]
 
 
 def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
     """Exact-fp32 mode: stride-1 'same' 3x3 layers (dilation d = padding, forward or backward-data geometry) go through
-    Winograd F(2x2,3x3) (csrc/winograd.hip) when cutting the d*d sub-images into 2x2 tiles leaves few enough multiplications:
-    (16 per tile) / (36 per 2x2 outputs) of the direct convolution <= DIGA_CONV_WINOGRAD_RATIO (default 0.62; dilation 24 on a
-    97x97 map has 5x5 sub-images -> 0.98 and stays direct, where the kernel also skips the dead taps).
-    DIGA_CONV_WINOGRAD=0 switches the path off."""
-    if os.environ.get("DIGA_CONV_WINOGRAD", "1") == "0":
+    Winograd (csrc/winograd.hip; tile from _wino_plan) when cutting the d*d sub-images into tiles leaves few enough
+    multiplications: share of the direct convolution <= WINOGRAD_RATIO (default 0.62; dilation 24 on a 97x97 map has 5x5
+    sub-images -> 0.98 and stays direct, where the kernel also skips the dead taps).  WINOGRAD = False switches the path off."""
+    if not WINOGRAD:
         return False
     d = abs(doff[0])
     if not (r == 3 and s == 3 and tuple(stride) == (1, 1) and doff[0] == doff[1] and d >= 1 and off0[0] == -doff[0]
             and off0[1] == -doff[1] and hi == ho and wi == wo and cin % 32 == 0 and cin >= 128 and k % 4 == 0 and k >= 128):
         return False
     ratio = _wino_ratio(hi, wi, d)
-    # (the batched GEMM indexes its 16 * tiles rows as a [rows / 256][256] image with 15-bit row coordinates)
-    return ratio <= float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62")) and n * hi * wi * ratio * 9.0 / 256.0 < 32000
+    # (the batched GEMM indexes its products * tiles rows as a [rows / 256][256] image with 15-bit row coordinates)
+    return ratio <= WINOGRAD_RATIO and n * hi * wi * ratio * 9.0 / 256.0 < 32000
 
 
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
@@ -198,31 +227,33 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
     if (_lib.get_conv_math() == 0 and copt is None and stats is None
             and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):
         d = abs(doff[0])
-        _log_flops(name, direct, direct * _wino_ratio(hi, wi, d))
-        nbytes = _lib.lib.diga_conv2d_winograd_workspace_bytes(n, hi, wi, cin, k, d)
+        tile, ratio = _wino_plan(hi, wi, d)
+        _log_flops(name, direct, direct * ratio)
+        nbytes = _lib.lib.diga_conv2d_winograd_workspace_bytes(n, hi, wi, cin, k, d, tile)
+        vkey = (w_krsc.data_ptr(), n, hi, wi, cin, d, tile)
         ws = _lib.workspace(nbytes, x.device, "winograd")
         if epi is not None:
             _lib.call("diga_conv2d_winograd_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                      n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, ctypes.byref(epi), tag, _lib.stream())
+                      n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, 1 if doff[0] < 0 else 0, ctypes.byref(epi), tag, _lib.stream())
             return None
         if in_ab is not None:
             # x holds the pre-activation values of a BatchNorm + ReLU: the input transform applies relu(fma(x, a, b)) on load
             if epi is not None or doff[0] < 0:
                 raise RuntimeError("DigaConv2d: a deferred BatchNorm input only feeds a forward convolution")
-            if keep_v is not None and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d) * 4, x.device):
-                keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d), dtype=torch.float32, device=x.device)
+            if keep_v is not None and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile) * 4, x.device, vkey):
+                keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), dtype=torch.float32, device=x.device)
             _lib.call("diga_conv2d_winograd_f32_ab", _lib.ptr(x), _lib.ptr(in_ab), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out),
                       _lib.ptr(keep_v[0]) if keep_v is not None else None, _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k,
-                      out.stride(2), d, tag, _lib.stream())
+                      out.stride(2), d, tile, tag, _lib.stream())
             return None
-        if keep_v is not None and doff[0] > 0 and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d) * 4, x.device):
+        if keep_v is not None and doff[0] > 0 and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile) * 4, x.device, vkey):
             # keep_v: a one-element list -- the transformed input stays alive for this layer's weight gradient
-            keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d), dtype=torch.float32, device=x.device)
+            keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), dtype=torch.float32, device=x.device)
             _lib.call("diga_conv2d_winograd_f32_keep", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(keep_v[0]),
-                      _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tag, _lib.stream())
+                      _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, tag, _lib.stream())
             return None
         _lib.call("diga_conv2d_winograd_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                  n, hi, wi, cin, x.stride(2), k, out.stride(2), d, 1 if doff[0] < 0 else 0, tag, _lib.stream())
+                  n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, 1 if doff[0] < 0 else 0, tag, _lib.stream())
         return None
     if in_ab is not None:
         raise RuntimeError("DigaConv2d: the input carries a deferred BatchNorm apply (_diga_lazy_ab) but this call is not on the "
@@ -353,7 +384,7 @@ class _Conv2dFn(torch.autograd.Function):
         # is 288 GB): the backward-weight pass then skips a bandwidth pass of 5x the input (DIGA_WINOGRAD_KEEP_V=0: recompute)
         keep_v = None
         if (ctx.needs_input_grad[1] and _lib.get_conv_math() == 0 and k % 256 == 0 and cp % 128 == 0 and stats is None
-                and (opts is None or not any(opts)) and os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
+                and (opts is None or not any(opts)) and WINOGRAD_KEEP_V
                 and _winograd_ok(n, hi, wi, cp, k, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
             keep_v = [None]
         if lazy_ab is not None and cp != c:
@@ -531,16 +562,17 @@ class _Conv2dFn(torch.autograd.Function):
                     return run_twin()
                 if (_lib.get_conv_math() == 0 and kp % 256 == 0 and cp % 128 == 0 and gyp.stride(2) % 4 == 0
                         and _winograd_ok(n, hi, wi, cp, kp, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
-                    _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * 9 * cp, 2.0 * n * ho * wo * kp * 9 * cp * _wino_ratio(hi, wi, dilation[0]))
-                    nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0], 1 if wino_v is not None else 0)
+                    tile, ratio = _wino_plan(hi, wi, dilation[0])
+                    _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * 9 * cp, 2.0 * n * ho * wo * kp * 9 * cp * ratio)
+                    nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0], tile, 1 if wino_v is not None else 0)
                     wsw = _lib.workspace(nb, w.device, "winograd_wgrad")
                     if in_ab is not None:
                         _lib.call("diga_conv2d_wgrad_winograd_f32_ab", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(in_ab), _lib.ptr(wino_v),
                                   _lib.ptr(dwp), _lib.ptr(wsw), wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0],
-                                  _lib.stream())
+                                  tile, _lib.stream())
                     else:
                         _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(wino_v), _lib.ptr(dwp), _lib.ptr(wsw),
-                                  wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], _lib.stream())
+                                  wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], tile, _lib.stream())
                     if not alias:
                         dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
                     return

@@ -337,47 +337,53 @@ int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, const float*
                           int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
                           float* stats_partial, int prof_tag, void* stream);
 
-/* Winograd F(2x2,3x3) in fp32 for a stride-1 3x3 convolution with padding = dilation (output H x W = input H x W):
- * same result as diga_conv2d_nhwc_f32 with R = S = 3, offsets (-dilation, +dilation) up to fp32 rounding (16 instead of 36
- * multiplications per 2x2 outputs; transforms with coefficients 0, +-1, +-1/2).  flip = 1 reads the taps in reverse order
+/* Winograd in fp32 for a stride-1 3x3 convolution with padding = dilation (output H x W = input H x W): same result as
+ * diga_conv2d_nhwc_f32 with R = S = 3, offsets (-dilation, +dilation) up to fp32 rounding.
+ *   tile = 2: F(2x2,3x3), 16 instead of 36 multiplications per 2x2 outputs, transforms with coefficients 0, +-1, +-1/2
+ *             (as accurate as the direct fmaf chain);
+ *   tile = 4: F(4x4,3x3), 36 instead of 144 multiplications per 4x4 outputs, points 0, +-1, +-2, inf (rounding error about
+ *             10x the direct kernel's: max 1e-5 of the output scale on a 256-channel layer) -- the choice for the
+ *             dilation 1 / 2 / 4 layers, whose d*d sub-images are large against a 4x4 tile.
+ * The caller picks `tile` per call (every entry point of one layer -- workspace queries, forward, kept V, weight gradient --
+ * must be given the same value); the library keeps no mode.  flip = 1 reads the taps in reverse order
  * (w[2-r][2-s]): with wgt = the [Cin][3][3][Cout] transpose this is the backward-data convolution.  No statistics / backward
  * epilogue.  Cin % 32 == 0, Cout % 4 == 0, Cout > 64.  Replaces the cuDNN call behind nn.Conv2d(3x3, dilation = padding) of
  * G5/model/seg_model_noaux.py:66-70,143-150,166-170.  workspace: diga_conv2d_winograd_workspace_bytes (16-byte aligned). */
-size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation);
+size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation, int64_t tile);
 int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                              size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
-                             int64_t out_ld, int64_t dilation, int flip, int prof_tag, void* stream);
+                             int64_t out_ld, int64_t dilation, int64_t tile, int flip, int prof_tag, void* stream);
 /* ... with the backward-data epilogue of diga_bwd_epilogue_t (declared above; same arithmetic per element as the `_epi` forms
  * of the direct kernels; `partials` rows are filled per group of tiles instead of per 128 pixel rows -- the finaliser
  * diga_bn_bwd_partials only adds the rows up). */
 int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes, int64_t N,
                                  int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation,
-                                 int flip, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
+                                 int64_t tile, int flip, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
 /* Backward-weight of the same layer through Winograd (dw [Cout][3][3][Cin] = G^T [sum over tiles (A dY A^T) (.) (B^T d B)] G):
- * transforms of dy and x, 16 products contracted over the tiles in one launch of the fp32 LDS-DMA backward-weight kernel
- * (fixed-order split-K: bit-reproducible), the 4x4 -> 3x3 transform.  Cout % 256 == 0, Cin % 128 == 0. */
+ * transforms of dy and x, the 16 (tile 2) / 36 (tile 4) products contracted over the tiles in one launch of the fp32 LDS-DMA
+ * backward-weight kernel (fixed-order split-K: bit-reproducible), the transform back to 3x3.  Cout % 256 == 0, Cin % 128 == 0. */
 size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation,
-                                                  int v_kept /* 1: the call will pass the forward's kept V */);
+                                                  int64_t tile, int v_kept /* 1: the call will pass the forward's kept V */);
 int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
                                    size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld, int64_t Cout,
-                                   int64_t dy_ld, int64_t dilation, void* stream);
+                                   int64_t dy_ld, int64_t dilation, int64_t tile, void* stream);
 /* Forward that leaves its transformed input V (diga_conv2d_winograd_v_floats floats, 4x the input tensor) in `v_keep` for the
  * weight gradient of the same layer: pass it as `v_kept` above (x may then be null) and the backward skips the input transform
  * -- HBM is 288 GB: the transform is a bandwidth pass of 5x the input's bytes per 3x3 layer. */
-size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation);
+size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation, int64_t tile);
 /* Forward / backward-weight whose input is the PRE-activation tensor of a train-mode BatchNorm + ReLU without residual
  * (bn1 of a bottleneck in front of its 3x3 conv2, G5/model/seg_model_noaux.py:89-93): the input transform reads
  * relu(fma(in, a[c], b[c])) with in_ab = [2][Cin] = the coefficients diga_bn_fwd* leaves in save_ab (call it with y = NULL:
  * statistics and coefficients only) -- the activated tensor is never written.  v_keep nullable. */
 int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out, float* v_keep,
                                 void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
-                                int64_t Cout, int64_t out_ld, int64_t dilation, int prof_tag, void* stream);
+                                int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int prof_tag, void* stream);
 int diga_conv2d_wgrad_winograd_f32_ab(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw,
                                       void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                      int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, void* stream);
+                                      int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream);
 int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, const float* bias, float* out, float* v_keep, void* workspace,
                                   size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
-                                  int64_t out_ld, int64_t dilation, int prof_tag, void* stream);
+                                  int64_t out_ld, int64_t dilation, int64_t tile, int prof_tag, void* stream);
 
 /* diga_conv2d_nhwc_f32 / _bf16x3 / _twin with a diga_conv_options_t (non-null; inference-only: no statistics output). */
 int diga_conv2d_nhwc_f32_opts(const float* in, const float* wgt, const float* bias, float* out, int64_t N, int64_t Hi, int64_t Wi,

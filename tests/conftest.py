@@ -54,6 +54,17 @@ def conv_math(request):
     _lib.set_conv_math(prev)
 
 
+def winograd_tile(n, cin, h, w, cout, k, stride, pad, dil):
+    """Output-tile edge of the Winograd path an exact-fp32 DigaConv2d of this geometry takes (0: a direct kernel).  Layers on
+    F(4x4,3x3) are held to 3e-5 (outputs, input gradients) / 5e-5 (weight gradients) of the tensor's scale instead of the 1e-5
+    of the direct and F(2x2) kernels: its transforms multiply by up to 8 and 1/24."""
+    from diga_amd.model import conv as dc
+    cp = dc._pad_to(cin)
+    if k != 3 or not dc._winograd_ok(n, h, w, cp, cout, 3, 3, (stride, stride), (-pad, -pad), (dil, dil), h, w):
+        return 0
+    return dc._wino_plan(h, w, dil)[0]
+
+
 def assert_close(a, b, rtol=1e-5, atol=1e-6, what=""):
     a = torch.as_tensor(a).detach().cpu().to(torch.float64)
     b = torch.as_tensor(b).detach().cpu().to(torch.float64)

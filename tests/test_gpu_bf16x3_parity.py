@@ -402,6 +402,9 @@ def test_fused_gradient_with_a_second_consumer_falls_back(bf16x3):
         assert float((g1[k] - g0[k]).abs().max()) <= 3e-5 * float(g0[k].abs().max()), k
 
 
+FWD_TOL_F32 = 1e-4      # placeholder until measured with the F(4x4,3x3) layers
+
+
 @pytest.mark.parametrize("arch_name,hw", [("TINY", (96, 128)), ("RESNET101", (64, 96))])
 def test_whole_model_gradients_vs_float64_with_pinned_switches(conv_math, arch_name, hw):
     """ONE backward pass through the whole network -- stem, max-pool, every strided / dilated stage transition, the
@@ -461,7 +464,9 @@ def test_whole_model_gradients_vs_float64_with_pinned_switches(conv_math, arch_n
     # ---- device: the production configuration (twin-only tensors, fused backward epilogues, junction chains on)
     _, _, out, feat = m(xd)
     assert torch.equal(out.detach(), out_plain), "twin-only tensors changed the forward result"
-    assert float((out.detach().cpu().double() - out_r.detach()).abs().max() / out_r.detach().abs().max()) < (1e-5 if conv_math == 0 else 2e-4)
+    e_fwd = float((out.detach().cpu().double() - out_r.detach()).abs().max() / out_r.detach().abs().max())
+    print(f"{arch_name} math={conv_math}: logits within {e_fwd:.1e} of scale of the float64 oracle")
+    assert e_fwd < (FWD_TOL_F32 if conv_math == 0 else 2e-4)
     ((out * probe.to(DEV)).sum() + (feat * probe_f.to(DEV)).sum()).backward()
     named = dict(m.named_parameters())
     # measured: fp32 2.2e-6 (small backbone) / 1.4e-5 (ResNet-101, 33 blocks deep); split bf16 4.3e-5 / 1.1e-4

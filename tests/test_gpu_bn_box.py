@@ -98,6 +98,7 @@ def test_deferred_bn1_apply_is_bit_identical(monkeypatch):
     relu(fma(y1, a, b)) on load (diga_conv2d_winograd_f32_ab; the weight gradient reads the kept transform or re-applies the
     coefficients): output, input gradient and every weight gradient equal the run with the stand-alone apply pass bit for bit."""
     from diga_amd import _lib
+    from diga_amd.model import conv as _dconv
     from diga_amd.model import seg_model_noaux as sm
     torch.manual_seed(3)
     blk = sm.Bottleneck(1024, 256, 1, dilation=2).to(DEV).train()
@@ -112,7 +113,7 @@ def test_deferred_bn1_apply_is_bit_identical(monkeypatch):
         res = []
         for fuse, keep in (("0", "1"), ("1", "1"), ("1", "0")):
             monkeypatch.setenv("DIGA_FUSE_BN1", fuse)
-            monkeypatch.setenv("DIGA_WINOGRAD_KEEP_V", keep)
+            monkeypatch.setattr(_dconv, "WINOGRAD_KEEP_V", keep == "1")
             for p_ in blk.parameters():
                 p_.grad = None
             sd = {k: v.clone() for k, v in blk.state_dict().items()}

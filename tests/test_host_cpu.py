@@ -300,11 +300,19 @@ def test_split_format_restatement_against_torch_bf16():
     assert [osp.lds_swz(r) for r in range(16)] == [0, 0, 2, 2, 2, 2, 0, 0, 3, 3, 1, 1, 1, 1, 3, 3]
 
 
-def test_winograd_gate_and_tile_ratio():
-    """Host side of the Winograd path (diga_amd/model/conv.py): the multiplication ratio 16 * tiles / (9 * H * W) of the
-    sub-image tiling -- 97x97 maps: 49 x 49 tiles per image at dilation 6, 12 and 24, 54 x 54 at 18 -- and the gate: 3x3,
+def test_winograd_gate_and_tile_ratio(monkeypatch):
+    """Host side of the Winograd path (diga_amd/model/conv.py): the multiplication ratio products * tiles / (9 * H * W) of the
+    sub-image tiling -- 97x97 maps with 2x2 tiles: 49 x 49 tiles per image at dilation 6, 12 and 24, 54 x 54 at 18; with 4x4 tiles
+    25 x 25 at every dilation that divides 96 -- the tile choice (fewest multiplications, F(2x2) on a tie) and the gate: 3x3,
     stride 1, padding = dilation in either direction (forward / backward-data offsets), wide enough, not too many tiles."""
     from diga_amd.model import conv as dc
+    monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", 4)
+    for d in (1, 2, 4, 6, 12, 24):
+        assert dc._wino_plan(97, 97, d) == (4, pytest.approx(36 * 25 * 25 / (9 * 97 * 97)))
+    assert dc._wino_plan(97, 97, 18) == (2, pytest.approx(16 * 54 * 54 / (9 * 97 * 97)))      # 36 x 36 tiles of 36 products: a tie
+    assert dc._wino_plan(65, 129, 4) == (4, pytest.approx(36 * 17 * 33 / (9 * 65 * 129)))
+    monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", 2)
+    assert dc._wino_plan(97, 97, 2)[0] == 2
     assert dc._wino_ratio(97, 97, 6) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))
     assert dc._wino_ratio(97, 97, 12) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))
     assert dc._wino_ratio(97, 97, 24) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))
