@@ -40,7 +40,8 @@ SIGNATURES = {
     "diga_upsample_bilinear_ac": (INT, [P, P, I64, I64, I64, I64, I64, P]),
     "diga_ema_update_flat": (INT, [P, P, I64, F32, F32, P]),
     "diga_ema_update_multi": (INT, [P, P, P, P, P, I64, I64, F32, F32, P]),
-    "diga_sgd_momentum_multi": (INT, [P, P, P, P, P, P, P, P, I64, I64, F32, F32, INT, F32, P]),
+    "diga_sgd_momentum_multi": (INT, [P, P, P, P, P, P, P, P, I64, I64, F32, F32, INT, F32, P, P]),
+    "diga_nonfinite_flag_f32": (INT, [P, I64, P, P]),
     "diga_label_hist256": (INT, [P, P, I64, I64, P]),
     "diga_classmix_paste": (INT, [P, P, P, P, P, P, P, I64, I64, I64, P]),
     "diga_centroid_softmax_weights": (INT, [P, P, P, P, I64, I64, I64, I64, P]),

@@ -469,18 +469,11 @@ extern "C" int diga_mit_attention_fwd(const void* q, int64_t ldq, const void* kv
     a.B = (int)B; a.heads = (int)heads; a.N = (int)N; a.Nk = (int)Nk;
     a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     ProfScope prof(DIGA_PROF_MIT_ATTN_FWD, st, 4.0 * (double)B * heads * (double)N * (double)Nk * 64.0);
-    // 32 queries per wave (124 VGPRs, two blocks per CU).  The 64-query variant (DIGA_MIT_ATTN_QT=4: K / V fragments read
-    // from LDS once per 64 MFMAs, 209 VGPRs, one block per CU) measured 15-25 % SLOWER on every MiT-B5 stage
-    // (tools/bench_mit_ops.py --cold: 245 vs 207 us on stage 1): the softmax's latency needs the second resident block.
-    static const int qt_env = [] { const char* e = getenv("DIGA_MIT_ATTN_QT"); return e ? atoi(e) : 0; }();
-    const bool wide = qt_env == 4;
-    if (wide) {
-        a.q_blocks = (int)ceil_div(N, 512);
-        hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)(B * heads * a.q_blocks)), dim3(512), 4 * kImg, st, a);
-    } else {
-        a.q_blocks = (int)ceil_div(N, 256);
-        hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)(B * heads * a.q_blocks)), dim3(512), 4 * kImg, st, a);
-    }
+    // 32 queries per wave (124 VGPRs, two blocks per CU).  A 64-query variant (K / V fragments read from LDS once per 64 MFMAs,
+    // 209 VGPRs, one block per CU) measured 15-25 % SLOWER on every MiT-B5 stage (tools/bench_mit_ops.py --cold: 245 vs 207 us on
+    // stage 1): the softmax's latency needs the second resident block.
+    a.q_blocks = (int)ceil_div(N, 256);
+    hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)(B * heads * a.q_blocks)), dim3(512), 4 * kImg, st, a);
     return launch_status("mit_attention_fwd");
 }
 

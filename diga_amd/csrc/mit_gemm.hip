@@ -446,9 +446,8 @@ extern "C" int diga_mit_gemm_nt(const void* A, int64_t lda, const void* B, int64
         // one round of blocks (3 per CU = 768 slots) AND the layer is wide: measured on the MiT-B5 shapes (tools/bench_mit_ops.py
         // --cold): N >= 256 gains 5-14 % (q / proj / fc1 / fc2 of stage 3, fc1 of stages 1-2), N = 128 loses 3-5 %, small-M
         // layers (kv, sr: 9216 rows) lose 8-28 %
-        static const int big_env = [] { const char* e = getenv("DIGA_MIT_GEMM_BIG"); return e ? atoi(e) : -1; }();
         const int64_t blocks128 = ceil_div(M, 128) * a.tiles_n;
-        const bool big = big_env >= 0 ? big_env != 0 : (blocks128 > 768 && N >= 256);
+        const bool big = blocks128 > 768 && N >= 256;
         if (big) {
             constexpr int SH = 3 * (256 * 64 + 128 * 64);
             static bool once = [] { return hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SH) == hipSuccess; }();

@@ -531,8 +531,7 @@ extern "C" int diga_mit_layernorm_fwd(const float* x, int64_t ldx, const float* 
 
 static int ln_rows_per_block(int64_t M) {                // ~512 blocks where the matrix is big enough, 16..256 rows each
     // measured (tools/bench_mit_ops.py --cold, MiT-B5 sizes): ~512 blocks beat 1024 / 2048 / 4096 on every stage
-    static const int target = [] { const char* e = getenv("DIGA_MIT_LN_BLOCKS"); return e ? atoi(e) : 512; }();
-    int64_t r = ceil_div(M, target);
+    int64_t r = ceil_div(M, 512);
     r = ceil_div(r, 16) * 16;
     if (r < 16) r = 16;
     if (r > 256) r = 256;

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
                                                         const int32_t* __restrict__ chunk_tensor,
                                                         const int64_t* __restrict__ chunk_start,
                                                         int64_t chunk_elems, float mom, float wd, int first,
-                                                        float gscale) {
+                                                        float gscale, const int32_t* __restrict__ skip_flag) {
+    // skip_flag (nullable): set by diga_nonfinite_flag_f32 when this step's gradients hold inf / NaN (a loss-scaled fp16
+    // backward that overflowed): the whole step leaves parameters and momentum untouched, on every block alike
+    if (skip_flag != nullptr && skip_flag[0] != 0) return;
     const int ti = chunk_tensor[blockIdx.x];
     const int64_t start = chunk_start[blockIdx.x];
     float* __restrict__ p = pp[ti];
@@ -122,9 +125,38 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* __restrict
     }
 }
 
+// flag[0] = 1 and flag[1] += 1 (once per launch) when x holds an inf or NaN
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, int64_t n, int32_t* __restrict__ flag) {
+    const int64_t n4 = n >> 2;
+    bool bad = false;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        // (an exponent of all ones: v - v is NaN for inf and NaN, 0 otherwise)
+        const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+        bad |= !(t == 0.f);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) bad |= !((x[i] - x[i]) == 0.f);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) {
+        if (atomicExch(&flag[0], 1) == 0) atomicAdd(&flag[1], 1);
+    }
+}
+
 }  // namespace diga
 
 using namespace diga;
+
+extern "C" int diga_nonfinite_flag_f32(const float* x, int64_t n, int32_t* flag, void* stream) {
+    DIGA_REQUIRE(x && flag && n >= 0, DIGA_EINVAL, "nonfinite_flag_f32: bad argument");
+    DIGA_REQUIRE(aligned16(x), DIGA_EALIGN, "nonfinite_flag_f32: x must be 16-byte aligned");
+    if (n == 0) return DIGA_OK;
+    int64_t blocks = ceil_div(n / 4 > 0 ? n / 4 : 1, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, (hipStream_t)stream, (double)n * 4.0);
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, flag);
+    return launch_status("diga_nonfinite_flag_f32");
+}
 
 extern "C" int diga_ema_update_flat(float* teacher, const float* student, int64_t n, float alpha,
                                     float one_minus_alpha, void* stream) {
@@ -159,7 +191,7 @@ extern "C" int diga_sgd_momentum_multi(float* const* param_ptrs, const float* co
                                        const int64_t* sizes, const int32_t* mult, const float* lr,
                                        const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks,
                                        int64_t chunk_elems, float momentum, float weight_decay, int first_step,
-                                       float grad_scale, void* stream) {
+                                       float grad_scale, const int32_t* skip_flag, void* stream) {
     DIGA_REQUIRE(param_ptrs && grad_ptrs && buf_ptrs && sizes && mult && lr && chunk_tensor && chunk_start,
                  DIGA_EINVAL, "sgd_momentum_multi: null table");
     DIGA_REQUIRE(n_chunks >= 0 && chunk_elems > 0 && (chunk_elems % 4) == 0, DIGA_EINVAL,
@@ -168,6 +200,6 @@ extern "C" int diga_sgd_momentum_multi(float* const* param_ptrs, const float* co
     ProfScope prof(DIGA_PROF_SGD, (hipStream_t)stream);
     hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, param_ptrs,
                        grad_ptrs, buf_ptrs, sizes, mult, lr, chunk_tensor, chunk_start, chunk_elems, momentum,
-                       weight_decay, first_step, grad_scale);
+                       weight_decay, first_step, grad_scale, skip_flag);
     return launch_status("diga_sgd_momentum_multi");
 }

@@ -32,16 +32,19 @@ def init_from_env(backend=None):
             backend = os.environ.get("DIGA_DDP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             ndev = max(torch.cuda.device_count(), 1)
-            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-            if ndev >= local_world:
-                # the production layout: ONE process per GPU, device index = LOCAL_RANK, nothing shared
-                if not 0 <= local < ndev:
-                    raise RuntimeError(f"LOCAL_RANK={local} but this node has {ndev} GPUs")
-            elif backend == "nccl":
-                raise RuntimeError(f"{local_world} ranks on {ndev} GPU(s): RCCL needs one device per rank "
-                                   "(only the gloo smoke configuration may share a device)")
-            else:
+            # LOCAL_WORLD_SIZE is set by torchrun; srun / mpirun / custom spawners of a multi-node job often set only RANK,
+            # LOCAL_RANK and WORLD_SIZE -- then LOCAL_RANK is trusted (world 16 on 2 x 8 GPUs is fine) and only validated
+            local_world = os.environ.get("LOCAL_WORLD_SIZE")
+            if local_world is not None and int(local_world) > ndev:
+                if backend == "nccl":
+                    raise RuntimeError(f"{local_world} ranks on {ndev} GPU(s): RCCL needs one device per rank "
+                                       "(only the gloo smoke configuration may share a device)")
                 local = local % ndev          # single-GPU smoke test over gloo: ranks share the device
+            elif local_world is None and backend != "nccl" and local >= ndev:
+                local = local % ndev          # (the same smoke configuration started without LOCAL_WORLD_SIZE)
+            elif not 0 <= local < ndev:
+                # the production layout: ONE process per GPU, device index = LOCAL_RANK, nothing shared
+                raise RuntimeError(f"LOCAL_RANK={local} but this node has {ndev} GPU(s)")
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         if dist.get_world_size() != world or dist.get_rank() != rank:

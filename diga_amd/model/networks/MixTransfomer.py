@@ -397,6 +397,12 @@ class _MitStageFn(torch.autograd.Function):
                 dx32, dx16, dg, db = ops.ln_bwd(d_a, bs["x"], par[bp + ".norm1.weight"], bs["m1"], bs["r1"], dx32, True, True, inv)
                 grads[bp + ".norm1.weight"], grads[bp + ".norm1.bias"] = dg, db
                 del bs
+            # ---- overflow check: the branch gradients of this stage travelled in fp16 under the loss scale; an inf / NaN born in
+            # any of them (dq, dkv, the Mix-FFN hidden gradients) has reached the fp32 residual-stream gradient by now.  One
+            # bandwidth pass over it sets the model's device flag: DigaSGD skips the step on it (no host sync), the host lowers
+            # the scale at its leisure (MixVisionTransformer.adjust_loss_scale).  The reference is fp32 and cannot overflow.
+            if cfg.get("overflow_flag") is not None:
+                _lib.call("diga_nonfinite_flag_f32", P(dx32), dx32.numel(), P(cfg["overflow_flag"]), _lib.stream())
             # ---- patch embedding: x0 = norm(proj(cols))
             pre = st["embed"]
             _, d_y, dg, db = ops.ln_bwd(dx32, ss["y32"], par[pre + ".norm.weight"], ss["e_mean"], ss["e_rstd"], None, False, True, inv)
@@ -427,6 +433,9 @@ class MixVisionTransformer(nn.Module):
         self.depths = depths
         self.embed_dims = list(embed_dims)
         self.loss_scale = float(os.environ.get("DIGA_MIT_LOSS_SCALE", "1024"))
+        # [0]: this step's backward met an inf / NaN (set on the device, cleared by the next training forward); [1]: such steps so far
+        self.register_buffer("grad_overflow", torch.zeros(2, dtype=torch.int32), persistent=False)
+        self._overflow_seen = 0
         self.patch_embed1 = OverlapPatchEmbed(img_size=img_size, patch_size=7, stride=4, in_chans=in_chans, embed_dim=embed_dims[0])
         self.patch_embed2 = OverlapPatchEmbed(img_size=img_size // 4, patch_size=3, stride=2, in_chans=embed_dims[0], embed_dim=embed_dims[1])
         self.patch_embed3 = OverlapPatchEmbed(img_size=img_size // 8, patch_size=3, stride=2, in_chans=embed_dims[1], embed_dim=embed_dims[2])
@@ -542,10 +551,26 @@ class MixVisionTransformer(nn.Module):
         return {"names": names, "stage_names": stage_names, "stages": stages, "eps": eps, "training": self.training,
                 "loss_scale": self.loss_scale}
 
+    def adjust_loss_scale(self, factor=0.5, floor=1.0):
+        """Host side of the overflow handling (one device->host read: call it every few hundred steps, not every step): when
+        backward passes overflowed since the last call, the static loss scale is multiplied by `factor`.  Returns the number of
+        overflowed (= skipped) steps since the last call.  A trainer that replays a captured HIP graph must re-capture after a
+        change (the scale is a kernel argument): DigaTrainer does."""
+        total = int(self.grad_overflow[1].item())
+        new = total - self._overflow_seen
+        self._overflow_seen = total
+        if new > 0:
+            self.loss_scale = max(floor, self.loss_scale * factor)
+        return new
+
     def forward_features(self, x):
         params = [p for _, p in self.named_parameters()]
         cfg = self._cfg()
         cfg["need_grad"] = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        cfg["overflow_flag"] = None
+        if cfg["need_grad"] and x.is_cuda:
+            self.grad_overflow[0:1].zero_()
+            cfg["overflow_flag"] = self.grad_overflow
         cfg["prep"] = self._prepare_weights() if x.is_cuda else None
         named = dict(self.named_parameters())
         outs, src = [], x

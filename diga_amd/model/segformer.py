@@ -38,6 +38,14 @@ class SegFormerStudent(nn.Module):
         res = self.final(c4)
         return c2, c4, res['out'], res['feat']
 
+    @property
+    def grad_overflow(self):
+        """Device flag of the fp16 backward's overflow check (diga_amd/model/networks/MixTransfomer.py): DigaSGD.step(found_inf=...)."""
+        return self.backbone.grad_overflow
+
+    def adjust_loss_scale(self, *a, **k):
+        return self.backbone.adjust_loss_scale(*a, **k)
+
     def get_1x_lr_params_NOscale(self):
         for p in self.backbone.parameters():
             if p.requires_grad:

@@ -81,17 +81,19 @@ class DigaTrainer:
             self._pf_stream = _prefetch_stream(labels.device)          # one per device and process, not per trainer
             self._pf = {}
         host, ev = U.classmix_present_async(labels, self._pf_stream)
-        self._pf[(labels.data_ptr(), labels._version, tuple(labels.shape))] = (host, ev)
+        # keyed by the tensor OBJECT (held here, so its address cannot be reused by another tensor while the entry lives) and
+        # its version counter: an in-place change of the labels invalidates the entry
+        self._pf[id(labels)] = (labels, labels._version, host, ev)
         if len(self._pf) > 4:
             self._pf.pop(next(iter(self._pf)))
 
     def _present(self, labels):
         pf = getattr(self, "_pf", None)
-        hit = pf.pop((labels.data_ptr(), labels._version, tuple(labels.shape)), None) if pf else None
-        if hit is None:
+        hit = pf.pop(id(labels), None) if pf else None
+        if hit is None or hit[0] is not labels or hit[1] != labels._version:
             return None
-        hit[1].synchronize()
-        return U.present_lists(hit[0])
+        hit[3].synchronize()
+        return U.present_lists(hit[2])
 
     # ------------------------------------------------------------------ common pieces
     def _begin(self, it):
@@ -167,7 +169,18 @@ class DigaTrainer:
             _lib.side_overlap = False
             _lib.join_side()
         self.reducer.reduce()
-        self.opt.step()
+        self._opt_step()
+
+    def _opt_step(self):
+        """SGD with the student's overflow flag (loss-scaled fp16 backward of the MiT student; None for the fp32 ResNet): the skip
+        is decided inside the kernel.  N > 1: the flag is max-reduced first so that every rank skips the same steps."""
+        flag = getattr(self.student, "grad_overflow", None)
+        if flag is not None and self.world > 1:
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        self.opt.step(found_inf=flag)
+        self._steps_done = getattr(self, "_steps_done", 0) + 1
+        if flag is not None and self._steps_done % 200 == 0 and self.student.adjust_loss_scale() > 0:
+            self._g = None            # the scale is baked into a captured graph: capture again
 
     # ------------------------------------------------------------------ warm-up step, static part as a HIP graph
     def _warmup_step_graphed(self, it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil):
@@ -212,17 +225,25 @@ class DigaTrainer:
                         os.environ.pop(k, None)
                     else:
                         os.environ[k] = v
-            g.update(graph=graph, out=(total.detach(), ce, di))
+            # the captured backward writes into THESE gradient tensors (memory of the graph's pool) on every replay
+            g.update(graph=graph, out=(total.detach(), ce, di),
+                     grads=[(p, p.grad) for p in self.student.parameters() if p.requires_grad])
         else:
             B = x.shape[0]
             g["cat"][:B].copy_(x)
             g["cat"][B:].copy_(mix)
             g["labels"].copy_(labels)
+        for p, captured in g["grads"]:
+            # an eager step on the same trainer (selftrain_step) or an external zero_grad() re-binds p.grad; the replay would then
+            # fill orphaned buffers while the optimizer read stale ones -- point the parameters back at the captured tensors
+            if p.grad is not captured:
+                p.grad = captured
         g["graph"].replay()
         self.reducer.reduce()
-        self.opt.step()
+        self._opt_step()
         total, ce, di = g["out"]
-        return {"total": total, "ce": ce, "distil": di}
+        # (clones: the graph's output tensors are overwritten by the next replay)
+        return {"total": total.clone(), "ce": ce.clone(), "distil": di.clone()}
 
     # ------------------------------------------------------------------ warm-up step
     def warmup_step(self, it, x, x_aug, rec_s2t, labels, lambda_seg=1.0, lambda_distil=0.5):

@@ -379,7 +379,9 @@ class DigaSGD(torch.optim.Optimizer):
         self._lr_dev = torch.empty(len(self._params), dtype=torch.float32, device=dev)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, found_inf=None):
+        """found_inf: a device int32 tensor; when its first element is non-zero at execution time the step changes nothing (the
+        decision is taken inside the kernel: no host sync).  DigaTrainer passes the student's `grad_overflow` flag."""
         if self._tab is None:
             self._build()
         g0 = self.param_groups[0]
@@ -411,7 +413,8 @@ class DigaSGD(torch.optim.Optimizer):
         _lib.call("diga_sgd_momentum_multi", _lib.ptr(pp), _lib.ptr(gp), _lib.ptr(bp), _lib.ptr(tab.sizes),
                   _lib.ptr(self._mult_dev), _lib.ptr(self._lr_dev), _lib.ptr(tab.chunk_tensor),
                   _lib.ptr(tab.chunk_start), tab.n_chunks, CHUNK_ELEMS, float(g0["momentum"]),
-                  float(g0["weight_decay"]), 1 if self._first else 0, self.grad_scale, _lib.stream())
+                  float(g0["weight_decay"]), 1 if self._first else 0, self.grad_scale,
+                  _lib.ptr(found_inf) if found_inf is not None else None, _lib.stream())
         self._first = False
         return None
 

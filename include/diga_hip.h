@@ -132,13 +132,18 @@ int diga_ema_update_multi(float* const* teacher_ptrs, const float* const* studen
  * G5/train_DiGA_gta2city_warm_up.py:156,301-305): tensor i occurs mult[i] times in its group, so one
  * step() is mult[i] sequential micro-steps  d = g + wd*p; buf = first_step ? d : momentum*buf + d;
  * p -= lr[i]*buf  fused in registers.  lr[i] is a device array (per tensor; poly-LR is written there
- * by the host each step). */
+ * by the host each step).  skip_flag (nullable, device int32): when skip_flag[0] != 0 the launch changes nothing -- the
+ * "found_inf" of a loss-scaled fp16 backward (the MiT student, diga_mit.h), decided on the device without a host sync. */
 int diga_sgd_momentum_multi(float* const* param_ptrs, const float* const* grad_ptrs, float* const* buf_ptrs,
                             const int64_t* sizes, const int32_t* mult, const float* lr,
                             const int32_t* chunk_tensor, const int64_t* chunk_start,
                             int64_t n_chunks, int64_t chunk_elems,
                             float momentum, float weight_decay, int first_step, float grad_scale,
-                            void* stream);
+                            const int32_t* skip_flag, void* stream);
+/* flag[0] = 1 and flag[1] += 1 when the n floats at x hold an inf or a NaN (flag: two device int32, zeroed by the caller at
+ * the start of a step; [1] counts the overflowed steps).  The reference is fp32 throughout and has no such failure mode
+ * (torch.cuda.amp.GradScaler is what a mixed-precision port of it would use: same found_inf / skipped-step semantics). */
+int diga_nonfinite_flag_f32(const float* x, int64_t n, int32_t* flag, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * ClassMix (G5/train_DiGA_gta2city_warm_up.py:240-259, ..._self_training.py:259-275,306-325)

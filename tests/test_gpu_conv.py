@@ -298,44 +298,58 @@ def test_wgrad_on_twins_vs_float64(geom, bf16x3):
     assert_close(dw.cpu(), want, rtol=0.0, atol=5e-5 * scale, what="dw from twins")
 
 
-_DMA_EQ_CODE = r"""
-import hashlib, sys, torch
-sys.path.insert(0, sys.argv[1])
-from diga_amd import _lib
-from diga_amd.model.conv import DigaConv2d
-_lib.set_conv_math(0)
-torch.manual_seed(11)                                   # (default initialisers of weight / bias)
-g = torch.Generator().manual_seed(4321)
-# name, N, Cin, H, W, Cout, k, stride, pad, dil
-cases = [("aspp_d24", 1, 256, 97, 97, 256, 3, 1, 24, 24), ("pw_tail", 2, 64, 37, 41, 192, 1, 1, 0, 1), ("pw_big", 3, 128, 193, 161, 256, 1, 1, 0, 1),
-         ("stride2", 2, 128, 65, 65, 128, 1, 2, 0, 1), ("d2_3x3", 3, 96, 33, 29, 160, 3, 1, 2, 2), ("d12", 1, 288, 97, 97, 256, 3, 1, 12, 12)]
-for name, n, cin, h, w, cout, k, s, p, d in cases:
-    x = torch.randn((n, cin, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
-    m = DigaConv2d(cin, cout, k, stride=s, padding=p, dilation=d, bias=(name == "d12")).cuda()
+def _conv_pair(cin, cout, k, s, p, d, wt, rows=None, cols=None):
+    """DigaConv2d on the device holding wt[rows, cols] (a slice of the full layer's weight)."""
+    from diga_amd.model.conv import DigaConv2d
+    w = wt if rows is None else wt[rows]
+    w = w if cols is None else w[:, cols]
+    m = DigaConv2d(w.shape[1], w.shape[0], k, stride=s, padding=p, dilation=d, bias=False).to(DEV)
     with torch.no_grad():
-        m.weight.copy_(torch.randn(m.weight.shape, generator=g).cuda() * 0.05)
-    y = m(x)
-    probe = torch.randn(y.shape, generator=g).cuda()
-    (y * probe).sum().backward()
-    for what, v in (("y", y), ("dx", x.grad)):
-        print(name, what, hashlib.sha256(v.detach().contiguous().cpu().numpy().tobytes()).hexdigest())
-"""
+        m.weight.copy_(w)
+    return m
 
 
-def test_f32_dma_kernel_bit_identical_to_register_staged_kernel():
-    """conv_fwd_dma_kernel (256 x 128 tiles, LDS-DMA operands, dead taps skipped) walks K in conv_fwd_kernel's order with the
-    same MFMA per (k-group, element): forward outputs and input gradients are equal bit for bit -- on a dilation-24
-    97 x 97 map, an M / Cout tail, a strided 1x1, and a dilated 3x3 (two processes: the switch is read once)."""
-    import subprocess
-    import sys
-    outs = []
-    for dma, persist in (("0", "0"), ("2", "0"), ("1", "1")):   # register-staged / LDS-DMA wherever it can run / the dispatch
-        # rules incl. the persistent GEMM for the big pointwise layer (pw_big: 730 tiles)
-        env = dict(os.environ, DIGA_CONV_F32_DMA=dma, DIGA_CONV_F32_PERSIST=persist, DIGA_CONV_WINOGRAD="0")
-        r = subprocess.run([sys.executable, "-c", _DMA_EQ_CODE, ROOT], capture_output=True, text=True, env=env, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([ln for ln in r.stdout.splitlines() if ln.count(" ") == 2])
-    assert len(outs[0]) == 12 and outs[0] == outs[1] and outs[0] == outs[2], outs
+DMA_EQ_CASES = [("aspp_d24", 1, 256, 97, 97, 256, 3, 1, 24, 24), ("pw_tail", 2, 256, 37, 41, 320, 1, 1, 0, 1),
+                ("pw_big", 3, 256, 193, 161, 256, 1, 1, 0, 1), ("stride2", 2, 256, 65, 65, 256, 1, 2, 0, 1),
+                ("d2_3x3", 3, 256, 33, 29, 256, 3, 1, 2, 2), ("d12", 1, 288, 97, 97, 256, 3, 1, 12, 12)]
+
+
+@pytest.mark.parametrize("case", DMA_EQ_CASES, ids=[c[0] for c in DMA_EQ_CASES])
+def test_f32_dma_and_persistent_kernels_bit_identical_to_register_staged_kernel(case, monkeypatch):
+    """conv_fwd_dma_kernel (256 x 128 tiles, LDS-DMA operands, dead taps skipped) and gemm_f32_persistent_kernel (the same tile
+    walked by 256 persistent blocks) run K in conv_fwd_kernel's order with the same MFMA per (k-group, element): outputs and
+    input gradients are equal BIT FOR BIT.  No switch is involved -- the dispatch is by shape, so the same layer is evaluated
+    twice: whole (>= 256 output channels from K >= 256: the LDS-DMA kernel; pw_big's 730 tiles: the persistent GEMM) and as two
+    layers on halves of its output channels (< 256 wide: the register-staged kernel); likewise the input gradient, whole and for
+    halves of the input channels (a backward-data convolution into < 256 channels).  Direct kernels only (Winograd off)."""
+    from diga_amd import _lib
+    from diga_amd.model import conv as dc
+    monkeypatch.setattr(dc, "WINOGRAD", False)
+    name, n, cin, h, w, cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) * 0.05
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(0)
+    calls, real = [], _lib.call
+    try:
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+        y = _conv_pair(cin, cout, k, s, p, d, wt)(xd)
+        probe = torch.randn(y.shape, generator=g).to(DEV)
+        (y * probe).sum().backward()
+        half = 128
+        for r0, r1 in ((0, half), (half, cout)):                 # forward: halves of the output channels
+            ys = _conv_pair(cin, cout, k, s, p, d, wt, rows=slice(r0, r1))(xd.detach())
+            assert torch.equal(ys, y[:, r0:r1]), (name, "y", r0)
+        for c0, c1 in ((0, half), (half, cin)):                  # backward-data: halves of the input channels
+            xs = x[:, c0:c1].to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+            monkeypatch.setattr(_lib, "call", lambda fn, *a: (calls.append(fn), real(fn, *a))[1])
+            (_conv_pair(cin, cout, k, s, p, d, wt, cols=slice(c0, c1))(xs) * probe).sum().backward()
+            monkeypatch.setattr(_lib, "call", real)
+            assert torch.equal(xs.grad, xd.grad[:, c0:c1]), (name, "dx", c0)
+    finally:
+        _lib.set_conv_math(prev)
+    assert not any("winograd" in c for c in calls), calls
 
 
 WINO_CASES = [("d1_ragged", 3, 128, 33, 29, 160, 1), ("d1_wide", 2, 384, 31, 37, 512, 1), ("d18_97", 1, 128, 97, 97, 256, 18), ("d2_97", 2, 256, 97, 97, 256, 2), ("d4_65x129", 1, 512, 65, 129, 128, 4),
@@ -405,33 +419,38 @@ def test_winograd_f32_vs_float64(case, tile, monkeypatch):
         assert torch.equal(m.weight.grad, dw_kept)
 
 
-_PERSIST_EQ_CODE = r"""
-import hashlib, sys, torch
-sys.path.insert(0, sys.argv[1])
-from diga_amd import _lib
-from diga_amd.model.conv import DigaConv2d
-_lib.set_conv_math(0)
-torch.manual_seed(5)
-g = torch.Generator().manual_seed(99)
-for name, n, cin, h, w, cout, d in [("d2", 2, 128, 97, 97, 256, 2), ("d6", 3, 256, 65, 129, 128, 6)]:
-    x = torch.randn((n, cin, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
-    m = DigaConv2d(cin, cout, 3, padding=d, dilation=d, bias=False).cuda()
-    y = m(x)
-    (y * torch.randn(y.shape, generator=g).cuda()).sum().backward()
-    for what, v in (("y", y), ("dx", x.grad)):
-        print(name, what, hashlib.sha256(v.detach().contiguous().cpu().numpy().tobytes()).hexdigest())
-"""
-
-
-def test_persistent_gemm_bit_identical_to_per_tile_launch():
-    """The 16 Winograd products on gemm_f32_persistent_kernel (256 blocks walking the tiles, next tile's stages prefetched under
-    the current one, accumulators stored from registers) equal the per-tile launch of conv_fwd_dma_kernel bit for bit."""
-    import subprocess
-    import sys
-    outs = []
-    for persist in ("0", "1"):
-        env = dict(os.environ, DIGA_CONV_F32_PERSIST=persist, DIGA_CONV_WINOGRAD="1", DIGA_CONV_WINOGRAD_RATIO="10")
-        r = subprocess.run([sys.executable, "-c", _PERSIST_EQ_CODE, ROOT], capture_output=True, text=True, env=env, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([ln for ln in r.stdout.splitlines() if ln.count(" ") == 2])
-    assert len(outs[0]) == 4 and outs[0] == outs[1], outs
+@pytest.mark.parametrize("tile", [2, 4], ids=["F2x2", "F4x4"])
+def test_persistent_gemm_bit_identical_to_per_tile_launch(tile, monkeypatch):
+    """The Winograd products on gemm_f32_persistent_kernel (256 blocks walking the tiles, next tile's stages prefetched under
+    the current one, accumulators stored from registers) equal the per-tile launch of conv_fwd_dma_kernel bit for bit.  By shape,
+    without a switch: three 97x97 images in one call make >= 512 GEMM tiles (the persistent walk), each image alone stays
+    below (one block per tile) -- and a tile's products do not depend on which other tiles are in the launch."""
+    from diga_amd import _lib
+    from diga_amd.model import conv as dc
+    from diga_amd.model.conv import DigaConv2d
+    monkeypatch.setattr(dc, "WINOGRAD", True)
+    monkeypatch.setattr(dc, "WINOGRAD_RATIO", 10.0)
+    monkeypatch.setattr(dc, "_wino_plan", lambda hi, wi, dd: (tile, 0.5))
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(0)
+    try:
+        torch.manual_seed(5)
+        g = torch.Generator().manual_seed(99)
+        for name, n, cin, h, w, cout, d in [("d2", 3, 128, 97, 97, 256, 2), ("d6", 3, 256, 97, 97, 256, 6)]:
+            prod = (tile + 2) ** 2
+            tiles_1 = sum(-(-((h - a + d - 1) // d) // tile) for a in range(d)) ** 2
+            grid = lambda imgs: prod * (-(-imgs * tiles_1 // 256) * 256) // 256 * (cout // 128)          # noqa: E731
+            assert grid(n) >= 512 > grid(1), (grid(n), grid(1))
+            x = torch.randn((n, cin, h, w), generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+            m = DigaConv2d(cin, cout, 3, padding=d, dilation=d, bias=False).to(DEV)
+            y = m(x)
+            probe = torch.randn(y.shape, generator=g).to(DEV)
+            (y * probe).sum().backward()
+            for i in range(n):
+                xi = x[i:i + 1].detach().clone(memory_format=torch.channels_last).requires_grad_()
+                yi = m(xi)
+                (yi * probe[i:i + 1]).sum().backward()
+                assert torch.equal(yi, y[i:i + 1]), (name, "y", i)
+                assert torch.equal(xi.grad, x.grad[i:i + 1]), (name, "dx", i)
+    finally:
+        _lib.set_conv_math(prev)

@@ -334,6 +334,38 @@ def test_sgd_large_vs_oracle(mods):
             assert_close(p, r, 2e-6, 1e-7, f"step {step}")
 
 
+def test_nonfinite_flag_and_sgd_skip(mods):
+    """diga_nonfinite_flag_f32 (inf / NaN anywhere in a tensor -> flag[0] = 1, flag[1] += 1, including the ragged tail) and the
+    skip_flag argument of diga_sgd_momentum_multi: a set flag leaves parameters and momentum bit-identical."""
+    from diga_amd import _lib
+    U = mods["utils"]
+    flag = torch.zeros(2, dtype=torch.int32, device=DEV)
+    x = torch.randn(100003, generator=synth.gen(5)).to(DEV)
+    _lib.call("diga_nonfinite_flag_f32", _lib.ptr(x), x.numel(), _lib.ptr(flag), _lib.stream())
+    assert flag.cpu().tolist() == [0, 0]
+    for pos, val in ((100002, float("inf")), (17, float("nan")), (51234, float("-inf"))):
+        y = x.clone()
+        y[pos] = val
+        flag[0] = 0
+        _lib.call("diga_nonfinite_flag_f32", _lib.ptr(y), y.numel(), _lib.ptr(flag), _lib.stream())
+        assert int(flag[0]) == 1, (pos, val)
+    assert int(flag[1]) == 3
+    _lib.call("diga_nonfinite_flag_f32", _lib.ptr(y), y.numel(), _lib.ptr(flag), _lib.stream())      # already set: counted once
+    assert flag.cpu().tolist() == [1, 3]
+    p = torch.nn.Parameter(torch.randn(1000, generator=synth.gen(6)).to(DEV))
+    opt = U.DigaSGD([{"params": [p, p]}], lr=0.1, momentum=0.9, weight_decay=0.0)
+    p.grad = torch.ones_like(p)
+    opt.step()
+    p1, b1 = p.detach().clone(), opt.momentum_buffers()[id(p)].clone()
+    p.grad = torch.full_like(p, float("nan"))
+    opt.step(found_inf=flag)                                         # flag[0] == 1: nothing moves
+    assert torch.equal(p.detach(), p1) and torch.equal(opt.momentum_buffers()[id(p)], b1)
+    flag.zero_()
+    p.grad = torch.ones_like(p)
+    opt.step(found_inf=flag)
+    assert not torch.equal(p.detach(), p1)
+
+
 # ----------------------------------------------------------------------------- ClassMix
 def test_classmix_golden(mods, golden):
     g = golden("classmix")

@@ -243,3 +243,30 @@ def test_prefetched_classmix_lists_give_the_same_steps():
         assert other[0] == res[0][0]
         for k in res[0][1]:
             assert torch.equal(other[1][k], res[0][1][k]), k
+
+
+def test_prefetch_cache_is_keyed_by_tensor_identity_and_version():
+    """An unconsumed prefetch entry must never serve a DIFFERENT labels tensor (the caching allocator hands a dead tensor's
+    address to the next one of the same shape) nor the same tensor after an in-place change: both miss and fall back to the
+    in-line histogram."""
+    from diga_amd.train_step import DigaTrainer
+    from diga_amd.util import utils as U
+    student, teacher = _model("TINY"), _model("TINY")
+    tr = DigaTrainer(student, teacher, rng=random.Random(3))
+    lab = torch.zeros((2, 64, 64), dtype=torch.int64, device=DEV)
+    lab[0, :8] = 3
+    lab[1, :8] = 7
+    tr.prefetch_classmix(lab)
+    other = lab.clone()
+    other[0, :8] = 11
+    assert tr._present(other) is None                          # a different tensor: miss (the entry for `lab` stays)
+    assert tr._present(lab) == U.classmix_present(lab) == [[0, 3], [0, 7]]
+    tr.prefetch_classmix(lab)
+    lab[1, :8] = 9                                             # in-place change after the prefetch: stale
+    assert tr._present(lab) is None
+    # address reuse: the entry holds its tensor, so a new tensor can never alias a live entry's key
+    tr.prefetch_classmix(lab)
+    ptr = lab.data_ptr()
+    del lab
+    fresh = torch.full((2, 64, 64), 5, dtype=torch.int64, device=DEV)
+    assert fresh.data_ptr() != ptr and tr._present(fresh) is None

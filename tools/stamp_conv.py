@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: phase breakdown of the wide split-bf16 conv kernel from in-kernel s_memtime stamps.
 
-    DIGA_CONV_STAMP=1 python tools/stamp_conv.py [--cin 1024 --cout 256 --k 1 --dil 1 --hw 97 --images 16]
+    DIGA_LIB=$PWD/diga_amd/libdiga_probe_STAMP.so python tools/stamp_conv.py [--cin 1024 --cout 256 --k 1 --dil 1 --hw 97 --images 16]
 Prints average cycles per K-step (wave 0 of every block) spent in: loads issue + MFMA, barrier 1, waiting for the
 global loads, split + ds_write, barrier 2.
 """
@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--hw", type=int, default=97)
     ap.add_argument("--images", type=int, default=16)
     a = ap.parse_args()
-    assert os.environ.get("DIGA_CONV_STAMP"), "set DIGA_CONV_STAMP=1"
+    assert "probe_STAMP" in os.environ.get("DIGA_LIB", ""), "load the stamped build: DIGA_LIB=.../libdiga_probe_STAMP.so (tools/diag/build_probe.sh)"
     dev = "cuda"
     n, h, w = a.images, a.hw, a.hw
     x = torch.randn((n, h, w, a.cin), device=dev)
