@@ -344,6 +344,16 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
     losses = {k: float(v) for k, v in out.items()}
     if not all(v == v and abs(v) < 1e6 for v in losses.values()):
         raise SystemExit(f"non-finite loss in the timed region: {losses}")
+    agree = None
+    if world > 1:
+        # data-parallel invariant: after the all-reduced steps every rank holds the same student, bit for bit
+        chk = torch.stack([p.detach().double().sum() for p in student.parameters()]).sum().reshape(1)
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        torch.distributed.all_gather(allc, chk)
+        agree = all(bool(torch.equal(c, allc[0])) for c in allc)
+        if not agree:
+            raise SystemExit(f"rank {rank}: student parameters differ across ranks after the timed region: {[float(c) for c in allc]}")
+    losses["_ranks_agree"] = agree
 
     def query(nsteps):
         fam = {}
@@ -639,7 +649,7 @@ def main():
                       "unit": "crops/s" if a.config != "c4" else "pairs/s", "n_gpus": world,
                       "steps": a.other_steps, "warmup": a.other_warmup, "ms_per_step": 1e3 * odt / a.other_steps,
                       "timed_region_s": odt, "roofline": oroof, "roofline_other_kernels": oother,
-                      "kernel_families": ofam, "losses_last_step": olosses}
+                      "kernel_families": ofam, "losses_last_step": {k: v for k, v in olosses.items() if not k.startswith("_")}}
     other_cfg = {}
     if not a.no_other_configs:
         for cfg, (st, wu) in (("c5", (a.c5_steps, max(a.warmup, 2))), ("c4", (a.c4_steps, a.c4_warmup)), ("c1", (5, 2))):
@@ -662,7 +672,7 @@ def main():
                 "hip_graph": bool(use_graph),
                 "roofline_conv_fwd": None if croof is None else {k: croof.get(k) for k in ("achieved", "peak", "unit", "frac", "frac_algorithmic")},
                 "roofline_other_kernels": cother if cfg == "c4" else None,
-                "losses_last_step": closs}
+                "losses_last_step": {k: v for k, v in closs.items() if not k.startswith("_")}}
             if cfg == "c5":
                 # MFMA-bound families of the encoder: declared algorithmic FLOPs / summed HIP-event durations, against the
                 # dense fp16 MFMA peak (= bf16's); the HBM-bound ones against 8 TB/s
@@ -708,6 +718,7 @@ def main():
                        "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
                        "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea}},
             "rccl_ranks": world, "backend": backend if world > 1 else "none (single process)",
+            "ranks_agree": losses.pop("_ranks_agree", None),
             "roofline": roof, "roofline_other_kernels": other, "bandwidth_kernels": bw, "cpu_baseline": cpu_line,
             "second_precision": other_line, "timed_region_s": dt, "other_configs": other_cfg or None, "miou_parity": miou, "kernel_families": families,
             "kernel_families_overlapped": None if a.serial_streams else families_ov, "losses_last_step": losses,
@@ -754,7 +765,7 @@ def compact(line):
     cfg = line["config"]
     out["config"] = {"workload": cfg["workload"][:220], "global_batch": cfg["global_batch"], "crop": cfg["crop"],
                      "parallelism": cfg["parallelism"]}
-    out.update(rccl_ranks=line["rccl_ranks"], roofline=roof, cpu_baseline=cpu, target=line.get("target"),
+    out.update(rccl_ranks=line["rccl_ranks"], backend=line.get("backend"), ranks_agree=line.get("ranks_agree"), roofline=roof, cpu_baseline=cpu, target=line.get("target"),
                second_precision=leg(line.get("second_precision")), c4_selftrain=leg(oc.get("c4")), c5_segformer=leg(oc.get("c5")),
                detail=line.get("detail_file"))
     return out

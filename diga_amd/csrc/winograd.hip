@@ -461,6 +461,9 @@ __device__ __forceinline__ float2 relu_fma(float2 v, float2 a, float2 b) {
 #ifndef DIGA_WINO4_OUT_VEC
 #define DIGA_WINO4_OUT_VEC float2     /* measured on l3.conv2: 82 vs 94 us (113 instead of 215 VGPRs); input / dy: no difference */
 #endif
+#ifndef DIGA_WINO4_EPI_VEC
+#define DIGA_WINO4_EPI_VEC float2
+#endif
 #ifndef DIGA_WINO4_DY_VEC
 #define DIGA_WINO4_DY_VEC float4
 #endif
@@ -646,94 +649,101 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
 }
 
-// one output pixel of a backward-data convolution through the epilogue of diga_bwd_epilogue_t (the arithmetic of
-// wino_output_epi_kernel / drain_stage<EPI>, element for element)
-__device__ __forceinline__ void wino_epi_pixel(float4 o, int64_t row, int k, float* __restrict__ y, int64_t ld, const WinoEpi& ep,
+// one output pixel (VW = 4 or 2 channels) of a backward-data convolution through the epilogue of diga_bwd_epilogue_t (the
+// arithmetic of wino_output_epi_kernel / drain_stage<EPI>, element for element)
+template <typename V>
+__device__ __forceinline__ void wino_epi_pixel(V o, int64_t row, int k, float* __restrict__ y, int64_t ld, const WinoEpi& ep,
                                                const float* ra, const float* rb, const float* mu, const float* is, float* sd,
                                                float* sd2) {
-    float v[4] = {o.x, o.y, o.z, o.w};
-    float xv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ep.add != nullptr) {
-        const float4 a4 = *reinterpret_cast<const float4*>(ep.add + row * ep.add_ld + k);
-        v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
-    }
-    if (ep.x != nullptr) {
-        const float4 x4 = *reinterpret_cast<const float4*>(ep.x + row * ep.x_ld + k);
-        xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
-    }
-    if (ep.masky != nullptr) {
-        const float4 y4 = *reinterpret_cast<const float4*>(ep.masky + row * ep.masky_ld + k);
-        v[0] = y4.x > 0.f ? v[0] : 0.f; v[1] = y4.y > 0.f ? v[1] : 0.f;
-        v[2] = y4.z > 0.f ? v[2] : 0.f; v[3] = y4.w > 0.f ? v[3] : 0.f;
-    } else if (ep.maskbits != nullptr) {
-        const unsigned b = ep.maskbits[row * ep.maskbits_ld + (k >> 3)] >> (k & 4);
+    constexpr int VW = sizeof(V) / 4;
+    float v[VW], xv[VW];
+    *reinterpret_cast<V*>(v) = o;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = ((b >> c) & 1u) ? v[c] : 0.f;
+    for (int c = 0; c < VW; ++c) xv[c] = 0.f;
+    if (ep.add != nullptr) {
+        float a4[VW];
+        *reinterpret_cast<V*>(a4) = *reinterpret_cast<const V*>(ep.add + row * ep.add_ld + k);
+#pragma unroll
+        for (int c = 0; c < VW; ++c) v[c] += a4[c];
+    }
+    if (ep.x != nullptr) *reinterpret_cast<V*>(xv) = *reinterpret_cast<const V*>(ep.x + row * ep.x_ld + k);
+    if (ep.masky != nullptr) {
+        float y4[VW];
+        *reinterpret_cast<V*>(y4) = *reinterpret_cast<const V*>(ep.masky + row * ep.masky_ld + k);
+#pragma unroll
+        for (int c = 0; c < VW; ++c) v[c] = y4[c] > 0.f ? v[c] : 0.f;
+    } else if (ep.maskbits != nullptr) {
+        const unsigned b = ep.maskbits[row * ep.maskbits_ld + (k >> 3)] >> (k & 7);
+#pragma unroll
+        for (int c = 0; c < VW; ++c) v[c] = ((b >> c) & 1u) ? v[c] : 0.f;
     } else if (ep.relu_ab != nullptr) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaf(xv[c], ra[c], rb[c]) > 0.f ? v[c] : 0.f;
+        for (int c = 0; c < VW; ++c) v[c] = __builtin_fmaf(xv[c], ra[c], rb[c]) > 0.f ? v[c] : 0.f;
     }
-    *reinterpret_cast<float4*>(y + row * ld + k) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<V*>(y + row * ld + k) = *reinterpret_cast<const V*>(v);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < VW; ++c) {
         sd[c] += v[c];
         sd2[c] += v[c] * ((xv[c] - mu[c]) * is[c]);
     }
 }
 
-// wino4_output_kernel with the backward-data epilogue: block / partial-row layout of wino_output_epi_kernel
+// wino4_output_kernel with the backward-data epilogue: block (g, s) = tiles [g * tpb, (g + 1) * tpb) x channels [64 VW s, 64 VW (s + 1)),
+// 64 channel groups x 4 tile lanes; partial-row layout and summation order of wino_output_epi_kernel (so V = float2 and float4
+// give the same bits).  float2: 130 instead of 256 VGPRs -- two more waves per SIMD for a pass that is all loads.
+template <typename V>
 __global__ __launch_bounds__(256) void wino4_output_epi_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
                                                                float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
                                                                int H, int W, int d, int tpb, WinoEpi ep) {
-    __shared__ float red[2][4][256];
+    constexpr int VW = sizeof(V) / 4;
+    __shared__ float red[2][4][64 * VW];
     const int q = threadIdx.x & 63, tl = threadIdx.x >> 6;
-    const int k = (blockIdx.y * 64 + q) * 4;
+    const int k = (blockIdx.y * 64 + q) * VW;
     const bool kok = k < K;
     const int64_t t0 = (int64_t)blockIdx.x * tpb;
     int64_t t1 = t0 + tpb;
     if (t1 > T) t1 = T;
     const int64_t plane = Tp * K;
-    float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
+    float ra[VW], rb[VW], mu[VW], is[VW], sd[VW], sd2[VW];
+#pragma unroll
+    for (int c = 0; c < VW; ++c) ra[c] = rb[c] = mu[c] = is[c] = sd[c] = sd2[c] = 0.f;
     if (kok && ep.relu_ab != nullptr) {
-        const float4 a0 = *reinterpret_cast<const float4*>(ep.relu_ab + k), a1 = *reinterpret_cast<const float4*>(ep.relu_ab + K + k);
-        ra[0] = a0.x; ra[1] = a0.y; ra[2] = a0.z; ra[3] = a0.w;
-        rb[0] = a1.x; rb[1] = a1.y; rb[2] = a1.z; rb[3] = a1.w;
+        *reinterpret_cast<V*>(ra) = *reinterpret_cast<const V*>(ep.relu_ab + k);
+        *reinterpret_cast<V*>(rb) = *reinterpret_cast<const V*>(ep.relu_ab + K + k);
     }
     if (kok && ep.partials != nullptr) {
-        const float4 a0 = *reinterpret_cast<const float4*>(ep.mean + k), a1 = *reinterpret_cast<const float4*>(ep.invstd + k);
-        mu[0] = a0.x; mu[1] = a0.y; mu[2] = a0.z; mu[3] = a0.w;
-        is[0] = a1.x; is[1] = a1.y; is[2] = a1.z; is[3] = a1.w;
+        *reinterpret_cast<V*>(mu) = *reinterpret_cast<const V*>(ep.mean + k);
+        *reinterpret_cast<V*>(is) = *reinterpret_cast<const V*>(ep.invstd + k);
     }
-    float sd[4] = {0.f, 0.f, 0.f, 0.f}, sd2[4] = {0.f, 0.f, 0.f, 0.f};
     if (kok) {
         for (int64_t t = t0 + tl; t < t1; t += 4) {
             const int4 e = tab[t];
-            float4 s[4][6];
-            wino4_load_rows(Mb + t * K + k, plane, s);
+            V s[4][6];
+            wino4_load_rows<V>(Mb + t * K + k, plane, s);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int yy = e.y + i * d;
                 if (yy >= H) continue;
-                float4 o[4];
+                V o[4];
                 at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int xx = e.z + j * d;
                     if (xx >= W) continue;
-                    wino_epi_pixel(o[j], (int64_t)(e.x * H + yy) * W + xx, k, y, ld, ep, ra, rb, mu, is, sd, sd2);
+                    wino_epi_pixel<V>(o[j], (int64_t)(e.x * H + yy) * W + xx, k, y, ld, ep, ra, rb, mu, is, sd, sd2);
                 }
             }
         }
     }
     if (ep.partials == nullptr) return;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        red[0][tl][q * 4 + c] = sd[c];
-        red[1][tl][q * 4 + c] = sd2[c];
+    for (int c = 0; c < VW; ++c) {
+        red[0][tl][q * VW + c] = sd[c];
+        red[1][tl][q * VW + c] = sd2[c];
     }
     __syncthreads();
-    const int ch = blockIdx.y * 256 + threadIdx.x;
-    if (ch < K) {
+    const int ch = blockIdx.y * 64 * VW + threadIdx.x;
+    if (threadIdx.x < 64 * VW && ch < K) {
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
@@ -918,8 +928,14 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
         ep.relu_ab = epi->relu_ab; ep.mean = epi->mean; ep.invstd = epi->invstd; ep.partials = epi->partials;
         const int64_t G = ceil_div(N * H * W, 128);
         const int tpb = (int)ceil_div(g.T, G);
-        hipLaunchKernelGGL(tile == 4 ? wino4_output_epi_kernel : wino_output_epi_kernel, dim3((unsigned)G, (unsigned)ceil_div(Cout, 256)),
-                           dim3(256), 0, st, Mb, tab, out, out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
+        if (tile == 4) {
+            constexpr int VW = sizeof(DIGA_WINO4_EPI_VEC) / 4;
+            hipLaunchKernelGGL(wino4_output_epi_kernel<DIGA_WINO4_EPI_VEC>, dim3((unsigned)G, (unsigned)ceil_div(Cout, 64 * VW)), dim3(256), 0, st,
+                               Mb, tab, out, out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
+        } else {
+            hipLaunchKernelGGL(wino_output_epi_kernel, dim3((unsigned)G, (unsigned)ceil_div(Cout, 256)), dim3(256), 0, st, Mb, tab, out,
+                               out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
+        }
     }
     return launch_status("diga_conv2d_winograd_f32");
 }

@@ -120,3 +120,21 @@ def test_two_rank_steps_equal_single_process_emulation(tmp_path, conv_math):
     cf = Class_Features(numbers=19)                                 # and hw above is the map size the library used
     f = torch.zeros((1, 256, 13, 17), device=DEV)
     assert cf._class_sums(f, torch.zeros((1, 19, 13, 17), device=DEV), labels_full=torch.zeros((1, 96, 128), dtype=torch.int64, device=DEV))[2] == hw
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per device (the 1-GPU test box skips it)")
+def test_bench_two_ranks_over_rccl():
+    """The distributed path as the driver launches it, on real RCCL: `bench.py --gpus 2 --lean` (two worker processes, one per
+    GPU, backend nccl) must finish, report two RCCL ranks, finite losses and -- checked inside bench.py by an all-gather of a
+    parameter checksum -- bit-identical students on both ranks after the all-reduced steps; rank 0 prints the one compact line."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lean", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1400, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert len(lines[0]) < 4000
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "nccl" and d["ranks_agree"] is True
+    assert d["config"]["global_batch"] == 16 and d["value"] > 0 and d["cpu_baseline"] is None

@@ -3,8 +3,9 @@ ops on the SAME fp16-rounded operands (so the bound is the kernel's own fp32-acc
 mit_b5 encoder, forward and backward, against the capture of the REFERENCE module (tests/golden/mit.npz) and mit_b1 at the
 benchmark geometry (768x768: 36864 queries x 576 keys) against tests/golden/mit768.npz.
 
-Tolerances (fp16 storage = 2^-11 relative per stored element): kernels 2e-3 of the output scale; encoder features 1e-2 of
-scale after 52 blocks of fp16 branches on an fp32 residual stream (measured ~2e-3); parameter-gradient norms 3e-2."""
+Tolerances (fp16 storage = 2^-11 relative per stored element): kernels 2e-3 of the output scale; against the
+captures of the reference module MIT_TOL below = 3x what is measured on the MI355X: encoder features 3e-3 of scale (6e-3 for the
+52-block mit_b5 at 768x768), sampled parameter gradients 7e-3, parameter-gradient norms within 0.3 %."""
 import ctypes
 
 import numpy as np
@@ -27,6 +28,12 @@ def _lib():
 def _rel(got, want):
     want = want.detach().double().cpu()
     return float((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+# tolerances of the reference captures: 3x the worst value measured on the MI355X (printed by the tests)
+# measured (round 4): mit_b5 at 128x96 features 9.7e-4, gradient samples 2.2e-3, norm ratios 0.9994 .. 1.0007; mit_b1 backward at
+# 768x768 gradient samples 1.6e-3, norm ratios 0.9998 .. 1.0004
+MIT_TOL = {"features": 3e-3, "grad_sample": 7e-3, "grad_norm": 0.003}
 
 
 def h16(t):
@@ -232,13 +239,13 @@ def test_mit_b5_forward_backward_vs_reference_capture(golden):
         assert tuple(o.shape) == tuple(want.shape)
         e = _rel(o, want)
         worst = max(worst, e)
-        assert e < 1e-2, (i, e)
+        assert e < MIT_TOL["features"], (i, e)
     sum((o * g.t(f"probe{i + 1}").to(DEV)).sum() for i, o in enumerate(outs)).backward()
     named = dict(m.named_parameters())
     keys = g["keys"].tolist()
     norms = np.array([float(named[k].grad.norm()) for k in keys])
     ratio = norms / np.maximum(g["grad_norms"], 1e-12)
-    bad = [(k, r) for k, r in zip(keys, ratio) if not 0.97 < r < 1.03]
+    bad = [(k, r) for k, r in zip(keys, ratio) if abs(r - 1.0) > MIT_TOL["grad_norm"]]
     assert not bad, bad[:10]
     gworst = 0.0
     for k in [n[2:] for n in g if n.startswith("g_")]:
@@ -247,7 +254,7 @@ def test_mit_b5_forward_backward_vs_reference_capture(golden):
         want = g.t("g_" + k)
         e = _rel(named[name].grad.reshape(-1)[::step], want)
         gworst = max(gworst, e)
-        assert e < 3e-2, (name, e)
+        assert e < MIT_TOL["grad_sample"], (name, e)
     print(f"mit_b5 vs reference: features max err {worst:.2e} of scale, sampled gradients {gworst:.2e}, "
           f"gradient-norm ratios {ratio.min():.4f} .. {ratio.max():.4f}")
 
@@ -305,9 +312,37 @@ def test_mit_b1_benchmark_geometry_vs_reference_capture(golden):
     assert [tuple(o.shape) for o in outs] == [(1, 64, 192, 192), (1, 128, 96, 96), (1, 320, 48, 48), (1, 512, 24, 24)]
     for o, key, step, mx in zip(outs, ("c1_sample", "c2_sample", "c3_sample", "c4_sample"), (211, 53, 7, 3), g["maxs"]):
         e = float((o.float().cpu().reshape(-1)[::step] - g.t(key)).abs().max()) / float(mx)
-        assert e < 1e-2, (key, e)
+        assert e < MIT_TOL["features"], (key, e)
     sums = np.array([float(o.abs().sum()) for o in outs])
     assert np.allclose(sums, g["sums"], rtol=2e-3)
+
+
+def test_mit_b1_benchmark_geometry_backward_vs_reference_capture(golden):
+    """Backward at 768x768 against the capture of the reference module (tests/golden/mit768bwd.npz: mit_b1, one image, probes on
+    all four stage outputs regenerated from their seed): the norm of EVERY parameter gradient and strided samples of the gradients
+    whose indexing depends on the geometry -- q / kv / spatial-reduction conv of every block (stage 1: 36 864 queries x 576 keys),
+    the four patch embeddings."""
+    g = golden("mit768bwd")
+    x = torch.rand((1, 3, 768, 768), generator=synth.gen(int(g["seed_x"]))) * 2 - 1
+    m = _model("mit_b1").eval()
+    outs = m(x.to(DEV))
+    gp = synth.gen(int(g["seed_probe"]))
+    probes = [torch.randn(tuple(o.shape), generator=gp) for o in outs]
+    assert np.allclose(np.array([float(o.detach().abs().sum()) for o in outs]), g["out_sums"], rtol=2e-3)
+    sum((o * p.to(DEV)).sum() for o, p in zip(outs, probes)).backward()
+    named = dict(m.named_parameters())
+    keys = g["keys"].tolist()
+    ratio = np.array([float(named[k].grad.norm()) for k in keys]) / np.maximum(g["grad_norms"], 1e-12)
+    worst = 0.0
+    for k in [n[2:] for n in g if n.startswith("g_")]:
+        name = [n for n in keys if n.replace(".", "_") == k][0]
+        e = _rel(named[name].grad.reshape(-1)[::int(g["gstep_" + k])], g.t("g_" + k))
+        worst = max(worst, e)
+        assert e < MIT_TOL["grad_sample"], (name, e)
+    print(f"mit_b1 backward at 768x768 vs reference: sampled gradients {worst:.2e} of scale, gradient-norm ratios "
+          f"{ratio.min():.4f} .. {ratio.max():.4f}")
+    bad = [(k, r) for k, r in zip(keys, ratio) if abs(r - 1.0) > MIT_TOL["grad_norm"]]
+    assert not bad, bad[:10]
 
 
 def test_mit_b5_benchmark_geometry_vs_reference_capture(golden):
@@ -319,7 +354,7 @@ def test_mit_b5_benchmark_geometry_vs_reference_capture(golden):
         outs = m(x.to(DEV))
     for o, key, step, mx in zip(outs, ("b5_c1_sample", "b5_c2_sample", "b5_c3_sample", "b5_c4_sample"), (211, 53, 7, 3), g["b5_maxs"]):
         e = float((o.float().cpu().reshape(-1)[::step] - g.t(key)).abs().max()) / float(mx)
-        assert e < 1e-2, (key, e)
+        assert e < 2 * MIT_TOL["features"], (key, e)          # (52 blocks deep: twice the bound of the shallow captures)
     assert np.allclose(np.array([float(o.abs().sum()) for o in outs]), g["b5_sums"], rtol=3e-3)
 
 

@@ -567,6 +567,37 @@ def gen_mit():
          b5_sums=np.array([float(o.abs().sum()) for o in o5]), b5_maxs=np.array([float(o.abs().max()) for o in o5]))
 
 
+def gen_mit768bwd():
+    """Backward capture at the BENCHMARK geometry (768x768: 36 864 queries against 576 keys in stage 1, MixTransfomer.py:85-144):
+    the reference's mit_b1 on one image, probes on all four stage outputs (regenerated from their seed by the test: c1's probe
+    alone is 9 MB), gradient norm of every parameter and strided samples of the gradients whose index arithmetic depends on the
+    geometry -- attention q / kv / spatial-reduction conv and the patch embeddings of every stage."""
+    from oracle import mit as om
+    ref = _import_reference_mit()
+    net = ref.mit_b1()
+    sd = om.state_dict(om.MIT_B1)
+    net.load_state_dict(sd)
+    net.eval()
+    x = torch.rand((1, 3, 768, 768), generator=synth.gen(56)) * 2 - 1          # the image of mit768.npz
+    outs = net(x)
+    gp = synth.gen(57)
+    probes = [torch.randn(o.shape, generator=gp) for o in outs]
+    sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+    named = dict(net.named_parameters())
+    res = {"seed_x": np.array(56), "seed_probe": np.array(57), "keys": np.array(list(sd.keys())),
+           "grad_norms": np.array([float(named[k].grad.norm()) for k in sd.keys()]),
+           "out_sums": np.array([float(o.detach().abs().sum()) for o in outs])}
+    picks = [k for k in sd.keys() if k.startswith(("patch_embed",)) and k.endswith("proj.weight")]
+    picks += [k for k in sd.keys() if ".attn.q.weight" in k or ".attn.kv.weight" in k or ".attn.sr.weight" in k]
+    picks += ["block1.0.norm1.weight", "block1.1.mlp.fc1.weight", "block1.1.mlp.dwconv.dwconv.weight", "block2.0.mlp.fc2.weight", "norm1.weight", "norm4.bias"]
+    for k in picks:
+        gr = named[k].grad
+        step = max(1, gr.numel() // 1024)
+        res["g_" + k.replace(".", "_")] = gr.reshape(-1)[::step].clone()
+        res["gstep_" + k.replace(".", "_")] = np.array(step)
+    save("mit768bwd", **res)
+
+
 # ------------------------------------------------------------------ G-step (warm-up, 3 steps)
 def gen_step():
     import torch.optim as optim
@@ -837,7 +868,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(mit=gen_mit, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(mit=gen_mit, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
