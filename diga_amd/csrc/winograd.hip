@@ -54,6 +54,7 @@ WinoGeom make_wino(int64_t N, int64_t H, int64_t W, int64_t d, int64_t m) {
     return g;
 }
 static inline int products(int64_t m) { return (int)((m + 2) * (m + 2)); }
+static inline bool tile_ok(int64_t m) { return m == 2 || m == 4 || m == 6; }
 
 // tab[t] = {image, oy, ox, 0}: top-left OUTPUT pixel of tile t (its m x m outputs are (oy + d i, ox + d j), its (m+2) x (m+2)
 // input patch (oy + d (i - 1), ox + d (j - 1))); image = -1 for the padding tiles
@@ -418,19 +419,19 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 }
 
 // ======================================================================================================================
-// F(4x4, 3x3): 36 products per 4x4 outputs (2.25 multiplications per output instead of 9 direct / 4 with F(2x2)); V is
-// 2.25x the input instead of 4x, M 2.25x the output.  Interpolation points 0, +-1, +-2, inf (Lavin & Gray 2016):
-//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-// fp32 rounding error of a 256-channel layer against float64: max 8e-6 of the output scale (F(2x2): 6e-7, the direct fmaf
-// chain 3e-7; measured) -- taken for the dilation 1 / 2 / 4 layers, whose sub-images are large enough
-// for 4x4 tiles; tests hold it to 3e-5 of scale per layer, the full-size captures to north_star's 1e-3.
+// Larger tiles: F(m x m, 3x3) with m = 4 (36 products per 16 outputs: 2.25 multiplications per output instead of 9 direct / 4 with
+// F(2x2); V is 2.25x the input, M 2.25x the output) and m = 6 (64 products per 36 outputs: 1.78 per output; V and M 1.78x).  The
+// 1-D transforms are generated (tools/gen_winograd_xforms.py -> winograd_xforms.h) from the exact Toom-Cook matrices:
+//   F(4,3): points 0, 1, -1, 2, -1/2, inf -- fp32 error of a 512-channel layer against float64: max 4.9e-6 of the output scale
+//           (Lavin & Gray's 0, +-1, +-2: 1.2e-5; F(2x2): 7.5e-7; the direct fmaf chain 3e-7);
+//   F(6,3): points 0, +-1, +-2, +-1/2, inf -- max 2.7e-5, rms 2.0e-6.
+// The caller picks the tile per layer (diga_amd/model/conv.py::_wino_plan: fewest multiplications); tests hold every tile size
+// to its own bound against float64 and the full-size captures to north_star's 1e-3.
 __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
     return make_float4(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y), __builtin_fmaf(s, a.z, b.z), __builtin_fmaf(s, a.w, b.w));
 }
 __device__ __forceinline__ float4 f4scale(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
-// the same helpers on channel pairs: the F(4x4) transforms hold 36 vectors per thread, float2 halves the registers (twice the waves)
+// the same helpers on channel pairs: the transforms hold (m+2)^2 vectors per thread, float2 halves the registers (twice the waves)
 __device__ __forceinline__ float2 f4add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 f4sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 f4fma(float s, float2 a, float2 b) { return make_float2(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y)); }
@@ -455,79 +456,40 @@ __device__ __forceinline__ float4 relu_fma(float4 v, float4 a, float4 b) {
 __device__ __forceinline__ float2 relu_fma(float2 v, float2 a, float2 b) {
     return make_float2(fmaxf(__builtin_fmaf(v.x, a.x, b.x), 0.f), fmaxf(__builtin_fmaf(v.y, a.y, b.y), 0.f));
 }
-#ifndef DIGA_WINO4_IN_VEC
-#define DIGA_WINO4_IN_VEC float4
-#endif
-#ifndef DIGA_WINO4_OUT_VEC
-#define DIGA_WINO4_OUT_VEC float2     /* measured on l3.conv2: 82 vs 94 us (113 instead of 215 VGPRs); input / dy: no difference */
-#endif
-#ifndef DIGA_WINO4_EPI_VEC
-#define DIGA_WINO4_EPI_VEC float2
-#endif
-#ifndef DIGA_WINO4_DY_VEC
-#define DIGA_WINO4_DY_VEC float4
-#endif
-// one column / row of B^T d (in place on six values)
-template <typename V>
-__device__ __forceinline__ void bt6(V d0, V d1, V d2, V d3, V d4, V d5, V* r) {
-    const V t0 = f4fma(-4.f, d2, d4), t1 = f4fma(-4.f, d1, d3), t2 = f4sub(d4, d2), t3 = f4sub(d3, d1);
-    r[0] = f4fma(4.f, d0, f4fma(-5.f, d2, d4));
-    r[1] = f4add(t0, t1);
-    r[2] = f4sub(t0, t1);
-    r[3] = f4fma(2.f, t3, t2);
-    r[4] = f4fma(-2.f, t3, t2);
-    r[5] = f4fma(4.f, d1, f4fma(-5.f, d3, d5));
-}
-// G g (three values -> six)
-template <typename V>
-__device__ __forceinline__ void g6(V g0, V g1, V g2, V* r) {
-    const V s = f4add(g0, g2);
-    const V e = f4fma(1.f / 6.f, g2, f4scale(1.f / 24.f, g0));
-    r[0] = f4scale(0.25f, g0);
-    r[1] = f4scale(-1.f / 6.f, f4add(s, g1));
-    r[2] = f4scale(-1.f / 6.f, f4sub(s, g1));
-    r[3] = f4fma(1.f / 12.f, g1, e);
-    r[4] = f4fma(-1.f / 12.f, g1, e);
-    r[5] = g2;
-}
-// A^T m (six values -> four)
-template <typename V>
-__device__ __forceinline__ void at4(V m0, V m1, V m2, V m3, V m4, V m5, V* r) {
-    const V s12 = f4add(m1, m2), d12 = f4sub(m1, m2), s34 = f4add(m3, m4), d34 = f4sub(m3, m4);
-    r[0] = f4add(f4add(m0, s12), s34);
-    r[1] = f4fma(2.f, d34, d12);
-    r[2] = f4fma(4.f, s34, s12);
-    r[3] = f4add(f4fma(8.f, d34, d12), m5);
-}
-// A g (four values -> six)
-template <typename V>
-__device__ __forceinline__ void a6(V g0, V g1, V g2, V g3, V* r) {
-    const V e = f4add(g0, g2), o = f4add(g1, g3);
-    const V e4 = f4fma(4.f, g2, g0), o4 = f4fma(8.f, g3, f4add(g1, g1));
-    r[0] = g0;
-    r[1] = f4add(e, o);
-    r[2] = f4sub(e, o);
-    r[3] = f4add(e4, o4);
-    r[4] = f4sub(e4, o4);
-    r[5] = g3;
-}
-// G^T u (six values -> three)
-template <typename V>
-__device__ __forceinline__ void gt3(V u0, V u1, V u2, V u3, V u4, V u5, V* r) {
-    const V s12 = f4add(u1, u2), d12 = f4sub(u1, u2), s34 = f4add(u3, u4), d34 = f4sub(u3, u4);
-    r[0] = f4fma(0.25f, u0, f4fma(-1.f / 6.f, s12, f4scale(1.f / 24.f, s34)));
-    r[1] = f4fma(-1.f / 6.f, d12, f4scale(1.f / 12.f, d34));
-    r[2] = f4add(f4fma(-1.f / 6.f, s12, f4scale(1.f / 6.f, s34)), u5);
-}
 
-// U[k = 6 i + j][co][c] = (G g G^T)[i][j]
-__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
+#include "winograd_xforms.h"      // (inside namespace diga::wino: the generated transforms use the helpers above)
+
+template <int M> struct Xf;
+template <> struct Xf<4> {
+    template <typename V> static __device__ __forceinline__ void bt(const V* x, V* r) { wino4_bt(x, r); }
+    template <typename V> static __device__ __forceinline__ void g(const V* x, V* r) { wino4_g(x, r); }
+    template <typename V> static __device__ __forceinline__ void at(const V* x, V* r) { wino4_at(x, r); }
+    template <typename V> static __device__ __forceinline__ void a(const V* x, V* r) { wino4_a(x, r); }
+    template <typename V> static __device__ __forceinline__ void gt(const V* x, V* r) { wino4_gt(x, r); }
+};
+template <> struct Xf<6> {
+    template <typename V> static __device__ __forceinline__ void bt(const V* x, V* r) { wino6_bt(x, r); }
+    template <typename V> static __device__ __forceinline__ void g(const V* x, V* r) { wino6_g(x, r); }
+    template <typename V> static __device__ __forceinline__ void at(const V* x, V* r) { wino6_at(x, r); }
+    template <typename V> static __device__ __forceinline__ void a(const V* x, V* r) { wino6_a(x, r); }
+    template <typename V> static __device__ __forceinline__ void gt(const V* x, V* r) { wino6_gt(x, r); }
+};
+// vector width of each pass (measured on l3.conv2, 16 images, 4x4 tiles: output 82 us with float2 vs 94 us with float4 -- 113
+// instead of 215 VGPRs; input / dy: no difference; the 8x8-patch passes of 6x6 tiles hold 64 vectors per thread: pairs throughout)
+template <int M> struct Vec;
+template <> struct Vec<4> { using In = float4; using Out = float2; using Dy = float4; };
+template <> struct Vec<6> { using In = float2; using Out = float2; using Dy = float2; };
+
+// U[k = A i + j][co][c] = (G g G^T)[i][j], A = M + 2
+template <int M>
+__global__ __launch_bounds__(256) void winoM_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
                                                            int flip) {
+    constexpr int A = M + 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c4n = Cin / 4;
     if (idx >= (int64_t)Cout * c4n) return;
     const int co = (int)(idx / c4n), c = (int)(idx - (int64_t)co * c4n) * 4;
-    float4 t[6][3];
+    float4 t[A][3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         float4 g[3];
@@ -536,28 +498,29 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
             const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
             g[r] = *reinterpret_cast<const float4*>(w + ((int64_t)co * 9 + rr * 3 + ss) * Cin + c);
         }
-        float4 col[6];
-        g6(g[0], g[1], g[2], col);
+        float4 col[A];
+        Xf<M>::g(g, col);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) t[i][s] = col[i];
+        for (int i = 0; i < A; ++i) t[i][s] = col[i];
     }
     const int64_t plane = (int64_t)Cout * Cin;
     float* o = U + (int64_t)co * Cin + c;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        float4 row[6];
-        g6(t[i][0], t[i][1], t[i][2], row);
+    for (int i = 0; i < A; ++i) {
+        float4 row[A];
+        Xf<M>::g(t[i], row);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(o + (6 * i + j) * plane) = row[j];
+        for (int j = 0; j < A; ++j) *reinterpret_cast<float4*>(o + (A * i + j) * plane) = row[j];
     }
 }
 
-// V[k = 6 i + j][t][c] = (B^T d B)[i][j] of the 6x6 patch of tile t (zero outside the image / for padding tiles); `ab` as in
+// V[k = A i + j][t][c] = (B^T d B)[i][j] of the A x A patch of tile t (zero outside the image / for padding tiles); `ab` as in
 // wino_input_kernel
-template <typename V>
-__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
+template <int M, typename V>
+__global__ __launch_bounds__(256) void winoM_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
                                                           float* __restrict__ Vo, int64_t Tp, int C, int H, int W, int d,
                                                           const float* __restrict__ ab) {
+    constexpr int A = M + 2;
     constexpr int VW = sizeof(V) / 4;
     const int c4n = C / VW;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -572,17 +535,17 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         bv = *reinterpret_cast<const V*>(ab + C + c);
     }
     const int img = max(e.x, 0);
-    V m[6][6];
+    V m[A][A];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < A; ++j) {
         // branch-free: every tap is loaded from a clamped (valid) address and zeroed afterwards when it lies outside the image,
-        // so the 36 loads of a thread issue back to back
+        // so the A * A loads of a thread issue back to back (measured on 4x4 tiles: 151 -> 109 us)
         const int xx = e.z + (j - 1) * d;
         const bool xok = e.x >= 0 && (unsigned)xx < (unsigned)W;
         const int xc = min(max(xx, 0), W - 1);
-        V p[6];
+        V p[A];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < A; ++i) {
             const int y = e.y + (i - 1) * d;
             const bool ok = xok && (unsigned)y < (unsigned)H;
             const int yc = min(max(y, 0), H - 1);
@@ -590,42 +553,44 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
             if (ab != nullptr) v = relu_fma(v, av, bv);
             p[i] = ok ? v : z;
         }
-        V col[6];
-        bt6(p[0], p[1], p[2], p[3], p[4], p[5], col);
+        V col[A];
+        Xf<M>::bt(p, col);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) m[i][j] = col[i];
+        for (int i = 0; i < A; ++i) m[i][j] = col[i];
     }
     float* o = Vo + t * C + c;
     const int64_t plane = Tp * C;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        V row[6];
-        bt6(m[i][0], m[i][1], m[i][2], m[i][3], m[i][4], m[i][5], row);
+    for (int i = 0; i < A; ++i) {
+        V row[A];
+        Xf<M>::bt(m[i], row);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) nt_store4(o + (6 * i + j) * plane, row[j]);
+        for (int j = 0; j < A; ++j) nt_store4(o + (A * i + j) * plane, row[j]);
     }
 }
 
-// s[i][j] = (A^T M)[i][j] of tile t, channels k..k+3: 4 x 6 values from the 36 product planes
-template <typename V>
-__device__ __forceinline__ void wino4_load_rows(const float* __restrict__ src, int64_t plane, V (*s)[6]) {
+// s[i][j] = (A^T Mt)[i][j] of tile t, channels k..: M x A values from the A * A product planes
+template <int M, typename V>
+__device__ __forceinline__ void winoM_load_rows(const float* __restrict__ src, int64_t plane, V (*s)[M + 2]) {
+    constexpr int A = M + 2;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        V m[6];
+    for (int j = 0; j < A; ++j) {
+        V m[A];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) m[i] = nt_loadv<V>(src + (6 * i + j) * plane);
-        V col[4];
-        at4(m[0], m[1], m[2], m[3], m[4], m[5], col);
+        for (int i = 0; i < A; ++i) m[i] = nt_loadv<V>(src + (A * i + j) * plane);
+        V col[M];
+        Xf<M>::at(m, col);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i][j] = col[i];
+        for (int i = 0; i < M; ++i) s[i][j] = col[i];
     }
 }
 
-// y[4x4 of tile t][co] = A^T M A + bias
-template <typename V>
-__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+// y[M x M of tile t][co] = A^T Mt A + bias
+template <int M, typename V>
+__global__ __launch_bounds__(256) void winoM_output_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
                                                            const float* __restrict__ bias, float* __restrict__ y, int64_t ld,
                                                            int64_t T, int64_t Tp, int K, int H, int W, int d) {
+    constexpr int A = M + 2;
     constexpr int VW = sizeof(V) / 4;
     const int k4n = K / VW;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -633,18 +598,18 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const int64_t t = idx / k4n;
     const int k = (int)(idx - t * k4n) * VW;
     const int4 e = tab[t];
-    V s[4][6];
-    wino4_load_rows(Mb + t * K + k, Tp * K, s);
+    V s[M][A];
+    winoM_load_rows<M, V>(Mb + t * K + k, Tp * K, s);
     const V b = bias != nullptr ? *reinterpret_cast<const V*>(bias + k) : vzero<V>();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < M; ++i) {
         const int yy = e.y + i * d;
         if (yy >= H) continue;
-        V o[4];
-        at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
+        V o[M];
+        Xf<M>::at(s[i], o);
         float* row = y + ((int64_t)(e.x * H + yy) * W) * ld + k;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < M; ++j)
             if (e.z + j * d < W) *reinterpret_cast<V*>(row + (int64_t)(e.z + j * d) * ld) = f4add(o[j], b);
     }
 }
@@ -688,13 +653,14 @@ __device__ __forceinline__ void wino_epi_pixel(V o, int64_t row, int k, float* _
     }
 }
 
-// wino4_output_kernel with the backward-data epilogue: block (g, s) = tiles [g * tpb, (g + 1) * tpb) x channels [64 VW s, 64 VW (s + 1)),
+// winoM_output_kernel with the backward-data epilogue: block (g, s) = tiles [g * tpb, (g + 1) * tpb) x channels [64 VW s, 64 VW (s + 1)),
 // 64 channel groups x 4 tile lanes; partial-row layout and summation order of wino_output_epi_kernel (so V = float2 and float4
 // give the same bits).  float2: 130 instead of 256 VGPRs -- two more waves per SIMD for a pass that is all loads.
-template <typename V>
-__global__ __launch_bounds__(256) void wino4_output_epi_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+template <int M, typename V>
+__global__ __launch_bounds__(256) void winoM_output_epi_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
                                                                float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
                                                                int H, int W, int d, int tpb, WinoEpi ep) {
+    constexpr int A = M + 2;
     constexpr int VW = sizeof(V) / 4;
     __shared__ float red[2][4][64 * VW];
     const int q = threadIdx.x & 63, tl = threadIdx.x >> 6;
@@ -718,16 +684,16 @@ __global__ __launch_bounds__(256) void wino4_output_epi_kernel(const float* __re
     if (kok) {
         for (int64_t t = t0 + tl; t < t1; t += 4) {
             const int4 e = tab[t];
-            V s[4][6];
-            wino4_load_rows<V>(Mb + t * K + k, plane, s);
+            V s[M][A];
+            winoM_load_rows<M, V>(Mb + t * K + k, plane, s);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < M; ++i) {
                 const int yy = e.y + i * d;
                 if (yy >= H) continue;
-                V o[4];
-                at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
+                V o[M];
+                Xf<M>::at(s[i], o);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < M; ++j) {
                     const int xx = e.z + j * d;
                     if (xx >= W) continue;
                     wino_epi_pixel<V>(o[j], (int64_t)(e.x * H + yy) * W + xx, k, y, ld, ep, ra, rb, mu, is, sd, sd2);
@@ -756,10 +722,11 @@ __global__ __launch_bounds__(256) void wino4_output_epi_kernel(const float* __re
     }
 }
 
-// Z[k = 6 i + j][t][co] = (A dY A^T)[i][j] of the 4x4 output-gradient tile t
-template <typename V>
-__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int64_t ld, const int4* __restrict__ tab,
+// Z[k = A i + j][t][co] = (A dY A^T)[i][j] of the M x M output-gradient tile t
+template <int M, typename V>
+__global__ __launch_bounds__(256) void winoM_dy_kernel(const float* __restrict__ dy, int64_t ld, const int4* __restrict__ tab,
                                                        float* __restrict__ Z, int64_t Tp, int K, int H, int W, int d) {
+    constexpr int A = M + 2;
     constexpr int VW = sizeof(V) / 4;
     const int k4n = K / VW;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -769,72 +736,112 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
     const int4 e = tab[t];
     const V z = vzero<V>();
     const int img = max(e.x, 0);
-    V r[6][4];
+    V r[A][M];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < M; ++j) {
         const int xx = e.z + j * d, xc = min(xx, W - 1);
-        V g[4];
+        V g[M];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < M; ++i) {
             const int yy = e.y + i * d;
             const bool ok = e.x >= 0 && yy < H && xx < W;
             const V v = *reinterpret_cast<const V*>(dy + ((int64_t)(img * H + min(yy, H - 1)) * W + xc) * ld + k);     // (clamped address)
             g[i] = ok ? v : z;
         }
-        V col[6];
-        a6(g[0], g[1], g[2], g[3], col);
+        V col[A];
+        Xf<M>::a(g, col);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) r[i][j] = col[i];
+        for (int i = 0; i < A; ++i) r[i][j] = col[i];
     }
     float* o = Z + t * K + k;
     const int64_t plane = Tp * K;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        V row[6];
-        a6(r[i][0], r[i][1], r[i][2], r[i][3], row);
+    for (int i = 0; i < A; ++i) {
+        V row[A];
+        Xf<M>::a(r[i], row);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) nt_store4(o + (6 * i + j) * plane, row[j]);
+        for (int j = 0; j < A; ++j) nt_store4(o + (A * i + j) * plane, row[j]);
     }
 }
 
-// dw[co][r][s][c] = (G^T dU G)[r][s], dU [co][36][c]
-__global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin) {
+// dw[co][r][s][c] = (G^T dU G)[r][s], dU [co][A * A][c]
+template <int M, typename V>
+__global__ __launch_bounds__(256) void winoM_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin) {
+    constexpr int A = M + 2;
+    constexpr int VW = sizeof(V) / 4;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int c4n = Cin / 4;
+    const int c4n = Cin / VW;
     if (idx >= (int64_t)Cout * c4n) return;
-    const int co = (int)(idx / c4n), c = (int)(idx - (int64_t)co * c4n) * 4;
-    const float* src = dU + (int64_t)co * 36 * Cin + c;
-    float4 t[3][6];
+    const int co = (int)(idx / c4n), c = (int)(idx - (int64_t)co * c4n) * VW;
+    const float* src = dU + (int64_t)co * A * A * Cin + c;
+    V t[3][A];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        float4 u[6];
+    for (int j = 0; j < A; ++j) {
+        V u[A];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) u[i] = *reinterpret_cast<const float4*>(src + (int64_t)(6 * i + j) * Cin);
-        float4 col[3];
-        gt3(u[0], u[1], u[2], u[3], u[4], u[5], col);
+        for (int i = 0; i < A; ++i) u[i] = *reinterpret_cast<const V*>(src + (int64_t)(A * i + j) * Cin);
+        V col[3];
+        Xf<M>::gt(u, col);
 #pragma unroll
         for (int r = 0; r < 3; ++r) t[r][j] = col[r];
     }
     float* o = dw + (int64_t)co * 9 * Cin + c;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        float4 row[3];
-        gt3(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], row);
+        V row[3];
+        Xf<M>::gt(t[r], row);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(o + (int64_t)(3 * r + q) * Cin) = row[q];
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<V*>(o + (int64_t)(3 * r + q) * Cin) = row[q];
     }
 }
 
+// ---- launches by tile size (2: the hand-written F(2x2) kernels above)
+template <int M>
+static void launch_input_m(const float* x, int64_t ld, const int4* tab, float* V, int64_t Tp, int64_t C, int64_t H, int64_t W, int64_t d,
+                           const float* ab, hipStream_t st) {
+    using VT = typename Vec<M>::In;
+    constexpr int VW = sizeof(VT) / 4;
+    hipLaunchKernelGGL((winoM_input_kernel<M, VT>), dim3((unsigned)ceil_div(Tp * (C / VW), 256)), dim3(256), 0, st, x, ld, tab, V, Tp, (int)C,
+                       (int)H, (int)W, (int)d, ab);
+}
 static void launch_input(int64_t tile, const float* x, int64_t ld, const int4* tab, float* V, int64_t Tp, int64_t C, int64_t H, int64_t W,
                          int64_t d, const float* ab, hipStream_t st) {
-    if (tile == 4) {
-        constexpr int VW = sizeof(DIGA_WINO4_IN_VEC) / 4;
-        hipLaunchKernelGGL(wino4_input_kernel<DIGA_WINO4_IN_VEC>, dim3((unsigned)ceil_div(Tp * (C / VW), 256)), dim3(256), 0, st, x, ld, tab, V,
-                           Tp, (int)C, (int)H, (int)W, (int)d, ab);
-    } else {
+    if (tile == 6) launch_input_m<6>(x, ld, tab, V, Tp, C, H, W, d, ab, st);
+    else if (tile == 4) launch_input_m<4>(x, ld, tab, V, Tp, C, H, W, d, ab, st);
+    else
         hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(Tp * (C / 4), 256)), dim3(256), 0, st, x, ld, tab, V, Tp, (int)C,
                            (int)H, (int)W, (int)d, ab);
-    }
+}
+template <int M>
+static void launch_weight_m(const float* w, float* U, int64_t Cout, int64_t Cin, int flip, hipStream_t st) {
+    hipLaunchKernelGGL(winoM_weight_kernel<M>, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, w, U, (int)Cout, (int)Cin, flip);
+}
+template <int M>
+static void launch_output_m(const float* Mb, const int4* tab, const float* bias, float* out, int64_t out_ld, const WinoGeom& g, int64_t Cout,
+                            hipStream_t st) {
+    using VT = typename Vec<M>::Out;
+    constexpr int VW = sizeof(VT) / 4;
+    hipLaunchKernelGGL((winoM_output_kernel<M, VT>), dim3((unsigned)ceil_div(g.T * (Cout / VW), 256)), dim3(256), 0, st, Mb, tab, bias, out,
+                       out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d);
+}
+template <int M>
+static void launch_output_epi_m(const float* Mb, const int4* tab, float* out, int64_t out_ld, const WinoGeom& g, int64_t Cout, int64_t G,
+                                int tpb, const WinoEpi& ep, hipStream_t st) {
+    using VT = typename Vec<M>::Out;
+    constexpr int VW = sizeof(VT) / 4;
+    hipLaunchKernelGGL((winoM_output_epi_kernel<M, VT>), dim3((unsigned)G, (unsigned)ceil_div(Cout, 64 * VW)), dim3(256), 0, st, Mb, tab, out,
+                       out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d, tpb, ep);
+}
+template <int M>
+static void launch_dy_m(const float* dy, int64_t dy_ld, const int4* tab, float* Z, const WinoGeom& g, int64_t Cout, hipStream_t st) {
+    using VT = typename Vec<M>::Dy;
+    constexpr int VW = sizeof(VT) / 4;
+    hipLaunchKernelGGL((winoM_dy_kernel<M, VT>), dim3((unsigned)ceil_div(g.Tp * (Cout / VW), 256)), dim3(256), 0, st, dy, dy_ld, tab, Z, g.Tp,
+                       (int)Cout, g.H, g.W, g.d);
+}
+template <int M>
+static void launch_dw_m(const float* dU, float* dw, int64_t Cout, int64_t Cin, hipStream_t st) {
+    hipLaunchKernelGGL((winoM_dw_kernel<M, float2>), dim3((unsigned)ceil_div(Cout * (Cin / 2), 256)), dim3(256), 0, st, dU, dw, (int)Cout, (int)Cin);
 }
 
 struct WinoWgradLayout {
@@ -873,7 +880,7 @@ using namespace diga;
 using namespace diga::wino;
 
 extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation, int64_t tile) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || (tile != 2 && tile != 4)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || !tile_ok(tile)) return 0;
     return wino_layout(make_wino(N, H, W, dilation, tile), Cin, Cout).total;
 }
 
@@ -883,7 +890,7 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
                          void* stream, float* v_keep = nullptr, const float* in_ab = nullptr) {
     DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
-    DIGA_REQUIRE(tile == 2 || tile == 4, DIGA_EINVAL, "conv2d_winograd: tile must be 2 (F(2x2,3x3)) or 4 (F(4x4,3x3))");
+    DIGA_REQUIRE(tile_ok(tile), DIGA_EINVAL, "conv2d_winograd: tile must be 2, 4 or 6 (F(2x2,3x3) / F(4x4,3x3) / F(6x6,3x3))");
     DIGA_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 && in_ld >= Cin && in_ld % 4 == 0 && out_ld >= Cout && out_ld % 4 == 0,
                  DIGA_EINVAL, "conv2d_winograd: Cin %% 32, Cout %% 4 (> 64) and leading dimensions %% 4 required");
     DIGA_REQUIRE(aligned16(in) && aligned16(wgt) && aligned16(out) && aligned16(workspace) && (!bias || aligned16(bias)), DIGA_EALIGN,
@@ -904,21 +911,21 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
                    2.0 * (double)(N * H * W) * (double)Cout * 9.0 * (double)Cin);
     hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
-    hipLaunchKernelGGL(tile == 4 ? wino4_weight_kernel : wino_weight_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0,
-                       st, wgt, U, (int)Cout, (int)Cin, flip);
+    if (tile == 6) launch_weight_m<6>(wgt, U, Cout, Cin, flip, st);
+    else if (tile == 4) launch_weight_m<4>(wgt, U, Cout, Cin, flip, st);
+    else
+        hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, wgt, U, (int)Cout, (int)Cin,
+                           flip);
     DIGA_REQUIRE(!in_ab || aligned16(in_ab), DIGA_EALIGN, "conv2d_winograd: in_ab must be 16-byte aligned");
     launch_input(tile, in, in_ld, tab, V, g.Tp, Cin, H, W, dilation, in_ab, st);
     int rc = gemm_batched_f32_dma(V, g.Tp, P, Cin, U, Cout, Mb, st);
     if (rc) return rc;
     if (epi == nullptr) {
-        if (tile == 4) {
-            constexpr int VW = sizeof(DIGA_WINO4_OUT_VEC) / 4;
-            hipLaunchKernelGGL(wino4_output_kernel<DIGA_WINO4_OUT_VEC>, dim3((unsigned)ceil_div(g.T * (Cout / VW), 256)), dim3(256), 0, st, Mb, tab,
-                               bias, out, out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
-        } else {
+        if (tile == 6) launch_output_m<6>(Mb, tab, bias, out, out_ld, g, Cout, st);
+        else if (tile == 4) launch_output_m<4>(Mb, tab, bias, out, out_ld, g, Cout, st);
+        else
             hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(g.T * (Cout / 4), 256)), dim3(256), 0, st, Mb, tab, bias, out,
                                out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
-        }
     } else {
         WinoEpi ep;
         ep.add = epi->addend; ep.add_ld = epi->addend_ld;
@@ -928,14 +935,11 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
         ep.relu_ab = epi->relu_ab; ep.mean = epi->mean; ep.invstd = epi->invstd; ep.partials = epi->partials;
         const int64_t G = ceil_div(N * H * W, 128);
         const int tpb = (int)ceil_div(g.T, G);
-        if (tile == 4) {
-            constexpr int VW = sizeof(DIGA_WINO4_EPI_VEC) / 4;
-            hipLaunchKernelGGL(wino4_output_epi_kernel<DIGA_WINO4_EPI_VEC>, dim3((unsigned)G, (unsigned)ceil_div(Cout, 64 * VW)), dim3(256), 0, st,
-                               Mb, tab, out, out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
-        } else {
+        if (tile == 6) launch_output_epi_m<6>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+        else if (tile == 4) launch_output_epi_m<4>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+        else
             hipLaunchKernelGGL(wino_output_epi_kernel, dim3((unsigned)G, (unsigned)ceil_div(Cout, 256)), dim3(256), 0, st, Mb, tab, out,
                                out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
-        }
     }
     return launch_status("diga_conv2d_winograd_f32");
 }
@@ -958,7 +962,7 @@ extern "C" int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, 
 }
 
 extern "C" size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation, int64_t tile) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || dilation <= 0 || (tile != 2 && tile != 4)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || dilation <= 0 || !tile_ok(tile)) return 0;
     return (size_t)products(tile) * make_wino(N, H, W, dilation, tile).Tp * Cin;
 }
 
@@ -992,7 +996,7 @@ extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, f
 
 extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                                              int64_t dilation, int64_t tile, int v_kept) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || Cout % 256 != 0 || Cin % 128 != 0 || (tile != 2 && tile != 4)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dilation <= 0 || Cout % 256 != 0 || Cin % 128 != 0 || !tile_ok(tile)) return 0;
     return wino_wgrad_layout(make_wino(N, H, W, dilation, tile), Cin, Cout, v_kept == 0).total;
 }
 
@@ -1001,7 +1005,7 @@ static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_a
                                int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream) {
     DIGA_REQUIRE(dy && (x || v_kept) && dw && workspace, DIGA_EINVAL, "conv2d_wgrad_winograd: null pointer");
     DIGA_REQUIRE(!v_kept || aligned16(v_kept), DIGA_EALIGN, "conv2d_wgrad_winograd: v_kept must be 16-byte aligned");
-    DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && N * H * W < (1ll << 31) && (tile == 2 || tile == 4),
+    DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && N * H * W < (1ll << 31) && tile_ok(tile),
                  DIGA_EINVAL, "conv2d_wgrad_winograd: bad shape / tile");
     DIGA_REQUIRE(Cout % 256 == 0 && Cin % 128 == 0 && x_ld >= Cin && x_ld % 4 == 0 && dy_ld >= Cout && dy_ld % 4 == 0, DIGA_EINVAL,
                  "conv2d_wgrad_winograd: Cout %% 256, Cin %% 128 and leading dimensions %% 4 required");
@@ -1022,18 +1026,17 @@ static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_a
     hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
     if (v_kept == nullptr)
         launch_input(tile, x, x_ld, tab, reinterpret_cast<float*>(ws + l.V), g.Tp, Cin, H, W, dilation, x_ab, st);
-    if (tile == 4) {
-        constexpr int VW = sizeof(DIGA_WINO4_DY_VEC) / 4;
-        hipLaunchKernelGGL(wino4_dy_kernel<DIGA_WINO4_DY_VEC>, dim3((unsigned)ceil_div(g.Tp * (Cout / VW), 256)), dim3(256), 0, st, dy, dy_ld, tab,
-                           Z, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation);
-    } else {
+    if (tile == 6) launch_dy_m<6>(dy, dy_ld, tab, Z, g, Cout, st);
+    else if (tile == 4) launch_dy_m<4>(dy, dy_ld, tab, Z, g, Cout, st);
+    else
         hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)ceil_div(g.Tp * (Cout / 4), 256)), dim3(256), 0, st, dy, dy_ld, tab, Z, g.Tp,
                            (int)Cout, (int)H, (int)W, (int)dilation);
-    }
     int rc = wgrad_batched_f32_dma(Z, V, dU, slab, g.Tp, products(tile), Cout, Cin, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(tile == 4 ? wino4_dw_kernel : wino_dw_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st,
-                       dU, dw, (int)Cout, (int)Cin);
+    if (tile == 6) launch_dw_m<6>(dU, dw, Cout, Cin, st);
+    else if (tile == 4) launch_dw_m<4>(dU, dw, Cout, Cin, st);
+    else
+        hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, dU, dw, (int)Cout, (int)Cin);
     return launch_status("diga_conv2d_wgrad_winograd_f32");
 }
 

@@ -92,7 +92,7 @@ def _log_flops(name, direct, executed):
 # A/B runs set the module attributes.  WINOGRAD_MAX_TILE 2 keeps every layer on F(2x2,3x3).
 WINOGRAD = os.environ.get("DIGA_CONV_WINOGRAD", "1") != "0"
 WINOGRAD_RATIO = float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62"))
-WINOGRAD_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "4"))
+WINOGRAD_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "6"))
 WINOGRAD_KEEP_V = os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
 _KEEP_DECISION = {}
 
@@ -117,15 +117,16 @@ def _room_for(nbytes, device, key):
 def _wino_plan(hi, wi, d):
     """(tile, ratio): the Winograd output-tile edge for a stride-1 3x3 layer with dilation d on an hi x wi map and the share of the
     direct convolution's multiplications it executes.  The d*d sub-images {(a + d i, b + d j)} are cut into m x m tiles of
-    (m + 2)^2 products each: F(2x2,3x3) 16 per 4 outputs, F(4x4,3x3) 36 per 16 outputs; the smaller count wins (97 x 97:
-    d = 1 / 2 / 4 -> 0.27 / 0.27 / 0.33 with 4x4 tiles against 0.45 / 0.45 / 0.48; d = 18 ties at 0.55 and stays on 2x2)."""
+    (m + 2)^2 products each: F(2x2,3x3) 16 per 4 outputs, F(4x4,3x3) 36 per 16, F(6x6,3x3) 64 per 36; the smallest count wins, the
+    smaller tile on a tie (97 x 97 map: dilation 1 / 2 / 4 / 18 -> 0.218 / 0.218 / 0.218 / 0.245 with 6x6 tiles, where 4x4 tiles
+    give 0.266 / 0.266 / 0.266 / 0.551; dilation 12 / 24 -> 0.266 with 4x4 tiles, 0.435 with 6x6; direct = 1)."""
     key = (hi, wi, d, WINOGRAD_MAX_TILE)
     plan = _WINO_CACHE.get(key)
     if plan is None:
         def tiles(length, m):
             return sum((((length - a + d - 1) // d if length > a else 0) + m - 1) // m for a in range(d))
         plan = None
-        for m in (2, 4):
+        for m in (2, 4, 6):
             if m > WINOGRAD_MAX_TILE:
                 continue
             ratio = float((m + 2) ** 2) * tiles(hi, m) * tiles(wi, m) / (9.0 * hi * wi)

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_close, winograd_tile
+from conftest import WINO_TOL, assert_close, winograd_tile
 from oracle import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,21 +39,22 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile_cap", [4, 2], ids=["", "F2x2cap"])
+@pytest.mark.parametrize("tile_cap", [6, 4, 2], ids=["", "F4x4cap", "F2x2cap"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_fwd_bwd(case, tile_cap, monkeypatch):
-    """tile_cap 2 re-runs the layers that take F(4x4,3x3) by default on F(2x2,3x3) / the direct kernels, at the tight bound."""
+    """tile_cap 4 / 2 re-run the layers that take larger Winograd tiles by default on F(4x4,3x3) / F(2x2,3x3) (or the direct kernels)
+    at those paths' own bounds (conftest.WINO_TOL)."""
     from diga_amd.model import conv as dc
     from diga_amd.model.conv import DigaConv2d
     name, n, cin, h, w, cout, k, stride, pad, dil, bias = case
-    f4 = winograd_tile(n, cin, h, w, cout, k, stride, pad, dil) == 4
-    if tile_cap == 2:
-        if not f4:
-            pytest.skip("takes no 4x4 tiles")
-        monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", 2)
-        f4 = False
-    # absolute part of the bound, in units of the tensor's scale: y / dx / dw (F(4x4,3x3): conftest.winograd_tile)
-    a_y, a_dx, a_dw = (3e-5, 3e-5, 5e-5) if f4 else (2e-6, 3e-6, 3e-6)
+    default_tile = winograd_tile(n, cin, h, w, cout, k, stride, pad, dil)
+    if tile_cap < 6:
+        if default_tile <= tile_cap:
+            pytest.skip("the default path is this one already")
+        monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", tile_cap)
+    tile = winograd_tile(n, cin, h, w, cout, k, stride, pad, dil)
+    # absolute part of the bound, in units of the tensor's scale: y / dx / dw
+    a_y, a_dx, a_dw = (WINO_TOL[tile][0], WINO_TOL[tile][0], WINO_TOL[tile][1]) if tile > 2 else (2e-6, 3e-6, 3e-6)
     g = synth.gen(zlib.crc32(name.encode()) % 10000)
     x = torch.randn((n, cin, h, w), generator=g)
     wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
@@ -357,7 +358,7 @@ WINO_CASES = [("d1_ragged", 3, 128, 33, 29, 160, 1), ("d1_wide", 2, 384, 31, 37,
               ("d3_tiny", 2, 128, 5, 7, 128, 3)]
 
 
-@pytest.mark.parametrize("tile", [2, 4], ids=["F2x2", "F4x4"])
+@pytest.mark.parametrize("tile", [2, 4, 6], ids=["F2x2", "F4x4", "F6x6"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
 def test_winograd_f32_vs_float64(case, tile, monkeypatch):
     """Winograd F(2x2,3x3) and F(4x4,3x3) (csrc/winograd.hip: sub-image tiling of the dilated conv, input / weight / output
@@ -405,7 +406,7 @@ def test_winograd_f32_vs_float64(case, tile, monkeypatch):
     assert ("diga_conv2d_wgrad_winograd_f32" in calls) == wide and ("diga_conv2d_winograd_f32_keep" in calls) == wide, calls
     for got, want, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (m.weight.grad, wr.grad, "dw")):
         e = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max())
-        assert e < (1e-5 if tile == 2 else (5e-5 if what == "dw" else 3e-5)), (what, e)
+        assert e < WINO_TOL[tile][1 if what == "dw" else 0], (what, e)
         print(f"winograd tile {tile} {name} {what}: max err / scale = {e:.2e}")
     if wide:                                           # ... and the same gradient when the backward recomputes V
         monkeypatch.setattr(dc, "WINOGRAD_KEEP_V", False)
@@ -419,7 +420,7 @@ def test_winograd_f32_vs_float64(case, tile, monkeypatch):
         assert torch.equal(m.weight.grad, dw_kept)
 
 
-@pytest.mark.parametrize("tile", [2, 4], ids=["F2x2", "F4x4"])
+@pytest.mark.parametrize("tile", [2, 4, 6], ids=["F2x2", "F4x4", "F6x6"])
 def test_persistent_gemm_bit_identical_to_per_tile_launch(tile, monkeypatch):
     """The Winograd products on gemm_f32_persistent_kernel (256 blocks walking the tiles, next tile's stages prefetched under
     the current one, accumulators stored from registers) equal the per-tile launch of conv_fwd_dma_kernel bit for bit.  By shape,

@@ -136,11 +136,12 @@ def test_aspp_dilations_at_97x97_vs_float64(conv_math, case):
     xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
     y = m(xd)
     (y * probe.to(DEV)).sum().backward()
-    # of the output scale; exact fp32: d = 6 / 12 / 24 run F(4x4,3x3) (3e-5, weight gradient 5e-5), d = 18 F(2x2,3x3)
-    from conftest import winograd_tile
-    f4 = conv_math == 0 and winograd_tile(1, cin, 97, 97, 256, 3, 1, d, d) == 4
-    tol = (3e-5 if f4 else 1e-5) if conv_math == 0 else 3e-5
+    # of the output scale; exact fp32: per Winograd tile (d = 6 / 18: 6x6, d = 12 / 24: 4x4 tiles), conftest.WINO_TOL
+    from conftest import WINO_TOL, winograd_tile
+    tile = winograd_tile(1, cin, 97, 97, 256, 3, 1, d, d) if conv_math == 0 else 0
+    f4 = tile > 2
+    tol = WINO_TOL[tile][0] if conv_math == 0 else 3e-5
     for got, want, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (m.weight.grad, wr.grad, "dw"), (m.bias.grad, br.grad, "db")):
         e = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max())
-        assert e < (5e-5 if f4 and what == "dw" else tol), (what, e)
+        assert e < (WINO_TOL[tile][1] if f4 and what == "dw" else tol), (what, e)
         print(f"aspp {case[0]} math={conv_math} {what}: {e:.2e} of scale")

@@ -311,6 +311,11 @@ def test_winograd_gate_and_tile_ratio(monkeypatch):
         assert dc._wino_plan(97, 97, d) == (4, pytest.approx(36 * 25 * 25 / (9 * 97 * 97)))
     assert dc._wino_plan(97, 97, 18) == (2, pytest.approx(16 * 54 * 54 / (9 * 97 * 97)))      # 36 x 36 tiles of 36 products: a tie
     assert dc._wino_plan(65, 129, 4) == (4, pytest.approx(36 * 17 * 33 / (9 * 65 * 129)))
+    monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", 6)
+    for d in (1, 2, 4):
+        assert dc._wino_plan(97, 97, d) == (6, pytest.approx(64 * 17 * 17 / (9 * 97 * 97)))
+    assert dc._wino_plan(97, 97, 18) == (6, pytest.approx(64 * 18 * 18 / (9 * 97 * 97)))       # 6- and 5-wide sub-images: one tile each
+    assert dc._wino_plan(97, 97, 12)[0] == 4 and dc._wino_plan(97, 97, 24)[0] == 4              # 9- / 5-wide sub-images: 4x4 tiles waste less
     monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", 2)
     assert dc._wino_plan(97, 97, 2)[0] == 2
     assert dc._wino_ratio(97, 97, 6) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))
