@@ -402,9 +402,9 @@ def test_fused_gradient_with_a_second_consumer_falls_back(bf16x3):
         assert float((g1[k] - g0[k]).abs().max()) <= 3e-5 * float(g0[k].abs().max()), k
 
 
-# exact fp32, logits against the float64 oracle: measured 1.7e-5 (small backbone) / 2.2e-5 (ResNet-101) of scale with the stride-1
-# 3x3 layers on Winograd F(4x4,3x3) (7e-6 on F(2x2)); bound = 3x
-FWD_TOL_F32 = 7e-5
+# exact fp32, logits against the float64 oracle: measured 1.5e-5 (small backbone) / 2.7e-5 (ResNet-101) of scale with the stride-1
+# 3x3 layers on Winograd F(6x6) / F(4x4) tiles (7e-6 on F(2x2)); bound = 3x
+FWD_TOL_F32 = 8e-5
 
 
 @pytest.mark.parametrize("arch_name,hw", [("TINY", (96, 128)), ("RESNET101", (64, 96))])
@@ -412,7 +412,7 @@ def test_whole_model_gradients_vs_float64_with_pinned_switches(conv_math, arch_n
     """ONE backward pass through the whole network -- stem, max-pool, every strided / dilated stage transition, the
     bottleneck junctions, the ASPP chain (five branches, GroupNorm, SE gate, bottleneck conv) -- against a float64 oracle whose
     ReLU patterns and max-pool choices are pinned to the ones the device produced (oracle.deeplab.forward_fixed_masks): every
-    parameter gradient ELEMENTWISE within 2e-5 (fp32 arithmetic) / 1e-4 (split bf16) of its scale on the small backbone, 4e-5 / 3e-4
+    parameter gradient ELEMENTWISE within 5e-5 (fp32 arithmetic) / 1e-4 (split bf16) of its scale on the small backbone, 1e-4 / 3e-4
     on the full ResNet-101 (all 133 trainable tensors).  Closes the gap the
     captured-gradient checks leave (norms and samples against fixed captures are loose because the network's gradients are
     discontinuous at its switches; here the switches cannot move)."""
@@ -471,8 +471,9 @@ def test_whole_model_gradients_vs_float64_with_pinned_switches(conv_math, arch_n
     assert e_fwd < (FWD_TOL_F32 if conv_math == 0 else 2e-4)
     ((out * probe.to(DEV)).sum() + (feat * probe_f.to(DEV)).sum()).backward()
     named = dict(m.named_parameters())
-    # measured: fp32 2.2e-6 (small backbone) / 1.4e-5 (ResNet-101, 33 blocks deep); split bf16 4.3e-5 / 1.1e-4
-    tol = (4e-5 if conv_math == 0 else 3e-4) if arch_name == "RESNET101" else (2e-5 if conv_math == 0 else 1e-4)
+    # measured: fp32 1.5e-5 (small backbone) / 3.2e-5 (ResNet-101, 33 blocks deep) with 6x6 / 4x4 Winograd tiles (2.2e-6 / 1.4e-5 on
+    # 2x2 tiles); split bf16 4.3e-5 / 1.8e-4.  Bounds = 3x (fp32) / 1.7x (split bf16)
+    tol = (1e-4 if conv_math == 0 else 3e-4) if arch_name == "RESNET101" else (5e-5 if conv_math == 0 else 1e-4)
     worst, worst_k = 0.0, None
     for k in trainable:
         ref = sd64[k].grad

@@ -70,13 +70,14 @@ def test_benchmark_geometry_vs_reference(golden, conv_math, name):
     #   * norms (L1, L2) agree to <= 2e-4 in fp32 and <= 9e-4 in bf16x3 everywhere;
     #   * layers whose gradient does not pass back through a trunk ReLU (bottleneck conv / GN / SE, the branch GroupNorms)
     #     agree elementwise to 1e-5 (fp32) / 2e-4 (bf16x3) of scale;
-    #   * every layer below a ReLU deviates by a uniform 2e-3..6e-3 (fp32) / 1e-2..3e-2 (bf16x3) in relative L2, largest
-    #     elements 2e-2 / 4e-2: the gradients are discontinuous where a pre-activation crosses zero (a
-    #     2e-7 weight perturbation moves them by 4e-3 in L2 on the CPU reference itself), and 1e-6 / 1e-5-level forward
-    #     differences flip a few of the 10^9 ReLUs.  An indexing error moves norms and samples by O(1).
+    #   * every layer below a ReLU deviates by a uniform 2e-3..6e-3 (fp32, F(2x2) Winograd: 7e-6 forward differences) /
+    #     9e-3..1.2e-2 (fp32 with the F(6x6) / F(4x4) tiles of round 4: 2.5e-5..4e-5 forward differences) / 1e-2..3e-2 (bf16x3:
+    #     1.6e-4) in relative L2, largest elements 2e-2 / 4e-2: the gradients are discontinuous where a pre-activation crosses zero
+    #     (a 2e-7 weight perturbation moves them by 4e-3 in L2 on the CPU reference itself), and 1e-6 / 1e-5-level
+    #     forward differences flip a few of the 10^9 ReLUs.  An indexing error moves norms and samples by O(1).
     fp32 = conv_math == 0
     tol_norm = 1e-3 if fp32 else 3e-3
-    tol_l2, tol_max = (1.2e-2, 4e-2) if fp32 else (5e-2, 8e-2)
+    tol_l2, tol_max = (2.5e-2, 6e-2) if fp32 else (5e-2, 8e-2)
     tol_smooth = 1e-4 if fp32 else 1e-3
     smooth = ("final_bottleneck_0_se_0_weight", "final_bottleneck_1_bias", "final_bottleneck_1_weight", "final_bottleneck_2_weight")
     keys = sorted(k[2:-5] for k in g if k.startswith("g_") and k.endswith("__sum"))

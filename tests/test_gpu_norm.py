@@ -203,11 +203,12 @@ def test_aspp_head_golden(golden, conv_math):
     assert_close(res["out"], g.t("out"), 1e-3, 1e-4, "head logits")
     assert_close(res["feat"], g.t("feat"), 1e-3, 1e-4, "head feat")
     ((res["out"] * g.t("probe").to(DEV)).sum() + (res["feat"] * g.t("probe_f").to(DEV)).sum()).backward()
-    if conv_math == 0:
-        close = assert_close
-    else:       # split-bf16: a few ReLU switches of the capture fall on the other side (see assert_mostly_close)
-        def close(a, b, rtol, atol, what):
-            assert_mostly_close(a, b, rtol, atol, 1e-2, 1e-2, what)
+    # against a FIXED capture a few ReLU switches fall on the other side (see assert_mostly_close): exact fp32 with the 3x3 branches on
+    # Winograd F(6x6) / F(4x4) tiles (1e-5-level forward differences) 3 of 122 496 input-gradient elements, split-bf16 more
+    frac, l2 = (1e-4, 1e-3) if conv_math == 0 else (1e-2, 1e-2)
+
+    def close(a, b, rtol, atol, what):
+        assert_mostly_close(a, b, rtol, atol, frac, l2, what)
     close(x.grad, g.t("gx"), 2e-3, 2e-5, "grad x")
     for k, p in head.named_parameters():
         gk = "gw_" + k.replace(".", "_")
