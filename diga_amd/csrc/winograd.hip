@@ -436,6 +436,12 @@ __device__ __forceinline__ float2 f4add(float2 a, float2 b) { return make_float2
 __device__ __forceinline__ float2 f4sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 f4fma(float s, float2 a, float2 b) { return make_float2(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y)); }
 __device__ __forceinline__ float2 f4scale(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
+// ... and on single channels (the 6x6-tile output passes: 8 x 8 products per thread)
+__device__ __forceinline__ float f4add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f4sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float f4fma(float s, float a, float b) { return __builtin_fmaf(s, a, b); }
+__device__ __forceinline__ float f4scale(float s, float a) { return s * a; }
+__device__ __forceinline__ void nt_store4(float* p, float v) { __builtin_nontemporal_store(v, p); }
 using f32x2nt = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ void nt_store4(float* p, float2 v) {
     __builtin_nontemporal_store((f32x2nt){v.x, v.y}, reinterpret_cast<f32x2nt*>(p));
@@ -446,13 +452,16 @@ template <> __device__ __forceinline__ float2 nt_loadv<float2>(const float* p) {
     const f32x2nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x2nt*>(p));
     return make_float2(v.x, v.y);
 }
+template <> __device__ __forceinline__ float nt_loadv<float>(const float* p) { return __builtin_nontemporal_load(p); }
 template <typename V> __device__ __forceinline__ V vzero();
+template <> __device__ __forceinline__ float vzero<float>() { return 0.f; }
 template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <> __device__ __forceinline__ float2 vzero<float2>() { return make_float2(0.f, 0.f); }
 __device__ __forceinline__ float4 relu_fma(float4 v, float4 a, float4 b) {
     return make_float4(fmaxf(__builtin_fmaf(v.x, a.x, b.x), 0.f), fmaxf(__builtin_fmaf(v.y, a.y, b.y), 0.f),
                        fmaxf(__builtin_fmaf(v.z, a.z, b.z), 0.f), fmaxf(__builtin_fmaf(v.w, a.w, b.w), 0.f));
 }
+__device__ __forceinline__ float relu_fma(float v, float a, float b) { return fmaxf(__builtin_fmaf(v, a, b), 0.f); }
 __device__ __forceinline__ float2 relu_fma(float2 v, float2 a, float2 b) {
     return make_float2(fmaxf(__builtin_fmaf(v.x, a.x, b.x), 0.f), fmaxf(__builtin_fmaf(v.y, a.y, b.y), 0.f));
 }
@@ -478,7 +487,13 @@ template <> struct Xf<6> {
 // instead of 215 VGPRs; input / dy: no difference; the 8x8-patch passes of 6x6 tiles hold 64 vectors per thread: pairs throughout)
 template <int M> struct Vec;
 template <> struct Vec<4> { using In = float4; using Out = float2; using Dy = float4; };
-template <> struct Vec<6> { using In = float2; using Out = float2; using Dy = float2; };
+#ifndef DIGA_WINO6_OUT_VEC
+#define DIGA_WINO6_OUT_VEC float
+#endif
+#ifndef DIGA_WINO6_IN_VEC
+#define DIGA_WINO6_IN_VEC float2
+#endif
+template <> struct Vec<6> { using In = DIGA_WINO6_IN_VEC; using Out = DIGA_WINO6_OUT_VEC; using Dy = DIGA_WINO6_IN_VEC; };
 
 // U[k = A i + j][co][c] = (G g G^T)[i][j], A = M + 2
 template <int M>
@@ -698,6 +713,9 @@ __global__ __launch_bounds__(256) void winoM_output_epi_kernel(const float* __re
                     if (xx >= W) continue;
                     wino_epi_pixel<V>(o[j], (int64_t)(e.x * H + yy) * W + xx, k, y, ld, ep, ra, rb, mu, is, sd, sd2);
                 }
+                // (one output row at a time: without the fence the compiler hoists the address arithmetic and loads of all M * M
+                //  pixels -- 250+ VGPRs, one wave per SIMD)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
