@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void centroid_weights_kernel(const float* __re
     const float* f[PX];
 #pragma unroll
     for (int u = 0; u < PX; ++u) f[u] = feat + ((int64_t)n * D) * HW + (p0 + 64 * u < HW ? p0 + 64 * u : 0);
-#pragma unroll 4
+    // 8 channels x PX plane loads in flight per lane: a wave's 64 channels are 8 dependent rounds (4-deep: 16 rounds, and the
+    // kernel is nothing but that latency chain: 68.7 MB of features at C4)
+#pragma unroll 8
     for (int d = d0; d < d1; ++d) {
         float x[PX];
 #pragma unroll
@@ -103,25 +105,32 @@ __global__ __launch_bounds__(256) void centroid_weights_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// Block = 64 x 4 output pixels.  The low-res weights its bilinear taps touch (<= 3 rows x <= 66 columns x K classes for
-// any upsampling factor >= 1) are staged in LDS once -- the 4 x K taps of a pixel were 76 gathers through L1 before.
-// Falls back to direct reads when the footprint does not fit (downsampling geometries).
-constexpr int kConsRows = 6, kConsCols = 68;
+// Block = 64 x 16 output pixels, four rows per thread (rows Y0 + (tid >> 6) + 4 r).  The low-res weights its bilinear taps touch
+// (<= 6 rows x <= 66 columns x K classes for the x8 upsampling of the path) are staged in LDS once -- the 4 x K taps of a pixel were
+// 76 gathers through L1 before -- and a thread's four label loads are issued before the staging barrier: the kernel is two
+// dependent global round trips per block, so fewer, fatter blocks (4096 instead of 16384 at C4) is what shortens it.
+// Falls back to direct reads when the footprint does not fit (small upsampling factors / downsampling geometries).
+constexpr int kConsRows = 6, kConsCols = 68, kConsRPT = 4;
 __global__ __launch_bounds__(256) void argmax_consensus_kernel(const float* __restrict__ wts,
                                                                const long long* __restrict__ pseudo_in,
                                                                long long* __restrict__ pseudo_out,
                                                                long long* __restrict__ feat_pseudo, int K, int h, int w,
                                                                int H, int W, float sy, float sx) {
     extern __shared__ float tile[];        // [K][rows][cols]
-    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 4;
+    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * (4 * kConsRPT);
     const int X = X0 + (threadIdx.x & 63);
-    const int Y = Y0 + (threadIdx.x >> 6);
     const int n = blockIdx.z;
+    long long pin[kConsRPT];
+#pragma unroll
+    for (int r = 0; r < kConsRPT; ++r) {
+        const int Y = Y0 + (threadIdx.x >> 6) + 4 * r;
+        pin[r] = (X < W && Y < H) ? pseudo_in[((int64_t)n * H + Y) * W + X] : 0;
+    }
     // footprint of the block (uniform): taps of the first and last pixel row / column
     int ia, ib, ja, jb;
     float t_;
     bilinear_cell(Y0, sy, h, ia, t_);
-    bilinear_cell(min(Y0 + 3, H - 1), sy, h, ib, t_);
+    bilinear_cell(min(Y0 + 4 * kConsRPT - 1, H - 1), sy, h, ib, t_);
     bilinear_cell(X0, sx, w, ja, t_);
     bilinear_cell(min(X0 + 63, W - 1), sx, w, jb, t_);
     const int rows = min(ib + 1, h - 1) - ia + 1, cols = min(jb + 1, w - 1) - ja + 1;
@@ -135,41 +144,47 @@ __global__ __launch_bounds__(256) void argmax_consensus_kernel(const float* __re
         }
         __syncthreads();
     }
-    if (X >= W || Y >= H) return;
-    int i0, j0;
-    float wy, wx;
-    bilinear_cell(Y, sy, h, i0, wy);
+    if (X >= W) return;
+    int j0;
+    float wx;
     bilinear_cell(X, sx, w, j0, wx);
-    float best = -INFINITY;
-    int arg = 0;
-    if (staged) {
-        const int dj = (w > 1) ? 1 : 0, di = (h > 1) ? cols : 0;
-        const float* t0 = tile + (i0 - ia) * cols + (j0 - ja);
-        const int per = rows * cols;
-        for (int k = 0; k < K; ++k) {
-            const float* p = t0 + k * per;
-            const float v = (1.f - wy) * ((1.f - wx) * p[0] + wx * p[dj]) + wy * ((1.f - wx) * p[di] + wx * p[di + dj]);
-            if (v > best) {  // strict: first maximum wins, as torch.max
-                best = v;
-                arg = k;
+#pragma unroll
+    for (int r = 0; r < kConsRPT; ++r) {
+        const int Y = Y0 + (threadIdx.x >> 6) + 4 * r;
+        if (Y >= H) continue;
+        int i0;
+        float wy;
+        bilinear_cell(Y, sy, h, i0, wy);
+        float best = -INFINITY;
+        int arg = 0;
+        if (staged) {
+            const int dj = (w > 1) ? 1 : 0, di = (h > 1) ? cols : 0;
+            const float* t0 = tile + (i0 - ia) * cols + (j0 - ja);
+            const int per = rows * cols;
+            for (int k = 0; k < K; ++k) {
+                const float* p = t0 + k * per;
+                const float v = (1.f - wy) * ((1.f - wx) * p[0] + wx * p[dj]) + wy * ((1.f - wx) * p[di] + wx * p[di + dj]);
+                if (v > best) {  // strict: first maximum wins, as torch.max
+                    best = v;
+                    arg = k;
+                }
+            }
+        } else {
+            const int dj = (w > 1) ? 1 : 0, di = (h > 1) ? w : 0;
+            const float* base = base_n + (int64_t)i0 * w + j0;
+            for (int k = 0; k < K; ++k) {
+                const float* p = base + (int64_t)k * h * w;
+                const float v = (1.f - wy) * ((1.f - wx) * p[0] + wx * p[dj]) + wy * ((1.f - wx) * p[di] + wx * p[di + dj]);
+                if (v > best) {
+                    best = v;
+                    arg = k;
+                }
             }
         }
-    } else {
-        const int dj = (w > 1) ? 1 : 0, di = (h > 1) ? w : 0;
-        const float* base = base_n + (int64_t)i0 * w + j0;
-        for (int k = 0; k < K; ++k) {
-            const float* p = base + (int64_t)k * h * w;
-            const float v = (1.f - wy) * ((1.f - wx) * p[0] + wx * p[dj]) + wy * ((1.f - wx) * p[di] + wx * p[di + dj]);
-            if (v > best) {
-                best = v;
-                arg = k;
-            }
-        }
+        const int64_t o = ((int64_t)n * H + Y) * W + X;
+        pseudo_out[o] = (pin[r] == (long long)arg) ? pin[r] : (long long)DIGA_IGNORE_LABEL;
+        if (feat_pseudo) feat_pseudo[o] = (long long)arg;
     }
-    const int64_t o = ((int64_t)n * H + Y) * W + X;
-    const long long pin = pseudo_in[o];
-    pseudo_out[o] = (pin == (long long)arg) ? pin : (long long)DIGA_IGNORE_LABEL;
-    if (feat_pseudo) feat_pseudo[o] = (long long)arg;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -228,7 +243,21 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict
     if (d < D) {
         const float* f = feat + ((int64_t)n * D + d) * hw;
         const uint8_t* id = ids + (int64_t)n * hw;
-        for (int64_t p = lane; p < hw; p += 64) bins[wv][id[p]][lane] += f[p];
+        // (8 pixels per round: the loads of a round are issued before its first LDS update -- the loop was one dependent
+        //  load -> read-modify-write chain per pixel, 131 rounds at C4; a lane's additions keep their order)
+        int64_t p = lane;
+        for (; p + 7 * 64 < hw; p += 8 * 64) {
+            float v[8];
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c[u] = id[p + 64 * u];
+                v[u] = f[p + 64 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bins[wv][c[u]][lane] += v[u];
+        }
+        for (; p < hw; p += 64) bins[wv][id[p]][lane] += f[p];
     }
     __syncthreads();
     if (d < D) {
@@ -300,18 +329,39 @@ extern "C" int diga_centroid_softmax_weights(const float* feat, const float* cen
     hipStream_t st = (hipStream_t)stream;
     // D*4 B of features per low-res pixel in, K*4 B of weights out (+ K*4 with distances)
     ProfScope prof(DIGA_PROF_CENTROID_WEIGHTS, st, (double)N * HW * (D * 4.0 + K * 4.0 * (neg_dist ? 2.0 : 1.0)));
+    // pixels per lane: the smallest PX whose blocks all fit on the chip at once (256 CUs x the blocks the LDS footprint allows per CU) --
+    // at C4 (8 x 8385 pixels) PX = 2 gives 528 blocks for 512 slots: a second, almost empty round doubled the kernel's time
+    auto pick_px = [&](int kp) {
+        for (int px = 1; px <= 4; ++px) {
+            const size_t sh = ((size_t)D * kp + (size_t)4 * kp * 64 * px) * sizeof(float);
+            const int64_t per_cu = std::min<int64_t>(8, (160 * 1024) / (int64_t)sh);
+            if (per_cu >= 1 && ceil_div(HW, 64 * px) * N <= 256 * per_cu) return px;
+        }
+        return 4;
+    };
+#define DIGA_CW_LAUNCH(KT_, KP_, PX_)                                                                                        \
+    do {                                                                                                                    \
+        dim3 grid((unsigned)ceil_div(HW, 64 * PX_), (unsigned)N);                                                           \
+        const size_t sh = ((size_t)D * KP_ + (size_t)4 * KT_ * 64 * PX_) * sizeof(float);                                    \
+        DIGA_REQUIRE(sh <= 160 * 1024, DIGA_EINVAL, "centroid_softmax_weights: D too large for LDS");                        \
+        (void)hipFuncSetAttribute((const void*)centroid_weights_kernel<KT_, PX_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((centroid_weights_kernel<KT_, PX_>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist, (int)D,     \
+                           (int)K, HW);                                                                                     \
+    } while (0)
     if (K <= 19 && K > 16) {
-        constexpr int PX = 2;
-        dim3 grid((unsigned)ceil_div(HW, 64 * PX), (unsigned)N);
-        const size_t sh = ((size_t)D * 20 + 4 * 19 * 64 * PX) * sizeof(float);
-        hipLaunchKernelGGL((centroid_weights_kernel<19, PX>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
-                           (int)D, (int)K, HW);
+        switch (pick_px(20)) {
+            case 1: DIGA_CW_LAUNCH(19, 20, 1); break;
+            case 2: DIGA_CW_LAUNCH(19, 20, 2); break;
+            case 3: DIGA_CW_LAUNCH(19, 20, 3); break;
+            default: DIGA_CW_LAUNCH(19, 20, 4); break;
+        }
     } else if (K <= 16) {
-        constexpr int PX = 2;
-        dim3 grid((unsigned)ceil_div(HW, 64 * PX), (unsigned)N);
-        const size_t sh = ((size_t)D * 16 + 4 * 16 * 64 * PX) * sizeof(float);
-        hipLaunchKernelGGL((centroid_weights_kernel<16, PX>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
-                           (int)D, (int)K, HW);
+        switch (pick_px(16)) {
+            case 1: DIGA_CW_LAUNCH(16, 16, 1); break;
+            case 2: DIGA_CW_LAUNCH(16, 16, 2); break;
+            case 3: DIGA_CW_LAUNCH(16, 16, 3); break;
+            default: DIGA_CW_LAUNCH(16, 16, 4); break;
+        }
     } else {
         dim3 grid((unsigned)ceil_div(HW, 64), (unsigned)N);
         const size_t sh = ((size_t)D * 32 + 4 * 32 * 64) * sizeof(float);
@@ -320,6 +370,7 @@ extern "C" int diga_centroid_softmax_weights(const float* feat, const float* cen
         hipLaunchKernelGGL((centroid_weights_kernel<32, 1>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
                            (int)D, (int)K, HW);
     }
+#undef DIGA_CW_LAUNCH
     return launch_status("diga_centroid_softmax_weights");
 }
 
@@ -328,7 +379,7 @@ extern "C" int diga_upsample_argmax_consensus(const float* weights, const int64_
                                               int64_t H, int64_t W, void* stream) {
     DIGA_REQUIRE(weights && pseudo_in && pseudo_out, DIGA_EINVAL, "upsample_argmax_consensus: null pointer");
     DIGA_REQUIRE(N > 0 && K >= 1 && h > 0 && w > 0 && H > 0 && W > 0, DIGA_EINVAL, "upsample_argmax_consensus: bad shape");
-    dim3 grid((unsigned)ceil_div(W, 64), (unsigned)ceil_div(H, 4), (unsigned)N);
+    dim3 grid((unsigned)ceil_div(W, 64), (unsigned)ceil_div(H, 4 * kConsRPT), (unsigned)N);
     // low-res weights in, int64 label map read and written [, second map written]
     ProfScope prof(DIGA_PROF_CONSENSUS, (hipStream_t)stream,
                    (double)N * (h * w * K * 4.0 + (double)H * W * (feat_pseudo ? 24.0 : 16.0)));

@@ -18,21 +18,30 @@ __global__ __launch_bounds__(256) void label_hist256_kernel(const long long* __r
     const int b = blockIdx.y;
     const long long* lab = labels + (int64_t)b * HW;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < HW; base += stride) {
-        const int64_t i = base + threadIdx.x;
-        long long v = -1;
-        if (i < HW) v = lab[i];
-        bool todo = (v >= 0 && v < 256);
-        // wave-aggregated increment: one LDS atomic per distinct value per wave
-        while (true) {
-            const unsigned long long pending = __ballot(todo);
-            if (pending == 0ull) break;
-            const int leader = __ffsll((long long)pending) - 1;
-            const int lv = __shfl((int)v, leader, 64);
-            const bool same = todo && ((int)v == lv);
-            const unsigned long long grp = __ballot(same);
-            if ((threadIdx.x & 63) == leader) atomicAdd(&sh[lv], (uint32_t)__popcll(grp));
-            todo = todo && !same;
+    // eight labels per thread and round, all eight loads in flight before the first is counted (the loop used to be one dependent
+    // load -> ballot chain per label: eight latencies per block for a 37 MB pass)
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < HW; base += 8 * stride) {
+        long long vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = base + u * stride + threadIdx.x;
+            vv[u] = i < HW ? lab[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long v = vv[u];
+            bool todo = (v >= 0 && v < 256);
+            // wave-aggregated increment: one LDS atomic per distinct value per wave
+            while (true) {
+                const unsigned long long pending = __ballot(todo);
+                if (pending == 0ull) break;
+                const int leader = __ffsll((long long)pending) - 1;
+                const int lv = __shfl((int)v, leader, 64);
+                const bool same = todo && ((int)v == lv);
+                const unsigned long long grp = __ballot(same);
+                if ((threadIdx.x & 63) == leader) atomicAdd(&sh[lv], (uint32_t)__popcll(grp));
+                todo = todo && !same;
+            }
         }
     }
     __syncthreads();
