@@ -2430,19 +2430,8 @@ struct GemmArgs {
     int64_t a_ld, out_ld;                            // floats between rows of A / out
     const float* bias;                               // nullable [Cout]
     float* stats;                                    // nullable [ceil(M / 64)][3][Cout]: {sum (y - s), sum (y - s)^2, s = first row} per 64-row chunk
-    // backward-data epilogue (diga_bwd_epilogue_t; EPI instantiation): out = mask(acc + addend), partials[ceil(M / 64)][2][Cout]
-    const float* e_add;
-    const float* e_masky;
-    const unsigned char* e_maskbits;
-    const float* e_x;
-    const float* e_relu_ab;
-    const float* e_mean;
-    const float* e_invstd;
-    float* e_partials;
-    int64_t e_add_ld, e_masky_ld, e_x_ld, e_maskbits_ld;
 };
 
-template <bool EPI = false>
 __global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g) {
     constexpr int A_BYTES = 256 * 128, B_BYTES = 128 * 128, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __align__(16) unsigned char smem_b[];
@@ -2573,69 +2562,6 @@ __global__ __launch_bounds__(768, 3) void gemm_f32_persistent_kernel(GemmArgs g)
             const int col_w = tile_n * 128 + wn * 64 + li;
             float* o = g.out + (int64_t)(row_w + 4 * lh) * g.out_ld + col_w;
             const int rows_left = g.M - (row_w + 4 * lh);                      // row offset r is valid iff r < rows_left
-            if constexpr (EPI) {
-                // the backward-data epilogue of diga_bwd_epilogue_t, element for element as drain_stage<EPI> applies it, on the
-                // accumulator layout: per 32x32 tile 16 rows per lane of one column; the loads of a tile (addend, x, mask) are all
-                // issued before their first use; sum g / sum g * xhat per 64-row chunk = this wave's rows
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = col_w + j * 32;
-                    float ra = 0.f, rb = 0.f, mu = 0.f, is = 0.f;
-                    if (g.e_relu_ab != nullptr) {
-                        ra = g.e_relu_ab[col];
-                        rb = g.e_relu_ab[g.Cout + col];
-                    }
-                    if (g.e_partials != nullptr) {
-                        mu = g.e_mean[col];
-                        is = g.e_invstd[col];
-                    }
-                    float sd = 0.f, sd2 = 0.f;
-#pragma unroll
-                    for (int ih = 0; ih < 4; ++ih) {                        // half an accumulator tile at a time (register budget)
-                        const int i = ih >> 1, e0 = (ih & 1) * 8;
-                        float va[8], vx[8], vy[8];
-                        unsigned vb[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int e = e0 + u;
-                            const int r = i * 32 + (e & 3) + 8 * (e >> 2);
-                            const unsigned row = (unsigned)min(row_w + 4 * lh + r, g.M - 1);      // (32-bit element offsets: host checks)
-                            va[u] = g.e_add != nullptr ? g.e_add[row * (unsigned)g.e_add_ld + (unsigned)col] : 0.f;
-                            vx[u] = g.e_x != nullptr ? g.e_x[row * (unsigned)g.e_x_ld + (unsigned)col] : 0.f;
-                            vy[u] = g.e_masky != nullptr ? g.e_masky[row * (unsigned)g.e_masky_ld + (unsigned)col] : 0.f;
-                            vb[u] = g.e_maskbits != nullptr ? g.e_maskbits[row * (unsigned)g.e_maskbits_ld + (unsigned)(col >> 3)] : 0u;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int e = e0 + u;
-                            const int r = i * 32 + (e & 3) + 8 * (e >> 2);
-                            float v = acc[i][j][e] + va[u];
-                            if (g.e_masky != nullptr) v = vy[u] > 0.f ? v : 0.f;
-                            else if (g.e_maskbits != nullptr) v = ((vb[u] >> (col & 7)) & 1u) ? v : 0.f;
-                            else if (g.e_relu_ab != nullptr) v = __builtin_fmaf(vx[u], ra, rb) > 0.f ? v : 0.f;
-                            if (r < rows_left) {
-                                __builtin_nontemporal_store(v, o + (int64_t)r * g.out_ld + j * 32);
-                                sd += v;
-                                sd2 += v * ((vx[u] - mu) * is);
-                            }
-                            acc[i][j][e] = 0.f;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);                  // (keep the next half's 32 loads from being hoisted up here)
-                    }
-                    if (g.e_partials != nullptr && row_w < g.M) {
-                        sd += __shfl_xor(sd, 32, 64);
-                        sd2 += __shfl_xor(sd2, 32, 64);
-                        if (lh == 0) {
-                            float* sp = g.e_partials + (int64_t)(row_w >> 6) * 2 * g.Cout + col;
-                            sp[0] = sd;
-                            sp[g.Cout] = sd2;
-                        }
-                    }
-                }
-                ks_in_tile = 0;
-                ++it;
-                continue;
-            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float bv = g.bias != nullptr ? g.bias[col_w + j * 32] : 0.f;
@@ -2702,10 +2628,8 @@ int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, in
         g.A = A; g.W = W; g.out = out; g.M = (int)M; g.K = (int)K; g.Cout = (int)Cout;
         g.tiles_m = (int)(M / 256); g.tiles_n = a.tiles_n; g.wb_tiles = a.wb_tiles; g.wb_stride = a.wb_stride;
         g.a_ld = K; g.out_ld = Cout; g.bias = nullptr; g.stats = nullptr;
-        g.e_add = g.e_masky = g.e_x = g.e_relu_ab = g.e_mean = g.e_invstd = nullptr;
-        g.e_maskbits = nullptr; g.e_partials = nullptr; g.e_add_ld = g.e_masky_ld = g.e_x_ld = g.e_maskbits_ld = 0;
-        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(gemm_f32_persistent_kernel<false>, dim3(256), dim3(768), sh, st, g);
+        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(gemm_f32_persistent_kernel, dim3(256), dim3(768), sh, st, g);
         return DIGA_OK;
     }
     (void)hipFuncSetAttribute((const void*)conv_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -2775,12 +2699,9 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
         g.A = in; g.W = wgt; g.out = out; g.M = a.M; g.K = (int)Cin; g.Cout = (int)Cout;
         g.tiles_m = (int)ceil_div(a.M, 256); g.tiles_n = (int)(Cout / 128); g.wb_tiles = 0; g.wb_stride = 0;
         g.a_ld = in_ld; g.out_ld = out_ld; g.bias = bias; g.stats = stats_partial;
-        g.e_add = a.e_add; g.e_masky = a.e_masky; g.e_maskbits = a.e_maskbits; g.e_x = a.e_x; g.e_relu_ab = a.e_relu_ab;
-        g.e_mean = a.e_mean; g.e_invstd = a.e_invstd; g.e_partials = a.e_partials;
-        g.e_add_ld = a.e_add_ld; g.e_masky_ld = a.e_masky_ld; g.e_x_ld = a.e_x_ld; g.e_maskbits_ld = a.e_maskbits_ld;
         const size_t shp = 3 * (256 + 128) * 128;
-        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp);
-        hipLaunchKernelGGL(gemm_f32_persistent_kernel<false>, dim3(256), dim3(768), shp, st, g);
+        (void)hipFuncSetAttribute((const void*)gemm_f32_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp);
+        hipLaunchKernelGGL(gemm_f32_persistent_kernel, dim3(256), dim3(768), shp, st, g);
         return launch_status("diga_conv2d_nhwc_f32");
     }
     if (a.M >= 256 && Cout >= 256 && R * S * Cin >= 256) {
