@@ -11,21 +11,21 @@ exec -- one per GPU, rendezvous on 127.0.0.1, backend "nccl" (= RCCL over xGMI);
 A step is one full DiGA warm-up iteration (EMA teacher update, ClassMix, student forward on 2B images, teacher
 forward on 2B images, fused upsample+CE+distillation, backward, gradient all-reduce, fused SGD) on BASELINE.json
 configs[1]: ResNet-101 DeepLabV2, B=8 source crops of 768x768 per GPU, synthetic inputs already resident in HBM.
-Rank 0 prints ONE JSON line; `value` is source crops/s over all ranks.
+
+Output: rank 0 prints ONE compact line of strict JSON (< 4000 bytes, self-checked by `emit`) as the last thing on stdout --
+the contract's fields (`value` = source crops/s over all ranks), `roofline` of the dominant kernel family (forward
+convolution; `achieved` / `frac` = FLOPs the matrix cores EXECUTE / summed launch time / peak, always <= 1; `frac_algorithmic`
+= the direct-convolution FLOPs of SURVEY section 8d over the same time, > 1 where Winograd executes fewer), `cpu_baseline`
+(the oracle on this box's host cores), `target` (north_star's 40 crops/s next to the exact-fp32 ceiling) and one-line
+summaries `second_precision` / `c4_selftrain` / `c5_segformer`.  Every table -- kernel families of the timed and the
+serialised steps, `roofline_other_kernels`, `bandwidth_kernels`, the full c4 / c5 / c1 / translator legs, `miou_parity` --
+goes to `bench_detail.json` next to this script (and to gpurun_out/bench_detail.json).
 
 Arithmetic (`--precision`): the convolutions run either in exact fp32 on the fp32 matrix cores ("f32", the default and
-the HEADLINE: the reference's own precision) or with fp32 operands split into bf16 hi+lo and three bf16 MFMAs per
-product, fp32 accumulate ("bf16x3": ~1e-5 relative per product; gradients of the twin-only bottlenecks within 1e-5 of
-scale of a float64 oracle, both benchmark geometries within north_star's 1e-3 of the reference's logits --
-tests/test_gpu_fullsize_golden.py).  Everything else is fp32.  BOTH arithmetics are timed with the same --steps /
---warmup, each with its own roofline: the headline fields (`value`, `ms_per_step`, `dtype`, `roofline`) are the chosen
-`--precision`, the other one is the top-level object `second_precision` (same fields, `steps`, `warmup`, `ms_per_step`).
-
-Also in the line: `roofline` (dominant kernel family: forward convolution), `roofline_other_kernels` (every other
-family of the step, from the algorithmic work each library call declares), `bandwidth_kernels` (the API-boundary loss
-kernels and the centroid pseudo-labeler at full size, timed on their own), `other_configs` (self-training step c4,
-small-backbone c1), `miou_parity` (fixed-seed validation mIoU against the capture of the reference, both arithmetics),
-`cpu_baseline` (the oracle on this box's host cores).
+the HEADLINE: the reference's own precision; stride-1 3x3 layers through Winograd F(6x6) / F(4x4) / F(2x2)) or
+with fp32 operands split into bf16 hi+lo and three bf16 MFMAs per product, fp32 accumulate ("bf16x3").  Everything else is
+fp32.  BOTH arithmetics are timed with the same --steps / --warmup, each with its own roofline; the self-training (c4) and
+SegFormer (c5) legs run with the same --steps / --warmup as well.
 """
 import argparse
 import json
@@ -47,7 +47,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak
 SERIAL_STEPS = 2          # steps of the serialised-stream pass that times kernels for the roofline
 FWD_GFLOP_768 = 1232.9           # model forward, one 768x768 image
 FWD_GFLOP_256 = 142.6
-PROFILE_TAGS = ("r03", "r02")    # profiles/<tag>_<precision>_serial_pmc_summary.json feeds roofline.traffic (newest first)
+PROFILE_TAGS = ("r04", "r03", "r02")    # profiles/<tag>_<precision>_serial_pmc_summary.json feeds roofline.traffic (newest first)
 
 CONFIGS = {
     # name: (arch, batch per GPU, H, W, label block, BASELINE.json entry, description)
@@ -483,7 +483,8 @@ def rooflines(config, precision, families, counts, geom):
         if pmc and (B, H, W) == (8, 768, 768) and config == "c2":
             # launch-weighted mean over the family's kernels (the 128-column instantiations carry > 95 % of its time;
             # the same kernels also serve backward-data, whose launches are in the PMC averages)
-            names = ("diga::gemm_f32_persistent_kernel", "diga::conv_fwd_dma_kernel", "diga::conv_fwd_kernel<2") if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t8_kernel<2", "diga::conv_fwd_x3t_kernel<2")
+            names = ("diga::gemm_f32_persistent_kernel", "diga::conv_fwd_dma_kernel", "diga::conv_fwd_kernel<2", "diga::wino::winoM_input_kernel",
+                     "diga::wino::winoM_output_kernel") if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t8_kernel<2", "diga::conv_fwd_x3t_kernel<2")
             ent = [v for k, v in pmc.items() if k.startswith(names)]
             nl = sum(v["launches"] for v in ent)
             traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ent) / nl if nl else None
