@@ -412,7 +412,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
 def target_statement(config, precision, families, B, H, W, n_stu, n_tea):
     """north_star asks for >= 40 crops/s/GPU; in exact fp32 the step is capped by the fp32 matrix pipe: the FLOPs the step's
     convolutions execute (after Winograd) / 157.3 TFLOP/s."""
-    if config != "c2" or precision != "f32":
+    if config != "c2" or precision != "f32" or (B, H, W) != (8, 768, 768):
         return None
     ex = sum(f.get("executed_flops_per_step", 0.0) for t, f in families.items() if t.startswith("conv_"))
     if not ex:
