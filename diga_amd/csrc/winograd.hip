@@ -629,33 +629,28 @@ __global__ __launch_bounds__(256) void winoM_output_kernel(const float* __restri
     }
 }
 
-// one output pixel (VW = 4 or 2 channels) of a backward-data convolution through the epilogue of diga_bwd_epilogue_t (the
-// arithmetic of wino_output_epi_kernel / drain_stage<EPI>, element for element)
+// one output pixel (VW = 4, 2 or 1 channels) of a backward-data convolution through the epilogue of diga_bwd_epilogue_t (the arithmetic
+// of wino_output_epi_kernel / drain_stage<EPI>, element for element), its operands already in registers
 template <typename V>
-__device__ __forceinline__ void wino_epi_pixel(V o, int64_t row, int k, float* __restrict__ y, int64_t ld, const WinoEpi& ep,
-                                               const float* ra, const float* rb, const float* mu, const float* is, float* sd,
-                                               float* sd2) {
+__device__ __forceinline__ void wino_epi_pixel_regs(V o, V add, V xin, V ym, unsigned bits, int64_t row, int k, float* __restrict__ y,
+                                                    int64_t ld, const WinoEpi& ep, const float* ra, const float* rb, const float* mu,
+                                                    const float* is, float* sd, float* sd2) {
     constexpr int VW = sizeof(V) / 4;
-    float v[VW], xv[VW];
+    float v[VW], xv[VW], a4[VW], y4[VW];
     *reinterpret_cast<V*>(v) = o;
-#pragma unroll
-    for (int c = 0; c < VW; ++c) xv[c] = 0.f;
+    *reinterpret_cast<V*>(a4) = add;
+    *reinterpret_cast<V*>(xv) = xin;
+    *reinterpret_cast<V*>(y4) = ym;
     if (ep.add != nullptr) {
-        float a4[VW];
-        *reinterpret_cast<V*>(a4) = *reinterpret_cast<const V*>(ep.add + row * ep.add_ld + k);
 #pragma unroll
         for (int c = 0; c < VW; ++c) v[c] += a4[c];
     }
-    if (ep.x != nullptr) *reinterpret_cast<V*>(xv) = *reinterpret_cast<const V*>(ep.x + row * ep.x_ld + k);
     if (ep.masky != nullptr) {
-        float y4[VW];
-        *reinterpret_cast<V*>(y4) = *reinterpret_cast<const V*>(ep.masky + row * ep.masky_ld + k);
 #pragma unroll
         for (int c = 0; c < VW; ++c) v[c] = y4[c] > 0.f ? v[c] : 0.f;
     } else if (ep.maskbits != nullptr) {
-        const unsigned b = ep.maskbits[row * ep.maskbits_ld + (k >> 3)] >> (k & 7);
 #pragma unroll
-        for (int c = 0; c < VW; ++c) v[c] = ((b >> c) & 1u) ? v[c] : 0.f;
+        for (int c = 0; c < VW; ++c) v[c] = ((bits >> c) & 1u) ? v[c] : 0.f;
     } else if (ep.relu_ab != nullptr) {
 #pragma unroll
         for (int c = 0; c < VW; ++c) v[c] = __builtin_fmaf(xv[c], ra[c], rb[c]) > 0.f ? v[c] : 0.f;
@@ -669,17 +664,17 @@ __device__ __forceinline__ void wino_epi_pixel(V o, int64_t row, int k, float* _
 }
 
 // winoM_output_kernel with the backward-data epilogue: block (g, s) = tiles [g * tpb, (g + 1) * tpb) x channels [64 VW s, 64 VW (s + 1)),
-// 64 channel groups x 4 tile lanes; partial-row layout and summation order of wino_output_epi_kernel (so V = float2 and float4
-// give the same bits).  float2: 130 instead of 256 VGPRs -- two more waves per SIMD for a pass that is all loads.
-template <int M, typename V>
+// 256 / TL channel groups x TL tile lanes; partial-row layout of wino_output_epi_kernel (the finaliser only adds the rows up).
+template <int M, typename V, int TL>
 __global__ __launch_bounds__(256) void winoM_output_epi_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
                                                                float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
                                                                int H, int W, int d, int tpb, WinoEpi ep) {
     constexpr int A = M + 2;
     constexpr int VW = sizeof(V) / 4;
-    __shared__ float red[2][4][64 * VW];
-    const int q = threadIdx.x & 63, tl = threadIdx.x >> 6;
-    const int k = (blockIdx.y * 64 + q) * VW;
+    constexpr int CG = 256 / TL;                 // channel groups per block; TL tile lanes
+    __shared__ float red[2][TL][CG * VW];
+    const int q = threadIdx.x % CG, tl = threadIdx.x / CG;
+    const int k = (blockIdx.y * CG + q) * VW;
     const bool kok = k < K;
     const int64_t t0 = (int64_t)blockIdx.x * tpb;
     int64_t t1 = t0 + tpb;
@@ -697,25 +692,51 @@ __global__ __launch_bounds__(256) void winoM_output_epi_kernel(const float* __re
         *reinterpret_cast<V*>(is) = *reinterpret_cast<const V*>(ep.invstd + k);
     }
     if (kok) {
-        for (int64_t t = t0 + tl; t < t1; t += 4) {
+        for (int64_t t = t0 + tl; t < t1; t += TL) {
             const int4 e = tab[t];
+            // ONE round trip per tile: the A * A product loads and, right behind them, the epilogue operands (addend, x, mask) of the
+            // tile's M * M pixels are all issued before anything is used (the pixel loads used to start only after the transform:
+            // two dependent latencies per tile at one or two waves per SIMD -- 2.3 TB/s)
+            V mt[A][A];
+#pragma unroll
+            for (int j = 0; j < A; ++j)
+#pragma unroll
+                for (int i = 0; i < A; ++i) mt[i][j] = nt_loadv<V>(Mb + t * K + k + (A * i + j) * plane);
+            V va[M][M], vx[M][M], vy[M][M];
+            unsigned vb[M][M];
+            bool ok[M][M];
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    const int yy = e.y + i * d, xx = e.z + j * d;
+                    ok[i][j] = yy < H && xx < W;
+                    const int64_t row = (int64_t)(e.x * H + min(yy, H - 1)) * W + min(xx, W - 1);     // (clamped: loads are unconditional)
+                    va[i][j] = ep.add != nullptr ? *reinterpret_cast<const V*>(ep.add + row * ep.add_ld + k) : vzero<V>();
+                    vx[i][j] = ep.x != nullptr ? *reinterpret_cast<const V*>(ep.x + row * ep.x_ld + k) : vzero<V>();
+                    vy[i][j] = ep.masky != nullptr ? *reinterpret_cast<const V*>(ep.masky + row * ep.masky_ld + k) : vzero<V>();
+                    vb[i][j] = ep.maskbits != nullptr ? (unsigned)ep.maskbits[row * ep.maskbits_ld + (k >> 3)] >> (k & 7) : 0u;
+                }
             V s[M][A];
-            winoM_load_rows<M, V>(Mb + t * K + k, plane, s);
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                V col_in[A], col[M];
+#pragma unroll
+                for (int i = 0; i < A; ++i) col_in[i] = mt[i][j];
+                Xf<M>::at(col_in, col);
+#pragma unroll
+                for (int i = 0; i < M; ++i) s[i][j] = col[i];
+            }
 #pragma unroll
             for (int i = 0; i < M; ++i) {
-                const int yy = e.y + i * d;
-                if (yy >= H) continue;
                 V o[M];
                 Xf<M>::at(s[i], o);
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
-                    const int xx = e.z + j * d;
-                    if (xx >= W) continue;
-                    wino_epi_pixel<V>(o[j], (int64_t)(e.x * H + yy) * W + xx, k, y, ld, ep, ra, rb, mu, is, sd, sd2);
+                    if (!ok[i][j]) continue;
+                    const int64_t row = (int64_t)(e.x * H + e.y + i * d) * W + e.z + j * d;
+                    wino_epi_pixel_regs<V>(o[j], va[i][j], vx[i][j], vy[i][j], vb[i][j], row, k, y, ld, ep, ra, rb, mu, is, sd, sd2);
                 }
-                // (one output row at a time: without the fence the compiler hoists the address arithmetic and loads of all M * M
-                //  pixels -- 250+ VGPRs, one wave per SIMD)
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -726,11 +747,11 @@ __global__ __launch_bounds__(256) void winoM_output_epi_kernel(const float* __re
         red[1][tl][q * VW + c] = sd2[c];
     }
     __syncthreads();
-    const int ch = blockIdx.y * 64 * VW + threadIdx.x;
-    if (threadIdx.x < 64 * VW && ch < K) {
+    const int ch = blockIdx.y * CG * VW + threadIdx.x;
+    if (threadIdx.x < CG * VW && ch < K) {
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
+        for (int l = 0; l < TL; ++l) {
             a0 += red[0][l][threadIdx.x];
             a1 += red[1][l][threadIdx.x];
         }
@@ -847,8 +868,12 @@ static void launch_output_epi_m(const float* Mb, const int4* tab, float* out, in
                                 int tpb, const WinoEpi& ep, hipStream_t st) {
     using VT = typename Vec<M>::Out;
     constexpr int VW = sizeof(VT) / 4;
-    hipLaunchKernelGGL((winoM_output_epi_kernel<M, VT>), dim3((unsigned)G, (unsigned)ceil_div(Cout, 64 * VW)), dim3(256), 0, st, Mb, tab, out,
-                       out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d, tpb, ep);
+#ifndef DIGA_WINO_EPI_TL
+#define DIGA_WINO_EPI_TL 2          /* measured on the C2 step: 11.5 / 10.1 / 9.8 ms per step with 4 / 2 / 1 tile lanes */
+#endif
+    constexpr int TL = DIGA_WINO_EPI_TL;
+    hipLaunchKernelGGL((winoM_output_epi_kernel<M, VT, TL>), dim3((unsigned)G, (unsigned)ceil_div(Cout, (256 / TL) * VW)), dim3(256), 0, st, Mb,
+                       tab, out, out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d, tpb, ep);
 }
 template <int M>
 static void launch_dy_m(const float* dy, int64_t dy_ld, const int4* tab, float* Z, const WinoGeom& g, int64_t Cout, hipStream_t st) {
