@@ -90,6 +90,9 @@ SIGNATURES = {
     "diga_gn_fwd": (INT, [P, I64, P, I64, P, P, P, P, P, I64, I64, I64, I64, INT, F32, P, SZ, P]),
     "diga_gn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, I64, I64, P, SZ, P]),
     "diga_avgpool_nhwc": (INT, [P, I64, P, I64, I64, I64, P, SZ, P]),
+    "diga_colsum_nhwc": (INT, [P, I64, P, I64, I64, P, SZ, P]),
+    "diga_small_linear_fwd": (INT, [P, P, P, P, I64, I64, I64, INT, P]),
+    "diga_small_linear_bwd": (INT, [P, P, P, P, P, P, P, P, I64, I64, I64, INT, P]),
     "diga_channel_affine": (INT, [P, I64, P, I64, P, P, I64, I64, I64, P]),
     "diga_channel_dot": (INT, [P, I64, P, I64, P, I64, I64, I64, P, SZ, P]),
     "diga_maxpool3x3s2_fwd": (INT, [P, P, P, I64, I64, I64, I64, I64, I64, P]),

@@ -450,6 +450,16 @@ __global__ void seg_mean_kernel(const float* __restrict__ partial, ColGeom g, fl
     out[idx] = (float)mean;
 }
 
+// out[seg][c] = sum over the segment's rows (bias gradient of a convolution), same merge in double
+__global__ void seg_sum_kernel(const float* __restrict__ partial, ColGeom g, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.nseg * g.C) return;
+    const int seg = idx / g.C, c = idx - seg * g.C;
+    double n, mean, m2;
+    merge_channel(partial, g, seg, c, n, mean, m2);
+    out[idx] = (float)(mean * n);
+}
+
 // out[seg][c] = sum_rows dy*x from bwd_partial's second plane (mean = 0, invstd = 1)
 __global__ void seg_dot_kernel(const float* __restrict__ partial, ColGeom g, float* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -834,6 +844,62 @@ static int check_norm(const char* who, int64_t C, std::initializer_list<int64_t>
     return DIGA_OK;
 }
 
+// ---- the two tiny dense layers of the SE block (G5/model/seg_model_noaux.py:122-137: Linear(1280, 80) -> ReLU -> Linear(80, 1280) ->
+// Sigmoid on the [N, 1280] pooled vector).  One wave per output element, lanes over the reduction; the backward pass as three
+// small kernels (dz = dy * act'(y) and the bias gradient; dW; dx).  N is the batch (16): nothing here is worth a GEMM library call.
+__device__ __forceinline__ float act_apply(float v, int act) { return act == 1 ? fmaxf(v, 0.f) : act == 2 ? 1.f / (1.f + expf(-v)) : v; }
+
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ y, int N, int K, int O,
+                                                               int act) {
+    const int wave = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (wave >= N * O) return;
+    const int n = wave / O, o = wave - n * O;
+    const float* xr = x + (int64_t)n * K;
+    const float* wr = w + (int64_t)o * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = __builtin_fmaf(xr[k], wr[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) y[(int64_t)n * O + o] = act_apply(acc + (b != nullptr ? b[o] : 0.f), act);
+}
+
+// dz[n][o] = dy[n][o] * act'(y[n][o]); db[o] = sum_n dz[n][o]  (one thread per output column o, N rows in sequence)
+__global__ __launch_bounds__(256) void small_linear_dz_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              float* __restrict__ dz, float* __restrict__ db, int N, int O, int act) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= O) return;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float yv = y[(int64_t)n * O + o], g = dy[(int64_t)n * O + o];
+        const float d = act == 1 ? (yv > 0.f ? g : 0.f) : act == 2 ? g * yv * (1.f - yv) : g;
+        dz[(int64_t)n * O + o] = d;
+        s += d;
+    }
+    if (db != nullptr) db[o] = s;
+}
+
+// dW[o][k] = sum_n dz[n][o] * x[n][k]
+__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                              float* __restrict__ dw, int N, int K, int O) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)O * K) return;
+    const int o = (int)(idx / K), k = (int)(idx - (int64_t)o * K);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = __builtin_fmaf(dz[(int64_t)n * O + o], x[(int64_t)n * K + k], s);
+    dw[idx] = s;
+}
+
+// dx[n][k] = sum_o dz[n][o] * W[o][k]
+__global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int N, int K, int O) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx - (int64_t)n * K);
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s = __builtin_fmaf(dz[(int64_t)n * O + o], w[(int64_t)o * K + k], s);
+    dx[idx] = s;
+}
+
 }  // namespace diga
 
 using namespace diga;
@@ -1063,6 +1129,21 @@ extern "C" int diga_avgpool_nhwc(const float* x, int64_t ld_x, float* out, int64
     return launch_status("diga_avgpool_nhwc");
 }
 
+extern "C" int diga_colsum_nhwc(const float* x, int64_t ld_x, float* out, int64_t M, int64_t C, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    DIGA_REQUIRE(x && out && workspace && M > 0, DIGA_EINVAL, "colsum: bad argument");
+    int rc = check_norm("colsum", C, {ld_x}, {x});
+    if (rc) return rc;
+    DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(M, 1, C), DIGA_EWORKSPACE, "colsum: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * 4.0);
+    const ColGeom g = make_geom(M, 1, C);
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(colstats_partial_kernel, dim3(g.nchunk, 1u), dim3(kNormThreads), 0, st, x, ld_x, g, partial);
+    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, partial, g, out);
+    return launch_status("diga_colsum_nhwc");
+}
+
 extern "C" int diga_channel_affine(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* a, const float* b,
                                    int64_t N, int64_t HW, int64_t C, void* stream) {
     DIGA_REQUIRE(x && y && a && N > 0 && HW > 0, DIGA_EINVAL, "channel_affine: bad argument");
@@ -1092,6 +1173,33 @@ extern "C" int diga_channel_dot(const float* dy, int64_t ld_dy, const float* x, 
                        (const float*)nullptr);
     hipLaunchKernelGGL(seg_dot_kernel, dim3((unsigned)ceil_div(N * C, 256)), dim3(256), 0, st, partial, g, out);
     return launch_status("diga_channel_dot");
+}
+
+
+extern "C" int diga_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t K, int64_t O, int act,
+                                     void* stream) {
+    DIGA_REQUIRE(x && w && y && N > 0 && K > 0 && O > 0 && act >= 0 && act <= 2 && N * O < (1ll << 24), DIGA_EINVAL,
+                 "small_linear_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st, (double)(O * K + N * K + N * O) * 4.0);
+    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((unsigned)ceil_div(N * O * 64, 256)), dim3(256), 0, st, x, w, b, y, (int)N, (int)K,
+                       (int)O, act);
+    return launch_status("diga_small_linear_fwd");
+}
+
+extern "C" int diga_small_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dz, float* dx, float* dw,
+                                     float* db, int64_t N, int64_t K, int64_t O, int act, void* stream) {
+    DIGA_REQUIRE(x && w && y && dy && dz && N > 0 && K > 0 && O > 0 && act >= 0 && act <= 2, DIGA_EINVAL, "small_linear_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_ELEMENTWISE, st, (double)(2 * O * K + 2 * N * K + 3 * N * O) * 4.0);
+    hipLaunchKernelGGL(small_linear_dz_kernel, dim3((unsigned)ceil_div(O, 256)), dim3(256), 0, st, dy, y, dz, db, (int)N, (int)O, act);
+    if (dw != nullptr)
+        hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)ceil_div(O * K, 256)), dim3(256), 0, st, (const float*)dz, x, dw, (int)N,
+                           (int)K, (int)O);
+    if (dx != nullptr)
+        hipLaunchKernelGGL(small_linear_dx_kernel, dim3((unsigned)ceil_div(N * K, 256)), dim3(256), 0, st, (const float*)dz, w, dx, (int)N,
+                           (int)K, (int)O);
+    return launch_status("diga_small_linear_bwd");
 }
 
 extern "C" int diga_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C,

@@ -35,6 +35,21 @@ def _pad_last(t, c_to):
     return out
 
 
+
+def _bias_grad(gy):
+    """Bias gradient of a convolution = column sums of the NHWC output gradient (torch: grad_output.sum((0, 2, 3))), on
+    diga_colsum_nhwc.  gy: [N,H,W,K] (a channel slice of a contiguous NHWC tensor is fine)."""
+    k = gy.shape[-1]
+    ld = gy.stride(2)
+    m = gy.shape[0] * gy.shape[1] * gy.shape[2]
+    if k % 4 != 0 or ld % 4 != 0 or gy.stride(3) != 1 or gy.stride(1) != gy.shape[2] * ld or gy.stride(0) != gy.shape[1] * gy.stride(1):
+        return gy.sum(dim=(0, 1, 2))                          # (odd layouts: the 19-class head has no bias in this model)
+    out = torch.empty(k, dtype=torch.float32, device=gy.device)
+    ws = _lib.workspace(_lib.lib.diga_norm_workspace_bytes(m, 1, k), gy.device, "norm")
+    _lib.call("diga_colsum_nhwc", _lib.ptr(gy), ld, _lib.ptr(out), m, k, _lib.ptr(ws), ws.numel(), _lib.stream())
+    return out
+
+
 def _use_twin(cin, k, taps, shared):
     """The staging-free kernel (both operands pre-split, LDS-DMA) needs one extra pass over the activations to build
     their split twin (read 4 B + write 4 B per element).  That pays when the tensor is read by many tiles: convs with
@@ -336,7 +351,7 @@ class _StemConvFn(torch.autograd.Function):
             dw = torch.empty_strided((k, c, r, s), w_strides, dtype=torch.float32, device=xcol.device)
             dw.copy_(dwp[:k, 0, 0, :kk].reshape(k, r, s, c).permute(0, 3, 1, 2))
         if has_bias and ctx.needs_input_grad[2]:
-            db = gy.sum(dim=(0, 1, 2))
+            db = _bias_grad(gy)
         return None, dw, db, None, None, None, None, None, None
 
 
@@ -609,7 +624,7 @@ class _Conv2dFn(torch.autograd.Function):
                 for tns in (gyp, xn, dwp, dw) + ((dy_twin, x_twin) if use_tw else ()) + ((wino_v,) if wino_v is not None else ()):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
-            db = gy.sum(dim=(0, 1, 2))
+            db = _bias_grad(gy)
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 

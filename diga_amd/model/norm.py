@@ -336,6 +336,42 @@ class _ChannelGateFn(torch.autograd.Function):
         return dx.permute(0, 3, 1, 2), dgate
 
 
+class _SmallLinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) for the SE block's two dense layers ([N, 1280] -> 80 -> 1280) on diga_small_linear_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        _lib.require_gpu(x, weight)
+        xc, wc = x.detach().float().contiguous(), weight.detach().float().contiguous()
+        bc = None if bias is None else bias.detach().float().contiguous()
+        n, k = xc.shape
+        o = wc.shape[0]
+        y = torch.empty((n, o), dtype=torch.float32, device=xc.device)
+        _lib.call("diga_small_linear_fwd", _lib.ptr(xc), _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(y), n, k, o, act, _lib.stream())
+        ctx.save_for_backward(xc, wc, y)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, wc, y = ctx.saved_tensors
+        n, k = xc.shape
+        o = wc.shape[0]
+        g = gy.float().contiguous()
+        dz = torch.empty_like(y)
+        dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(wc) if ctx.needs_input_grad[1] else None
+        db = torch.empty(o, dtype=torch.float32, device=xc.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        _lib.call("diga_small_linear_bwd", _lib.ptr(xc), _lib.ptr(wc), _lib.ptr(y), _lib.ptr(g), _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dw),
+                  _lib.ptr(db), n, k, o, ctx.act, _lib.stream())
+        return dx, dw, db, None
+
+
+def small_linear(x, linear, act):
+    """act(linear(x)) for an nn.Linear `linear` (a parameter container here); act: 0 none, 1 ReLU, 2 sigmoid."""
+    return _SmallLinearFn.apply(x, linear.weight, linear.bias, act)
+
+
 def global_avg_pool(x):
     return _AvgPoolFn.apply(x)
 

@@ -498,6 +498,18 @@ int diga_avgpool_nhwc(const float* x, int64_t ld_x, float* out, int64_t N, int64
                       size_t workspace_bytes, void* stream);
 int diga_channel_affine(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* a, const float* b,
                         int64_t N, int64_t HW, int64_t C, void* stream);
+/* The dense layers of the SE block (G5/model/seg_model_noaux.py:122-137: nn.Linear(1280, 80) -> ReLU -> nn.Linear(80, 1280) -> Sigmoid
+ * on the pooled [N, 1280] vector; torch runs them through a GEMM library):  y[N][O] = act(x[N][K] . W[O][K]^T + b),
+ * act 0 = none, 1 = ReLU, 2 = sigmoid.  Backward from the ACTIVATED output y: dz = dy * act'(y) (workspace dz [N][O], caller-owned),
+ * db[O] = sum_n dz, dW[O][K] = dz^T x, dx[N][K] = dz W (db / dW / dx nullable). */
+int diga_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t N, int64_t K, int64_t O, int act, void* stream);
+int diga_small_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dz, float* dx, float* dw, float* db,
+                          int64_t N, int64_t K, int64_t O, int act, void* stream);
+/* Bias gradient of a convolution with bias (the ASPP branches / bottleneck, G5/model/seg_model_noaux.py:143-170; torch computes
+ * grad_output.sum((0, 2, 3))): out[c] = sum over the M rows of x [M][ld_x] (channels contiguous), shifted sums merged in double.
+ * workspace: diga_norm_workspace_bytes(M, 1, C). */
+int diga_colsum_nhwc(const float* x, int64_t ld_x, float* out, int64_t M, int64_t C, void* workspace, size_t workspace_bytes,
+                     void* stream);
 int diga_channel_dot(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, float* out, int64_t N, int64_t HW,
                      int64_t C, void* workspace, size_t workspace_bytes, void* stream);
 

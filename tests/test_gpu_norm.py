@@ -218,3 +218,29 @@ def test_aspp_head_golden(golden, conv_math):
         else:
             ref = g.t(gk + "__sample")
             close(p.grad.reshape(-1)[::97], ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, gk)
+
+
+@pytest.mark.parametrize("n,k,o,act", [(16, 1280, 80, 1), (16, 80, 1280, 2), (3, 37, 5, 0), (1, 64, 64, 2)])
+def test_small_linear_forward_backward_vs_float64(n, k, o, act):
+    """The SE block's dense layers (diga_small_linear_fwd / _bwd: Linear + none / ReLU / sigmoid) against torch in float64:
+    output, input gradient, weight gradient, bias gradient."""
+    from diga_amd.model import norm as dn
+    g = synth.gen(1000 + n + k + o + act)
+    lin = torch.nn.Linear(k, o)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn((o, k), generator=g) / k ** 0.5)
+        lin.bias.copy_(torch.randn(o, generator=g))
+    x = torch.randn((n, k), generator=g)
+    probe = torch.randn((n, o), generator=g)
+    xr = x.double().requires_grad_()
+    wr, br = lin.weight.detach().double().requires_grad_(), lin.bias.detach().double().requires_grad_()
+    z = xr @ wr.t() + br
+    yr = torch.relu(z) if act == 1 else torch.sigmoid(z) if act == 2 else z
+    (yr * probe.double()).sum().backward()
+    lin = lin.to(DEV)
+    xd = x.to(DEV).requires_grad_()
+    y = dn.small_linear(xd, lin, act)
+    (y * probe.to(DEV)).sum().backward()
+    for got, want, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (lin.weight.grad, wr.grad, "dw"), (lin.bias.grad, br.grad, "db")):
+        e = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max().clamp_min(1e-30))
+        assert e < 2e-6, (what, e)
