@@ -118,8 +118,10 @@ class SEBlock(nn.Module):
     def forward(self, x):
         # (the Sequential is the parameter container with the reference's state-dict keys se.0.* / se.2.*; its Linear -> ReLU -> Linear
         #  -> Sigmoid runs on two launches of diga_small_linear_fwd instead of two GEMM-library calls and two elementwise kernels)
-        gate = dn.small_linear(dn.small_linear(dn.global_avg_pool(x), self.se[0], 1), self.se[2], 2)
-        return dn.channel_gate(x, gate)
+        hidden = dn.small_linear(dn.global_avg_pool(x), self.se[0], 1)
+        for hook in self.se[1]._forward_hooks.values():         # (the ReLU module is fused away: its forward hooks still see its output)
+            hook(self.se[1], (hidden,), hidden)
+        return dn.channel_gate(x, dn.small_linear(hidden, self.se[2], 2))
 
 
 class Classifier_Module2(nn.Module):
