@@ -143,7 +143,8 @@ def cpu_baseline(threads, part):
 
     if part == "768":
         timed(od.TINY, 330, 1, 128, 1)                         # spin the thread pool / oneDNN primitives up
-        return {"threads": threads, "s_per_step_768": timed(od.RESNET101, 320, 1, 768, 1)}
+        t = [timed(od.RESNET101, 320 + i, 1, 768, 1) for i in range(2)]        # two independent steps: the better one counts
+        return {"threads": threads, "s_per_step_768": min(t), "s_per_step_768_all": t}
     return {"threads": threads, "s_per_step_256": timed(od.RESNET101, 300, 2, 256, 2), "s_per_step_c1": timed(od.TINY, 310, 2, 256, 2)}
 
 
@@ -182,8 +183,8 @@ def cpu_baseline_subprocess():
     if ok:
         cores = min(ok, key=ok.get)
         out.update(value=1.0 / ok[cores], cores=cores,
-                   sample=f"oracle warm-up step, ResNet-101, B=1 source crop of 768x768 fp32 (2 student + 2 teacher images), one "
-                          f"step, measured (not scaled): {ok[cores]:.2f} s with {cores} threads"
+                   sample=f"oracle warm-up step, ResNet-101, B=1 source crop of 768x768 fp32 (2 student + 2 teacher images), best of "
+                          f"2 steps, measured (not scaled): {ok[cores]:.2f} s with {cores} threads"
                           + "".join(f"; {v:.2f} s with {k} threads" for k, v in ok.items() if k != cores)
                           + f"; host has {os.cpu_count()} cores")
     else:
