@@ -123,6 +123,8 @@ def _room_for(nbytes, device, key):
     key = (idx, nbytes) + tuple(key)
     ok = _KEEP_DECISION.get(key)
     if ok is None:
+        if len(_KEEP_DECISION) > 4096:          # (keys hold a weight address: a caller that re-materialises its weights every call
+            _KEEP_DECISION.clear()              #  must not grow the table without bound)
         free, total = torch.cuda.mem_get_info(idx)
         cached = torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx)
         ok = _KEEP_DECISION[key] = bool(free + cached - nbytes > 0.4 * total)
