@@ -331,3 +331,15 @@ def test_winograd_gate_and_tile_ratio(monkeypatch):
     assert not ok(16, 97, 97, 64, 256, 3, 3, (1, 1), (-2, -2), (2, 2), 97, 97)         # narrow input
     assert not ok(16, 97, 97, 256, 256, 1, 1, (1, 1), (0, 0), (1, 1), 97, 97)          # pointwise
     assert not ok(64, 385, 385, 256, 256, 3, 3, (1, 1), (-1, -1), (1, 1), 385, 385)    # more tile rows than one launch indexes
+
+
+def test_generated_winograd_transforms_are_current(tmp_path):
+    """diga_amd/csrc/winograd_xforms.h is what tools/gen_winograd_xforms.py generates (the generator checks F(m,3) =
+    A^T[(G g) . (B^T d)] against a direct correlation in exact rational arithmetic before it prints anything)."""
+    pytest.importorskip("sympy")
+    import subprocess
+    import sys
+    out = tmp_path / "xf.h"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_winograd_xforms.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.read_text() == open(os.path.join(ROOT, "diga_amd", "csrc", "winograd_xforms.h")).read()

@@ -2,7 +2,7 @@
 """Generates diga_amd/csrc/winograd_xforms.h: the 1-D transforms of Winograd F(m,3) for m = 4 and m = 6 as straight-line
 device code (exact rational Toom-Cook construction with sympy, coefficients printed as fp32 literals).
 
-    python tools/gen_winograd_xforms.py            # rewrites the header (committed; the build does not need sympy)
+    python tools/gen_winograd_xforms.py [out.h]    # rewrites the header (committed; the build does not need sympy)
 
 For interpolation points p_0 .. p_{n-1} (n = m + 1) and the point at infinity, with f_j = prod_{k != j} (p_j - p_k):
     A^T [m x (m+2)]      A^T[i][j] = p_j^i,  last column e_{m-1}
@@ -144,7 +144,8 @@ def main():
         out.append(emit_matvec(f"wino{m}_a", AT.T, f"r[{m + 2}] = A x[{m}]   (output-gradient transform of the weight gradient)"))
         out.append(emit_matvec(f"wino{m}_gt", G.T, f"r[3] = G^T x[{m + 2}]   (back to the 3 taps of the weight gradient)"))
         out.append("")
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diga_amd", "csrc", "winograd_xforms.h")
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diga_amd",
+                                                              "csrc", "winograd_xforms.h")
     with open(path, "w") as fh:
         fh.write("\n".join(out) + "\n")
     print("wrote", path)
