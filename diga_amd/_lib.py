@@ -76,6 +76,9 @@ SIGNATURES = {
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
     "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
     "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
+    "diga_bn_apply": (INT, [P, I64, P, I64, P, I64, P, I64, I64, INT, P, P]),
+    "diga_conv2d_junction_ok": (INT, [I64, I64, I64]),
+    "diga_conv2d_junction_f32": (INT, [P, I64, P, I64, P, P, I64, P, P, P, I64, P, I64, I64, I64, P]),
     "diga_conv2d_winograd_workspace_bytes": (SZ, [I64] * 7),
     "diga_conv2d_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [INT, INT, P]),
     "diga_conv2d_winograd_f32_epi": (INT, [P, P, P, P, SZ] + [I64] * 9 + [INT, P, INT, P]),

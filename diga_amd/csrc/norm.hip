@@ -919,7 +919,7 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "bn_fwd: relu_bits needs relu and C % 32 == 0");
     DIGA_REQUIRE(!y_twin || (C % 8 == 0 && ld_y == C), DIGA_EINVAL, "bn_fwd: twin output needs C % 8 == 0 and a dense y");
     DIGA_REQUIRE(x && gamma && beta && save_mean && save_invstd && workspace && M > 0, DIGA_EINVAL, "bn_fwd: bad argument");
-    DIGA_REQUIRE(y || (save_ab && !residual && !relu_bits && !y_twin), DIGA_EINVAL, "bn_fwd: y = null (coefficients only) needs save_ab and no residual / bits / twin");
+    DIGA_REQUIRE(y || (save_ab && !y_twin), DIGA_EINVAL, "bn_fwd: y = null (statistics and coefficients only; residual / relu_bits are then the consumer's) needs save_ab");
     DIGA_REQUIRE(training || (running_mean && running_var), DIGA_EINVAL, "bn_fwd: eval mode needs running statistics");
     int rc = check_norm("bn_fwd", C, {ld_x, y ? ld_y : C, residual ? ld_r : C}, {x, y ? (const void*)y : (const void*)x, residual});
     if (rc) return rc;
@@ -954,7 +954,7 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
     DIGA_REQUIRE(x && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0 && chunk_rows > 0,
                  DIGA_EINVAL, "bn_fwd_partials: bad argument");
     // y == nullptr: statistics and coefficients only (save_ab required) -- the consumer applies relu(fma(x, a, b)) on load
-    DIGA_REQUIRE(y || (save_ab && !residual && !relu_bits && !y_twin), DIGA_EINVAL, "bn_fwd_partials: y = null needs save_ab and no residual / bits / twin");
+    DIGA_REQUIRE(y || (save_ab && !y_twin), DIGA_EINVAL, "bn_fwd_partials: y = null (statistics and coefficients only) needs save_ab");
     int rc = check_norm("bn_fwd_partials", C, {ld_x, y ? ld_y : C, residual ? ld_r : C}, {x, y ? (const void*)y : (const void*)x, residual});
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -988,6 +988,19 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
         hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
                            ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
     return launch_status("diga_bn_fwd_partials");
+}
+
+extern "C" int diga_bn_apply(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r, const float* ab,
+                             int64_t M, int64_t C, int relu, unsigned char* relu_bits, void* stream) {
+    DIGA_REQUIRE(x && y && ab && M > 0, DIGA_EINVAL, "bn_apply: bad argument");
+    DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "bn_apply: relu_bits needs relu and C % 32 == 0");
+    int rc = check_norm("bn_apply", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * (8.0 + (residual ? 4.0 : 0.0)));
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab, ab + C,
+                       (int64_t)0, M, M, (int)C, relu, 0, relu_bits);
+    return launch_status("diga_bn_apply");
 }
 
 extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,

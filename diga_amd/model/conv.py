@@ -174,7 +174,7 @@ def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
 
 
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
-                 opts=None, keep_v=None, in_ab=None):
+                 opts=None, keep_v=None, in_ab=None, junction=None):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x.
     epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue.
@@ -242,6 +242,16 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         return None
     direct = 2.0 * n * ho * wo * k * r * s * cin
     name = "conv_bwd_data" if tag == _TAG_BWD_DATA else "conv_fwd"
+    if junction is not None and not junction["filled"]:
+        # x is the not-yet-filled output of a residual junction (norm.py: defer_junction): this GEMM's loader waves compute it from
+        # (y3, skip, coefficients) on the way into LDS, its column-tile-0 blocks store x and the ReLU mask bits (DigaConv2d.forward
+        # made sure the shape is eligible)
+        _log_flops(name, direct, direct)
+        _lib.call("diga_conv2d_junction_f32", _lib.ptr(junction["y3"]), cin, _lib.ptr(junction["skip"]), cin, _lib.ptr(junction["ab"]),
+                  _lib.ptr(x), x.stride(2), _lib.ptr(junction["bits"]), _lib.ptr(w_krsc), _lib.ptr(out), out.stride(2), _lib.ptr(stats),
+                  n * hi * wi, cin, k, _lib.stream())
+        junction["filled"] = True
+        return None
     if (_lib.get_conv_math() == 0 and copt is None and stats is None
             and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):
         d = abs(doff[0])
@@ -372,7 +382,7 @@ def _set_mask(epi, box, xn, cp):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None, x_is_twin=False,
-                dy_is_twin=False, bn_box=None, opts=None, chain=None, lazy_ab=None):
+                dy_is_twin=False, bn_box=None, opts=None, chain=None, lazy_ab=None, junction=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         if x_is_twin:          # the producer wrote the split twin instead of fp32 (same bytes per element): hand it on
@@ -408,7 +418,7 @@ class _Conv2dFn(torch.autograd.Function):
         if lazy_ab is not None and cp != c:
             raise RuntimeError("DigaConv2d: a deferred BatchNorm input needs Cin % 32 == 0")
         x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box,
-                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v, in_ab=lazy_ab)
+                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v, in_ab=lazy_ab, junction=junction)
         ctx.wino_v = keep_v[0] if keep_v is not None else None
         ctx.in_ab = lazy_ab                 # (the saved xn then holds pre-activation values: the weight gradient applies them too)
         ctx.save_for_backward(xn, w)
@@ -627,7 +637,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = _bias_grad(gy)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -681,6 +691,23 @@ class DigaConv2d(nn.Conv2d):
         x_is_twin = bool(getattr(x, "_diga_is_twin", False))
         if x_is_twin and fn is not _Conv2dFn:
             raise RuntimeError("DigaConv2d: twin-only input on the stem path")
+        # the residual junction in front deferred its apply pass to this conv (norm.py: defer_junction): fuse it when this is a stride-1
+        # pointwise layer the persistent GEMM takes (exact fp32, no bias, >= 512 tiles), else run the stand-alone pass now
+        junction = getattr(x, "_diga_lazy_junction", None)
+        if junction is not None and junction["filled"]:
+            junction = None
+        if junction is not None:
+            nj, cj, hj, wj = x.shape
+            ok = (fn is _Conv2dFn and _lib.get_conv_math() == 0 and tuple(self.kernel_size) == (1, 1) and tuple(self.stride) == (1, 1)
+                  and tuple(self.padding) == (0, 0) and self.bias is None and (opts is None or not any(opts)) and not twin_grad
+                  and cj == self.in_channels and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+                  and bool(_lib.lib.diga_conv2d_junction_ok(nj * hj * wj, cj, self.out_channels)))
+            from diga_amd.model import norm as _dn
+            if ok and _dn.JUNCTION_FUSION < 2 and self.out_channels != 128:
+                ok = False                    # (measured slower with more than one column tile: norm.junction_fusion)
+            if not ok:
+                _dn.materialize_junction(junction)
+                junction = None
         lazy_ab = getattr(x, "_diga_lazy_ab", None)       # the BatchNorm in front deferred its apply to this conv's input transform
         if lazy_ab is not None and (fn is not _Conv2dFn or x_is_twin or twin_grad or chain is not None or (opts is not None and any(opts))):
             raise RuntimeError("DigaConv2d: a deferred BatchNorm input (_diga_lazy_ab) reached a call that cannot apply it")
@@ -692,14 +719,14 @@ class DigaConv2d(nn.Conv2d):
                 raise RuntimeError("DigaConv2d: folded padding / upsampling / activation need the implicit-GEMM path without BN statistics")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), None, uses,
                          twin_box, False, False, None, tuple(int(v) for v in opts))
-        elif x_is_twin or twin_grad or bn_box is not None or chain is not None or lazy_ab is not None:
+        elif x_is_twin or twin_grad or bn_box is not None or chain is not None or lazy_ab is not None or junction is not None:
             if fn is not _Conv2dFn or (self.bias is not None and twin_grad):
                 if chain is not None:
                     chain["disabled"] = True
                 else:
                     raise RuntimeError("DigaConv2d: twin gradient needs a bias-free conv on the implicit-GEMM path")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
-                         twin_box, x_is_twin, bool(twin_grad), bn_box, None, chain, lazy_ab) if fn is _Conv2dFn else \
+                         twin_box, x_is_twin, bool(twin_grad), bn_box, None, chain, lazy_ab, junction) if fn is _Conv2dFn else \
                 fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses, twin_box)
         else:
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,

@@ -6,6 +6,8 @@ the following ReLU and the residual add), nn.GroupNorm(32) (fused with ReLU / th
 scale, able to write straight into a channel slice of the ASPP concat buffer), SEBlock pieces and the
 stem max-pool.  Tensors cross module boundaries as NCHW-shaped views of NHWC memory.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -51,6 +53,47 @@ def _ws(rows_per_seg, nseg, c, device):
     return _lib.workspace(_lib.lib.diga_norm_workspace_bytes(rows_per_seg, nseg, c), device, "norm")
 
 
+# --------------------------------------------------------------------------------------------- residual junctions, fused forward
+_JUNCTION_DEPTH = [0]
+
+
+class junction_fusion:
+    """Context of a WHOLE-network forward (SegModel / ResNetMulti.forward): inside it the last BatchNorm of a bottleneck may leave its
+    apply pass -- relu(fma(y3, a, b) + skip), three tensors of the block's size -- to conv1 of the NEXT bottleneck, whose GEMM applies
+    it while staging its operand (diga_conv2d_junction_f32).  Outside the context (a block or a layer called on its own) every module
+    returns finished tensors.  JUNCTION_FUSION (DIGA_FUSE_JUNCTION, read once at import): 0 (DEFAULT) off; 1 consumers with ONE
+    column tile (128 output channels: layer2 -- stand-alone 0.326 vs 0.369 ms for the pair, but 435.6 / 437.0 vs 432.5 / 435.0 ms on
+    the step); 2 every eligible consumer (layer3: 1.056 vs 1.005 ms, layer4: 3.66 vs 3.25 ms -- each of a row tile's 2 / 4 column-tile
+    blocks loads and transforms y3 and skip again and the GEMM stalls on it; step 437.6 vs 432.6 ms).  Bit-identical in every mode
+    (tests/test_gpu_bn_box.py); measured with tools/diag/junction_probe.py and bench.py --lean; DESIGN section 11."""
+
+    def __enter__(self):
+        _JUNCTION_DEPTH[0] += 1
+
+    def __exit__(self, *exc):
+        _JUNCTION_DEPTH[0] -= 1
+        return False
+
+
+JUNCTION_FUSION = int(os.environ.get("DIGA_FUSE_JUNCTION", "0"))
+
+
+def junction_fusion_active():
+    return JUNCTION_FUSION > 0 and _JUNCTION_DEPTH[0] > 0 and _lib.get_conv_math() == 0
+
+
+def materialize_junction(lj):
+    """The stand-alone apply pass of a deferred junction (the consumer could not fuse it): fills lj['out'] and its mask bits."""
+    if lj["filled"]:
+        return
+    y3, out = lj["y3"], lj["out"]
+    c = y3.shape[-1]
+    m = y3.numel() // c
+    _lib.call("diga_bn_apply", _lib.ptr(y3), c, _lib.ptr(out), c, _lib.ptr(lj["skip"]), c, _lib.ptr(lj["ab"]), m, c, 1, _lib.ptr(lj["bits"]),
+              _lib.stream())
+    lj["filled"] = True
+
+
 # --------------------------------------------------------------------------------------------- BatchNorm
 class _BnFn(torch.autograd.Function):
     """Train-mode BatchNorm (+ReLU, +residual).  `box` (a dict, or None) ties this BN to the convolution that consumes its
@@ -61,7 +104,7 @@ class _BnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, relu, momentum, eps,
-                partials=None, twin_out=False, dx_twin=False, box=None, res_box=None, lazy=None):
+                partials=None, twin_out=False, dx_twin=False, box=None, res_box=None, lazy=None, junction=None):
         _lib.require_gpu(x)
         xn = nhwc(x.detach())
         n, h, w, c = xn.shape
@@ -72,11 +115,17 @@ class _BnFn(torch.autograd.Function):
         defer = lazy is not None
         if defer and not (relu and residual is None and not twin_out):
             raise RuntimeError("DigaBatchNorm2d: a deferred apply needs ReLU, no residual and an fp32 output")
+        # junction (a dict, ReLU WITH residual): statistics and coefficients only as well, but the output tensor exists (uninitialised):
+        # conv1 of the next bottleneck fills it -- and the mask bits -- while staging its operand (model/conv.py, `junction`)
+        junc = junction is not None
+        if junc and not (relu and residual is not None and not twin_out and c % 32 == 0):
+            raise RuntimeError("DigaBatchNorm2d: a deferred junction needs ReLU, a residual, an fp32 output and C % 32 == 0")
         y = xn if defer else torch.empty_like(xn)
         save_mean = torch.empty(c, dtype=torch.float32, device=xn.device)
         save_invstd = torch.empty_like(save_mean)
         # ReLU without residual: the backward re-derives the mask from x and the forward coefficients (no y read)
         save_ab = torch.empty(2 * c, dtype=torch.float32, device=xn.device) if (relu and residual is None) else None
+        junc_ab = torch.empty(2 * c, dtype=torch.float32, device=xn.device) if junc else None
         ws = _ws(m, 1, c, xn.device)
         # a BN with residual keeps its ReLU mask as one bit per element for the backward epilogue of the conv that reads
         # y (instead of y itself: 1/32 of the bytes); DIGA_RELU_BITS=0 reads y as before
@@ -85,18 +134,22 @@ class _BnFn(torch.autograd.Function):
             bits = torch.empty((m, c // 8), dtype=torch.uint8, device=xn.device)
         if partials is not None and training:
             # the producing conv already reduced its output tile by tile: finalise + apply only
-            _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, None if defer else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
+            _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, None if (defer or junc) else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
-                      _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0, _lib.ptr(bits),
+                      _lib.ptr(save_invstd), _lib.ptr(junc_ab if junc else save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
+                      None if junc else _lib.ptr(bits),
                       float(momentum), float(eps), _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(),
                       _lib.stream())
         else:
-            _lib.call("diga_bn_fwd", _lib.ptr(xn), c, None if defer else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
+            _lib.call("diga_bn_fwd", _lib.ptr(xn), c, None if (defer or junc) else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
                       _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd),
-                      _lib.ptr(save_ab), m, c, 1 if training else 0, 1 if relu else 0, 1 if twin_out else 0, _lib.ptr(bits),
+                      _lib.ptr(junc_ab if junc else save_ab), m, c, 1 if training else 0, 1 if relu else 0, 1 if twin_out else 0,
+                      None if junc else _lib.ptr(bits),
                       float(momentum), float(eps), _lib.ptr(ws), ws.numel(), _lib.stream())
         if defer:
             lazy["ab"] = save_ab
+        if junc:
+            junction.update(y3=xn, skip=rn, ab=junc_ab, bits=bits, out=y, filled=False)
         ctx.save_for_backward(xn, y if (relu and save_ab is None) else None, weight, save_mean, save_invstd, save_ab)
         ctx.flags = (training, residual is not None)
         ctx.dx_twin = bool(dx_twin and c % 8 == 0)
@@ -137,7 +190,7 @@ class _BnFn(torch.autograd.Function):
             ctx.res_box["dres"] = dres
             dres = None
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
-                None, None, None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class DigaBatchNorm2d(nn.BatchNorm2d):
@@ -145,7 +198,7 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
     G5/model/seg_model_noaux.py:64-76) -- gradients flow to the input only.  forward(x, residual, relu)
     computes relu(bn(x) + residual) in one pass."""
 
-    def forward(self, x, residual=None, relu=False, twin_out=False, dx_twin=False, defer_apply=False):
+    def forward(self, x, residual=None, relu=False, twin_out=False, dx_twin=False, defer_apply=False, defer_junction=False):
         """twin_out (ReLU, no residual, C % 8 == 0): the result is written as the split twin the staging-free conv
         kernels read (same 4 bytes per element, diga_make_twin's format) INSTEAD of fp32; the returned tensor has the
         usual shape and dtype but holds twin bytes (`_diga_is_twin`) -- only a DigaConv2d on the twin path may read it."""
@@ -170,8 +223,18 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
         # and carries the coefficients (`_diga_lazy_ab`) -- only a DigaConv2d on the Winograd path may read it (it applies
         # relu(fma(x, a, b)) in its input transform, diga_conv2d_winograd_f32_ab)
         lazy = {} if (defer_apply and relu and residual is None and not twin_out) else None
+        # defer_junction (ReLU with residual, inside a whole-network forward): the apply pass is left to conv1 of the next bottleneck;
+        # the returned tensor is allocated but NOT YET FILLED and carries `_diga_lazy_junction` -- a DigaConv2d that reads it fills it
+        # (fused, or with the stand-alone pass when it cannot fuse).  Never with forward hooks on this module: they would see garbage.
+        junction = None
+        if (defer_junction and relu and residual is not None and not twin_out and x.shape[1] % 32 == 0 and x.is_cuda
+                and junction_fusion_active() and not self._forward_hooks and not torch.nn.modules.module._global_forward_hooks):
+            junction = {}
         y = _BnFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, training, relu,
-                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin), box, res_box, lazy)
+                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin), box, res_box, lazy,
+                        junction)
+        if junction is not None:
+            y._diga_lazy_junction = junction
         if lazy is not None:
             y._diga_lazy_ab = lazy["ab"]
         if twin_out:

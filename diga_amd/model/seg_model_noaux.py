@@ -66,6 +66,10 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)          # kept for module-tree parity; the ReLUs run inside the BN kernels
         self.downsample = downsample
         self.stride = stride
+        # set by ResNetMulti on every block whose output goes straight into another bottleneck: bn3 may then leave its apply pass
+        # (relu(bn3(y3) + skip)) to that block's conv1 (norm.junction_fusion; never for a block or layer called on its own)
+        self.defer_out = False
+        self.next_conv1 = None                     # (out_channels, stride) of the conv1 that reads this block's output
         for conv in (self.conv1, self.conv2, self.conv3) + ((downsample[0],) if downsample is not None else ()):
             conv.emit_bn_stats = True              # BN statistics come out of the conv epilogue
 
@@ -105,7 +109,10 @@ class Bottleneck(nn.Module):
             skip = self.downsample[1](self.downsample[0](x, chain=chain))
         else:
             skip = self.downsample(x)
-        return self.bn3(self.conv3(y, twin_grad=tw3), residual=skip, relu=True, dx_twin=tw3)
+        # (only where the consumer will fuse under the current policy: norm.JUNCTION_FUSION 1 = single-column-tile consumers)
+        defer = (self.defer_out and not tw3 and not self._forward_hooks and self.next_conv1 is not None
+                 and self.next_conv1[1] == (1, 1) and (dn.JUNCTION_FUSION >= 2 or self.next_conv1[0] == 128))
+        return self.bn3(self.conv3(y, twin_grad=tw3), residual=skip, relu=True, dx_twin=tw3, defer_junction=defer)
 
 
 class SEBlock(nn.Module):
@@ -199,6 +206,10 @@ class ResNetMulti(nn.Module):
             self.bn_pretrain = dn.DigaBatchNorm2d(self.inplanes, affine=True)
             for p in self.bn_pretrain.parameters():
                 p.requires_grad = False
+        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+        for b, nxt in zip(blocks[:-1], blocks[1:]):  # every bottleneck but the last feeds another bottleneck (see Bottleneck.defer_out)
+            b.defer_out = True
+            b.next_conv1 = (nxt.conv1.out_channels, tuple(nxt.conv1.stride))
         for m in self.modules():                     # the reference's global init runs after the head's own
             if isinstance(m, nn.Conv2d):
                 m.weight.data.normal_(0, 0.01)
@@ -222,7 +233,8 @@ class ResNetMulti(nn.Module):
     def forward(self, x):
         if self.training:
             dn.bump_batches_tracked(self)
-        x = self.layer4(self.layer3(self.layer2(self.layer1(self.stem(x)))))
+        with dn.junction_fusion():
+            x = self.layer4(self.layer3(self.layer2(self.layer1(self.stem(x)))))
         if self.bn_clr:
             x = self.bn_pretrain(x)
         return self.layer5(x)
