@@ -39,8 +39,11 @@ def test_benchmark_geometry_vs_reference(golden, conv_math, name):
     assert tuple(out.shape) == tuple(want.shape)
     scale = float(want.abs().max())
     err = float((out.detach().cpu() - want).abs().max())
-    # north_star: logits within 1e-3 relative of the reference's CPU path -- in BOTH arithmetics
+    # north_star: logits within 1e-3 relative of the reference's CPU path -- in BOTH arithmetics ...
     assert err < 1e-3 * scale, (name, err, scale)
+    # ... and within 3x of what the kernels measure (exact fp32 with 6x6 / 4x4 Winograd tiles: 2.5e-5 / 4.3e-5 of scale at 768x768 /
+    # 512x1024; split bf16: 1.6e-4): a regression of the arithmetic shows long before it reaches the contract's bound
+    assert err < (1.5e-4 if conv_math == 0 else 5e-4) * scale, (name, err, scale)
     if conv_math == 0:
         assert_close(out, want, 1e-3, 3e-4 * scale, "train logits (fp32 mode, elementwise)")
     # features / trunk outputs: strided samples and L1 sums of the reference
