@@ -343,3 +343,34 @@ def test_generated_winograd_transforms_are_current(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_winograd_xforms.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert out.read_text() == open(os.path.join(ROOT, "diga_amd", "csrc", "winograd_xforms.h")).read()
+
+
+def test_bench_compact_line_is_small_strict_json_with_the_contract_fields():
+    """bench.py's one stdout line, rebuilt from the committed detail record of a real run: strict JSON, under the 4000-byte self-limit
+    (the round-3 line of 21.9 KB was more than the driver keeps of stdout), the contract's fields, a roofline whose fraction is a
+    utilisation (<= 1) and a CPU baseline."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    detail = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_detail_final.json")))
+    text = json.dumps(bench.compact(detail), allow_nan=False, separators=(",", ":"))
+    assert len(text.encode()) < bench.COMPACT_LIMIT and "\n" not in text
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["vs_baseline"] is None and line["dtype"] == "f32" and line["scaling"] == "weak" and "workload" in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.0 < r["frac"] <= 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+    assert r["frac_algorithmic"] > r["frac"] and r["traffic"] is not None
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert line["value"] == pytest.approx(8 * 1000.0 / line["ms_per_step"], rel=1e-3)          # crops/s = batch / step time
+    assert line["value"] > 100 * c["value"]
