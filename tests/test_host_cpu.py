@@ -62,6 +62,16 @@ def test_abi_argument_errors_without_gpu():
     assert rc == -1
     assert _lib.lib.diga_upsample_loss_workspace_bytes(16, 19, 97, 97) > 16 * 96 * 96 * 78 * 4
     assert _lib.lib.diga_loss_workspace_bytes(8 * 768 * 768) >= (8 * 768 * 768 // 256) * 4
+    # round-4 entry points: the Winograd tile edge is an argument (2 / 4 / 6), sizes follow it; shape rules are queryable
+    ws = {t: _lib.lib.diga_conv2d_winograd_workspace_bytes(16, 97, 97, 256, 256, 2, t) for t in (2, 4, 6)}
+    assert ws[2] > ws[4] > ws[6] > 0 and _lib.lib.diga_conv2d_winograd_workspace_bytes(16, 97, 97, 256, 256, 2, 3) == 0
+    assert _lib.lib.diga_conv2d_winograd_v_floats(16, 97, 97, 256, 2, 6) == 64 * 4864 * 256      # 16 x 17^2 tiles -> 4864 rows, 64 products
+    rc = _lib.lib.diga_conv2d_winograd_f32(1, 1, None, 1, 1, 1 << 30, 1, 8, 8, 128, 128, 128, 128, 1, 5, 0, 0, None)
+    assert rc == -1 and "tile" in _lib.last_error()
+    assert _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 1024, 256) == 1 and _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 1024, 64) == 0
+    assert _lib.lib.diga_conv2d_junction_ok(4 * 97 * 97, 1024, 256) == 0 and _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 4096, 256) == 0
+    assert _lib.lib.diga_small_linear_fwd(None, None, None, None, 1, 1, 1, 0, None) == -1
+    assert _lib.lib.diga_nonfinite_flag_f32(None, 4, None, None) == -1 and _lib.lib.diga_colsum_nhwc(None, 4, None, 4, 4, None, 0, None) == -1
 
 
 def test_no_cpu_fallback():
