@@ -617,6 +617,10 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         return spawn_workers(a)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("DIGA_BENCH_FAULT_AFTER"):
+        # debugging aid for a stuck multi-rank run: every rank dumps its Python stacks to stderr after N seconds and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DIGA_BENCH_FAULT_AFTER"]), exit=True)
     cpu_line = None
     if world_env == 1 and not a.no_cpu_baseline:
         cpu_line = cpu_baseline_subprocess()
