@@ -80,7 +80,10 @@ def parse():
     ap.add_argument("--no-other-precision", action="store_true", help="skip the run of the other arithmetic")
     ap.add_argument("--other-steps", type=int, default=None, help="steps of the other arithmetic (default: --steps)")
     ap.add_argument("--other-warmup", type=int, default=None, help="warm-ups of the other arithmetic (default: --warmup)")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the c4 / c1 legs")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the c4 / c5 / c1 legs")
+    ap.add_argument("--multi-gpu-legs", action="store_true",
+                    help="N > 1: also run the c4 / c5 legs on every rank (default: N > 1 measures the headline configuration and the "
+                         "second arithmetic only -- the scaling curve is about `value`; the legs are 1-GPU results)")
     ap.add_argument("--c4-steps", type=int, default=None, help="steps of the self-training leg (default: --steps)")
     ap.add_argument("--c4-warmup", type=int, default=None, help="warm-ups of the self-training leg (default: --warmup)")
     ap.add_argument("--c5-steps", type=int, default=None, help="steps of the SegFormer leg (default: --steps)")
@@ -657,7 +660,7 @@ def main():
                       "timed_region_s": odt, "roofline": oroof, "roofline_other_kernels": oother,
                       "kernel_families": ofam, "losses_last_step": {k: v for k, v in olosses.items() if not k.startswith("_")}}
     other_cfg = {}
-    if not a.no_other_configs:
+    if not a.no_other_configs and (world == 1 or a.multi_gpu_legs):
         for cfg, (st, wu) in (("c5", (a.c5_steps, max(a.warmup, 2))), ("c4", (a.c4_steps, a.c4_warmup)), ("c1", (5, 2))):
             if cfg == a.config or (cfg == "c1" and world > 1):
                 continue
