@@ -3,7 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N = 1 runs in this process.  N > 1: when the process was not started by torch.distributed.run (no WORLD_SIZE in
+N = 1 runs in this process (headline + second arithmetic + the c4 / c5 / c1 legs + CPU baseline + bandwidth kernels + mIoU parity).
+N > 1 measures the headline configuration and the second arithmetic on every rank (the legs are 1-GPU results: --multi-gpu-legs runs
+them on all ranks too), no CPU-baseline child; rank 0 prints the same compact line.  N > 1: when the process was not started by torch.distributed.run (no WORLD_SIZE in
 the environment) it starts N worker processes itself -- before anything touches the GPU, as children, never by
 exec -- one per GPU, rendezvous on 127.0.0.1, backend "nccl" (= RCCL over xGMI); under
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one of the ranks.
