@@ -59,8 +59,9 @@ CONFIGS = {
            "small-backbone (Bottleneck 1-1-2-1, 16..128 planes) DeepLab warm-up step; the reference cannot build a "
            "ResNet-18 (seg_model_noaux.py:253 raises for BasicBlock)"),
     "c5": ("MIT_B5", 8, 768, 768, 32, "configs[4]",
-           "SegFormer-B5 (MiT-B5 encoder, fp16 storage / fp32 accumulate) distillation student + EMA teacher, DiGA warm-up "
-           "step; ASPP head on the last stage (the build's own wiring: the reference ships the encoder unwired)"),
+           "SegFormer-B5 (MiT-B5 encoder, fp16 storage / fp32 accumulate; SegFormer all-MLP decode head on the four stages, logits "
+           "at 1/4 scale) distillation student + EMA teacher, DiGA warm-up step (the build's own wiring: the reference ships "
+           "encoder and head unwired)"),
     "c4": ("RESNET101", 8, 512, 1024, 32, "configs[3]",
            "self-training step (centroid pseudo-labeler + two ClassMix blocks + centroid EMA), synthetic "
            "Cityscapes-shape, B source + B target crops per GPU"),
@@ -89,6 +90,9 @@ def parse():
     ap.add_argument("--c4-steps", type=int, default=None, help="steps of the self-training leg (default: --steps)")
     ap.add_argument("--c4-warmup", type=int, default=None, help="warm-ups of the self-training leg (default: --warmup)")
     ap.add_argument("--c5-steps", type=int, default=None, help="steps of the SegFormer leg (default: --steps)")
+    ap.add_argument("--c5-head", choices=["segformer", "aspp"], default="segformer",
+                    help="decode head of the SegFormer leg: the SegFormer all-MLP head (default) or the round-3 wiring (the DeepLab ASPP "
+                         "classifier on the last stage only: a much lighter workload)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
                     help="file the full tables go to (kernel families, every roofline, bandwidth kernels, mIoU parity)")
     ap.add_argument("--no-graph", action="store_true", help="run the launch-bound legs (c1, c5) eagerly instead of from a HIP graph")
@@ -278,7 +282,8 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
     torch.manual_seed(0)                       # identical random-init weights on every rank
     if arch_name.startswith("MIT_"):
         from diga_amd.model.segformer import SegFormerStudent
-        student, teacher = SegFormerStudent(arch_name.lower()).to(dev), SegFormerStudent(arch_name.lower()).to(dev)
+        student = SegFormerStudent(arch_name.lower(), head=a.c5_head).to(dev)
+        teacher = SegFormerStudent(arch_name.lower(), head=a.c5_head).to(dev)
     else:
         arch = getattr(sm, arch_name)
         student, teacher = SegModel(arch=arch).to(dev), SegModel(arch=arch).to(dev)
@@ -680,7 +685,7 @@ def main():
                 "dtype": ("fp16 storage / fp32 accumulate (MiT encoder); head convs " + a.precision) if cfg == "c5" else a.precision,
                 "kernel_families": cfam if cfg in ("c5", "c4") else None,
                 "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea},
-                "hip_graph": bool(use_graph),
+                "hip_graph": bool(use_graph), **({"head": a.c5_head} if cfg == "c5" else {}),
                 "roofline_conv_fwd": None if croof is None else {k: croof.get(k) for k in ("achieved", "peak", "unit", "frac", "frac_algorithmic")},
                 "roofline_other_kernels": cother if cfg == "c4" else None,
                 "losses_last_step": {k: v for k, v in closs.items() if not k.startswith("_")}}
@@ -766,7 +771,8 @@ def compact(line):
             return None
         r = d.get("roofline") or d.get("roofline_conv_fwd") or {}
         return {"value": num(d["value"]), "unit": d["unit"], "ms_per_step": num(d["ms_per_step"]), "steps": d["steps"],
-                "warmup": d["warmup"], "dtype": d["dtype"].split(" (")[0], "frac": num(r.get("frac"))}
+                "warmup": d["warmup"], "dtype": d["dtype"].split(" (")[0], "frac": num(r.get("frac")),
+                **({"head": d["head"]} if "head" in d else {})}
 
     oc = line.get("other_configs") or {}
     out = {k: (num(line[k], 6) if isinstance(line[k], float) else line[k]) for k in

@@ -74,6 +74,9 @@ SIGNATURES = {
     "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, INT, P, F32, F32, P, SZ, P]),
     "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, I64, P, SZ, P]),
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
+    "diga_bn_bwd_affine": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, P, SZ, P]),
+    "diga_pyramid_sum_fwd": (INT, [P, I64, I64, P, P, I64, I64, P, I64, I64, P, I64, I64, I64, I64, P]),
+    "diga_pyramid_sum_bwd": (INT, [P, I64, I64, P, I64, I64, I64, I64, P]),
     "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
     "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_bn_apply": (INT, [P, I64, P, I64, P, I64, P, I64, I64, INT, P, P]),

@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ invstd, float* __restrict__ kk,
-                                                               int training) {
+                                                               int training, float* __restrict__ dgamma = nullptr,
+                                                               float* __restrict__ dbeta = nullptr) {
     __shared__ double red[2][kFinLn][kFinCh];
     const int cl = threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
     const int c = blockIdx.x * kFinCh + cl;
@@ -714,6 +715,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __re
     kk[c] = k1;
     kk[g.C + c] = training ? (float)(k1 * (t1 / M)) : 0.f;
     kk[2 * g.C + c] = training ? (float)(k1 * (t2 / M)) : 0.f;
+    // a trainable affine pair (the SegFormer head's BatchNorm): the two column sums ARE its gradients
+    if (dgamma) dgamma[c] = (float)t2;
+    if (dbeta) dbeta[c] = (float)t1;
 }
 
 // one wave per (image, group): lane = (channel j = lane % cpg_pad, chunk lane); requires cpg <= 64
@@ -1003,11 +1007,11 @@ extern "C" int diga_bn_apply(const float* x, int64_t ld_x, float* y, int64_t ld_
     return launch_status("diga_bn_apply");
 }
 
-extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+static int bn_bwd_impl(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
                            const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd,
                            float* dx, int64_t ld_dx,
                            float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, int dx_twin, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+                           size_t workspace_bytes, void* stream, float* dgamma, float* dbeta) {
     DIGA_REQUIRE(!dx_twin || (C % 8 == 0 && ld_dx == C), DIGA_EINVAL, "bn_bwd: twin output needs C % 8 == 0 and a dense dx");
     DIGA_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && workspace && M > 0, DIGA_EINVAL, "bn_bwd: bad argument");
     int rc = check_norm("bn_bwd", C, {ld_dy, ld_x, y ? ld_y : C, ld_dx, dres ? ld_dr : C}, {dy, x, y, dx, dres});
@@ -1025,10 +1029,28 @@ extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, 1), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
                            save_mean, save_invstd, 0, 1, g, partial, relu_ab);
     hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma,
-                       save_invstd, kk, training);
+                       save_invstd, kk, training, dgamma, dbeta);
     hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y, save_mean,
                        save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, dres, ld_dr, M, M, (int)C, relu_ab, dx_twin);
-    return launch_status("diga_bn_bwd");
+    return launch_status(dgamma ? "diga_bn_bwd_affine" : "diga_bn_bwd");
+}
+
+extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+                           const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd,
+                           float* dx, int64_t ld_dx,
+                           float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, int dx_twin, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    return bn_bwd_impl(dy, ld_dy, x, ld_x, y, ld_y, relu_ab, gamma, save_mean, save_invstd, dx, ld_dx, dres, ld_dr, M, C, training,
+                       dx_twin, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int diga_bn_bwd_affine(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+                                  const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd,
+                                  float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int64_t M, int64_t C, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(dgamma && dbeta, DIGA_EINVAL, "bn_bwd_affine: dgamma and dbeta are required");
+    return bn_bwd_impl(dy, ld_dy, x, ld_x, y, ld_y, relu_ab, gamma, save_mean, save_invstd, dx, ld_dx, nullptr, 0, M, C, 1, 0, workspace,
+                       workspace_bytes, stream, dgamma, dbeta);
 }
 
 extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,
@@ -1142,9 +1164,67 @@ extern "C" int diga_avgpool_nhwc(const float* x, int64_t ld_x, float* out, int64
     return launch_status("diga_avgpool_nhwc");
 }
 
+// Column sums of a NARROW matrix (C <= 64, any C: the 19-class prediction conv's bias gradient, [M][19] with M = 16 x 192 x 192 for
+// the SegFormer head -- torch's column reduce of that shape took 2.3 ms): CP = 32 or 64 column lanes x 256 / CP row lanes per block,
+// eight rows in flight per thread, partial sums per block, merged in double by one small block.
+template <int CP>
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int C, int64_t chunk_rows,
+                                                            float* __restrict__ partial) {
+    constexpr int RL = 256 / CP;
+    __shared__ float red[RL][CP];
+    const int tc = threadIdx.x % CP, tr = threadIdx.x / CP;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = r0 + chunk_rows < M ? r0 + chunk_rows : M;
+    float acc = 0.f;
+    if (tc < C) {
+        int64_t r = r0 + tr;
+        for (; r + 7 * RL < r1; r += 8 * RL) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(r + u * RL) * ld + tc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; r < r1; r += RL) acc += x[r * ld + tc];
+    }
+    red[tr][tc] = acc;
+    __syncthreads();
+    if (tr == 0 && tc < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < RL; ++l) s += red[l][tc];
+        partial[(int64_t)blockIdx.x * C + tc] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void colsum_narrow_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += (double)partial[(int64_t)k * C + c];
+    out[c] = (float)s;
+}
+
 extern "C" int diga_colsum_nhwc(const float* x, int64_t ld_x, float* out, int64_t M, int64_t C, void* workspace, size_t workspace_bytes,
                                 void* stream) {
     DIGA_REQUIRE(x && out && workspace && M > 0, DIGA_EINVAL, "colsum: bad argument");
+    if (C > 0 && C <= 64 && (C % 4 != 0 || ld_x % 4 != 0)) {
+        DIGA_REQUIRE(ld_x >= C, DIGA_EINVAL, "colsum: leading dimension %lld invalid", (long long)ld_x);
+        int64_t nblk = ceil_div(M, 256);
+        if (nblk > 512) nblk = 512;
+        const int64_t chunk = ceil_div(M, nblk);
+        nblk = ceil_div(M, chunk);
+        DIGA_REQUIRE(workspace_bytes >= (size_t)nblk * C * sizeof(float), DIGA_EWORKSPACE, "colsum: workspace too small");
+        hipStream_t st = (hipStream_t)stream;
+        ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * 4.0);
+        float* partial = (float*)workspace;
+        if (C <= 32)
+            hipLaunchKernelGGL(colsum_narrow_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, st, x, ld_x, M, (int)C, chunk, partial);
+        else
+            hipLaunchKernelGGL(colsum_narrow_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, st, x, ld_x, M, (int)C, chunk, partial);
+        hipLaunchKernelGGL(colsum_narrow_final_kernel, dim3(1), dim3(64), 0, st, partial, (int)nblk, (int)C, out);
+        return launch_status("diga_colsum_nhwc");
+    }
     int rc = check_norm("colsum", C, {ld_x}, {x});
     if (rc) return rc;
     DIGA_REQUIRE(workspace_bytes >= diga_norm_workspace_bytes(M, 1, C), DIGA_EWORKSPACE, "colsum: workspace too small");

@@ -42,8 +42,9 @@ def _bias_grad(gy):
     k = gy.shape[-1]
     ld = gy.stride(2)
     m = gy.shape[0] * gy.shape[1] * gy.shape[2]
-    if k % 4 != 0 or ld % 4 != 0 or gy.stride(3) != 1 or gy.stride(1) != gy.shape[2] * ld or gy.stride(0) != gy.shape[1] * gy.stride(1):
-        return gy.sum(dim=(0, 1, 2))                          # (odd layouts: the 19-class head has no bias in this model)
+    dense = gy.stride(3) == 1 and gy.stride(1) == gy.shape[2] * ld and gy.stride(0) == gy.shape[1] * gy.stride(1)
+    if not dense or ((k % 4 != 0 or ld % 4 != 0) and k > 64):
+        return gy.sum(dim=(0, 1, 2))                          # (layouts no model of this repository produces)
     out = torch.empty(k, dtype=torch.float32, device=gy.device)
     ws = _lib.workspace(_lib.lib.diga_norm_workspace_bytes(m, 1, k), gy.device, "norm")
     _lib.call("diga_colsum_nhwc", _lib.ptr(gy), ld, _lib.ptr(out), m, k, _lib.ptr(ws), ws.numel(), _lib.stream())
@@ -90,6 +91,7 @@ def takes_twin_only_input(conv, pointwise_ok=False):
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
 
 
+INLINE_WGRAD = "inline"       # `uses` of a functional _Conv2dFn call whose weight is a non-leaf tensor (see backward)
 _WINO_CACHE = {}
 # bench.py sets this to a dict to learn what the convolutions of a step multiply: name -> [FLOPs of the direct
 # convolution (the algorithmic work), FLOPs the matrix cores execute (16/36 of it per 2x2 tile on the Winograd path)]
@@ -620,13 +622,16 @@ class _Conv2dFn(torch.autograd.Function):
             # A weight that entered the graph more than once (the self-training step runs the student twice) gets its
             # contributions summed by autograd on the main stream: only the first one of a backward pass may still be
             # in flight on the side stream when it is handed over, the later ones run in line after a join.
+            # A weight that is NOT a leaf (uses == INLINE_WGRAD: the folded matrices of the SegFormer head, whose gradient the next
+            # autograd node reads at once) is computed in line on the main stream.
             later = False
-            if ctx.uses is not None:
+            inline = isinstance(ctx.uses, str)
+            if ctx.uses is not None and not inline:
                 later = ctx.uses[0] > 0
                 ctx.uses[0] += 1
             if later:
                 _lib.join_side()
-            side = None if later else _lib.side_stream(w.device)
+            side = None if (later or inline) else _lib.side_stream(w.device)
             if side is None:
                 run()
             else:

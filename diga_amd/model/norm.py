@@ -167,6 +167,18 @@ class _BnFn(torch.autograd.Function):
         m = n * h * w
         g, ld_g = as_rows(gy.permute(0, 2, 3, 1))
         dx = torch.empty_like(xn)
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            # trainable affine pair (DigaTrainableBatchNorm2d): the two column sums of the input gradient are its gradients
+            if not training or has_res or ctx.box is not None:
+                raise RuntimeError("DigaTrainableBatchNorm2d: train mode, no residual")
+            dgamma, dbeta = torch.empty(c, dtype=torch.float32, device=xn.device), torch.empty(c, dtype=torch.float32, device=xn.device)
+            ws = _ws(m, 1, c, xn.device)
+            _lib.call("diga_bn_bwd_affine", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(save_ab), _lib.ptr(weight),
+                      _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dgamma), _lib.ptr(dbeta), m, c, _lib.ptr(ws),
+                      ws.numel(), _lib.stream())
+            return (dx.permute(0, 3, 1, 2), None, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
+                    None, None, None, None, None, None, None, None, None, None, None, None, None)
         pre = ctx.box.pop("premasked", None) if ctx.box is not None else None
         # (same buffer AND untouched since the conv wrote it: autograd sums a second gradient into a NEW tensor while the
         #  box holds a reference to this one; the version check also catches an in-place accumulation)
@@ -190,7 +202,7 @@ class _BnFn(torch.autograd.Function):
             ctx.res_box["dres"] = dres
             dres = None
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
-                None, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
+                dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class DigaBatchNorm2d(nn.BatchNorm2d):
@@ -242,6 +254,21 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
         if box is not None:
             y._diga_bn_box = box
         return y
+
+
+class DigaTrainableBatchNorm2d(DigaBatchNorm2d):
+    """BatchNorm2d (+ReLU) whose affine pair TRAINS: the BatchNorm of the SegFormer head's `linear_fuse` ConvModule
+    (G5/model/networks/segformer_head.py:63-68, norm_cfg=dict(type='BN', requires_grad=True)).  Same forward kernels as the frozen
+    BatchNorm of the DeepLab path; the backward is diga_bn_bwd_affine (the input gradient's two column sums are d gamma, d beta)."""
+
+    def forward(self, x, relu=False):
+        training = self.training or self.running_mean is None
+        if getattr(self, "_nbt_external", False):
+            self._nbt_external = False                # (bump_batches_tracked counted this call)
+        elif self.training and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return _BnFn.apply(x, None, self.weight, self.bias, self.running_mean, self.running_var, training, relu, self.momentum, self.eps,
+                           getattr(x, "_diga_bn_partials", None), False, False, None, None, None, None)
 
 
 def bump_batches_tracked(model):

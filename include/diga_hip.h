@@ -492,6 +492,14 @@ int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, co
                 int64_t ld_dx, float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, int dx_twin, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* diga_bn_bwd (train mode) for a BatchNorm whose affine pair TRAINS -- the `linear_fuse` ConvModule of the SegFormer decode head,
+ * G5/model/networks/segformer_head.py:63-68 (norm_cfg BN, requires_grad=True): additionally dgamma[c] = sum g*xhat and
+ * dbeta[c] = sum g (the two column sums the input gradient needs anyway: no extra pass). */
+int diga_bn_bwd_affine(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+                       const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
+                       int64_t ld_dx, float* dgamma, float* dbeta, int64_t M, int64_t C, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* diga_bn_bwd for a gradient that arrives already masked and reduced: `g` and `partial` ([ceil(M/chunk_rows)][2][C]:
  * sum g, sum g*xhat per chunk) come out of the epilogue of the backward-data convolution that produced g
  * (diga_conv2d_nhwc_*_epi, chunk_rows = 128): one finalise launch + the apply pass (read g, x; write dx).
@@ -525,11 +533,24 @@ int diga_small_linear_bwd(const float* x, const float* w, const float* y, const 
                           int64_t N, int64_t K, int64_t O, int act, void* stream);
 /* Bias gradient of a convolution with bias (the ASPP branches / bottleneck, G5/model/seg_model_noaux.py:143-170; torch computes
  * grad_output.sum((0, 2, 3))): out[c] = sum over the M rows of x [M][ld_x] (channels contiguous), shifted sums merged in double.
+ * C % 4 == 0 and ld_x % 4 == 0, or any C <= 64 (the 19-class prediction conv of the SegFormer head, segformer_head.py:70).
  * workspace: diga_norm_workspace_bytes(M, 1, C). */
 int diga_colsum_nhwc(const float* x, int64_t ld_x, float* out, int64_t M, int64_t C, void* workspace, size_t workspace_bytes,
                      void* stream);
 int diga_channel_dot(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, float* out, int64_t N, int64_t HW,
                      int64_t C, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Multi-scale fusion of the SegFormer decode head (G5/model/networks/segformer_head.py:145-159: every embedded stage output is
+ * resized to the 1/4-scale grid with F.interpolate(mode='bilinear', align_corners=False), :472-488, concatenated and reduced by the
+ * 1x1 `linear_fuse` conv; resize and 1x1 conv commute, so the host applies the fuse weights at each map's own resolution and only the
+ * SUM is formed at the fine scale): dst [N][H][W][C] (fp32, channels contiguous, C % 4 == 0, holds the finest map on entry)
+ * += bias[c] (nullable) + sum_k resize(s_k [N][h_k][w_k][C]) for the non-null sources -- torch's half-pixel source index and tap order.
+ * _bwd: the adjoint for ONE source, ds [N][h][w][C] = resize^T(dout) (the gradient wrt the finest map is dout itself); a gather
+ * over each coarse pixel's footprint with the forward's weights, deterministic. */
+int diga_pyramid_sum_fwd(float* dst, int64_t H, int64_t W, const float* bias, const float* s0, int64_t h0, int64_t w0,
+                         const float* s1, int64_t h1, int64_t w1, const float* s2, int64_t h2, int64_t w2, int64_t N, int64_t C,
+                         void* stream);
+int diga_pyramid_sum_bwd(const float* dout, int64_t H, int64_t W, float* ds, int64_t h, int64_t w, int64_t N, int64_t C, void* stream);
 
 /* 3x3 stride-2 pad-1 max-pool with ceil_mode (Ho = ceil((H-1)/2)+1 clipped so the last window starts inside);
  * idx [N,Ho,Wo,C] uint8 = winning tap (first maximum); backward gathers, no atomics. */

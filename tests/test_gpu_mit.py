@@ -407,7 +407,7 @@ def test_segformer_student_warmup_step_vs_oracle_composition():
             sd_h[k] = detweights.fill("seg." + k, shp, kind)
 
         def make():
-            m = SegFormerStudent("mit_b1")
+            m = SegFormerStudent("mit_b1", head="aspp")
             m.backbone.load_state_dict(sd_b)
             m.final.load_state_dict({k[len("final."):]: v for k, v in sd_h.items()})
             m.final.head[0].p = 0.0

@@ -176,7 +176,7 @@ def test_tiny_model_16_class_step_vs_oracle():
         assert_close(student.state_dict()[k], otr.s[k], 2e-3, 2e-5, k)
 
 
-@pytest.mark.parametrize("which", ["tiny_deeplab", "mit_b1"])
+@pytest.mark.parametrize("which", ["tiny_deeplab", "mit_b1", "segformer_b1"])
 def test_graph_captured_step_equals_eager_step(which, conv_math):
     """DigaTrainer(graph=True): the static part of the warm-up step replayed from a HIP graph (torch.cuda.CUDAGraph capture of
     the library's launches) must reproduce the eager step bit for bit -- losses of every step and the parameters after five
@@ -184,16 +184,20 @@ def test_graph_captured_step_equals_eager_step(which, conv_math):
     from diga_amd.train_step import DigaTrainer
 
     def make():
-        if which == "mit_b1":
+        if which in ("mit_b1", "segformer_b1"):
             from diga_amd.model.segformer import SegFormerStudent
             from oracle import mit as om
-            m = SegFormerStudent("mit_b1")
+            m = SegFormerStudent("mit_b1", head="aspp" if which == "mit_b1" else "segformer")
             m.backbone.load_state_dict(om.state_dict(om.MIT_B1))
             m.backbone.reset_drop_path(0.0)
-            torch.manual_seed(5)
-            for p in m.final.parameters():
-                torch.nn.init.normal_(p, std=0.05)
-            m.final.head[0].p = 0.0
+            if which == "mit_b1":
+                torch.manual_seed(5)
+                for p in m.final.parameters():
+                    torch.nn.init.normal_(p, std=0.05)
+            else:                                  # the SegFormer all-MLP head (its BatchNorm affine pair trains)
+                from oracle import segformer_head as oh
+                m.final.load_state_dict(oh.state_dict())
+            m.set_head_dropout(0.0)
             return m.to(DEV)
         m = _model("TINY")
         m.final.head[0].p = 0.0

@@ -244,3 +244,16 @@ def test_small_linear_forward_backward_vs_float64(n, k, o, act):
     for got, want, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (lin.weight.grad, wr.grad, "dw"), (lin.bias.grad, br.grad, "db")):
         e = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max().clamp_min(1e-30))
         assert e < 2e-6, (what, e)
+
+
+@pytest.mark.parametrize("m,c,ld", [(16 * 192 * 192, 19, 19), (1000, 19, 19), (77, 7, 24), (5000, 64, 64), (300000, 33, 40), (2049, 256, 256)])
+def test_bias_gradient_column_sums(m, c, ld):
+    """conv._bias_grad -> diga_colsum_nhwc: the float4 path (C % 4 == 0) and the narrow path (any C <= 64: the 19-class prediction
+    conv of the SegFormer head; a channel slice with ld > C) against float64 column sums."""
+    from diga_amd.model.conv import _bias_grad
+    buf = torch.randn((m, ld), generator=synth.gen(m % 1000 + c)).to(DEV)
+    gy = buf.view(1, 1, m, ld)[..., :c]
+    got = _bias_grad(gy)
+    want = buf[:, :c].double().sum(0)
+    scale = float(buf[:, :c].double().abs().sum(0).max())
+    assert float((got.double() - want).abs().max()) < 2e-6 * scale

@@ -599,6 +599,81 @@ def gen_mit768bwd():
 
 
 # ------------------------------------------------------------------ G-step (warm-up, 3 steps)
+# ------------------------------------------------------------------ G-segformer-head (decode head of BASELINE configs[4])
+def _import_reference_segformer_head():
+    """The reference's model/networks/segformer_head.py imports mmcv (absent).  `normal_init` is initialisation (unused: the
+    capture loads deterministic weights); `DepthwiseSeparableConvModule` belongs to DAFormerHead (not captured).  `ConvModule` IS
+    arithmetic: SegFormerHead builds `linear_fuse` from it (:63-68).  The stand-in is mmcv 1.x's documented behaviour for that
+    call -- Conv2d without bias (bias='auto' with a norm layer), BatchNorm2d, ReLU, children named `conv`, `bn`, `activate` -- so
+    that block of the capture is pinned to mmcv's documentation, not its code (oracle/segformer_head.py header says so).  Every other
+    module and tensor op that runs (MLP, the resizes, the concatenation order, Dropout2d, linear_pred) is the reference's."""
+    import importlib.util
+
+    class _ConvModule(torch.nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size, norm_cfg=None, **kw):
+            super().__init__()
+            assert norm_cfg is not None and norm_cfg["type"] == "BN" and not kw
+            self.conv = torch.nn.Conv2d(in_channels, out_channels, kernel_size, bias=False)
+            self.bn = torch.nn.BatchNorm2d(out_channels)
+            self.activate = torch.nn.ReLU(inplace=True)
+
+        def forward(self, x):
+            return self.activate(self.bn(self.conv(x)))
+
+    mm = types.ModuleType("mmcv")
+    cnn = types.ModuleType("mmcv.cnn")
+    cnn.ConvModule, cnn.normal_init, cnn.DepthwiseSeparableConvModule = _ConvModule, (lambda *a, **k: None), None
+    mm.cnn = cnn
+    sys.modules.update({"mmcv": mm, "mmcv.cnn": cnn})
+    spec = importlib.util.spec_from_file_location("ref_segformer_head", os.path.join(REF, "model", "networks", "segformer_head.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def gen_segformer_head():
+    from oracle import segformer_head as oh
+    ref = _import_reference_segformer_head()
+    chans = [64, 128, 320, 512]
+    head = ref.SegFormerHead(in_channels=chans, channels=128, feature_strides=[4, 8, 16, 32], num_classes=19, in_index=[0, 1, 2, 3],
+                             dropout_ratio=0.1, align_corners=False)
+    sd = oh.state_dict(chans, 19)
+    assert list(head.state_dict().keys()) == list(sd.keys()), (list(head.state_dict().keys()), list(sd.keys()))
+    head.load_state_dict(sd)
+    head.train()
+    head.dropout.p = 0.0                                        # Dropout2d off: its draws are not part of the pin
+    g = synth.gen(91)
+    # stage maps of a 2 x (3, 128, 96) image: 32x24, 16x12, 8x6, 4x3
+    feats = [(torch.randn((2, c, 128 // s, 96 // s), generator=g)).requires_grad_() for c, s in zip(chans, (4, 8, 16, 32))]
+    logits, c_raw = head(feats)
+    probe = torch.randn(logits.shape, generator=g)
+    (logits * probe).sum().backward()
+    named = dict(head.named_parameters())
+    res = {"keys": np.array(list(sd.keys())), "probe": probe, "logits": logits, "c_raw_sum": np.array(synth.checksum(c_raw)),
+           "c_raw_sample": c_raw.detach().reshape(-1)[::397].clone(),
+           "running_mean": head.linear_fuse.bn.running_mean, "running_var": head.linear_fuse.bn.running_var,
+           "nbt": head.linear_fuse.bn.num_batches_tracked}
+    for i, f in enumerate(feats):
+        res[f"c{i + 1}"] = f
+        res[f"dc{i + 1}"] = f.grad
+    for k, p in named.items():
+        gr = p.grad
+        res["gnorm_" + k.replace(".", "_")] = np.array(float(gr.norm()))
+        step = max(1, gr.numel() // 4096)
+        res["g_" + k.replace(".", "_")] = gr.reshape(-1)[::step].clone()
+        res["gstep_" + k.replace(".", "_")] = np.array(step)
+    # eval mode (running statistics as loaded + one update), forward only, a second geometry with odd sizes (100 x 76 image)
+    head.eval()
+    g2 = synth.gen(92)
+    feats2 = [torch.randn((1, c, h, w), generator=g2) for c, (h, w) in zip(chans, ((25, 19), (13, 10), (7, 5), (4, 3)))]
+    with torch.no_grad():
+        lo2, _ = head(feats2)
+    for i, f in enumerate(feats2):
+        res[f"e{i + 1}"] = f
+    res["logits_eval"] = lo2
+    save("segformer_head", **res)
+
+
 def gen_step():
     import torch.optim as optim
     B, H, W = 2, 128, 128
@@ -868,7 +943,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(mit=gen_mit, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
