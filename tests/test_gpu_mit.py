@@ -384,33 +384,38 @@ def test_drop_path_training_mode_statistics():
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
 
 
-def test_segformer_student_warmup_step_vs_oracle_composition():
-    """The build's own wiring (diga_amd/model/segformer.py): MiT encoder + the reference's ASPP head inside the DiGA warm-up
-    step (DigaTrainer unchanged), against the same composition of the oracles on the CPU: oracle/mit.py encoder -> oracle
-    ASPP head -> oracle loss block; losses and the post-step head weights."""
+@pytest.mark.parametrize("head", ["aspp", "segformer"])
+def test_segformer_student_warmup_step_vs_oracle_composition(head):
+    """The build's own wiring (diga_amd/model/segformer.py): MiT encoder + a decode head inside the DiGA warm-up step (DigaTrainer
+    unchanged), against the same composition of the oracles on the CPU: oracle/mit.py encoder -> oracle head (the reference's ASPP
+    classifier on the last stage, or the SegFormer all-MLP head on all four, oracle/segformer_head.py) -> oracle loss block; losses
+    of the step."""
     import random
     from diga_amd import _lib
     from diga_amd.model.segformer import SegFormerStudent
     from diga_amd.train_step import DigaTrainer
     from oracle import deeplab as od
-    from oracle import detweights, losses as ol
+    from oracle import detweights, losses as ol, segformer_head as oh
     prev = _lib.get_conv_math()
     _lib.set_conv_math(0)
     try:
         arch = od.Arch(droprate=0.0)
         sd_b = om.state_dict(om.MIT_B1)
-        head_shapes = {k: v for k, v in od.state_shapes(od.RESNET101).items() if k.startswith("final.")}
-        sd_h = {}
-        for k, (shp, kind) in head_shapes.items():
-            if k.startswith("final.conv2d_list.") and k.endswith(".0.weight"):
-                shp = (shp[0], 512, shp[2], shp[3])                 # the head reads the 512-channel last stage
-            sd_h[k] = detweights.fill("seg." + k, shp, kind)
+        if head == "aspp":
+            head_shapes = {k: v for k, v in od.state_shapes(od.RESNET101).items() if k.startswith("final.")}
+            sd_h = {}
+            for k, (shp, kind) in head_shapes.items():
+                if k.startswith("final.conv2d_list.") and k.endswith(".0.weight"):
+                    shp = (shp[0], 512, shp[2], shp[3])                 # the head reads the 512-channel last stage
+                sd_h[k] = detweights.fill("seg." + k, shp, kind)
+        else:
+            sd_h = {"final." + k: v for k, v in oh.state_dict().items()}
 
         def make():
-            m = SegFormerStudent("mit_b1", head="aspp")
+            m = SegFormerStudent("mit_b1", head=head)
             m.backbone.load_state_dict(sd_b)
             m.final.load_state_dict({k[len("final."):]: v for k, v in sd_h.items()})
-            m.final.head[0].p = 0.0
+            m.set_head_dropout(0.0)
             m.backbone.reset_drop_path(0.0)
             return m.to(DEV)
 
@@ -425,13 +430,16 @@ def test_segformer_student_warmup_step_vs_oracle_composition():
         random.seed(5)
         mix, _, _ = ocm.classmix(rec, x_aug, lab, random)
         cat = torch.cat([x, mix])
-        sd = {**{k: v.clone().requires_grad_() for k, v in sd_b.items()}, **{k: v.clone().requires_grad_() for k, v in sd_h.items()}}
-        c4 = om.forward(sd, cat, om.MIT_B1)[3]
-        out, _ = od.aspp_head(sd, c4, arch, keep_mask=torch.ones(4, 256))
+        with torch.no_grad():
+            feats = om.forward(sd_b, cat, om.MIT_B1)
+            if head == "aspp":
+                out, _ = od.aspp_head({**sd_b, **sd_h}, feats[3], arch, keep_mask=torch.ones(4, 256))
+            else:
+                out, _, _ = oh.forward({k[len("final."):]: v for k, v in sd_h.items()}, list(feats), training=True)
         up = torch.nn.Upsample(size=[128, 160], mode="bilinear", align_corners=True)
         s_up = up(out)
         ce = ol.cross_entropy2d(s_up[:2], lab)
-        di = ol.distillation_loss(s_up.detach(), s_up)
+        di = ol.distillation_loss(s_up, s_up)
         assert float(got["ce"]) == pytest.approx(float(ce), rel=5e-3)
         assert float(got["distil"]) == pytest.approx(float(di), rel=5e-3)
     finally:
