@@ -277,6 +277,132 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const _Float16* __restri
     }
 }
 
+// The same convolution with a sliding window over ROWS: a thread owns 8 channels of a (PX wide, R tall) column strip, keeps the three
+// input rows of the current output row in registers and fetches ONE new row of PX + 2 vectors per output row (issued before the
+// current row is computed).  dwconv3x3_kernel fetches 3 (PX + 2) vectors per PX outputs (4.5 per output: every input element goes
+// through the L1 / L2 path 4.5 times -- 424 MB per stage-3 launch against 94 MB of input); here it is (R + 2)(PX + 2) / (R PX): 1.9
+// at R = 8, 2.25 at R = 4.  R is chosen at launch so that the grid keeps >= ~1000 blocks.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_rows_kernel(const _Float16* __restrict__ x, const float* __restrict__ wt,
+                                                             const float* __restrict__ bias, _Float16* __restrict__ u16,
+                                                             _Float16* __restrict__ out16, int B, int H, int W, int C, int R) {
+    const int cg = C / 8;
+    const int strips = (W + kDwPX - 1) / kDwPX;
+    const int rgroups = (H + R - 1) / R;
+    const int64_t total = (int64_t)B * rgroups * strips * cg;
+    const int64_t idx = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % cg);
+    int64_t rest = idx / cg;
+    const int sx = (int)(rest % strips);
+    rest /= strips;
+    const int rg = (int)(rest % rgroups);
+    const int b = (int)(rest / rgroups);
+    const int x0 = sx * kDwPX, y0 = rg * R, y1 = min(y0 + R, H);
+    float w[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wt + (int64_t)t * C + c8 * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(wt + (int64_t)t * C + c8 * 8 + 4);
+        w[t][0] = w0.x; w[t][1] = w0.y; w[t][2] = w0.z; w[t][3] = w0.w;
+        w[t][4] = w1.x; w[t][5] = w1.y; w[t][6] = w1.z; w[t][7] = w1.w;
+    }
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0 && bias != nullptr) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const _Float16* img = x + ((int64_t)b * H * W) * C + c8 * 8;
+    // column offsets (clamped: always loadable) and validity of the PX + 2 columns of this strip
+    int64_t coff[kDwPX + 2];
+    bool cok[kDwPX + 2];
+#pragma unroll
+    for (int j = 0; j < kDwPX + 2; ++j) {
+        const int xx = x0 + j - 1;
+        cok[j] = xx >= 0 && xx < W;
+        coff[j] = (int64_t)min(max(xx, 0), W - 1) * C;
+    }
+    auto load_row = [&](int yy, f16x8 (&row)[kDwPX + 2]) {
+        const _Float16* rp = img + (int64_t)min(max(yy, 0), H - 1) * W * C;
+#pragma unroll
+        for (int j = 0; j < kDwPX + 2; ++j) row[j] = *reinterpret_cast<const f16x8*>(rp + coff[j]);
+    };
+    auto mask_row = [&](int yy, f16x8 (&row)[kDwPX + 2]) {
+        const bool yok = yy >= 0 && yy < H;
+#pragma unroll
+        for (int j = 0; j < kDwPX + 2; ++j) row[j] = (yok && cok[j]) ? row[j] : zero8;
+    };
+    // three row buffers: output row y is computed from (ra, rb, rc) = input rows y - 1, y, y + 1; then the window moves down by register
+    // moves (48 v_mov against 288 FMAs) and input row y + 2 is fetched into rc -- the next row's dy = 0 / 1 taps run under that load
+    f16x8 ra[kDwPX + 2], rb[kDwPX + 2], rc[kDwPX + 2];
+    load_row(y0 - 1, ra);
+    load_row(y0, rb);
+    load_row(y0 + 1, rc);
+    mask_row(y0 - 1, ra);
+    mask_row(y0, rb);
+#pragma unroll 1
+    for (int y = y0; y < y1; ++y) {
+        float acc[kDwPX][8];
+#pragma unroll
+        for (int p = 0; p < kDwPX; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            if (dy == 2) mask_row(y + 1, rc);                 // (fetched raw)
+            f16x8 (&row)[kDwPX + 2] = dy == 0 ? ra : dy == 1 ? rb : rc;
+#pragma unroll
+            for (int j = 0; j < kDwPX + 2; ++j) {
+                // v_fma_mix_f32 reads the fp16 halves where they are (op_sel picks the half): written as acc += w * (float)v the
+                // compiler converts every input vector to fp32 once for its three taps -- 144 more live registers, spills at 256
+                const u32x4 pk = __builtin_bit_cast(u32x4, row[j]);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int p = j - dx;
+                    if (p < 0 || p >= kDwPX) continue;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[p][e]) : "v"(pk[e >> 1]), "v"(w[dy * 3 + dx][e]));
+                        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[p][e + 1]) : "v"(pk[e >> 1]), "v"(w[dy * 3 + dx][e + 1]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kDwPX + 2; ++j) {
+            ra[j] = rb[j];
+            rb[j] = rc[j];
+        }
+        if (y + 1 < y1) load_row(y + 2, rc);
+#pragma unroll
+        for (int p = 0; p < kDwPX; ++p) {
+            if (x0 + p >= W) break;
+            const int64_t o = (((int64_t)b * H + y) * W + x0 + p) * C + c8 * 8;
+            f16x8 uo, ho;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = acc[p][e] + bv[e];
+                uo[e] = (_Float16)u;
+                ho[e] = MODE == 0 ? (_Float16)gelu_f((float)uo[e]) : (_Float16)u;     // (GELU of the ROUNDED pre-activation, as above)
+            }
+            if (MODE == 0 && u16 != nullptr) *reinterpret_cast<f16x8*>(u16 + o) = uo;
+            *reinterpret_cast<f16x8*>(out16 + o) = ho;
+        }
+    }
+}
+
+static int dw_rows_per_thread(int64_t B, int64_t H, int64_t W, int64_t C) {
+    // the tallest strip (8, 4, 2 rows) that still leaves ~1000 blocks of 256 threads; 0: the one-row kernel
+    const int64_t per_row = B * ceil_div(W, kDwPX) * (C / 8);
+    for (int r = 8; r >= 2; r >>= 1)
+        if (ceil_div(per_row * ceil_div(H, r), 256) >= 1000) return r;
+    return 0;
+}
+
 // du = dh * gelu'(u) -> du16; per-block partial sums of the depthwise weight / bias gradients:
 //   dw[t][c] = sum_p du[p][c] * x[p + t][c],  db[c] = sum_p du[p][c]     (x = the conv input, zero outside the image)
 // A block covers `rows_per_block` image rows of one image with gw * phases threads (gw = min(C / 8, 256) channel groups;
@@ -583,8 +709,15 @@ extern "C" int diga_mit_dwconv_gelu_fwd(const void* x, const float* wt9, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);
     ProfScope prof(DIGA_PROF_MIT_DWCONV, st, (double)B * H * W * C * (u16 ? 6.0 : 4.0));
-    hipLaunchKernelGGL(dwconv3x3_kernel<0>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, st, static_cast<const _Float16*>(x), wt9, bias,
-                       static_cast<_Float16*>(u16), static_cast<_Float16*>(h16), (int)B, (int)H, (int)W, (int)C);
+    const int R = dw_rows_per_thread(B, H, W, C);
+    if (R > 0) {
+        const int64_t ritems = B * ceil_div(H, R) * ceil_div(W, kDwPX) * (C / 8);
+        hipLaunchKernelGGL(dwconv3x3_rows_kernel<0>, dim3((unsigned)ceil_div(ritems, 256)), dim3(256), 0, st, static_cast<const _Float16*>(x), wt9,
+                           bias, static_cast<_Float16*>(u16), static_cast<_Float16*>(h16), (int)B, (int)H, (int)W, (int)C, R);
+    } else {
+        hipLaunchKernelGGL(dwconv3x3_kernel<0>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, st, static_cast<const _Float16*>(x), wt9, bias,
+                           static_cast<_Float16*>(u16), static_cast<_Float16*>(h16), (int)B, (int)H, (int)W, (int)C);
+    }
     return launch_status("mit_dwconv_gelu_fwd");
 }
 
@@ -622,8 +755,15 @@ extern "C" int diga_mit_dwconv_gelu_bwd(const void* dh, const void* u, const voi
     hipLaunchKernelGGL(partial_reduce_kernel<2>, dim3((unsigned)ceil_div(10 * C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), blocks,
                        (int)(10 * C), dw, db, (int)C, param_scale, accumulate);
     const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);
-    hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, st, static_cast<const _Float16*>(du16), wt9_flipped,
-                       (const float*)nullptr, (_Float16*)nullptr, static_cast<_Float16*>(dx16), (int)B, (int)H, (int)W, (int)C);
+    const int R = dw_rows_per_thread(B, H, W, C);
+    if (R > 0) {
+        const int64_t ritems = B * ceil_div(H, R) * ceil_div(W, kDwPX) * (C / 8);
+        hipLaunchKernelGGL(dwconv3x3_rows_kernel<1>, dim3((unsigned)ceil_div(ritems, 256)), dim3(256), 0, st, static_cast<const _Float16*>(du16),
+                           wt9_flipped, (const float*)nullptr, (_Float16*)nullptr, static_cast<_Float16*>(dx16), (int)B, (int)H, (int)W, (int)C, R);
+    } else {
+        hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, st, static_cast<const _Float16*>(du16), wt9_flipped,
+                           (const float*)nullptr, (_Float16*)nullptr, static_cast<_Float16*>(dx16), (int)B, (int)H, (int)W, (int)C);
+    }
     return launch_status("mit_dwconv_gelu_bwd");
 }
 

@@ -143,6 +143,45 @@ def test_dwconv_gelu_forward_backward(b, h, w, c):
     assert _rel(dbias, 2.0 * br.grad) < 5e-4
 
 
+@pytest.mark.parametrize("b,h,w,c", [(16, 48, 48, 1280), (16, 50, 46, 1024), (8, 192, 192, 256)])
+def test_dwconv_row_sliding_kernel_bit_identical_to_one_row_kernel(b, h, w, c):
+    """Large tensors take dwconv3x3_rows_kernel (a thread walks 8 / 4 / 2 rows with a sliding three-row window, v_fma_mix_f32 on
+    the fp16 operands), small ones the one-row kernel -- chosen by the launch grid alone.  Same taps in the same order: the whole
+    batch in one call (rows kernel; ragged row groups and strips in the second shape) must equal image-by-image calls (one-row
+    kernel: a single image never reaches 1000 blocks) bit for bit, forward (u, gelu(u)) and backward-data."""
+    lib = _lib()
+    P = lib.ptr
+    g = synth.gen(h * 7 + c)
+    x = h16(torch.randn((b, h, w, c), generator=g)).to(DEV)
+    wt9 = (0.4 * torch.randn((9, c), generator=g)).to(DEV)
+    bias = (0.1 * torch.randn(c, generator=g)).to(DEV)
+
+    def fwd(xx, n):
+        u, hh = torch.empty_like(xx), torch.empty_like(xx)
+        lib.call("diga_mit_dwconv_gelu_fwd", P(xx), P(wt9), P(bias), P(u), P(hh), n, h, w, c, lib.stream())
+        return u, hh
+
+    def bwd(dh, u, xx, n):
+        du, dx = torch.empty_like(xx), torch.empty_like(xx)
+        dw, db = torch.empty((c, 9), device=DEV), torch.empty(c, device=DEV)
+        ws = torch.empty(lib.lib.diga_mit_dwconv_bwd_workspace_bytes(n, h, c), dtype=torch.uint8, device=DEV)
+        lib.call("diga_mit_dwconv_gelu_bwd", P(dh), P(u), P(xx), P(wt9.flip(0).contiguous()), P(du), P(dx), P(dw), P(db), 1.0, 0, P(ws),
+                 ws.numel(), n, h, w, c, lib.stream())
+        return du, dx
+
+    u, hh = fwd(x, b)
+    dh = h16(torch.randn((b, h, w, c), generator=g)).to(DEV)
+    du, dx = bwd(dh, u, x, b)
+    for i in range(0, b, max(1, b // 4)):
+        ui, hi = fwd(x[i:i + 1].contiguous(), 1)
+        assert torch.equal(ui[0], u[i]) and torch.equal(hi[0], hh[i]), i
+        dui, dxi = bwd(dh[i:i + 1].contiguous(), ui, x[i:i + 1].contiguous(), 1)
+        assert torch.equal(dui[0], du[i]) and torch.equal(dxi[0], dx[i]), i
+    # and against float64 on one image
+    ur = F.conv2d(x[:1].double().cpu().permute(0, 3, 1, 2), wt9.t().reshape(c, 1, 3, 3).double().cpu(), bias.double().cpu(), 1, 1, 1, c)
+    assert _rel(u[:1].permute(0, 3, 1, 2), ur) < 1e-3
+
+
 @pytest.mark.parametrize("kind,c,k,stride,pad,hw", [(2, 3, 7, 4, 3, (37, 29)), (0, 64, 3, 2, 1, (17, 12)), (1, 128, 4, 4, 0, (16, 12)),
                                                     (1, 64, 8, 8, 0, (24, 16)), (0, 320, 3, 2, 1, (9, 7))])
 def test_im2col_gemm_is_the_convolution_and_col2im_its_adjoint(kind, c, k, stride, pad, hw):
