@@ -721,6 +721,124 @@ extern "C" int diga_mit_dwconv_gelu_fwd(const void* x, const float* wt9, const f
     return launch_status("mit_dwconv_gelu_fwd");
 }
 
+constexpr int kPrepPX = 2;      // strip width of the kernel below (4: 17 registers spilled at the 256 of two waves per SIMD)
+
+// dwconv_bwd_prep_kernel in the row-sliding form of dwconv3x3_rows_kernel: a block = gw channel groups (lanes: 16 contiguous bytes
+// each) x 256 / gw strip lanes over R image rows of one image; a thread walks its strips (4 pixels wide) down the R rows with the
+// three-row window of x in registers -- per row 2 dh + 2 u + 4 new x vectors, ALL issued before the row's arithmetic (the walk along x
+// of the kernel above has one dependent 5-load round trip per pixel in flight: 175 us on the stage-3 tensor, latency-bound).
+// 144 v_fma_mix_f32 per row accumulate the nine tap sums; the strip lanes are folded through LDS in fixed order.
+// partial[part = image, row group][10][C].
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_prep_rows_kernel(const _Float16* __restrict__ dh, const _Float16* __restrict__ u,
+                                                                      const _Float16* __restrict__ x, _Float16* __restrict__ du16,
+                                                                      float* __restrict__ partial, int B, int H, int W, int C, int R, int gw) {
+    __shared__ float red[256 * 8];
+    const int cg = C / 8;
+    const int SL = 256 / gw;
+    const int gi = threadIdx.x % gw, sl = threadIdx.x / gw;
+    const int rgroups = (H + R - 1) / R;
+    const int part = xcd_remap(blockIdx.y, gridDim.y);           // neighbouring row groups on one XCD (shared halo rows in its L2)
+    const int b = part / rgroups, rg = part - b * rgroups;
+    const int y0 = rg * R, y1 = min(y0 + R, H);
+    const int c8 = blockIdx.x * gw + gi;
+    const bool live = c8 < cg;
+    const int strips = (W + kPrepPX - 1) / kPrepPX;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    float s[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[t][e] = 0.f;
+    if (live) {
+        const int64_t img = ((int64_t)b * H * W) * C + c8 * 8;
+        for (int sx = sl; sx < strips; sx += SL) {
+            const int x0 = sx * kPrepPX;
+            int coff[kPrepPX + 2];                               // (element offsets inside an image row: W * C < 2^31)
+            bool cok[kPrepPX + 2];
+#pragma unroll
+            for (int j = 0; j < kPrepPX + 2; ++j) {
+                const int xx = x0 + j - 1;
+                cok[j] = xx >= 0 && xx < W;
+                coff[j] = min(max(xx, 0), W - 1) * C;
+            }
+            auto load_row = [&](int yy, f16x8 (&row)[kPrepPX + 2]) {
+                const _Float16* rp = x + img + (int64_t)min(max(yy, 0), H - 1) * W * C;
+#pragma unroll
+                for (int j = 0; j < kPrepPX + 2; ++j) row[j] = *reinterpret_cast<const f16x8*>(rp + coff[j]);
+            };
+            auto mask_row = [&](int yy, f16x8 (&row)[kPrepPX + 2]) {
+                const bool yok = yy >= 0 && yy < H;
+#pragma unroll
+                for (int j = 0; j < kPrepPX + 2; ++j) row[j] = (yok && cok[j]) ? row[j] : zero8;
+            };
+            f16x8 ra[kPrepPX + 2], rb[kPrepPX + 2], rc[kPrepPX + 2];
+            load_row(y0 - 1, ra);
+            load_row(y0, rb);
+            load_row(y0 + 1, rc);
+            mask_row(y0 - 1, ra);
+            mask_row(y0, rb);
+#pragma unroll 1
+            for (int y = y0; y < y1; ++y) {
+                const int64_t o = img + (int64_t)y * W * C;
+                f16x8 g8[kPrepPX], u8[kPrepPX];
+#pragma unroll
+                for (int p = 0; p < kPrepPX; ++p) {
+                    g8[p] = *reinterpret_cast<const f16x8*>(dh + o + coff[p + 1]);
+                    u8[p] = *reinterpret_cast<const f16x8*>(u + o + coff[p + 1]);
+                }
+                mask_row(y + 1, rc);                          // (fetched raw)
+#pragma unroll
+                for (int p = 0; p < kPrepPX; ++p) {
+                    const bool pok = x0 + p < W;
+                    f16x8 d8;
+                    float d[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        d8[e] = pok ? (_Float16)((float)g8[p][e] * gelu_grad_f((float)u8[p][e])) : (_Float16)0.f;
+                        d[e] = (float)d8[e];
+                        s[9][e] += d[e];
+                    }
+                    if (pok) *reinterpret_cast<f16x8*>(du16 + o + coff[p + 1]) = d8;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        f16x8 (&row)[kPrepPX + 2] = dy == 0 ? ra : dy == 1 ? rb : rc;
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const u32x4 pk = __builtin_bit_cast(u32x4, row[p + dx]);     // x[y + dy - 1][x0 + p + dx - 1]
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s[dy * 3 + dx][e]) : "v"(pk[e >> 1]), "v"(d[e]));
+                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s[dy * 3 + dx][e + 1]) : "v"(pk[e >> 1]), "v"(d[e + 1]));
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kPrepPX + 2; ++j) {
+                    ra[j] = rb[j];
+                    rb[j] = rc[j];
+                }
+                if (y + 1 < y1) load_row(y + 2, rc);
+            }
+        }
+    }
+    // fold the strip lanes in fixed order, one tap at a time through LDS
+    for (int t = 0; t < 10; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[t][e];
+        __syncthreads();
+        if (sl == 0 && live) {
+            float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < SL; ++p)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tot[e] += red[(p * gw + gi) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) partial[((int64_t)part * 10 + t) * C + c8 * 8 + e] = tot[e];
+        }
+    }
+}
+
 static int dw_rows_per_block(int64_t B, int64_t H) {     // ~1500+ blocks when the tensor has that many image rows
     int64_t r = (B * H) / 1536;
     if (r < 1) r = 1;
@@ -741,17 +859,34 @@ extern "C" int diga_mit_dwconv_gelu_bwd(const void* dh, const void* u, const voi
     DIGA_REQUIRE(dh && u && x && wt9_flipped && du16 && dx16 && dw && db && workspace && B > 0 && H > 0 && W > 0 && C % 8 == 0 && C > 0,
                  DIGA_EINVAL, "mit_dwconv_gelu_bwd: bad argument");
     const int rpb = dw_rows_per_block(B, H);
-    const int blocks = (int)(B * ceil_div(H, rpb));
+    int blocks = (int)(B * ceil_div(H, rpb));
     DIGA_REQUIRE(workspace_bytes >= (size_t)blocks * 10 * (size_t)C * sizeof(float), DIGA_EWORKSPACE, "mit_dwconv_gelu_bwd: workspace too small");
-    const int gw = (int)(C / 8 < 256 ? C / 8 : 256);
-    int phases = 512 / gw;
-    if (phases > W) phases = (int)W;
-    if (phases < 1) phases = 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(DIGA_PROF_MIT_DWCONV, st, (double)B * H * W * C * 12.0);
-    hipLaunchKernelGGL(dwconv_bwd_prep_kernel, dim3(blocks), dim3(gw * phases), (size_t)gw * phases * 8 * sizeof(float), st,
-                       static_cast<const _Float16*>(dh), static_cast<const _Float16*>(u), static_cast<const _Float16*>(x),
-                       static_cast<_Float16*>(du16), static_cast<float*>(workspace), (int)B, (int)H, (int)W, (int)C, rpb, gw, phases);
+    // row-sliding form where the tensor is large enough for >= 512 blocks of (32 or 64 channel groups) x (8 or 4 strip lanes) x R rows;
+    // R >= rpb keeps the partial sums inside the workspace the caller sized with diga_mit_dwconv_bwd_workspace_bytes
+    const int cgn = (int)(C / 8);
+    const int gwr = cgn % 64 == 0 || cgn > 96 ? 64 : 32;
+    int Rr = 0;
+    for (int r = 8; r >= 1; r >>= 1)
+        if (r >= rpb && ceil_div(cgn, gwr) * B * ceil_div(H, r) >= 512) {
+            Rr = r;
+            break;
+        }
+    if (Rr > 0 && cgn >= 32) {
+        blocks = (int)(B * ceil_div(H, Rr));
+        hipLaunchKernelGGL(dwconv_bwd_prep_rows_kernel, dim3((unsigned)ceil_div(cgn, gwr), (unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const _Float16*>(dh), static_cast<const _Float16*>(u), static_cast<const _Float16*>(x),
+                           static_cast<_Float16*>(du16), static_cast<float*>(workspace), (int)B, (int)H, (int)W, (int)C, Rr, gwr);
+    } else {
+        const int gw = (int)(C / 8 < 256 ? C / 8 : 256);
+        int phases = 512 / gw;
+        if (phases > W) phases = (int)W;
+        if (phases < 1) phases = 1;
+        hipLaunchKernelGGL(dwconv_bwd_prep_kernel, dim3(blocks), dim3(gw * phases), (size_t)gw * phases * 8 * sizeof(float), st,
+                           static_cast<const _Float16*>(dh), static_cast<const _Float16*>(u), static_cast<const _Float16*>(x),
+                           static_cast<_Float16*>(du16), static_cast<float*>(workspace), (int)B, (int)H, (int)W, (int)C, rpb, gw, phases);
+    }
     hipLaunchKernelGGL(partial_reduce_kernel<2>, dim3((unsigned)ceil_div(10 * C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), blocks,
                        (int)(10 * C), dw, db, (int)C, param_scale, accumulate);
     const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);

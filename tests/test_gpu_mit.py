@@ -148,7 +148,8 @@ def test_dwconv_row_sliding_kernel_bit_identical_to_one_row_kernel(b, h, w, c):
     """Large tensors take dwconv3x3_rows_kernel (a thread walks 8 / 4 / 2 rows with a sliding three-row window, v_fma_mix_f32 on
     the fp16 operands), small ones the one-row kernel -- chosen by the launch grid alone.  Same taps in the same order: the whole
     batch in one call (rows kernel; ragged row groups and strips in the second shape) must equal image-by-image calls (one-row
-    kernel: a single image never reaches 1000 blocks) bit for bit, forward (u, gelu(u)) and backward-data."""
+    kernel: a single image never reaches 1000 blocks) bit for bit in the forward (u, gelu(u)); the backward (du from the row-sliding
+    prep kernel, dx) to one fp16 ulp."""
     lib = _lib()
     P = lib.ptr
     g = synth.gen(h * 7 + c)
@@ -167,16 +168,28 @@ def test_dwconv_row_sliding_kernel_bit_identical_to_one_row_kernel(b, h, w, c):
         ws = torch.empty(lib.lib.diga_mit_dwconv_bwd_workspace_bytes(n, h, c), dtype=torch.uint8, device=DEV)
         lib.call("diga_mit_dwconv_gelu_bwd", P(dh), P(u), P(xx), P(wt9.flip(0).contiguous()), P(du), P(dx), P(dw), P(db), 1.0, 0, P(ws),
                  ws.numel(), n, h, w, c, lib.stream())
-        return du, dx
+        return du, dx, dw, db
 
     u, hh = fwd(x, b)
     dh = h16(torch.randn((b, h, w, c), generator=g)).to(DEV)
-    du, dx = bwd(dh, u, x, b)
+    du, dx, dw, db = bwd(dh, u, x, b)
+    dw_sum, db_sum = torch.zeros_like(dw, dtype=torch.float64), torch.zeros_like(db, dtype=torch.float64)
+    for i in range(b):
+        ui, hi = fwd(x[i:i + 1].contiguous(), 1)
+        _, _, dwi, dbi = bwd(dh[i:i + 1].contiguous(), ui, x[i:i + 1].contiguous(), 1)
+        dw_sum += dwi.double()
+        db_sum += dbi.double()
+    # weight / bias gradients of the row-sliding prep kernel against the image-by-image sums of the one-row kernel
+    assert _rel(dw, dw_sum) < 1e-4 and _rel(db, db_sum) < 1e-4
     for i in range(0, b, max(1, b // 4)):
         ui, hi = fwd(x[i:i + 1].contiguous(), 1)
         assert torch.equal(ui[0], u[i]) and torch.equal(hi[0], hh[i]), i
-        dui, dxi = bwd(dh[i:i + 1].contiguous(), ui, x[i:i + 1].contiguous(), 1)
-        assert torch.equal(dui[0], du[i]) and torch.equal(dxi[0], dx[i]), i
+        # backward: the two du kernels are different code (the compiler contracts g * gelu'(u) differently): a few elements differ by
+        # one fp16 ulp, the conv adjoint of those by as much
+        dui, dxi, _, _ = bwd(dh[i:i + 1].contiguous(), ui, x[i:i + 1].contiguous(), 1)
+        ddu = (dui[0].float() - du[i].float()).abs()
+        assert float((ddu > 0).float().mean()) < 2e-3 and bool((ddu <= 1.01e-3 * du[i].float().abs() + 1e-7).all()), i
+        assert _rel(dxi[0], dx[i]) < 1e-3, i
     # and against float64 on one image
     ur = F.conv2d(x[:1].double().cpu().permute(0, 3, 1, 2), wt9.t().reshape(c, 1, 3, 3).double().cpu(), bias.double().cpu(), 1, 1, 1, c)
     assert _rel(u[:1].permute(0, 3, 1, 2), ur) < 1e-3
