@@ -359,13 +359,18 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
     const float* __restrict__ stu_lr, const float* __restrict__ tea_lr, const long long* __restrict__ labels,
     const int* __restrict__ ystart, const int* __restrict__ xstart, float* __restrict__ cellpart, int B,
     int n_ce /* images that carry a CE term */, int h, int w, int H, int W, float sy, float sx, float k_ce,
-    float k_di, float scale) {
+    float k_di, float scale, int cpw /* cells per wave: 1, 2, 4 or 8 neighbours along x, 64 / cpw lanes each */) {
     constexpr int ROWS = cell_rows<C>();
     __shared__ float red[ROWS * 65];
-    const int lane = threadIdx.x;
-    const int cj = blockIdx.x, ci = blockIdx.y, n = blockIdx.z;
+    // small cells (logits at 1/4 scale: 4 x 4 full-resolution pixels per cell) would leave most of a wave idle and pay the LDS fold
+    // per 16 pixels: `cpw` neighbouring cells share the wave, lane group `sub` owns cell blockIdx.x * cpw + sub
+    const int lpc = 64 / cpw;
+    const int lane = threadIdx.x % lpc, sub = threadIdx.x / lpc;
+    const int cj_raw = blockIdx.x * cpw + sub, ci = blockIdx.y, n = blockIdx.z;
+    const bool cell_ok = cj_raw < w - 1;
+    const int cj = cell_ok ? cj_raw : w - 2;
     const int ylo = ystart[ci], yhi = ystart[ci + 1], xlo = xstart[cj], xhi = xstart[cj + 1];
-    const int nx = xhi - xlo, npx = (yhi - ylo) * nx;
+    const int nx = xhi - xlo, npx = cell_ok ? (yhi - ylo) * nx : 0;
     const int64_t plane = (int64_t)h * w;
     const float* S = stu_lr + ((int64_t)n * C) * plane + (int64_t)ci * w + cj;
     const int partner = DISTILL ? (n < B ? n + B : n - B) : 0;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
         for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
     float ce_sum = 0.f, di_sum = 0.f;
 
-    for (int base = 0; base < npx; base += 64) {
+    for (int base = 0; base < npx; base += lpc) {
         const int idx = base + lane;
         const bool live = idx < npx;
         const int py = ylo + (live ? idx / nx : 0), px = xlo + (live ? idx % nx : 0);
@@ -442,20 +447,22 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
         ce_sum += valid ? (lse - xt) : 0.f;
         if (DISTILL && live) di_sum += wgt * di_px;
     }
-    // transposed wave reduction through LDS: row r = value index, column = lane
+    // transposed wave reduction through LDS: row r = value index, column = lane (of the whole wave); each cell folds its lane group
+    const int wl = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < C; ++c) red[(k * C + c) * 65 + lane] = acc[k][c];
-    red[(4 * C) * 65 + lane] = ce_sum;
-    red[(4 * C + 1) * 65 + lane] = di_sum;
+        for (int c = 0; c < C; ++c) red[(k * C + c) * 65 + wl] = acc[k][c];
+    red[(4 * C) * 65 + wl] = ce_sum;
+    red[(4 * C + 1) * 65 + wl] = di_sum;
     __syncthreads();
-    float* out = cellpart + (((int64_t)n * (h - 1) + ci) * (w - 1) + cj) * ROWS;
-    for (int r = lane; r < ROWS; r += 64) {
+    float* out = cellpart + (((int64_t)n * (h - 1) + ci) * (w - 1) + (int64_t)blockIdx.x * cpw) * ROWS;
+    const int ncell = min(cpw, (w - 1) - (int)blockIdx.x * cpw);
+    for (int o = wl; o < ROWS * ncell; o += 64) {
+        const int sc = o / ROWS, r = o - sc * ROWS;
         float t = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) t += red[r * 65 + k];
-        out[r] = t;
+        for (int k = 0; k < lpc; ++k) t += red[r * 65 + sc * lpc + k];
+        out[(int64_t)sc * ROWS + r] = t;
     }
 }
 
@@ -626,15 +633,18 @@ int run_upsample_loss(const float* stu_lr, const float* tea_lr, const int64_t* l
     const int tmax = (int)(h > w ? h : w);
     hipLaunchKernelGGL(cell_starts_kernel, dim3((tmax + 255) / 256), dim3(256), 0, st, cw.ystart, cw.xstart, (int)h,
                        (int)w, (int)H, (int)W, sy, sx);
-    dim3 grid((unsigned)(w - 1), (unsigned)(h - 1), (unsigned)N);
+    // cells per wave from the mean cell size (8 x 8 pixels at DeepLab's 1/8 scale: 1; 4 x 4 at SegFormer's 1/4 scale: 4)
+    const double cell_px = ((double)H / (double)(h - 1)) * ((double)W / (double)(w - 1));
+    const int cpw = cell_px >= 48.0 ? 1 : cell_px >= 24.0 ? 2 : cell_px >= 12.0 ? 4 : 8;
+    dim3 grid((unsigned)ceil_div(w - 1, cpw), (unsigned)(h - 1), (unsigned)N);
     if (distill)
         hipLaunchKernelGGL((upsample_loss_cells_kernel<C, true>), grid, dim3(64), 0, st, stu_lr, tea_lr,
                            (const long long*)labels, cw.ystart, cw.xstart, cw.cellpart, (int)B, (int)n_ce, (int)h,
-                           (int)w, (int)H, (int)W, sy, sx, k_ce, k_di, scale);
+                           (int)w, (int)H, (int)W, sy, sx, k_ce, k_di, scale, cpw);
     else
         hipLaunchKernelGGL((upsample_loss_cells_kernel<C, false>), grid, dim3(64), 0, st, stu_lr, tea_lr,
                            (const long long*)labels, cw.ystart, cw.xstart, cw.cellpart, (int)B, (int)n_ce, (int)h,
-                           (int)w, (int)H, (int)W, sy, sx, k_ce, k_di, scale);
+                           (int)w, (int)H, (int)W, sy, sx, k_ce, k_di, scale, cpw);
     const int64_t total = N * C * h * w;
     hipLaunchKernelGGL((upsample_loss_gather_kernel<C>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st,
                        cw.cellpart, grad_lr, (int)N, (int)h, (int)w);

@@ -721,6 +721,9 @@ extern "C" int diga_mit_dwconv_gelu_fwd(const void* x, const float* wt9, const f
     return launch_status("mit_dwconv_gelu_fwd");
 }
 
+namespace diga {
+namespace mit {
+
 constexpr int kPrepPX = 2;      // strip width of the kernel below (4: 17 registers spilled at the 256 of two waves per SIMD)
 
 // dwconv_bwd_prep_kernel in the row-sliding form of dwconv3x3_rows_kernel: a block = gw channel groups (lanes: 16 contiguous bytes
@@ -838,6 +841,9 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_prep_rows_kernel(const _Flo
         }
     }
 }
+
+}  // namespace mit
+}  // namespace diga
 
 static int dw_rows_per_block(int64_t B, int64_t H) {     // ~1500+ blocks when the tensor has that many image rows
     int64_t r = (B * H) / 1536;

@@ -165,7 +165,9 @@ def test_fused_loss_block_golden(mods, golden):
 
 
 @pytest.mark.parametrize("B,hw,HW", [(2, (17, 17), (128, 128)), (1, (9, 13), (65, 97)), (3, (5, 7), (33, 50)),
-                                     (2, (33, 33), (256, 256)), (1, (6, 6), (6, 6)), (1, (8, 8), (5, 5))])
+                                     (2, (33, 33), (256, 256)), (1, (6, 6), (6, 6)), (1, (8, 8), (5, 5)),
+                                     # small cells: 4, 2 and 8 neighbouring cells share a wave (logits at 1/4 scale: the SegFormer head)
+                                     (2, (32, 32), (128, 128)), (1, (24, 40), (96, 120)), (2, (33, 21), (128, 128)), (1, (48, 50), (96, 100))])
 def test_fused_loss_block_vs_oracle(mods, B, hw, HW):
     g = synth.gen(B * 100 + hw[0] + HW[1])
     stu = 2.0 * torch.randn((2 * B, 19, *hw), generator=g)
