@@ -13,8 +13,12 @@ from oracle import synth
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
 CHANS = [64, 128, 320, 512]
-# measured (fp32 / split-bf16 convs): logits 2e-6 / 4e-6 of scale, input gradients 4e-6 / 8e-6, parameter gradients 3e-5 / 5e-5
-TOL = {"logits": 2e-5, "dinput": 5e-5, "dparam": 2e-4}
+# measured against the capture of the reference class (tools/diag run, both conv arithmetics), in units of each tensor's scale:
+#   exact fp32 : logits 1.2e-6, input gradients 1.2e-6, parameter gradients 1.2e-6
+#   split bf16 : logits 8.8e-6, input gradients 8.2e-6, parameter gradients 9.6e-6
+# the bounds are 3-4x that, per arithmetic
+TOLS = {0: {"logits": 4e-6, "dinput": 4e-6, "dparam": 5e-6}, 1: {"logits": 3e-5, "dinput": 3e-5, "dparam": 3e-5}}
+TOL = TOLS[1]                 # (tests that do not take the conv_math fixture run in whatever mode the process is in)
 
 
 def _head(embed=768, return_raw=False, sd=None, classes=19):
@@ -33,6 +37,7 @@ def test_state_dict_keys_are_the_references(golden):
 
 
 def test_train_step_vs_reference_capture(golden, conv_math):
+    TOL = TOLS[conv_math]
     g = golden("segformer_head")
     h = _head().train()
     feats = [g.t(f"c{i}").to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() for i in (1, 2, 3, 4)]
@@ -57,13 +62,15 @@ def test_train_step_vs_reference_capture(golden, conv_math):
             continue
         e = float((got - w).abs().max() / w.abs().max())
         assert e < TOL["dparam"], (name, e)
-        assert abs(float(named[name].grad.norm()) / float(g["gnorm_" + k]) - 1) < TOL["dparam"], name
+        # (whole-tensor norms in float64 on both sides: torch's fp32 norm of the 2.4 M-element fuse weight is off by 5e-5)
+        assert abs(float(named[name].grad.double().norm()) / float(g["gnorm_" + k]) - 1) < TOL["dparam"], name
     assert_close(h.linear_fuse.bn.running_mean, g.t("running_mean"), 1e-4, 1e-5, "running_mean")
     assert_close(h.linear_fuse.bn.running_var, g.t("running_var"), 1e-4, 1e-5, "running_var")
     assert int(h.linear_fuse.bn.num_batches_tracked) == 1
 
 
 def test_eval_mode_odd_sizes_vs_reference_capture(golden, conv_math):
+    TOL = TOLS[conv_math]
     g = golden("segformer_head")
     sd = oh.state_dict()
     sd["linear_fuse.bn.running_mean"], sd["linear_fuse.bn.running_var"] = g.t("running_mean"), g.t("running_var")

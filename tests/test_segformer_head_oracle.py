@@ -37,7 +37,7 @@ def test_forward_backward_vs_reference(golden):
             assert float(w.abs().max()) < 2e-5 and float(got.abs().max()) < 2e-5, name
             continue
         assert float((got - w).abs().max()) < 2e-4 * float(w.abs().max()) + 1e-7, name
-        assert abs(float(sd[name].grad.norm()) / float(g["gnorm_" + k]) - 1) < 2e-4, name
+        assert abs(float(sd[name].grad.double().norm()) / float(g["gnorm_" + k]) - 1) < 1e-5, name
     # what the train-mode forward blended into the running buffers (momentum 0.1)
     mean, var = oh.batch_stats(sd, feats)
     rm = 0.9 * sd["linear_fuse.bn.running_mean"] + 0.1 * mean

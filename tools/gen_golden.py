@@ -658,7 +658,7 @@ def gen_segformer_head():
         res[f"dc{i + 1}"] = f.grad
     for k, p in named.items():
         gr = p.grad
-        res["gnorm_" + k.replace(".", "_")] = np.array(float(gr.norm()))
+        res["gnorm_" + k.replace(".", "_")] = np.array(float(gr.double().norm()))     # (float64: the fp32 norm of 2.4 M elements is off by 5e-5)
         step = max(1, gr.numel() // 4096)
         res["g_" + k.replace(".", "_")] = gr.reshape(-1)[::step].clone()
         res["gstep_" + k.replace(".", "_")] = np.array(step)
