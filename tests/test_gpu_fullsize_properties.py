@@ -64,12 +64,14 @@ def test_distill_fullsize_properties():
     assert 0.45 < r < 0.55
 
 
-def test_fused_loss_block_fullsize_vs_unfused_kernels():
-    """Low-res fused kernel (no full-res tensors) == explicit upsample + the two full-res loss kernels."""
+@pytest.mark.parametrize("hw", [97, 192], ids=["deeplab_1_8", "segformer_1_4"])
+def test_fused_loss_block_fullsize_vs_unfused_kernels(hw):
+    """Low-res fused kernel (no full-res tensors) == explicit upsample + the two full-res loss kernels; logits at DeepLab's 1/8
+    scale (one wave per 8 x 8-pixel cell) and at the SegFormer head's 1/4 scale (four 4 x 4-pixel cells per wave)."""
     from diga_amd import _lib
     from diga_amd.util import loss as L
     g = synth.gen(3)
-    B, C, h, w, H, W = 8, 19, 97, 97, 768, 768
+    B, C, h, w, H, W = 8, 19, hw, hw, 768, 768
     stu = (2.0 * torch.randn((2 * B, C, h, w), generator=g)).to(DEV).requires_grad_()
     tea = (2.0 * torch.randn((2 * B, C, h, w), generator=g)).to(DEV)
     lab = _labels(g, B, H, W).to(DEV)
@@ -87,6 +89,8 @@ def test_fused_loss_block_fullsize_vs_unfused_kernels():
     assert float(di) == pytest.approx(float(di2), rel=1e-5)
     # gradient: sum over the low-res gradient equals sum over the full-res one (bilinear weights sum to 1): 0 per pixel
     assert abs(float(stu.grad.sum())) < 1e-5
+    # ... and per low-res pixel the class gradients sum to zero (every full-resolution softmax gradient does)
+    assert float(stu.grad.sum(1).abs().max()) < 1e-5 * float(stu.grad.abs().max())
     # and a constant shift of the low-res logits changes nothing
     total2, _, _ = L.upsample_ce_distill(stu.detach() + 0.7, tea - 1.3, lab, 1.0, 0.5)
     assert float(total2) == pytest.approx(float(total), rel=1e-5)
