@@ -77,6 +77,8 @@ SIGNATURES = {
     "diga_bn_bwd_affine": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, P, SZ, P]),
     "diga_pyramid_sum_fwd": (INT, [P, I64, I64, P, P, I64, I64, P, I64, I64, P, I64, I64, I64, I64, P]),
     "diga_pyramid_sum_bwd": (INT, [P, I64, I64, P, I64, I64, I64, I64, P]),
+    "diga_pyramid_sum_fwd3": (INT, [P, I64, I64, P, P, P, P, P, I64, I64, P]),
+    "diga_pyramid_sum_bwd3": (INT, [P, I64, I64, P, P, P, I64, I64, P]),
     "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
     "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_bn_apply": (INT, [P, I64, P, I64, P, I64, P, I64, I64, INT, P, P]),

@@ -52,6 +52,7 @@ def _fold(wf, w):
 class _PyramidSumFn(torch.autograd.Function):
     """fine + bias + sum_k resize(coarse_k), written over `fine` (the caller passes a fresh conv output nobody else reads and must
     not use it afterwards)."""
+    last_stats = None
 
     @staticmethod
     def forward(ctx, fine, bias, *coarse):
@@ -63,11 +64,21 @@ class _PyramidSumFn(torch.autograd.Function):
         cs = [nhwc(t.detach()) for t in coarse]
         if len(cs) > 3 or any(t.shape[0] != n or t.shape[3] != c for t in cs):
             raise RuntimeError("SegFormerHead: at most three coarse maps of the fine map's batch and channel count")
-        args = []
-        for k in range(3):
-            args += [_lib.ptr(cs[k]), cs[k].shape[1], cs[k].shape[2]] if k < len(cs) else [None, 0, 0]
         b = None if bias is None else bias.detach().float().contiguous()
-        _lib.call("diga_pyramid_sum_fwd", _lib.ptr(f), h, w, _lib.ptr(b), *args, n, c, _lib.stream())
+        by_ratio = {(h // t.shape[1], w // t.shape[2]): t for t in cs if h % t.shape[1] == 0 and w % t.shape[2] == 0}
+        _PyramidSumFn.last_stats = None
+        if (len(cs) == 3 and h % 16 == 0 and w % 16 == 0 and c % 32 == 0 and n * (c // 32) < 65536
+                and sorted(by_ratio) == [(2, 2), (4, 4), (8, 8)]):
+            # the SegFormer geometry: tiled kernel, and the BatchNorm behind it gets its statistics from this pass
+            stats = torch.empty((n * h * w // 64, 3, c), dtype=torch.float32, device=f.device)
+            _lib.call("diga_pyramid_sum_fwd3", _lib.ptr(f), h, w, _lib.ptr(b), _lib.ptr(by_ratio[(2, 2)]), _lib.ptr(by_ratio[(4, 4)]),
+                      _lib.ptr(by_ratio[(8, 8)]), _lib.ptr(stats), n, c, _lib.stream())
+            _PyramidSumFn.last_stats = (stats, 64)              # (read by the caller right after apply: forward's ctx is gone under no_grad)
+        else:
+            args = []
+            for k in range(3):
+                args += [_lib.ptr(cs[k]), cs[k].shape[1], cs[k].shape[2]] if k < len(cs) else [None, 0, 0]
+            _lib.call("diga_pyramid_sum_fwd", _lib.ptr(f), h, w, _lib.ptr(b), *args, n, c, _lib.stream())
         ctx.shapes = [tuple(t.shape) for t in cs]
         ctx.has_bias = bias is not None
         # the result lives in `fine`'s buffer (a conv output that no backward reads: convs save their input and weight); it is handed
@@ -86,6 +97,15 @@ class _PyramidSumFn(torch.autograd.Function):
             ws = _lib.workspace(_lib.lib.diga_norm_workspace_bytes(n * h * w, 1, c), gn.device, "norm")
             _lib.call("diga_colsum_nhwc", _lib.ptr(gn), c, _lib.ptr(db), n * h * w, c, _lib.ptr(ws), ws.numel(), _lib.stream())
         outs = []
+        want = [ctx.needs_input_grad[2 + k] for k in range(len(ctx.shapes))]
+        by_ratio = {(h // s[1], w // s[2]): k for k, s in enumerate(ctx.shapes) if h % s[1] == 0 and w % s[2] == 0}
+        if (len(ctx.shapes) == 3 and all(want) and h % 16 == 0 and w % 16 == 0 and c % 16 == 0 and n * (c // 16) < 65536
+                and sorted(by_ratio) == [(2, 2), (4, 4), (8, 8)]):
+            # the SegFormer geometry (1/8, 1/16, 1/32 maps under a 1/4 map): one pass over the fine gradient for all three
+            ds = [torch.empty(s, dtype=torch.float32, device=gn.device) for s in ctx.shapes]
+            _lib.call("diga_pyramid_sum_bwd3", _lib.ptr(gn), h, w, _lib.ptr(ds[by_ratio[(2, 2)]]), _lib.ptr(ds[by_ratio[(4, 4)]]),
+                      _lib.ptr(ds[by_ratio[(8, 8)]]), n, c, _lib.stream())
+            return (g, db, *[d.permute(0, 3, 1, 2) for d in ds])
         for k, shp in enumerate(ctx.shapes):
             if not ctx.needs_input_grad[2 + k]:
                 outs.append(None)
@@ -197,6 +217,9 @@ class SegFormerHead(nn.Module):
         bcat = torch.cat([lin.proj.bias for lin, _ in order])[None]
         bias = _SmallLinearFn.apply(bcat, wf[:, :, 0, 0], None, 0)[0]
         fused = _PyramidSumFn.apply(maps[3], bias, maps[2], maps[1], maps[0])
+        stats, _PyramidSumFn.last_stats = _PyramidSumFn.last_stats, None
+        if stats is not None:
+            fused._diga_bn_partials = stats                    # (what a DigaConv2d with emit_bn_stats hands its BatchNorm)
         _c = self.linear_fuse.bn(fused, relu=True)
         x = self.dropout(_c) if self.dropout is not None else _c
         x = self.linear_pred(x)

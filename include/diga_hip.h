@@ -551,6 +551,16 @@ int diga_pyramid_sum_fwd(float* dst, int64_t H, int64_t W, const float* bias, co
                          const float* s1, int64_t h1, int64_t w1, const float* s2, int64_t h2, int64_t w2, int64_t N, int64_t C,
                          void* stream);
 int diga_pyramid_sum_bwd(const float* dout, int64_t H, int64_t W, float* ds, int64_t h, int64_t w, int64_t N, int64_t C, void* stream);
+/* The three adjoints of the SegFormer geometry in one pass over dout: ds2 [N][H/2][W/2][C], ds4 [N][H/4][W/4][C], ds8 [N][H/8][W/8][C]
+ * (the stage maps of segformer_head.py:141-147 for a crop whose side is a multiple of 64); H % 16 == 0, W % 16 == 0, C % 16 == 0.
+ * Same weights as diga_pyramid_sum_bwd, another summation order (fixed: deterministic). */
+/* diga_pyramid_sum_fwd for that geometry (s2 / s4 / s8: the maps at 1/2, 1/4, 1/8 of dst's grid; H % 16 == 0, W % 16 == 0,
+ * C % 32 == 0), tiled through LDS, the same taps in the same order; stats (nullable, [N * H * W / 64][3][C]) receives what the BatchNorm behind
+ * `linear_fuse` needs -- per 64-pixel chunk and channel {sum (y - s), sum (y - s)^2, s}, the layout diga_bn_fwd_partials finalises
+ * with chunk_rows = 64 (a chunk = four rows of a 16 x 16 tile; the finaliser only needs every chunk to hold 64 values). */
+int diga_pyramid_sum_fwd3(float* dst, int64_t H, int64_t W, const float* bias, const float* s2, const float* s4, const float* s8,
+                          float* stats, int64_t N, int64_t C, void* stream);
+int diga_pyramid_sum_bwd3(const float* dout, int64_t H, int64_t W, float* ds2, float* ds4, float* ds8, int64_t N, int64_t C, void* stream);
 
 /* 3x3 stride-2 pad-1 max-pool with ceil_mode (Ho = ceil((H-1)/2)+1 clipped so the last window starts inside);
  * idx [N,Ho,Wo,C] uint8 = winning tap (first maximum); backward gathers, no atomics. */

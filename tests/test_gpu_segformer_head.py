@@ -121,6 +121,48 @@ def test_pyramid_sum_kernels_vs_torch(geom):
         assert_close(got.grad, want.grad, 1e-5, 1e-5 * float(want.grad.abs().max()), "grad " + what)
 
 
+@pytest.mark.parametrize("n,c,H,W", [(2, 32, 48, 64), (1, 16, 16, 16), (3, 48, 32, 80)])
+def test_fused_three_ratio_backward_vs_per_ratio_kernels(n, c, H, W):
+    """diga_pyramid_sum_bwd3 (LDS-staged tile, all of ratios 2 / 4 / 8 from one pass over the fine gradient) against the three
+    per-ratio gathers: same weights, another summation order."""
+    from diga_amd import _lib
+    gen = synth.gen(H + W + c)
+    g = torch.randn((n, H, W, c), generator=gen).to(DEV)
+    outs3 = [torch.empty((n, H // r, W // r, c), device=DEV) for r in (2, 4, 8)]
+    _lib.call("diga_pyramid_sum_bwd3", _lib.ptr(g), H, W, *[_lib.ptr(o) for o in outs3], n, c, _lib.stream())
+    for r, o3 in zip((2, 4, 8), outs3):
+        o1 = torch.empty_like(o3)
+        _lib.call("diga_pyramid_sum_bwd", _lib.ptr(g), H, W, _lib.ptr(o1), H // r, W // r, n, c, _lib.stream())
+        assert_close(o3, o1, 2e-6, 2e-6 * float(o1.abs().max()), f"ratio {r}")
+
+
+@pytest.mark.parametrize("n,c,H,W", [(2, 64, 48, 64), (1, 32, 16, 16), (3, 96, 32, 80)])
+def test_tiled_forward_bit_identical_and_its_batchnorm_statistics(n, c, H, W):
+    """diga_pyramid_sum_fwd3 (coarse tiles staged in LDS) must reproduce the flat kernel to the last bits, and the per-chunk statistics it
+    leaves for the BatchNorm must finalise to the mean / variance of the map (float64 reference)."""
+    from diga_amd import _lib
+    gen = synth.gen(H * 3 + W + c)
+    fine = torch.randn((n, H, W, c), generator=gen).to(DEV)
+    bias = torch.randn(c, generator=gen).to(DEV)
+    srcs = [torch.randn((n, H // r, W // r, c), generator=gen).to(DEV) for r in (2, 4, 8)]
+    a, b = fine.clone(), fine.clone()
+    _lib.call("diga_pyramid_sum_fwd", _lib.ptr(a), H, W, _lib.ptr(bias), _lib.ptr(srcs[0]), H // 2, W // 2, _lib.ptr(srcs[1]), H // 4, W // 4,
+              _lib.ptr(srcs[2]), H // 8, W // 8, n, c, _lib.stream())
+    stats = torch.empty((n * H * W // 64, 3, c), device=DEV)
+    _lib.call("diga_pyramid_sum_fwd3", _lib.ptr(b), H, W, _lib.ptr(bias), *[_lib.ptr(t) for t in srcs], _lib.ptr(stats), n, c, _lib.stream())
+    # same taps in the same order; the compiler contracts the two kernels' expressions differently: last-bit differences
+    assert_close(b, a, 1e-6, 2e-6, "tiled vs flat")
+    # per chunk: sum (y - s), sum (y - s)^2, s  ->  total mean and (biased) variance
+    sd, sd2, sh = stats[:, 0].double(), stats[:, 1].double(), stats[:, 2].double()
+    m_chunk = sh + sd / 64.0
+    mean = m_chunk.mean(0)
+    ex2 = (sd2 / 64.0 + 2 * sh * (sd / 64.0) + sh * sh).mean(0)      # E[y^2] per chunk = E[(d + s)^2]
+    var = ex2 - mean * mean
+    y = b.double().reshape(-1, c)
+    assert_close(mean, y.mean(0), 1e-5, 1e-5, "mean")
+    assert_close(var, y.var(0, unbiased=False), 1e-4, 1e-5, "var")
+
+
 def test_pyramid_sum_bwd_is_the_exact_adjoint():
     """<resize(s), g> == <s, resize^T(g)> to fp32 rounding at the benchmark's ratios (8, 4, 2) -- the property the gather relies on."""
     from diga_amd import _lib
