@@ -228,7 +228,8 @@ def test_im2col_gemm_is_the_convolution_and_col2im_its_adjoint(kind, c, k, strid
     assert _rel(acc.permute(0, 3, 1, 2), base.double().cpu().permute(0, 3, 1, 2) + xr.grad) < 3e-3
 
 
-ATTN_CASES = [(2, 2, 300, 12), (1, 1, 600, 576), (1, 5, 70, 130), (2, 8, 12, 12), (1, 2, 257, 64), (1, 1, 2304, 576)]
+ATTN_CASES = [(2, 2, 300, 12), (1, 1, 600, 576), (1, 5, 70, 130), (2, 8, 12, 12), (1, 2, 257, 64), (1, 1, 2304, 576),
+              (2, 2, 1000, 100), (1, 8, 576, 576), (1, 1, 513, 608)]       # (the last three: many query blocks per (image, head), ragged N and Nk)
 
 
 @pytest.mark.parametrize("b,heads,n,nk", ATTN_CASES)
