@@ -66,6 +66,11 @@ __device__ __forceinline__ f16x8 col_frag(const unsigned char* img, int kk, int 
                    img + r1 * kRowB + ((chunk ^ swz128(r1)) << 4) + ((pp & 1) << 3));
 }
 
+// exp2 as ONE v_exp_f32: exp2f() wraps the instruction in a denormal-range rescue (compare, select, ldexp: five instructions per
+// element, 34 v_exp_f32 + 36 v_ldexp_f32 + 57 v_cmp + 104 v_cndmask per key block in the forward) for results below 2^-126 -- which
+// vanish in every sum and fp16 cast they enter here
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ f16x8 pack8(const f32x4& a, const f32x4& b) {
     return (f16x8){(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
 }
@@ -147,7 +152,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
                 s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[t][1], acc, 0, 0, 0);
             }
         }
-        const bool tail = kb * 64 + 64 > a.Nk;
+        if (kb * 64 + 64 > a.Nk) {                             // last key block of a ragged sequence (uniform branch): keys past Nk
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kb * 64 + 16 * kt + 4 * g + e >= a.Nk) s[kt][t][e] = -1e30f;
+        }
         f16x8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -156,10 +169,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (tail && kb * 64 + 16 * kt + 4 * g + e >= a.Nk) s[kt][t][e] = -1e30f;
-                    bm = fmaxf(bm, s[kt][t][e]);
-                }
+                for (int e = 0; e < 4; ++e) bm = fmaxf(bm, s[kt][t][e]);
             bm = group_max(bm);
             const float mn = fmaxf(m[t], bm);
             if (__any(mn > m[t])) {                                 // wave-uniform: the running maximum rarely moves after the first blocks
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p = exp2f(fmaf(s[kt][t][e], a.scale_log2e, off));
+                    const float p = fast_exp2(fmaf(s[kt][t][e], a.scale_log2e, off));
                     s[kt][t][e] = p;
                     ps += p;
                 }
@@ -286,11 +296,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
                 pa = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, df[t][1], pa, 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float p = exp2f(sa[e] * a.scale_log2e - lse[t]);
-                    if (tail && kb * 64 + 16 * kt + 4 * g + e >= a.Nk) p = 0.f;
+                    const float p = fast_exp2(sa[e] * a.scale_log2e - lse[t]);
                     ds[kt][t][e] = p * (pa[e] - delta[t]) * a.scale;
                 }
             }
+        }
+        if (tail) {                                            // (uniform branch) keys past Nk: clamped copies of the last key
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kb * 64 + 16 * kt + 4 * g + e >= a.Nk) ds[kt][t][e] = 0.f;
         }
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -394,11 +412,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             const float le[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float pe = exp2f(sa[e] * a.scale_log2e - le[e]);
-                if (qtail && qb * 64 + 16 * qt + 4 * g + e >= a.N) pe = 0.f;        // rows past N were filled with a clamped query
+                const float pe = fast_exp2(sa[e] * a.scale_log2e - le[e]);
                 p[qt][e] = pe;
                 ds[qt][e] = pe * (pa[e] - de[e]) * a.scale;
             }
+        }
+        if (qtail) {                                           // (uniform branch) rows past N were filled with a clamped query
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (qb * 64 + 16 * qt + 4 * g + e >= a.N) p[qt][e] = ds[qt][e] = 0.f;
         }
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
