@@ -56,7 +56,9 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 // largest single cost of the depthwise-conv kernels.)
 __device__ __forceinline__ void gelu_terms(float u, float& cdf, float& pdf) {
     const float x = fabsf(u) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.f + 0.3275911f * x);
+    // (__builtin_amdgcn_rcpf: the bare v_rcp_f32, 1 ulp; __frcp_rn is the correctly rounded reciprocal = the IEEE division sequence,
+    //  div_scale x 2 + rcp + 4 fma + div_fmas + div_fixup per element -- a third of the depthwise forward's VALU instructions)
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
     const float e = __expf(-x * x);                                  // = exp(-u^2 / 2)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.f - poly * e;
