@@ -135,6 +135,84 @@ __device__ __forceinline__ void epilogue_tile(f32x16 (&acc)[TM][TN], float* __re
     drain_stage<TM, TN, EPI>(stage, a, m0, n0, t, tile_m);
 }
 
+// Row loop of the backward-data epilogue (drain_stage, EPI), one instantiation per operand combination:
+//   ADD: out = acc + addend;  MK: 0 no mask, 1 keep where mask_y > 0, 2 mask bits, 3 keep where fma(x, a, b) > 0;  XX: x is given
+//   (needed by MK == 3 and by the BatchNorm-backward sums).  Same expressions in the same order as the generic loop it replaces.
+template <int TM, int TN, int NTHR, bool ADD, int MK, bool XX>
+__device__ __forceinline__ void epi_rows(const float* __restrict__ stage, const ConvArgs& a, int m0, int n, bool col_ok, int cq, int rg,
+                                         const float (&ra)[4], const float (&rb)[4], const float (&mu)[4], const float (&is)[4],
+                                         float (&sd)[4], float (&sd2)[4]) {
+    constexpr int BN = 64 * TN, LDS_LD = BN + 4, CQ = BN / 4, RG = NTHR / CQ, RPT = 128 / RG;
+    constexpr int RB = RPT >= 4 ? 4 : RPT;
+    static_assert(MK != 3 || XX, "the relu_ab mask reads x");
+    const int nn = col_ok ? n : 0;
+    const int mlast = a.M - 1;
+    // running row pointers (rows rg, rg + RG, ...): one 64-bit add per row and operand instead of a 64-bit multiply
+    const int mfirst = m0 + rg;
+    const int64_t r0 = mfirst < a.M ? mfirst : mlast;
+    const float* pa = ADD ? a.e_add + r0 * a.e_add_ld + nn : nullptr;
+    const float* px = XX ? a.e_x + r0 * a.e_x_ld + nn : nullptr;
+    const float* py = MK == 1 ? a.e_masky + r0 * a.e_masky_ld + nn : nullptr;
+    const unsigned char* pb = MK == 2 ? a.e_maskbits + r0 * a.e_maskbits_ld + (nn >> 3) : nullptr;
+    float* po = a.out + (int64_t)mfirst * a.out_ld + n;
+    const int64_t sa = (int64_t)RG * a.e_add_ld, sx = (int64_t)RG * a.e_x_ld, sy = (int64_t)RG * a.e_masky_ld,
+                  sb = (int64_t)RG * a.e_maskbits_ld, so = (int64_t)RG * a.out_ld;
+    const bool whole = m0 + 128 <= a.M;                         // (uniform) every row of this half-tile exists
+    const int shb = nn & 4;
+#pragma unroll
+    for (int k0 = 0; k0 < RPT; k0 += RB) {
+        float4 va[RB], vx[RB], vy[RB];
+        unsigned vb[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            // rows beyond M (last tile only): the pointers stop advancing past the last row -- loads stay in bounds, nothing is stored
+            if (ADD) va[u] = *reinterpret_cast<const float4*>(pa);
+            if (XX) vx[u] = *reinterpret_cast<const float4*>(px);
+            if (MK == 1) vy[u] = *reinterpret_cast<const float4*>(py);
+            if (MK == 2) vb[u] = (unsigned)*pb >> shb;
+            if (k0 + u + 1 < RPT) {
+                const bool nxt = whole || m0 + rg + RG * (k0 + u + 1) <= mlast;
+                if (ADD) pa += nxt ? sa : 0;
+                if (XX) px += nxt ? sx : 0;
+                if (MK == 1) py += nxt ? sy : 0;
+                if (MK == 2) pb += nxt ? sb : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int r = rg + RG * (k0 + u);
+            const float4 v4 = *reinterpret_cast<const float4*>(stage + r * LDS_LD + cq * 4);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            if (ADD) {
+                v[0] += va[u].x; v[1] += va[u].y; v[2] += va[u].z; v[3] += va[u].w;
+            } else {
+                v[0] += 0.f; v[1] += 0.f; v[2] += 0.f; v[3] += 0.f;      // (the generic loop added a zero addend: -0 -> +0)
+            }
+            float xx[4] = {0.f, 0.f, 0.f, 0.f};
+            if (XX) { xx[0] = vx[u].x; xx[1] = vx[u].y; xx[2] = vx[u].z; xx[3] = vx[u].w; }
+            if (MK == 1) {
+                v[0] = vy[u].x > 0.f ? v[0] : 0.f; v[1] = vy[u].y > 0.f ? v[1] : 0.f;
+                v[2] = vy[u].z > 0.f ? v[2] : 0.f; v[3] = vy[u].w > 0.f ? v[3] : 0.f;
+            } else if (MK == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ((vb[u] >> e) & 1u) ? v[e] : 0.f;
+            } else if (MK == 3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xx[e], ra[e], rb[e]) > 0.f ? v[e] : 0.f;
+            }
+            if (col_ok && (whole || m0 + r < a.M)) {
+                store4_stream(po, v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sd[e] += v[e];
+                    sd2[e] += v[e] * ((xx[e] - mu[e]) * is[e]);
+                }
+            }
+            po += so;
+        }
+    }
+}
+
 // Second half of the epilogue: 128 staged rows x 64*TN columns (row stride 64*TN + 4 floats) -> global memory
 // (+ bias, + BatchNorm partials for 128-row chunk `tile_m`).  Entered after a barrier that follows the stage writes.
 // active = false: a thread group whose 128-row half lies beyond M still walks the barriers (nothing is stored).
@@ -180,52 +258,26 @@ __device__ __forceinline__ void drain_stage(const float* stage_in, const ConvArg
             is[0] = t1.x; is[1] = t1.y; is[2] = t1.z; is[3] = t1.w;
         }
         // The epilogue moves 3-4x the bytes of the tile itself: rows are taken four at a time with all their loads
-        // (up to 12 x 16 B per thread, ~48 KB per block) in flight before the first use.
-        constexpr int RB = RPT >= 4 ? 4 : RPT;      // (acc registers are dead here: 48 row-buffer registers fit)
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k0 = 0; k0 < RPT; k0 += RB) {
-            float4 va[RB], vx[RB], vy[RB];
-            unsigned vb[RB];
-            bool ok[RB];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int m = m0 + rg + RG * (k0 + u);
-                ok[u] = m < a.M && col_ok;
-                const int64_t mm = ok[u] ? m : 0;
-                const int nn = col_ok ? n : 0;
-                va[u] = a.e_add != nullptr ? *reinterpret_cast<const float4*>(a.e_add + mm * a.e_add_ld + nn) : z4;
-                vx[u] = a.e_x != nullptr ? *reinterpret_cast<const float4*>(a.e_x + mm * a.e_x_ld + nn) : z4;
-                vy[u] = a.e_masky != nullptr ? *reinterpret_cast<const float4*>(a.e_masky + mm * a.e_masky_ld + nn) : z4;
-                vb[u] = a.e_maskbits != nullptr ? a.e_maskbits[mm * a.e_maskbits_ld + (nn >> 3)] >> (nn & 4) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int r = rg + RG * (k0 + u);
-                const int m = m0 + r;
-                const float4 v4 = *reinterpret_cast<const float4*>(stage + r * LDS_LD + cq * 4);
-                float v[4] = {v4.x + va[u].x, v4.y + va[u].y, v4.z + va[u].z, v4.w + va[u].w};
-                const float xx[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
-                if (a.e_masky != nullptr) {
-                    v[0] = vy[u].x > 0.f ? v[0] : 0.f; v[1] = vy[u].y > 0.f ? v[1] : 0.f;
-                    v[2] = vy[u].z > 0.f ? v[2] : 0.f; v[3] = vy[u].w > 0.f ? v[3] : 0.f;
-                } else if (a.e_maskbits != nullptr) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ((vb[u] >> e) & 1u) ? v[e] : 0.f;
-                } else if (a.e_relu_ab != nullptr) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xx[e], ra[e], rb[e]) > 0.f ? v[e] : 0.f;
-                }
-                if (ok[u]) {
-                    store4_stream(a.out + (int64_t)m * a.out_ld + n, v[0], v[1], v[2], v[3]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        sd[e] += v[e];
-                        sd2[e] += v[e] * ((xx[e] - mu[e]) * is[e]);
-                    }
-                }
-            }
+        // (up to 12 x 16 B per thread, ~48 KB per block) in flight before the first use.  Which operands exist is uniform over the
+        // grid: one instantiation of the row loop per combination (addend?, mask kind, x?), entered through scalar branches, with
+        // running row pointers -- written with the nullable pointers tested per element the loop was 3000 VALU instructions per
+        // thread (selects, 64-bit multiplies for every row address): 24 000 cycles per tile and SIMD against the 65 000 of a
+        // K = 256 tile's MFMAs, during which the matrix pipe idles (the 60 % of conv_fwd_dma_kernel<true>).
+        const int mk = a.e_masky != nullptr ? 1 : a.e_maskbits != nullptr ? 2 : a.e_relu_ab != nullptr ? 3 : 0;
+        const bool has_add = a.e_add != nullptr, has_x = a.e_x != nullptr;
+#define DIGA_EPI_ROWS(ADD, MK, XX) epi_rows<TM, TN, NTHR, ADD, MK, XX>(stage, a, m0, n, col_ok, cq, rg, ra, rb, mu, is, sd, sd2)
+        if (has_add) {
+            if (mk == 2) { if (has_x) DIGA_EPI_ROWS(true, 2, true); else DIGA_EPI_ROWS(true, 2, false); }
+            else if (mk == 3) DIGA_EPI_ROWS(true, 3, true);
+            else if (mk == 1) { if (has_x) DIGA_EPI_ROWS(true, 1, true); else DIGA_EPI_ROWS(true, 1, false); }
+            else { if (has_x) DIGA_EPI_ROWS(true, 0, true); else DIGA_EPI_ROWS(true, 0, false); }
+        } else {
+            if (mk == 2) { if (has_x) DIGA_EPI_ROWS(false, 2, true); else DIGA_EPI_ROWS(false, 2, false); }
+            else if (mk == 3) DIGA_EPI_ROWS(false, 3, true);
+            else if (mk == 1) { if (has_x) DIGA_EPI_ROWS(false, 1, true); else DIGA_EPI_ROWS(false, 1, false); }
+            else { if (has_x) DIGA_EPI_ROWS(false, 0, true); else DIGA_EPI_ROWS(false, 0, false); }
         }
+#undef DIGA_EPI_ROWS
         if (a.e_partials == nullptr) return;   // uniform over the grid
         __syncthreads();
         float* red = stage;                    // [2][RG][BN]
