@@ -2751,20 +2751,37 @@ __global__ __launch_bounds__(JUNC ? 1024 : 768, JUNC ? 4 : 3) void gemm_f32_pers
                 // first row (register 0 of the lower lane half), sum (y - s), sum (y - s)^2 over the valid rows
                 const float sh = __shfl(acc[0][j][0] + bv, li, 64);
                 float sd = 0.f, sd2 = 0.f;
+                if (row_w + 64 <= g.M) {
+                    // (uniform branch) all 64 rows of the wave's piece exist -- every tile but the last row tile: no per-element
+                    // compare + exec-mask around each of the 64 stores
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int r = i * 32 + (e & 3) + 8 * (e >> 2);
-                        const float v = acc[i][j][e] + bv;
-                        if (r < rows_left) {
+                        for (int e = 0; e < 16; ++e) {
+                            const int r = i * 32 + (e & 3) + 8 * (e >> 2);
+                            const float v = acc[i][j][e] + bv;
                             __builtin_nontemporal_store(v, o + (int64_t)r * g.out_ld + j * 32);
                             const float d = v - sh;
                             sd += d;
                             sd2 += d * d;
+                            acc[i][j][e] = 0.f;
                         }
-                        acc[i][j][e] = 0.f;
-                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int r = i * 32 + (e & 3) + 8 * (e >> 2);
+                            const float v = acc[i][j][e] + bv;
+                            if (r < rows_left) {
+                                __builtin_nontemporal_store(v, o + (int64_t)r * g.out_ld + j * 32);
+                                const float d = v - sh;
+                                sd += d;
+                                sd2 += d * d;
+                            }
+                            acc[i][j][e] = 0.f;
+                        }
+                }
                 if (g.stats != nullptr && row_w < g.M) {
                     sd += __shfl_xor(sd, 32, 64);
                     sd2 += __shfl_xor(sd2, 32, 64);
