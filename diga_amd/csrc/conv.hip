@@ -143,7 +143,7 @@ __device__ __forceinline__ void epi_rows(const float* __restrict__ stage, const 
                                          const float (&ra)[4], const float (&rb)[4], const float (&mu)[4], const float (&is)[4],
                                          float (&sd)[4], float (&sd2)[4]) {
     constexpr int BN = 64 * TN, LDS_LD = BN + 4, CQ = BN / 4, RG = NTHR / CQ, RPT = 128 / RG;
-    constexpr int RB = RPT >= 4 ? 4 : RPT;
+    constexpr int RB = RPT >= 8 ? 8 : RPT;
     static_assert(MK != 3 || XX, "the relu_ab mask reads x");
     const int nn = col_ok ? n : 0;
     const int mlast = a.M - 1;
