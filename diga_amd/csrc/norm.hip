@@ -36,8 +36,15 @@ struct ColGeom {
 
 // thread -> (channel quad q, row lane rl): tq = C/4 quads; if tq >= 256 every thread walks quads q, q+256, ...
 // over all rows of the chunk; else 256/tq row lanes share a quad and are summed through LDS.
-template <int NV, class F>
-__device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk, float* __restrict__ out, F&& f) {
+struct NoPrep {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// prep(c) runs once per column group a thread walks, before its rows: per-channel coefficients belong there -- loaded inside f they
+// are re-fetched for every row (the compiler cannot hoist them past the stores of the reduction: bwd_partial_kernel issued 16 scalar
+// loads next to the 2 row loads of every row and ran at a quarter of the HBM rate)
+template <int NV, class F, class P = NoPrep>
+__device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk, float* __restrict__ out, F&& f, P&& prep = NoPrep()) {
     // out: [NV][C] partial sums of this (seg, chunk); f(row_global, c, acc[NV][4]) accumulates one float4 column group
     __shared__ float red[kNormThreads][4];
     const int tq = g.C >> 2;
@@ -52,6 +59,7 @@ __device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk,
             for (int v = 0; v < NV; ++v)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[v][e] = 0.f;
+            prep(q * 4);
 #pragma unroll 8
             for (int64_t r = r0; r < r1; ++r) f(r, r0, q * 4, acc);
 #pragma unroll
@@ -68,6 +76,7 @@ __device__ __forceinline__ void chunk_walk(const ColGeom& g, int seg, int chunk,
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[v][e] = 0.f;
         if (rl < lanes) {
+            prep(q * 4);
             // 8 independent row loads in flight per thread: these kernels are pure HBM streams
             int64_t r = r0 + rl;
             for (; r + 7 * (int64_t)lanes < r1; r += 8 * (int64_t)lanes) {
@@ -274,6 +283,7 @@ __global__ __launch_bounds__(kNormThreads) void bwd_partial_kernel(const float* 
     // relu_ab (BatchNorm without residual, y == nullptr): [2][C] forward coefficients; mask = fma(x, a, b) > 0
     const int chunk = blockIdx.x, seg = blockIdx.y;
     float* out = partial + ((int64_t)seg * g.nchunk + chunk) * 2 * g.C;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f}, ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
     chunk_walk<2>(g, seg, chunk, out, [&](int64_t r, int64_t, int c, float (&acc)[2][4]) {
         const float4 gv = *reinterpret_cast<const float4*>(dy + r * ld_dy + c);
         const float4 xv = *reinterpret_cast<const float4*>(x + r * ld_x + c);
@@ -286,15 +296,22 @@ __global__ __launch_bounds__(kNormThreads) void bwd_partial_kernel(const float* 
             for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
         } else if (relu_ab != nullptr) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                gg[e] = __builtin_fmaf(xx[e], relu_ab[c + e], relu_ab[g.C + c + e]) > 0.f ? gg[e] : 0.f;
+            for (int e = 0; e < 4; ++e) gg[e] = __builtin_fmaf(xx[e], ra[e], rb[e]) > 0.f ? gg[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int si = seg * st_seg_stride + (c + e) / cdiv;
-            const float xh = mean != nullptr ? (xx[e] - mean[si]) * invstd[si] : xx[e];      // null statistics: mean 0, invstd 1
+            const float xh = (xx[e] - mu[e]) * is[e];                  // null statistics: mean 0, invstd 1
             acc[0][e] += gg[e];
             acc[1][e] += gg[e] * xh;
+        }
+    }, [&](int c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int si = seg * st_seg_stride + (c + e) / cdiv;
+            mu[e] = mean != nullptr ? mean[si] : 0.f;
+            is[e] = mean != nullptr ? invstd[si] : 1.f;
+            ra[e] = relu_ab != nullptr ? relu_ab[c + e] : 0.f;
+            rb[e] = relu_ab != nullptr ? relu_ab[g.C + c + e] : 0.f;
         }
     });
 }
