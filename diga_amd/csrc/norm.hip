@@ -108,14 +108,14 @@ __global__ __launch_bounds__(kNormThreads) void colstats_partial_kernel(const fl
                                                                          ColGeom g, float* __restrict__ partial) {
     const int chunk = blockIdx.x, seg = blockIdx.y;
     float* out = partial + ((int64_t)seg * g.nchunk + chunk) * 3 * g.C;
-    chunk_walk<2>(g, seg, chunk, out, [&](int64_t r, int64_t r0, int c, float (&acc)[2][4]) {
+    const int64_t r0 = (int64_t)seg * g.rows_per_seg + (int64_t)chunk * g.chunk_rows;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);                    // the shift: the chunk's first row, fetched once per column group
+    chunk_walk<2>(g, seg, chunk, out, [&](int64_t r, int64_t, int c, float (&acc)[2][4]) {
         const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
-        const float4 s = *reinterpret_cast<const float4*>(x + r0 * ld + c);
         const float d0 = v.x - s.x, d1 = v.y - s.y, d2 = v.z - s.z, d3 = v.w - s.w;
         acc[0][0] += d0; acc[0][1] += d1; acc[0][2] += d2; acc[0][3] += d3;
         acc[1][0] += d0 * d0; acc[1][1] += d1 * d1; acc[1][2] += d2 * d2; acc[1][3] += d3 * d3;
-    });
-    const int64_t r0 = (int64_t)seg * g.rows_per_seg + (int64_t)chunk * g.chunk_rows;
+    }, [&](int c) { s = *reinterpret_cast<const float4*>(x + r0 * ld + c); });
     for (int c = threadIdx.x; c < g.C; c += kNormThreads) out[2 * g.C + c] = x[r0 * ld + c];
 }
 
