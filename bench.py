@@ -225,6 +225,40 @@ def miou_parity_subprocess(limit_s=300):
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 launcher
+def rank_threads(local_world):
+    """Host threads one rank may use: the step is ~2 600 asynchronous launches from ONE Python thread (+ autograd's backward
+    thread); torch's intra-op pool is only touched by the few CPU-side tensor ops of ClassMix.  cores / ranks, capped at 8."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    return max(1, min(8, cores // max(local_world, 1)))
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """Multi-rank host hygiene, called BEFORE the rank touches the GPU: the rank's threads are confined to its own contiguous
+    slice of the cores this process may run on (8 ranks x 256 unpinned torch threads on a 2-socket host otherwise migrate across
+    sockets while they drive thousands of launches per step), and OMP / torch intra-op threads are capped (`rank_threads`).
+    Contiguous slices keep a rank on one socket / NUMA node for the usual core numbering.  DIGA_BENCH_PIN=0 switches it off.
+    Returns a dict for the bench line (`host`)."""
+    info = {"local_rank": local_rank, "local_world": local_world, "pinned": False}
+    threads = rank_threads(local_world)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    info["omp_num_threads"] = int(os.environ["OMP_NUM_THREADS"])
+    if local_world <= 1 or os.environ.get("DIGA_BENCH_PIN", "1") == "0":
+        return info
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per >= 1:
+            mine = cores[local_rank * per:(local_rank + 1) * per]
+            os.sched_setaffinity(0, mine)
+            info.update(pinned=True, cores=[mine[0], mine[-1]], n_cores=len(mine))
+    except (AttributeError, OSError) as e:          # (not fatal: a container may forbid it)
+        info["pin_error"] = str(e)
+    return info
+
+
 def spawn_workers(a):
     """--gpus N > 1 without a torchrun environment: start N fresh worker processes (this process has not touched the
     GPU and never will), one rank per GPU; rank 0 inherits stdout and prints the JSON line."""
@@ -232,9 +266,11 @@ def spawn_workers(a):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    threads = rank_threads(a.gpus)
     for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(threads)),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         out = None if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
     rc = 0
@@ -339,6 +375,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
     if prof_timed:
         _lib.call("diga_prof_reset")
         _lib.call("diga_prof_enable", 1)
+    torch.cuda.reset_peak_memory_stats(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -347,6 +384,9 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    # peak device memory of the timed region: what the step's tensors occupy at their high-water mark (allocated) and what the
+    # caching allocator holds from the driver for them (reserved); workspaces and kept Winograd transforms included
+    peak_mem = {"allocated": torch.cuda.max_memory_allocated(dev) / 1e9, "reserved": torch.cuda.max_memory_reserved(dev) / 1e9}
     if prof_timed:
         _lib.call("diga_prof_enable", 0)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -365,6 +405,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
         if not agree:
             raise SystemExit(f"rank {rank}: student parameters differ across ranks after the timed region: {[float(c) for c in allc]}")
     losses["_ranks_agree"] = agree
+    losses["_peak_mem_gb"] = peak_mem
 
     def query(nsteps):
         fam = {}
@@ -634,8 +675,14 @@ def main():
     cpu_line = None
     if world_env == 1 and not a.no_cpu_baseline:
         cpu_line = cpu_baseline_subprocess()
+    host = None
+    if world_env > 1:
+        # (before `import torch` reads OMP_NUM_THREADS and before anything touches the GPU)
+        host = pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world_env))))
     import torch
     from diga_amd import ddp
+    if host is not None:
+        torch.set_num_threads(host["omp_num_threads"])
     rank, world, local = ddp.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
@@ -664,7 +711,7 @@ def main():
                       "dtype": DTYPE[oprec], "value": world * B * a.other_steps / odt,
                       "unit": "crops/s" if a.config != "c4" else "pairs/s", "n_gpus": world,
                       "steps": a.other_steps, "warmup": a.other_warmup, "ms_per_step": 1e3 * odt / a.other_steps,
-                      "timed_region_s": odt, "roofline": oroof, "roofline_other_kernels": oother,
+                      "timed_region_s": odt, "peak_mem_gb": olosses.get("_peak_mem_gb"), "roofline": oroof, "roofline_other_kernels": oother,
                       "kernel_families": ofam, "losses_last_step": {k: v for k, v in olosses.items() if not k.startswith("_")}}
     other_cfg = {}
     if not a.no_other_configs and (world == 1 or a.multi_gpu_legs):
@@ -681,7 +728,7 @@ def main():
                 "metric": (f"{cH}x{cW} 19-class (source,target) crop pairs/sec (DiGA self-training step)" if cfg == "c4"
                            else f"{cH}x{cW} 19-class crops/sec (DiGA warm-up step)"),
                 "value": world * cB * st / cdt, "unit": "pairs/s" if cfg == "c4" else "crops/s", "steps": st, "warmup": wu,
-                "ms_per_step": 1e3 * cdt / st, "n_gpus": world,
+                "ms_per_step": 1e3 * cdt / st, "n_gpus": world, "peak_mem_gb": closs.get("_peak_mem_gb"),
                 "dtype": ("fp16 storage / fp32 accumulate (MiT encoder); head convs " + a.precision) if cfg == "c5" else a.precision,
                 "kernel_families": cfam if cfg in ("c5", "c4") else None,
                 "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea},
@@ -734,7 +781,7 @@ def main():
                        "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
                        "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea}},
             "rccl_ranks": world, "backend": backend if world > 1 else "none (single process)",
-            "ranks_agree": losses.pop("_ranks_agree", None),
+            "ranks_agree": losses.pop("_ranks_agree", None), "peak_mem_gb": losses.pop("_peak_mem_gb", None), "host": host,
             "roofline": roof, "roofline_other_kernels": other, "bandwidth_kernels": bw, "cpu_baseline": cpu_line,
             "second_precision": other_line, "timed_region_s": dt, "other_configs": other_cfg or None, "miou_parity": miou, "kernel_families": families,
             "kernel_families_overlapped": None if a.serial_streams else families_ov, "losses_last_step": losses,
@@ -772,6 +819,7 @@ def compact(line):
         r = d.get("roofline") or d.get("roofline_conv_fwd") or {}
         return {"value": num(d["value"]), "unit": d["unit"], "ms_per_step": num(d["ms_per_step"]), "steps": d["steps"],
                 "warmup": d["warmup"], "dtype": d["dtype"].split(" (")[0], "frac": num(r.get("frac")),
+                "peak_mem_gb": num((d.get("peak_mem_gb") or {}).get("allocated"), 4),
                 **({"head": d["head"]} if "head" in d else {})}
 
     oc = line.get("other_configs") or {}
@@ -782,6 +830,8 @@ def compact(line):
     cfg = line["config"]
     out["config"] = {"workload": cfg["workload"][:220], "global_batch": cfg["global_batch"], "crop": cfg["crop"],
                      "parallelism": cfg["parallelism"]}
+    pm = line.get("peak_mem_gb") or {}
+    out["peak_mem_gb"] = {k: num(v, 4) for k, v in pm.items()} or None
     out.update(rccl_ranks=line["rccl_ranks"], backend=line.get("backend"), ranks_agree=line.get("ranks_agree"), roofline=roof, cpu_baseline=cpu, target=line.get("target"),
                second_precision=leg(line.get("second_precision")), c4_selftrain=leg(oc.get("c4")), c5_segformer=leg(oc.get("c5")),
                detail=line.get("detail_file"))

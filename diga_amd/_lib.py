@@ -74,7 +74,7 @@ SIGNATURES = {
     "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, INT, P, F32, F32, P, SZ, P]),
     "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, I64, P, SZ, P]),
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
-    "diga_bn_bwd_affine": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, P, SZ, P]),
+    "diga_bn_bwd_affine": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, INT, P, SZ, P]),
     "diga_pyramid_sum_fwd": (INT, [P, I64, I64, P, P, I64, I64, P, I64, I64, P, I64, I64, I64, I64, P]),
     "diga_pyramid_sum_bwd": (INT, [P, I64, I64, P, I64, I64, I64, I64, P]),
     "diga_pyramid_sum_fwd3": (INT, [P, I64, I64, P, P, P, P, P, I64, I64, P]),
@@ -181,14 +181,23 @@ CONV_MATH_F32, CONV_MATH_BF16X3 = 0, 1
 _conv_math = CONV_MATH_BF16X3 if os.environ.get("DIGA_CONV_MATH", "") in ("bf16x3", "1") else CONV_MATH_F32
 
 
-def set_conv_math(mode):
-    """0 / "f32": exact fp32 on the fp32 matrix cores; 1 / "bf16x3": fp32 operands split into bf16 hi+lo, three bf16 MFMAs
-    per product.  Selects which entry points DigaConv2d calls from now on; graphs already built keep the arithmetic of
-    their forward pass only where they hold split-twin tensors (DigaConv2d checks and raises otherwise)."""
+def set_conv_math(mode, exact=None):
+    """0 / "f32": fp32 operands and fp32 accumulation on the fp32 matrix cores -- the 1x1 / strided / stem layers as a k-ordered
+    fmaf chain, the stride-1 3x3 layers through fp32 Winograd with output tiles up to 6x6 (per-layer error vs float64 <= 2.7e-5 of
+    scale instead of the direct chain's 3e-7); 1 / "bf16x3": fp32 operands split into bf16 hi+lo, three bf16
+    MFMAs per product.  `exact=True` (fp32 only) caps every Winograd layer at F(2x2,3x3), whose transforms hold 0, +-1, +-1/2 only:
+    the direct kernels' error level (7e-7), at ~25 % more step time; `exact=False` restores the default tiles; None leaves the
+    tile cap alone.  Selects which entry points DigaConv2d calls from now on; graphs already built keep the arithmetic of their
+    forward pass only where they hold split-twin tensors (DigaConv2d checks and raises otherwise)."""
     global _conv_math
     mode = {"f32": 0, "bf16x3": 1}.get(mode, mode)
     if mode not in (CONV_MATH_F32, CONV_MATH_BF16X3):
         raise ValueError(f"conv math must be 0 / 'f32' or 1 / 'bf16x3', not {mode!r}")
+    if exact is not None:
+        if exact and mode != CONV_MATH_F32:
+            raise ValueError("exact=True belongs to the fp32 arithmetic")
+        from diga_amd.model import conv as _conv
+        _conv.WINOGRAD_MAX_TILE = 2 if exact else _conv.WINOGRAD_DEFAULT_MAX_TILE
     _conv_math = int(mode)
 
 

@@ -709,7 +709,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __re
     const int cl = threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
     const int c = blockIdx.x * kFinCh + cl;
     const bool live = c < g.C;
-    const int K = training ? g.nseg * g.nchunk : 0;
+    // (eval mode with a trainable affine pair: the partial sums exist -- they ARE dgamma / dbeta -- but dx takes no mean terms)
+    const int K = (training || dgamma) ? g.nseg * g.nchunk : 0;
     double s1 = 0.0, s2 = 0.0;
     if (live)
 #pragma unroll 4
@@ -1042,7 +1043,7 @@ static int bn_bwd_impl(const float* dy, int64_t ld_dy, const float* x, int64_t l
     float* partial = (float*)workspace;
     float* kk = partial + (size_t)g.nchunk * 3 * C;
     DIGA_REQUIRE(!(y && relu_ab), DIGA_EINVAL, "bn_bwd: pass y or relu_ab, not both");
-    if (training)
+    if (training || dgamma)
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.nchunk, 1), dim3(kNormThreads), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
                            save_mean, save_invstd, 0, 1, g, partial, relu_ab);
     hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma,
@@ -1063,11 +1064,11 @@ extern "C" int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
 
 extern "C" int diga_bn_bwd_affine(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
                                   const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd,
-                                  float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int64_t M, int64_t C, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int training,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(dgamma && dbeta, DIGA_EINVAL, "bn_bwd_affine: dgamma and dbeta are required");
-    return bn_bwd_impl(dy, ld_dy, x, ld_x, y, ld_y, relu_ab, gamma, save_mean, save_invstd, dx, ld_dx, nullptr, 0, M, C, 1, 0, workspace,
-                       workspace_bytes, stream, dgamma, dbeta);
+    return bn_bwd_impl(dy, ld_dy, x, ld_x, y, ld_y, relu_ab, gamma, save_mean, save_invstd, dx, ld_dx, nullptr, 0, M, C, training ? 1 : 0, 0,
+                       workspace, workspace_bytes, stream, dgamma, dbeta);
 }
 
 extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,

@@ -72,13 +72,21 @@ class GradReducer:
     """Bucketed all-reduce(sum) of the gradients of `params` (unique tensors, reverse order so the
     buckets of the last layers -- whose gradients exist first -- go out first).
 
-    With more than one rank every parameter carries a post-accumulate-grad hook: the moment the last
-    gradient of a bucket exists (inside backward) the bucket is packed by one multi-tensor copy and its
-    all-reduce is started asynchronously on RCCL's stream, so all but the last bucket travel under the
-    rest of the backward pass; `reduce()` starts whatever is still pending (gradients that were set by
-    hand), waits, and unpacks with one multi-tensor copy per bucket."""
+    Every bucket is ONE flat buffer, allocated once (first use) and kept for the life of the reducer, and -- with more than one
+    rank and `as_views` -- the gradients LIVE in it: `grad_view(p)` hands out a fresh tensor of p's shape and strides over p's
+    slice of its bucket.  A producer that writes its gradient there (DigaConv2d's weight-gradient kernels do: the parameter
+    carries the callable as `p._diga_grad_view`) has packed it; a gradient that arrives in a tensor of its own (biases, GroupNorm
+    affines, a weight used twice in one graph) is copied into its slice when the bucket is launched and `p.grad` is re-pointed at
+    the slice, so nothing is unpacked after the all-reduce: RCCL reduces the bucket in place and the optimizer reads p.grad =
+    the bucket.  Round 4 packed AND unpacked every bucket with multi-tensor copies (2 x 260 MB read + written per step).
 
-    def __init__(self, params, bucket_bytes=None, group=None, overlap=True):
+    Every parameter carries a post-accumulate-grad hook: the moment the last gradient of a bucket exists (inside backward) its
+    all-reduce is started asynchronously on RCCL's stream, so all but the last bucket travel under the rest of the backward
+    pass; `reduce()` starts whatever is still pending (gradients that were set by hand) and waits.
+    `as_views=False` (the HIP-graph step: the captured backward writes into ITS static gradient tensors, which must stay
+    p.grad): pack, all-reduce, copy back."""
+
+    def __init__(self, params, bucket_bytes=None, group=None, overlap=True, as_views=None):
         self.group = group
         if bucket_bytes is None:
             # ~25 MB buckets (SURVEY 5.8): 260 MB of ResNet-101 gradients leave in ~11 ring all-reduces while backward is
@@ -105,11 +113,33 @@ class GradReducer:
         self._flat = [None] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._ready = [0] * len(self.buckets)
+        self._copy_back = [None] * len(self.buckets)
         self._hooks = []
-        if overlap and world_size() > 1 and os.environ.get("DIGA_DDP_OVERLAP", "1") != "0":
+        self._where = {}                      # id(param) -> (bucket, element offset)
+        for i, bucket in enumerate(self.buckets):
+            off = 0
+            for p in bucket:
+                self._where[id(p)] = (i, off)
+                off += p.numel()
+        active = world_size() > 1
+        self.as_views = (overlap if as_views is None else bool(as_views)) and active and os.environ.get("DIGA_DDP_GRAD_VIEWS", "1") != "0"
+        if overlap and active and os.environ.get("DIGA_DDP_OVERLAP", "1") != "0":
             for i, bucket in enumerate(self.buckets):
                 for p in bucket:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        if self.as_views:
+            for p in self.params:
+                if p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last)):
+                    p._diga_grad_view = self._make_view_fn(p)
+
+    def close(self):
+        """Detach from the parameters (hooks, view callables): a second reducer / trainer on the same parameters starts clean."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            if getattr(p, "_diga_grad_view", None) is not None:
+                del p._diga_grad_view
 
     def _make_hook(self, i):
         def hook(_param):
@@ -124,39 +154,72 @@ class GradReducer:
                 self._launch(i)
         return hook
 
-    def _views(self, i):
-        flat, views, off = self._flat[i], [], 0
-        for p in self.buckets[i]:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        return views
+    def _bucket(self, i, like):
+        flat = self._flat[i]
+        if flat is None or flat.device != like.device or flat.dtype != like.dtype:
+            n = sum(p.numel() for p in self.buckets[i])
+            flat = self._flat[i] = torch.empty(n, dtype=like.dtype, device=like.device)
+        return flat
+
+    def _slice(self, p):
+        i, off = self._where[id(p)]
+        return self._bucket(i, p)[off:off + p.numel()]
+
+    def grad_view(self, p):
+        """A FRESH tensor of p's shape and strides over p's slice of its bucket (fresh: autograd's AccumulateGrad takes a
+        gradient over without a copy only when nothing else holds the tensor object)."""
+        return self._slice(p).as_strided(p.shape, p.stride())
+
+    def _make_view_fn(self, p):
+        def view():
+            return self.grad_view(p)
+        return view
 
     def _launch(self, i):
-        grads = [p.grad for p in self.buckets[i]]
+        bucket = self.buckets[i]
+        grads = [p.grad for p in bucket]
         if any(g is None for g in grads):
             raise RuntimeError("GradReducer: a parameter has no gradient")
-        n = sum(g.numel() for g in grads)
-        flat = self._flat[i]
-        if flat is None or flat.numel() != n or flat.device != grads[0].device:
-            self._flat[i] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        flat = self._bucket(i, grads[0])
+        esz = flat.element_size()
+        dst, src, back = [], [], []
+        for p, g in zip(bucket, grads):
+            _, off = self._where[id(p)]
+            if g.data_ptr() == flat.data_ptr() + off * esz and g.stride() == p.stride():
+                continue                                    # produced in place (or still there from the re-pointing below)
+            if self.as_views and g.stride() == p.stride():
+                v = self.grad_view(p)
+                dst.append(v)
+                src.append(g.detach())
+                p.grad = v                                  # no copy back: the optimizer reads the bucket
+            else:
+                v = flat[off:off + p.numel()].view(g.shape) if g.is_contiguous() else None
+                if v is None:
+                    raise RuntimeError("GradReducer: a gradient that is neither dense nor laid out like its parameter")
+                dst.append(v)
+                src.append(g.detach())
+                back.append((g, v))
+        self._copy_back[i] = back
         side = None
-        if grads[0].is_cuda:
+        if flat.is_cuda:
             from diga_amd import _lib
-            side = _lib.active_side_stream(grads[0].device)
+            side = _lib.active_side_stream(flat.device)
         if side is not None:
             # Weight gradients of this bucket may still be running on the side stream.  Pack and launch FROM the side
             # stream (it first waits for the main stream's work so far: bias / GroupNorm gradients live there): RCCL's
             # stream then orders itself behind the side stream only, and the main stream -- the backward-data /
             # BatchNorm chain -- is never made to wait for a weight gradient inside backward.
-            side.wait_stream(torch.cuda.current_stream(grads[0].device))
+            side.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(side):
-                torch._foreach_copy_(self._views(i), [g.detach() for g in grads])
-                self._work[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            for g in grads:
+                if dst:
+                    torch._foreach_copy_(dst, src)
+                self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            for g in src:
                 g.record_stream(side)
         else:
-            torch._foreach_copy_(self._views(i), [g.detach() for g in grads])
-            self._work[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if dst:
+                torch._foreach_copy_(dst, src)
+            self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def reduce(self):
         """Sum gradients over all ranks in place.  No-op for world size 1."""
@@ -165,9 +228,12 @@ class GradReducer:
         for i in range(len(self.buckets)):
             if self._work[i] is None:
                 self._launch(i)
-        for i, bucket in enumerate(self.buckets):
+        for i in range(len(self.buckets)):
             self._work[i].wait()
-            torch._foreach_copy_([p.grad for p in bucket], self._views(i))
+            back = self._copy_back[i]
+            if back:
+                torch._foreach_copy_([g for g, _ in back], [v for _, v in back])
+            self._copy_back[i] = None
             self._work[i] = None
             self._ready[i] = 0
 

@@ -109,28 +109,48 @@ def _log_flops(name, direct, executed):
 # A/B runs set the module attributes.  WINOGRAD_MAX_TILE 2 keeps every layer on F(2x2,3x3).
 WINOGRAD = os.environ.get("DIGA_CONV_WINOGRAD", "1") != "0"
 WINOGRAD_RATIO = float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62"))
-WINOGRAD_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "6"))
+WINOGRAD_DEFAULT_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "6"))
+WINOGRAD_MAX_TILE = WINOGRAD_DEFAULT_MAX_TILE           # (_lib.set_conv_math(0, exact=True) sets 2)
 WINOGRAD_KEEP_V = os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
-_KEEP_DECISION = {}
+# the keep-V policy is a function of the layer's shape and of STATIC device properties only (round 5; it used to ask the driver how
+# much memory was free at a layer's first forward, so the same binary took different paths -- and speeds -- next to another process):
+KEEP_V_MAX_BYTES = int(float(os.environ.get("DIGA_WINOGRAD_KEEP_V_MAX_GB", "8")) * (1 << 30))         # per layer
+KEEP_V_MIN_DEVICE_BYTES = int(float(os.environ.get("DIGA_WINOGRAD_KEEP_V_MIN_DEVICE_GB", "160")) * (1 << 30))
+_DEVICE_TOTAL = {}
+_KEEP_OFF = set()             # devices on which a keep-V allocation failed: the recompute path from then on (reset_keep_decisions())
 
 
-def _room_for(nbytes, device, key):
-    """Keeping a transformed input alive until the backward pass is a memory-for-bandwidth trade: only while, after the
-    allocation, 40 % of the device (115 of the MI355X's 288 GB) would still be free -- counting what the driver reports
-    free (other processes on the GPU included: two test ranks may share one) plus this process's cached blocks.  The C2 step
-    peaks at 128 GB with everything kept.  Decided ONCE per layer and shape (`key`), at its first forward -- when the kept
-    tensors of the layers in front of it are already allocated -- and cached: later steps (and a captured HIP graph) repeat the
-    first step's choices without a driver query."""
+def reset_keep_decisions():
+    """Forget that a kept-transform allocation ran out of memory (e.g. after the caller freed a second model)."""
+    _KEEP_OFF.clear()
+
+
+def _room_for(nbytes, device):
+    """Keeping a layer's transformed input V alive until its weight gradient is a memory-for-bandwidth trade (the backward-weight
+    pass skips one input transform: a bandwidth pass over the input + V; 26 layers, ~4 ms of a 424 ms C2 step).  Decision:
+    DIGA_WINOGRAD_KEEP_V on (default), the layer's V <= KEEP_V_MAX_BYTES (8 GiB; the largest C2 layer keeps 2.2 GB) and the device
+    has >= KEEP_V_MIN_DEVICE_BYTES of memory in total (160 GiB: an MI355X has 288 GB; the C2 step keeps ~21 GB of V and peaks at
+    the figure bench.py reports as peak_mem_gb) -- shape and static device properties only, no free-memory query.  If the
+    allocation itself fails, `_alloc_keep_v` switches the device to the recompute path."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, nbytes) + tuple(key)
-    ok = _KEEP_DECISION.get(key)
-    if ok is None:
-        if len(_KEEP_DECISION) > 4096:          # (keys hold a weight address: a caller that re-materialises its weights every call
-            _KEEP_DECISION.clear()              #  must not grow the table without bound)
-        free, total = torch.cuda.mem_get_info(idx)
-        cached = torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx)
-        ok = _KEEP_DECISION[key] = bool(free + cached - nbytes > 0.4 * total)
-    return ok
+    if not WINOGRAD_KEEP_V or idx in _KEEP_OFF or nbytes > KEEP_V_MAX_BYTES:
+        return False
+    total = _DEVICE_TOTAL.get(idx)
+    if total is None:
+        total = _DEVICE_TOTAL[idx] = torch.cuda.get_device_properties(idx).total_memory
+    return total >= KEEP_V_MIN_DEVICE_BYTES
+
+
+def _alloc_keep_v(nfloats, device):
+    """The kept transform's buffer, or None when the policy says recompute or the allocation fails (out of memory: the device is
+    switched to the recompute path instead of failing the step)."""
+    if not _room_for(nfloats * 4, device):
+        return None
+    try:
+        return torch.empty(nfloats, dtype=torch.float32, device=device)
+    except torch.cuda.OutOfMemoryError:
+        _KEEP_OFF.add(device.index if device.index is not None else torch.cuda.current_device())
+        return None
 
 
 def _wino_plan(hi, wi, d):
@@ -260,7 +280,6 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         tile, ratio = _wino_plan(hi, wi, d)
         _log_flops(name, direct, direct * ratio)
         nbytes = _lib.lib.diga_conv2d_winograd_workspace_bytes(n, hi, wi, cin, k, d, tile)
-        vkey = (w_krsc.data_ptr(), n, hi, wi, cin, d, tile)
         ws = _lib.workspace(nbytes, x.device, "winograd")
         if epi is not None:
             _lib.call("diga_conv2d_winograd_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
@@ -270,15 +289,16 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
             # x holds the pre-activation values of a BatchNorm + ReLU: the input transform applies relu(fma(x, a, b)) on load
             if epi is not None or doff[0] < 0:
                 raise RuntimeError("DigaConv2d: a deferred BatchNorm input only feeds a forward convolution")
-            if keep_v is not None and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile) * 4, x.device, vkey):
-                keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), dtype=torch.float32, device=x.device)
+            if keep_v is not None:
+                keep_v[0] = _alloc_keep_v(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), x.device)
             _lib.call("diga_conv2d_winograd_f32_ab", _lib.ptr(x), _lib.ptr(in_ab), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out),
                       _lib.ptr(keep_v[0]) if keep_v is not None else None, _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k,
                       out.stride(2), d, tile, tag, _lib.stream())
             return None
-        if keep_v is not None and doff[0] > 0 and _room_for(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile) * 4, x.device, vkey):
+        if keep_v is not None and doff[0] > 0:
             # keep_v: a one-element list -- the transformed input stays alive for this layer's weight gradient
-            keep_v[0] = torch.empty(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), dtype=torch.float32, device=x.device)
+            keep_v[0] = _alloc_keep_v(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), x.device)
+        if keep_v is not None and doff[0] > 0 and keep_v[0] is not None:
             _lib.call("diga_conv2d_winograd_f32_keep", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(keep_v[0]),
                       _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, tag, _lib.stream())
             return None
@@ -434,6 +454,7 @@ class _Conv2dFn(torch.autograd.Function):
                                "(check takes_twin_only_input before asking the producer for a twin)")
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         ctx.uses = uses
+        ctx.grad_view = getattr(weight, "_diga_grad_view", None) if isinstance(weight, nn.Parameter) else None
         # the arithmetic / twin decisions of this forward bind its backward: saved tensors may hold twin bytes
         ctx.math = _lib.get_conv_math()
         ctx.x_is_twin = bool(x_is_twin)
@@ -562,7 +583,22 @@ class _Conv2dFn(torch.autograd.Function):
             if ctx.chain is not None and not ctx.chain.get("disabled") and ctx.chain["remaining"] > 0:
                 dx = None                           # the running sum travels on through the chain; the last member returns it
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_strided((k, c_true, r, s), w_strides, dtype=torch.float32, device=w.device)
+            # A weight that entered the graph more than once (the self-training step runs the student twice) gets its
+            # contributions summed by autograd on the main stream: only the first one of a backward pass may still be
+            # in flight on the side stream when it is handed over, the later ones run in line after a join.
+            # A weight that is NOT a leaf (uses == INLINE_WGRAD: the folded matrices of the SegFormer head, whose gradient the next
+            # autograd node reads at once) is computed in line on the main stream.
+            later = False
+            inline = isinstance(ctx.uses, str)
+            if ctx.uses is not None and not inline:
+                later = ctx.uses[0] > 0
+                ctx.uses[0] += 1
+            # data-parallel runs: the gradient is written straight into the parameter's slice of its all-reduce bucket
+            # (ddp.GradReducer.grad_view: a fresh tensor of the weight's shape and strides over that slice) -- nothing packs it
+            gv = getattr(ctx, "grad_view", None)
+            dw = gv() if (gv is not None and not later and not inline and kp == k and cp == c_true) else None
+            if dw is None or tuple(dw.stride()) != tuple(w_strides) or dw.device != w.device:
+                dw = torch.empty_strided((k, c_true, r, s), w_strides, dtype=torch.float32, device=w.device)
             # the kernels write [K][R][S][C]: for an unpadded channels_last weight that IS dw's memory (no copy afterwards)
             alias = kp == k and cp == c_true and dw.permute(0, 2, 3, 1).is_contiguous()
             dwp = dw.permute(0, 2, 3, 1) if alias else torch.empty((kp, r, s, cp), dtype=torch.float32, device=w.device)
@@ -618,17 +654,8 @@ class _Conv2dFn(torch.autograd.Function):
                     dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
 
             # The weight gradient is a leaf of the backward graph: under the step driver it runs on a second stream
-            # next to the backward-data / BatchNorm chain (the driver joins the streams before the optimizer step).
-            # A weight that entered the graph more than once (the self-training step runs the student twice) gets its
-            # contributions summed by autograd on the main stream: only the first one of a backward pass may still be
-            # in flight on the side stream when it is handed over, the later ones run in line after a join.
-            # A weight that is NOT a leaf (uses == INLINE_WGRAD: the folded matrices of the SegFormer head, whose gradient the next
-            # autograd node reads at once) is computed in line on the main stream.
-            later = False
-            inline = isinstance(ctx.uses, str)
-            if ctx.uses is not None and not inline:
-                later = ctx.uses[0] > 0
-                ctx.uses[0] += 1
+            # next to the backward-data / BatchNorm chain (the driver joins the streams before the optimizer step);
+            # `later` / `inline` (above) keep the exceptions in line.
             if later:
                 _lib.join_side()
             side = None if (later or inline) else _lib.side_stream(w.device)

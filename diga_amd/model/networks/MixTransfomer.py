@@ -409,6 +409,10 @@ class _MitStageFn(torch.autograd.Function):
             grads[pre + ".norm.weight"], grads[pre + ".norm.bias"] = dg, db
             k = st["patch"]
             dwp, grads[pre + ".proj.bias"] = ops.wgrad(d_y, ss["cols"], inv, bias=True)
+            if cfg.get("overflow_flag") is not None:
+                # (d_y is fp16 under the loss scale as well: an overflow born in the patch embedding's LayerNorm backward shows in
+                #  its projection's weight gradient -- a few thousand fp32 values; covers stage 1, which no later check sees)
+                _lib.call("diga_nonfinite_flag_f32", P(dwp), dwp.numel(), P(cfg["overflow_flag"]), _lib.stream())
             grads[pre + ".proj.weight"] = dwp[:, :k * k * sc].reshape(C, k, k, sc).permute(0, 3, 1, 2)
             if ctx.src_needs_grad and ctx.needs_input_grad[0]:
                 d_cols = ops.gemm(d_y, ss["wt16"], None, ss["kp"])
@@ -551,16 +555,27 @@ class MixVisionTransformer(nn.Module):
         return {"names": names, "stage_names": stage_names, "stages": stages, "eps": eps, "training": self.training,
                 "loss_scale": self.loss_scale}
 
-    def adjust_loss_scale(self, factor=0.5, floor=1.0):
-        """Host side of the overflow handling (one device->host read: call it every few hundred steps, not every step): when
-        backward passes overflowed since the last call, the static loss scale is multiplied by `factor`.  Returns the number of
-        overflowed (= skipped) steps since the last call.  A trainer that replays a captured HIP graph must re-capture after a
-        change (the scale is a kernel argument): DigaTrainer does."""
+    def adjust_loss_scale(self, factor=0.5, floor=1.0, steps=200, growth=2.0, growth_interval=1000):
+        """Host side of the overflow handling, a standard dynamic loss scaler at window granularity (one device->host read: call it
+        every `steps` steps, not every step).  Backward passes overflowed since the last call -> the scale is multiplied by `factor`
+        (not below `floor`); `growth_interval` consecutive clean steps -> multiplied by `growth`, capped at the scale the model was
+        built with (a transient spike early in an 80 000-iteration run must not leave the fp16 branch gradients at a reduced scale
+        for the rest of training: they would underflow silently).  Returns the number of overflowed (= skipped) steps since the
+        last call.  A trainer that replays a captured HIP graph must re-capture whenever `loss_scale` changed (the scale is a kernel
+        argument): DigaTrainer compares it before and after."""
         total = int(self.grad_overflow[1].item())
         new = total - self._overflow_seen
         self._overflow_seen = total
+        if not hasattr(self, "_scale_cap"):
+            self._scale_cap, self._clean_steps = float(self.loss_scale), 0
         if new > 0:
             self.loss_scale = max(floor, self.loss_scale * factor)
+            self._clean_steps = 0
+        else:
+            self._clean_steps += int(steps)
+            if self._clean_steps >= growth_interval and self.loss_scale < self._scale_cap:
+                self.loss_scale = min(self._scale_cap, self.loss_scale * growth)
+                self._clean_steps = 0
         return new
 
     def forward_features(self, x):

@@ -139,6 +139,16 @@ class ConvModule(nn.Module):
         self.conv = DigaConv2d(in_channels, out_channels, kernel_size, bias=False)
         self.bn = DigaTrainableBatchNorm2d(out_channels)
         self.activate = nn.ReLU(inplace=True)
+        self.init_weights()
+
+    def init_weights(self):
+        """mmcv's ConvModule initialises itself in its constructor (mmcv 1.x `ConvModule.init_weights`: `kaiming_init(self.conv,
+        a=0, nonlinearity='relu')` = kaiming NORMAL, mode fan_out; `constant_init(self.norm, 1, bias=0)`), which is what a head built
+        from scratch by segformer_head.py:63-68 starts from -- std = sqrt(2 / out_channels) = 0.051 for the 3072 -> 768 fuse conv,
+        not nn.Conv2d's default kaiming-uniform (std 0.010): behind the BatchNorm that is a 25x different effective step size."""
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode="fan_out", nonlinearity="relu")
+        nn.init.constant_(self.bn.weight, 1.0)
+        nn.init.constant_(self.bn.bias, 0.0)
 
     def forward(self, x):
         return self.bn(self.conv(x), relu=True)

@@ -170,13 +170,13 @@ class _BnFn(torch.autograd.Function):
         dgamma = dbeta = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             # trainable affine pair (DigaTrainableBatchNorm2d): the two column sums of the input gradient are its gradients
-            if not training or has_res or ctx.box is not None:
-                raise RuntimeError("DigaTrainableBatchNorm2d: train mode, no residual")
+            if has_res or ctx.box is not None:
+                raise RuntimeError("DigaTrainableBatchNorm2d: no residual input / fused backward epilogue with a trainable affine pair")
             dgamma, dbeta = torch.empty(c, dtype=torch.float32, device=xn.device), torch.empty(c, dtype=torch.float32, device=xn.device)
             ws = _ws(m, 1, c, xn.device)
             _lib.call("diga_bn_bwd_affine", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(save_ab), _lib.ptr(weight),
-                      _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dgamma), _lib.ptr(dbeta), m, c, _lib.ptr(ws),
-                      ws.numel(), _lib.stream())
+                      _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dgamma), _lib.ptr(dbeta), m, c,
+                      1 if training else 0, _lib.ptr(ws), ws.numel(), _lib.stream())
             return (dx.permute(0, 3, 1, 2), None, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
                     None, None, None, None, None, None, None, None, None, None, None, None, None)
         pre = ctx.box.pop("premasked", None) if ctx.box is not None else None

@@ -73,6 +73,10 @@ class SegFormerStudent(nn.Module):
     def adjust_loss_scale(self, *a, **k):
         return self.backbone.adjust_loss_scale(*a, **k)
 
+    @property
+    def loss_scale(self):
+        return self.backbone.loss_scale
+
     def get_1x_lr_params_NOscale(self):
         for p in self.backbone.parameters():
             if p.requires_grad:

@@ -179,8 +179,11 @@ class DigaTrainer:
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
         self.opt.step(found_inf=flag)
         self._steps_done = getattr(self, "_steps_done", 0) + 1
-        if flag is not None and self._steps_done % 200 == 0 and self.student.adjust_loss_scale() > 0:
-            self._g = None            # the scale is baked into a captured graph: capture again
+        if flag is not None and self._steps_done % 200 == 0:
+            before = self.student.loss_scale
+            self.student.adjust_loss_scale(steps=200)
+            if self.student.loss_scale != before:
+                self._g = None        # the scale is baked into a captured graph: capture again
 
     # ------------------------------------------------------------------ warm-up step, static part as a HIP graph
     def _warmup_step_graphed(self, it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil):

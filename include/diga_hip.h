@@ -492,13 +492,15 @@ int diga_bn_bwd(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, co
                 int64_t ld_dx, float* dres, int64_t ld_dr, int64_t M, int64_t C, int training, int dx_twin, void* workspace,
                 size_t workspace_bytes, void* stream);
 
-/* diga_bn_bwd (train mode) for a BatchNorm whose affine pair TRAINS -- the `linear_fuse` ConvModule of the SegFormer decode head,
+/* diga_bn_bwd for a BatchNorm whose affine pair TRAINS -- the `linear_fuse` ConvModule of the SegFormer decode head,
  * G5/model/networks/segformer_head.py:63-68 (norm_cfg BN, requires_grad=True): additionally dgamma[c] = sum g*xhat and
- * dbeta[c] = sum g (the two column sums the input gradient needs anyway: no extra pass). */
+ * dbeta[c] = sum g (in train mode the two column sums the input gradient needs anyway: no extra pass).  training = 0 (the module in
+ * eval(): BN-frozen fine-tuning, test-time adaptation): save_mean / save_invstd are the RUNNING statistics the forward used,
+ * dx = gamma*invstd*g without the mean terms, dgamma / dbeta as above -- what nn.BatchNorm2d returns in eval mode. */
 int diga_bn_bwd_affine(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
                        const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
-                       int64_t ld_dx, float* dgamma, float* dbeta, int64_t M, int64_t C, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       int64_t ld_dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int training, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* diga_bn_bwd for a gradient that arrives already masked and reduced: `g` and `partial` ([ceil(M/chunk_rows)][2][C]:
  * sum g, sum g*xhat per chunk) come out of the epilogue of the backward-data convolution that produced g

@@ -350,6 +350,13 @@ def test_fp16_backward_overflow_sets_the_flag_and_skips_the_step(golden):
         assert torch.equal(p.detach(), before[k]), k                 # the step was skipped on the device
     assert m.loss_scale == 1024.0 and m.adjust_loss_scale() == 1 and m.loss_scale == 512.0
     assert m.adjust_loss_scale() == 0 and m.loss_scale == 512.0
+    # the scaler grows back: 1000 clean steps (five 200-step windows, the first one counted above) double the scale, capped at the
+    # scale the model was built with -- a transient spike does not leave the run at a reduced scale for good
+    for _ in range(3):
+        assert m.adjust_loss_scale(steps=200) == 0 and m.loss_scale == 512.0
+    assert m.adjust_loss_scale(steps=200) == 0 and m.loss_scale == 1024.0
+    for _ in range(6):
+        assert m.adjust_loss_scale(steps=200) == 0 and m.loss_scale == 1024.0
     assert run(1.0) == [0, 1]                                      # flag cleared by the next training forward; the step is taken
     assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
     assert any(not torch.equal(p.detach(), before[k]) for k, p in m.named_parameters())

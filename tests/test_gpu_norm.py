@@ -207,17 +207,33 @@ def test_aspp_head_golden(golden, conv_math):
     # Winograd F(6x6) / F(4x4) tiles (1e-5-level forward differences) 3 of 122 496 input-gradient elements, split-bf16 more
     frac, l2 = (1e-4, 1e-3) if conv_math == 0 else (1e-2, 1e-2)
 
-    def close(a, b, rtol, atol, what):
-        assert_mostly_close(a, b, rtol, atol, frac, l2, what)
+    # head-side tensors whose gradient does not pass back through a ReLU switch (the bottleneck conv and its GroupNorm, the prediction
+    # conv): smooth functions of the arithmetic, held to the STRICT elementwise bound in exact fp32 (round 4 had loosened every tensor
+    # of this test to assert_mostly_close when the larger Winograd tiles arrived)
+    smooth = ("bottleneck.1.weight", "bottleneck.1.bias", "bottleneck.2.weight", "bottleneck.2.bias", "head.1.weight")
+
+    def close(a, b, rtol, atol, what, strict=False):
+        if strict and conv_math == 0:
+            assert_close(a, b, rtol, atol, what)
+        else:
+            assert_mostly_close(a, b, rtol, atol, frac, l2, what)
     close(x.grad, g.t("gx"), 2e-3, 2e-5, "grad x")
+    seen_smooth = 0
     for k, p in head.named_parameters():
         gk = "gw_" + k.replace(".", "_")
+        if k in smooth:
+            seen_smooth += 1
+            ref = g.t(gk) if gk in g else g.t(gk + "__sample")
+            got = p.grad if gk in g else p.grad.reshape(-1)[::97]
+            close(got, ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, gk, strict=True)
+            continue
         if gk in g:
             ref = g.t(gk)
             close(p.grad, ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, gk)
         else:
             ref = g.t(gk + "__sample")
             close(p.grad.reshape(-1)[::97], ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, gk)
+    assert seen_smooth == len(smooth)
 
 
 @pytest.mark.parametrize("n,k,o,act", [(16, 1280, 80, 1), (16, 80, 1280, 2), (3, 37, 5, 0), (1, 64, 64, 2)])
@@ -257,3 +273,34 @@ def test_bias_gradient_column_sums(m, c, ld):
     want = buf[:, :c].double().sum(0)
     scale = float(buf[:, :c].double().abs().sum(0).max())
     assert float((got.double() - want).abs().max()) < 2e-6 * scale
+
+
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+@pytest.mark.parametrize("relu", [False, True])
+def test_trainable_batchnorm_backward_train_and_eval_vs_float64(training, relu):
+    """DigaTrainableBatchNorm2d (the SegFormer head's linear_fuse BatchNorm): dx, dgamma, dbeta against nn.functional.batch_norm in
+    float64 -- in train mode AND in eval mode (running statistics; BN-frozen fine-tuning / test-time adaptation of a head in .eval()
+    used to raise instead of returning what nn.BatchNorm2d returns)."""
+    from diga_amd.model.norm import DigaTrainableBatchNorm2d
+    n, c, h, w = 3, 96, 11, 13
+    g = synth.gen(4242 + int(training) + 2 * int(relu))
+    x = torch.randn((n, c, h, w), generator=g) * 1.5 + torch.randn((1, c, 1, 1), generator=g)
+    gam, bet = 1 + 0.2 * torch.randn(c, generator=g), 0.3 * torch.randn(c, generator=g)
+    rm0, rv0 = 0.3 * torch.randn(c, generator=g), 1 + 0.5 * torch.rand(c, generator=g)
+    probe = torch.randn((n, c, h, w), generator=g)
+    xr = x.double().requires_grad_()
+    gr, br = gam.double().requires_grad_(), bet.double().requires_grad_()
+    yr = F.batch_norm(xr, rm0.double().clone(), rv0.double().clone(), gr, br, training, 0.1, 1e-5)
+    if relu:
+        yr = F.relu(yr)
+    (yr * probe.double()).sum().backward()
+    m = DigaTrainableBatchNorm2d(c)
+    with torch.no_grad():
+        m.weight.copy_(gam); m.bias.copy_(bet); m.running_mean.copy_(rm0); m.running_var.copy_(rv0)
+    m = m.to(DEV).train(training)
+    xd = _cl(x).requires_grad_()
+    y = m(xd, relu=relu)
+    (y * probe.to(DEV)).sum().backward()
+    for got, want, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (m.weight.grad, gr.grad, "dgamma"), (m.bias.grad, br.grad, "dbeta")):
+        e = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max().clamp_min(1e-30))
+        assert e < 5e-6, (what, training, relu, e)

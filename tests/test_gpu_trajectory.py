@@ -1,0 +1,169 @@
+"""Training TRAJECTORIES of the HIP path against captures of the reference's own warm-up loop
+(tools/gen_golden.py::_gen_traj re-enacts G5/train_DiGA_gta2city_warm_up.py:197-305 on the reference's classes):
+  traj25   25 optimizer steps, B = 2 crops of 128 x 128 (4 student + 4 teacher images per step)
+  traj768  3 optimizer steps, B = 1 crop of 768 x 768 (the benchmark geometry: 97 x 97 maps, the tile counts of BASELINE configs[1])
+Every step's CE / distillation loss, and at the end the student's head weight, the CHANGE of nine trunk / ASPP weights since
+step 0 (strided samples), BatchNorm running statistics of both networks and eval-mode probe logits of student and teacher.
+
+What this pins that the 3-step golden (test_gpu_model.py::test_warmup_three_steps_golden) cannot: that a per-layer arithmetic
+difference (the F(6x6,3x3) / F(4x4,3x3) Winograd tiles of the exact-fp32 path: 2.7e-5 of scale per layer against 7e-7 for
+F(2x2); the split-bf16 path: 3e-5) does not COMPOUND through batch-statistics BatchNorm + momentum SGD + the EMA teacher.  The
+test runs the same trajectory with the default tiles, with every layer capped at F(2x2) (conv.WINOGRAD_MAX_TILE = 2: the direct
+kernels' error level) and in split bf16, prints the per-step deviation of each, and holds each to a small multiple of the trajectory's
+own rounding floor -- the distance between two runs of the REFERENCE that differ only in summation order, stored in the capture.  The deviation of the large tiles must not grow faster than
+F(2x2)'s: `growth` = mean deviation of the last five steps / mean of the first five.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import deeplab as od
+from oracle import detweights, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Bounds.  The captures carry the trajectory's own sensitivity to fp32 rounding (`floor_*`: the reference run a second time with
+# torch's CPU convolutions on their other implementation -- oneDNN off -- against the capture; tools/gen_golden.py::_gen_traj):
+# after 25 steps at 128 x 128 two runs of the REFERENCE differ by 6.7e-5 in the loss, 1.7e-3 in the head's change, 10 % in single
+# trunk weights' changes and 9e-3 of scale in probe logits -- random-weight batch-statistics BatchNorm + ReLU switches amplify
+# rounding by ~1.5x per step.  Every arithmetic of the build is held to FACTOR x that floor (plus a small absolute term where the
+# floor of a 3-step run is itself rounding-sized).  Measured on an MI355X (round 5; DESIGN.md section 2 "Trajectories"):
+#   traj25   default tiles 6.3e-5 / 2.0e-3 / 0.107 / 8.8e-3;  F(2x2) only 5.7e-5 / 1.9e-3 / 0.106 / 7.5e-3;  split bf16 7.0e-5 /
+#            2.4e-3 / 0.124 / 9.6e-3   (loss / head change / worst trunk change / probe logits) -- all AT the floor, the large
+#            tiles no further from the reference than F(2x2) or than the reference from itself
+#   traj768  default tiles 1.1e-7 / 1.6e-5 / 1.4e-2 / 2.3e-5;  F(2x2) 1.1e-7 / 1.1e-5 / 8.5e-3 / 1.2e-5;  split bf16 6.5e-7 / 3.5e-5 /
+#            2.8e-2 / 5.5e-5
+FACTOR = {"f32": 3.0, "f32_tile2": 3.0, "bf16x3": 4.0}
+ABS = dict(loss=5e-7, head_delta=3e-5, trunk_delta=2e-2, probe=5e-5, bn=2e-6)          # x FACTOR / 3; what 3 steps of pure rounding give
+
+
+def bounds(g, mode):
+    f = FACTOR[mode]
+    floor = dict(loss=max(float(g["floor_ce_dev"].max()), float(g["floor_distil_dev"].max())), head_delta=float(g["floor_head_delta"]),
+                 trunk_delta=float(g["floor_trunk_delta"].max()), probe=float(g["floor_probe"].max()), bn=float(g["floor_bn"].max()))
+    return {k: f * (floor[k] + ABS[k]) for k in floor}, floor
+
+
+BN_KEYS = ["layer1.0.bn1.running_mean", "layer3.22.bn3.running_mean", "layer4.2.bn3.running_var", "layer2.3.bn2.running_var"]
+
+
+def _model():
+    from diga_amd.model import seg_model_noaux as sm
+    from diga_amd.model.model_noaux import SegModel
+    m = SegModel(arch=sm.RESNET101)
+    m.load_state_dict(detweights.state_dict(od.RESNET101))
+    return m.to(DEV)
+
+
+def _rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def run_trajectory(g, mode):
+    """Runs the capture's trajectory through DigaTrainer; returns the deviations (a dict of floats / lists)."""
+    from diga_amd import _lib
+    from diga_amd.model import conv as dc
+    from diga_amd.train_step import DigaTrainer
+    B, H, W, steps, seed0, block, mix_seed = (int(v) for v in g["geometry"])
+    prev_math, prev_tile = _lib.get_conv_math(), dc.WINOGRAD_MAX_TILE
+    _lib.set_conv_math(1 if mode == "bf16x3" else 0)
+    dc.WINOGRAD_MAX_TILE = 2 if mode == "f32_tile2" else 6
+    try:
+        student, teacher = _model(), _model()
+        for mdl in (student, teacher):
+            mdl.final.head[0].p = 0.0
+        teacher.train()
+        w0 = {n: p.detach().clone() for n, p in student.state_dict().items() if n.endswith("weight") and p.dim() == 4}
+        tr = DigaTrainer(student, teacher, rng=random)
+        random.seed(mix_seed)
+        dce, ddi = [], []
+        for it in range(steps):
+            x, x_aug, rec, lab = (t.to(DEV) for t in synth.warmup_batch(seed0 + it, B, H, W, block=block))
+            log = tr.warmup_step(it, x, x_aug, rec, lab)
+            assert tr.opt.param_groups[0]["lr"] == pytest.approx(float(g["lr"][it]), rel=1e-12)
+            dce.append(abs(float(log["ce"]) - float(g["ce"][it])) / abs(float(g["ce"][it])))
+            ddi.append(abs(float(log["distil"]) - float(g["distil"][it])) / abs(float(g["distil"][it])))
+        sd, td = student.state_dict(), teacher.state_dict()
+        res = dict(mode=mode, steps=steps, ce_dev=dce, distil_dev=ddi)
+        res["head_delta"] = _rel_l2(sd["final.head.1.weight"].cpu() - w0["final.head.1.weight"].cpu(), g.t("student_head_delta"))
+        res["head"] = _rel_l2(sd["final.head.1.weight"], g.t("student_head"))
+        res["teacher_head"] = _rel_l2(td["final.head.1.weight"], g.t("teacher_head"))
+        trunk = {}
+        for key in g:
+            if key.startswith("ps_") and key.endswith("__delta_sample"):
+                base = key[3:-len("__delta_sample")]
+                name = next(n for n in w0 if n.replace(".", "_") == base)
+                step = int(g["ps_" + base + "__step"])
+                got = (sd[name] - w0[name]).reshape(-1)[::step].cpu()
+                trunk[name] = _rel_l2(got, g.t(key))
+                assert float(sd[name].double().norm()) == pytest.approx(float(g["ps_" + base + "__norms"][0]), rel=1e-5), name
+        res["trunk_delta"] = trunk
+        res["bn"] = {}
+        for n in BN_KEYS:
+            k = n.replace(".", "_")
+            scale = float(g.t("stu_" + k).abs().max())
+            res["bn"]["stu_" + n] = float((sd[n].cpu() - g.t("stu_" + k)).abs().max()) / scale
+            res["bn"]["tea_" + n] = float((td[n].cpu() - g.t("tea_" + k)).abs().max()) / float(g.t("tea_" + k).abs().max())
+        student.eval()
+        teacher.eval()
+        xp = synth.warmup_batch(seed0 + 1000, 1, min(H, 256), min(W, 256), block=block)[0].to(DEV)
+        with torch.no_grad():
+            so, to = student(xp)[2].cpu(), teacher(xp)[2].cpu()
+        res["probe_student"] = float((so - g.t("probe_student")).abs().max() / g.t("probe_student").abs().max())
+        res["probe_teacher"] = float((to - g.t("probe_teacher")).abs().max() / g.t("probe_teacher").abs().max())
+        k = max(1, min(5, steps // 2))
+        both = [max(a, b) for a, b in zip(dce, ddi)]
+        res["growth"] = float(np.mean(both[-k:]) / max(np.mean(both[:k]), 1e-12))
+        return res
+    finally:
+        _lib.set_conv_math(prev_math)
+        dc.WINOGRAD_MAX_TILE = prev_tile
+        _lib.join_side()
+
+
+def _report(name, res):
+    print(f"\n[{name} / {res['mode']}] per-step |dCE|/CE:   " + " ".join(f"{v:.1e}" for v in res["ce_dev"]))
+    print(f"[{name} / {res['mode']}] per-step |ddist|/dist: " + " ".join(f"{v:.1e}" for v in res["distil_dev"]))
+    print(f"[{name} / {res['mode']}] head change L2 {res['head_delta']:.2e}  head {res['head']:.2e}  teacher head {res['teacher_head']:.2e}  "
+          f"trunk changes L2 max {max(res['trunk_delta'].values()):.2e}  probe {res['probe_student']:.2e} / {res['probe_teacher']:.2e}  "
+          f"bn max {max(res['bn'].values()):.2e}  growth {res['growth']:.2f}")
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and os.access(out, os.W_OK):
+        with open(os.path.join(out, f"traj_{name}_{res['mode']}.json"), "w") as f:
+            json.dump(res, f, indent=1)
+
+
+@pytest.mark.parametrize("mode", ["f32", "f32_tile2", "bf16x3"])
+@pytest.mark.parametrize("name", ["traj25", "traj768"])
+def test_training_trajectory_vs_reference(golden, name, mode):
+    g = golden(name)
+    res = run_trajectory(g, mode)
+    _report(name, res)
+    tol, floor = bounds(g, mode)
+    print(f"[{name} / {mode}] reference-vs-reference rounding floor: " + "  ".join(f"{k} {v:.2e}" for k, v in floor.items()))
+    assert max(res["ce_dev"]) < tol["loss"] and max(res["distil_dev"]) < tol["loss"], (max(res["ce_dev"]), max(res["distil_dev"]), tol["loss"])
+    assert max(res["ce_dev"] + res["distil_dev"]) < 1e-3                       # north_star's bound on the losses, whatever the floor says
+    assert res["head_delta"] < tol["head_delta"], (res["head_delta"], tol["head_delta"])
+    assert max(res["trunk_delta"].values()) < tol["trunk_delta"], (res["trunk_delta"], tol["trunk_delta"])
+    assert max(res["probe_student"], res["probe_teacher"]) < tol["probe"], (res["probe_student"], res["probe_teacher"], tol["probe"])
+    assert max(res["bn"].values()) < tol["bn"], (res["bn"], tol["bn"])
+
+
+def test_large_tiles_do_not_drift_faster_than_f2x2(golden):
+    """The compounding check itself: over the 25 steps the deviation of the default (F(6x6) / F(4x4)) tiles from the reference
+    trajectory must not grow faster than that of the F(2x2)-only run, and must end within 4x of it in absolute terms."""
+    g = golden("traj25")
+    big, small = run_trajectory(g, "f32"), run_trajectory(g, "f32_tile2")
+    _report("traj25_growth", big)
+    last = lambda r: float(np.mean([max(a, b) for a, b in zip(r["ce_dev"], r["distil_dev"])][-5:]))      # noqa: E731
+    print(f"\nlast-5-step mean loss deviation: default tiles {last(big):.2e}, F(2x2) {last(small):.2e}; growth {big['growth']:.2f} vs {small['growth']:.2f}")
+    assert big["growth"] < max(3.0, 3.0 * small["growth"])
+    assert last(big) < max(4.0 * last(small), 2e-6)
+    assert big["head_delta"] < max(4.0 * small["head_delta"], 1e-4)

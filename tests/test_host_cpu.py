@@ -282,6 +282,145 @@ def test_ddp_exchange_gloo_world2():
     assert devs[0] == devs[1] and 0 < devs[0] < 1e-3
 
 
+def _worker8(rank, world, port, out):
+    """World-8 layout of one node (BASELINE configs[2] / configs[3]): the centroid exchange's rank-major order over eight ranks, and
+    the gradient reducer with the gradients living in the all-reduce buckets."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from diga_amd import ddp
+    from oracle import centroids as oc
+    r, w, _ = ddp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    d, n_img = 16, 2
+    gen = torch.Generator().manual_seed(900 + rank)
+    sums = torch.randn((n_img, 19, d), generator=gen) * 30.0
+    counts = torch.randint(0, 40, (n_img, 19), generator=gen, dtype=torch.int32)
+    counts[:, 3] = 1                                              # below the 5-pixel rule everywhere
+    s_all, c_all = ddp.gather_class_sums(sums, counts)
+    # what ONE process would have seen on the concatenated batch: regenerate every rank's shard, rank-major
+    ref_s, ref_c = [], []
+    for rr in range(world):
+        g2 = torch.Generator().manual_seed(900 + rr)
+        ref_s.append(torch.randn((n_img, 19, d), generator=g2) * 30.0)
+        ref_c.append(torch.randint(0, 40, (n_img, 19), generator=g2, dtype=torch.int32))
+        ref_c[-1][:, 3] = 1
+    ok_order = torch.equal(s_all, torch.cat(ref_s)) and torch.equal(c_all, torch.cat(ref_c))
+    # exact sequential EMA in that order (the oracle's restatement of calc_centroids.py:147-164) -- identical on every rank
+    cents0 = torch.randn((19, d), generator=torch.Generator().manual_seed(7))
+    vecs, ids = [], []
+    for n in range(s_all.shape[0]):
+        for t in range(19):
+            if int(c_all[n, t]) >= 5:
+                vecs.append(s_all[n, t] / float(c_all[n, t]))
+                ids.append(t)
+    cents_e, nums_e = cents0.clone(), torch.zeros(19)
+    oc.centroid_ema_apply(cents_e, nums_e, vecs, ids, momentum=1e-4)
+    gathered = [torch.zeros_like(cents_e) for _ in range(world)]
+    dist.all_gather(gathered, cents_e)
+    ok_same = all(torch.equal(gathered[0], t) for t in gathered)
+    ms, nv = ddp.allreduce_class_means(sums, counts, 5)
+    cents_a, nums_a = cents0.clone(), torch.zeros(19)
+    ddp.apply_mean_of_vectors(cents_a, nums_a, ms, nv, 1e-4)
+    dev = float((cents_a - cents_e).abs().max() / (cents_e - cents0).abs().max())
+    ok_approx = torch.equal(nums_a, nums_e) and float(nums_a[3]) == 0 and dev < 2e-3
+    # gradients living in the buckets: a producer that writes into grad_view (as DigaConv2d's backward does), a plain autograd
+    # gradient (copied in when the bucket launches, p.grad re-pointed), and a channels_last weight
+    g = torch.Generator().manual_seed(100)
+    params = [torch.nn.Parameter(torch.randn(s_, generator=g)) for s_ in [(6, 4, 3, 3), (300,), (8, 8, 1, 1), (5000,)]]
+    params[0].data = params[0].data.contiguous(memory_format=torch.channels_last)
+    red = ddp.GradReducer(params, bucket_bytes=8192)
+    ok_views = red.as_views and all(callable(getattr(p, "_diga_grad_view", None)) for p in params)
+
+    class WritesInPlace(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, wt, scale):
+            ctx.view, ctx.scale = wt._diga_grad_view, scale
+            return wt.sum() * scale
+
+        @staticmethod
+        def backward(ctx, go):
+            dw = ctx.view()
+            dw.fill_(ctx.scale)
+            return dw * go if False else dw, None
+
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        sc = float(rank + 1 + step)
+        loss = WritesInPlace.apply(params[0], sc) + WritesInPlace.apply(params[2], 2 * sc) + sc * params[1].sum() + 3 * sc * params[3].sum()
+        loss.backward()
+        ok_views &= all(w_ is not None for w_ in red._work)
+        red.reduce()
+        tot = float(sum(rr + 1 + step for rr in range(world)))
+        for p, mult in zip(params, (1.0, 1.0, 2.0, 3.0)):
+            i, off = red._where[id(p)]
+            ok_views &= bool(torch.allclose(p.grad, torch.full_like(p, tot * mult)))
+            ok_views &= p.grad.data_ptr() == red._flat[i].data_ptr() + off * 4 and p.grad.stride() == p.stride()
+    red.close()
+    ok_views &= not hasattr(params[0], "_diga_grad_view")
+    out[rank] = (ok_order, ok_same, ok_approx, ok_views)
+    out[f"dev_{rank}"] = dev
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_exchange_gloo_world8():
+    """Eight ranks (one node of BASELINE configs[2] / [3]) over gloo: gather_class_sums returns the shards in rank-major order, the
+    oracle's sequential centroid EMA over that order is identical on all eight ranks (= one process on the concatenated batch), the
+    all-reduce variant stays within 2e-3 of it, and GradReducer's gradients live in its buckets (no pack / unpack copies)."""
+    world = 8
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = dict(out)
+    devs = [res.pop(f"dev_{r}") for r in range(world)]
+    assert res == {r: (True, True, True, True) for r in range(world)}, res
+    assert len(set(devs)) == 1 and 0 < devs[0] < 2e-3
+
+
+def test_c_abi_prototypes_match_the_ctypes_signatures():
+    """include/*.h is maintained by hand next to diga_amd/_lib.py::SIGNATURES; ctypes cannot notice an arity or width mismatch.  This
+    parses every prototype of the headers and holds the binding to it: same set of names, same number of arguments, and per
+    argument the same class -- pointer, signed 64-bit integer, 32-bit integer, size_t / unsigned 64-bit, float, double -- and the same return type."""
+    import ctypes as C
+    import re
+    from diga_amd import _lib
+    protos = {}
+    for hdr in ("diga_hip.h", "diga_mit.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        for m in re.finditer(r"\b(int|size_t|const\s+char\s*\*)\s+(diga_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+            ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+            protos[name] = (ret, [] if args in ("", "void") else [a.strip() for a in args.split(",")])
+    assert set(protos) == set(_lib.SIGNATURES), (sorted(set(protos) ^ set(_lib.SIGNATURES)))
+
+    def klass(decl):
+        if "*" in decl:
+            return "ptr"
+        ty = decl.rsplit(" ", 1)[0].replace("const ", "").strip() if " " in decl else decl
+        return {"int64_t": "i64", "int": "i32", "int32_t": "i32", "size_t": "u64", "float": "f32", "double": "f64",
+                "uint32_t": "u32", "uint64_t": "u64"}[ty]
+
+    ct = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_int64: "i64", C.c_int: "i32", C.c_size_t: "u64", C.c_float: "f32",
+          C.c_double: "f64", C.c_uint32: "u32", C.c_uint64: "u64"}
+    for name, (ret, args) in sorted(protos.items()):
+        res, argtypes = _lib.SIGNATURES[name]
+        want_ret = {"int": C.c_int, "size_t": C.c_size_t}.get(ret, C.c_char_p)
+        assert res is want_ret, f"{name}: return type {res} vs header '{ret}'"
+        assert len(argtypes) == len(args), f"{name}: {len(argtypes)} ctypes arguments, header has {len(args)}: {args}"
+        for i, (a, t) in enumerate(zip(args, argtypes)):
+            if isinstance(t, type) and issubclass(t, C._Pointer):
+                got = "ptr"
+            else:
+                got = ct[t]
+            assert klass(a) == got, f"{name}: argument {i} ('{a}') is bound as {t.__name__}"
+
+
 def test_ddp_single_process_is_noop():
     from diga_amd import ddp
     p = torch.nn.Parameter(torch.ones(3))
@@ -384,3 +523,20 @@ def test_bench_compact_line_is_small_strict_json_with_the_contract_fields():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert line["value"] == pytest.approx(8 * 1000.0 / line["ms_per_step"], rel=1e-3)          # crops/s = batch / step time
     assert line["value"] > 100 * c["value"]
+
+
+def test_segformer_head_fresh_initialisation_is_mmcvs():
+    """A SegFormerHead built from scratch starts where the reference's would (segformer_head.py:63-68 through mmcv's ConvModule, which
+    initialises itself in its constructor): kaiming-normal fan_out / relu on the fuse conv -- std sqrt(2 / 768) = 0.051, not
+    nn.Conv2d's default 0.010 --, BatchNorm weight 1 / bias 0; init_weights() gives the prediction conv N(0, 0.01) and a zero bias."""
+    from diga_amd.model.networks.segformer_head import SegFormerHead
+    torch.manual_seed(3)
+    head = SegFormerHead(in_channels=[64, 128, 320, 512], channels=128, feature_strides=[4, 8, 16, 32], num_classes=19,
+                         in_index=[0, 1, 2, 3], dropout_ratio=0.1, align_corners=False)
+    head.init_weights()
+    w = head.linear_fuse.conv.weight
+    assert tuple(w.shape) == (768, 3072, 1, 1)
+    assert float(w.std()) == pytest.approx((2.0 / 768) ** 0.5, rel=0.02) and abs(float(w.mean())) < 1e-3
+    assert torch.equal(head.linear_fuse.bn.weight.detach(), torch.ones(768)) and torch.equal(head.linear_fuse.bn.bias.detach(), torch.zeros(768))
+    assert head.linear_fuse.bn.weight.requires_grad and head.linear_fuse.bn.bias.requires_grad
+    assert float(head.linear_pred.weight.std()) == pytest.approx(0.01, rel=0.05) and float(head.linear_pred.bias.abs().max()) == 0.0

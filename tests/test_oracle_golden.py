@@ -350,3 +350,22 @@ def test_warmup_three_steps(golden):
         to = od.forward(tr.t, xp, training=False)[2]
     assert_close(so, g.t("probe_student"), 2e-3, 2e-4, "student probe logits")
     assert_close(to, g.t("probe_teacher"), 2e-3, 2e-4, "teacher probe logits")
+
+
+@pytest.mark.timeout(900)
+def test_warmup_trajectory_first_steps(golden):
+    """The oracle's step against the 25-step capture of the reference's loop (tests/golden/traj25.npz): the first six steps, each
+    loss within the capture's own rounding floor (two runs of the reference that differ in summation order: `floor_*`)."""
+    from oracle import step as ost
+    g = golden("traj25")
+    B, H, W, steps, seed0, block, mix_seed = (int(v) for v in g["geometry"])
+    tr = ost.Trainer(detweights.state_dict(), detweights.state_dict())
+    random.seed(mix_seed)
+    floor = max(float(g["floor_ce_dev"].max()), float(g["floor_distil_dev"].max()))
+    assert 1e-6 < floor < 1e-3 and steps == 25
+    for it in range(6):
+        x, x_aug, rec, lab = synth.warmup_batch(seed0 + it, B, H, W, block=block)
+        log = tr.warmup_step(it, x, x_aug, rec, lab, random)
+        assert log["ce"] == pytest.approx(float(g["ce"][it]), rel=3 * floor), it
+        assert log["distil"] == pytest.approx(float(g["distil"][it]), rel=3 * floor), it
+        assert log["lr"] == pytest.approx(float(g["lr"][it]), rel=1e-12)

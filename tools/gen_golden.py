@@ -736,6 +736,120 @@ def gen_step():
     save("step", probe_student=so, probe_teacher=to, **res)
 
 
+# ------------------------------------------------------------------ G-traj (training trajectories, round 5)
+TRAJ_SAMPLES = ["layer0.0.weight", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.0.conv2.weight",
+                "layer3.10.conv2.weight", "layer3.22.conv3.weight", "layer4.2.conv2.weight", "final.conv2d_list.2.0.weight",
+                "final.bottleneck.1.weight"]
+
+
+def _gen_traj(name, B, H, W, steps, seed0, block, mix_seed, variant=None):
+    """The reference's warm-up loop body (train_DiGA_gta2city_warm_up.py:197-305: adjust_learning_rate, update_teacher_params,
+    inline ClassMix, student(cat) / teacher(cat), nn.Upsample(bilinear, align_corners=True), cross_entropy2d + 0.5 *
+    distillation_loss, torch.optim.SGD over SegModel.optim_parameters) run for `steps` iterations on the reference's own
+    classes, every batch regenerated from its seed (seed0 + it).  Stored per step: CE, distillation loss, total, lr, the student
+    head's weight norm and the norm of its change; at the end: the head in full, strided samples + norms of nine trunk / ASPP
+    weights (and of their change since step 0), BN running statistics of both networks, eval-mode probe logits of both."""
+    import torch.optim as optim
+    student, teacher = _ref_model(), _ref_model()
+    for mdl in (student, teacher):
+        mdl.final.head[0].p = 0.0
+    opt = optim.SGD(student.optim_parameters(2.5e-4), lr=2.5e-4, momentum=0.9, weight_decay=0.0005)
+    up = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+    teacher = create_teacher_params(teacher, student)
+    w0 = {n: student.state_dict()[n].clone() for n in TRAJ_SAMPLES + ["final.head.1.weight"]}
+    random.seed(mix_seed)
+    log = {"ce": [], "distil": [], "total": [], "lr": [], "head_norm": [], "head_delta": []}
+    for it in range(steps):
+        student.train()
+        adjust_learning_rate([opt], base_lr=2.5e-4, i_iter=it, max_iter=80000, power=0.9)
+        with torch.no_grad():
+            teacher = update_teacher_params(teacher, student, it)
+        x, x_aug, rec, lab = synth.warmup_batch(seed0 + it, B, H, W, block=block)
+        mask = torch.zeros(lab.size())
+        for i in range(B):
+            present = torch.unique(lab[i]).tolist()
+            pick = random.sample(present, len(present) // 2)
+            if 255 not in pick:
+                pick.append(255)
+            for c in pick:
+                mask[i][lab[i] == c] = 1
+        mix = torch.zeros(rec.size())
+        for i in range(B):
+            mix[i] = torch.mul(rec[i], 1 - mask[i]) + torch.mul(x_aug[i], mask[i])
+        cat = torch.cat([x, mix])
+        _, _, s_cat, _ = student(cat)
+        s_cat = up(s_cat)
+        _, _, t_cat, _ = teacher(cat)
+        t_cat = up(t_cat)
+        ce = cross_entropy2d(s_cat[:B], lab)
+        di = distillation_loss(t_cat, s_cat)
+        total = 1.0 * ce + 0.5 * di
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        hw = student.state_dict()["final.head.1.weight"]
+        log["ce"].append(float(ce)); log["distil"].append(float(di)); log["total"].append(float(total))
+        log["lr"].append(opt.param_groups[0]["lr"])
+        log["head_norm"].append(float(hw.double().norm())); log["head_delta"].append(float((hw - w0["final.head.1.weight"]).double().norm()))
+        print(name, "step", it, log["ce"][-1], log["distil"][-1], log["head_delta"][-1], flush=True)
+    student.eval()
+    teacher.eval()
+    xp = synth.warmup_batch(seed0 + 1000, 1, min(H, 256), min(W, 256), block=block)[0]
+    with torch.no_grad():
+        _, _, so, _ = student(xp)
+        _, _, to, _ = teacher(xp)
+    res = {k: np.array(v, dtype=np.float64) for k, v in log.items()}
+    res["geometry"] = np.array([B, H, W, steps, seed0, block, mix_seed])
+    sd, td = student.state_dict(), teacher.state_dict()
+    for n in TRAJ_SAMPLES:
+        key = n.replace(".", "_")
+        step = max(1, sd[n].numel() // 2048)
+        res["ps_" + key + "__sample"] = sd[n].reshape(-1)[::step].clone()
+        res["ps_" + key + "__delta_sample"] = (sd[n] - w0[n]).reshape(-1)[::step].clone()
+        res["ps_" + key + "__step"] = np.array(step)
+        res["ps_" + key + "__norms"] = np.array([float(sd[n].double().norm()), float((sd[n] - w0[n]).double().norm()),
+                                                 float(td[n].double().norm()), synth.checksum(sd[n]), synth.checksum(td[n])])
+    res["student_head"] = sd["final.head.1.weight"]
+    res["teacher_head"] = td["final.head.1.weight"]
+    res["student_head_delta"] = sd["final.head.1.weight"] - w0["final.head.1.weight"]
+    for n in ["layer1.0.bn1.running_mean", "layer3.22.bn3.running_mean", "layer4.2.bn3.running_var", "layer2.3.bn2.running_var"]:
+        res["stu_" + n.replace(".", "_")] = sd[n]
+        res["tea_" + n.replace(".", "_")] = td[n]
+    res.update(probe_student=so, probe_teacher=to)
+    if variant is not None:
+        return res
+    # The trajectory's own sensitivity to fp32 ROUNDING: the same loop, the same reference classes, run a second time with
+    # torch's CPU convolutions on their other implementation (oneDNN switched off: im2col + GEMM instead of oneDNN's blocked
+    # direct kernels -- same mathematics, another summation order).  What separates the two reference runs after `steps` steps is
+    # the floor any other fp32 implementation is measured against (tests/test_gpu_trajectory.py): `floor_*`.
+    with torch.backends.mkldnn.flags(enabled=False):
+        alt = _gen_traj(name + "/no-onednn", B, H, W, steps, seed0, block, mix_seed, variant="no_onednn")
+
+    def rel(a, b):
+        a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+        return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+    res["floor_ce_dev"] = np.abs(alt["ce"] - res["ce"]) / np.abs(res["ce"])
+    res["floor_distil_dev"] = np.abs(alt["distil"] - res["distil"]) / np.abs(res["distil"])
+    res["floor_head_delta"] = np.array(rel(alt["student_head_delta"], res["student_head_delta"]))
+    res["floor_trunk_delta"] = np.array([rel(alt[k], res[k]) for k in sorted(res) if k.endswith("__delta_sample")])
+    res["floor_probe"] = np.array([float((alt[k] - res[k]).abs().max() / res[k].abs().max()) for k in ("probe_student", "probe_teacher")])
+    res["floor_bn"] = np.array([float((alt[k] - res[k]).abs().max() / res[k].abs().max()) for k in sorted(res)
+                                if k.startswith(("stu_layer", "tea_layer"))])
+    print(name, "rounding floor: loss", float(res["floor_ce_dev"].max()), float(res["floor_distil_dev"].max()), "head change",
+          float(res["floor_head_delta"]), "trunk change", float(res["floor_trunk_delta"].max()), "probe", res["floor_probe"].tolist(),
+          "bn", float(res["floor_bn"].max()), flush=True)
+    save(name, **res)
+
+
+def gen_traj25():
+    _gen_traj("traj25", 2, 128, 128, 25, 5000, 16, 79)
+
+
+def gen_traj768():
+    _gen_traj("traj768", 1, 768, 768, 3, 6000, 32, 80)
+
+
 # ------------------------------------------------------------------ G-selftrain (one self-training step)
 def gen_selftrain():
     import torch.optim as optim
@@ -943,7 +1057,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(traj25=gen_traj25, traj768=gen_traj768, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
