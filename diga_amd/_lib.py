@@ -73,6 +73,7 @@ SIGNATURES = {
     "diga_norm_workspace_bytes": (SZ, [I64, I64, I64]),
     "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, INT, P, F32, F32, P, SZ, P]),
     "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, I64, P, SZ, P]),
+    "diga_bn_fwd_records": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, P, I64, P, SZ, P]),
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
     "diga_bn_bwd_affine": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, INT, P, SZ, P]),
     "diga_pyramid_sum_fwd": (INT, [P, I64, I64, P, P, I64, I64, P, I64, I64, P, I64, I64, I64, I64, P]),
@@ -85,14 +86,18 @@ SIGNATURES = {
     "diga_conv2d_junction_ok": (INT, [I64, I64, I64]),
     "diga_conv2d_junction_f32": (INT, [P, I64, P, I64, P, P, I64, P, P, P, I64, P, I64, I64, I64, P]),
     "diga_conv2d_winograd_workspace_bytes": (SZ, [I64] * 7),
-    "diga_conv2d_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [INT, INT, P]),
-    "diga_conv2d_winograd_f32_epi": (INT, [P, P, P, P, SZ] + [I64] * 9 + [INT, P, INT, P]),
+    "diga_conv2d_winograd_tile_table_bytes": (SZ, [I64] * 5),
+    "diga_conv2d_winograd_tile_table": (INT, [P] + [I64] * 5 + [P]),
+    "diga_conv2d_winograd_stats_records": (SZ, [I64] * 6),
+    "diga_conv2d_winograd_stats_floats": (SZ, [I64] * 6),
+    "diga_conv2d_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [INT, P, P, INT, P]),
+    "diga_conv2d_winograd_f32_epi": (INT, [P, P, P, P, SZ] + [I64] * 9 + [INT, P, P, INT, P]),
     "diga_conv2d_wgrad_winograd_workspace_bytes": (SZ, [I64] * 7 + [INT]),
-    "diga_conv2d_wgrad_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [P]),
+    "diga_conv2d_wgrad_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [P, P]),
     "diga_conv2d_winograd_v_floats": (SZ, [I64] * 6),
-    "diga_conv2d_winograd_f32_ab": (INT, [P, P, P, P, P, P, P, SZ] + [I64] * 9 + [INT, P]),
-    "diga_conv2d_wgrad_winograd_f32_ab": (INT, [P, P, P, P, P, P, SZ] + [I64] * 9 + [P]),
-    "diga_conv2d_winograd_f32_keep": (INT, [P, P, P, P, P, P, SZ] + [I64] * 9 + [INT, P]),
+    "diga_conv2d_winograd_f32_ab": (INT, [P, P, P, P, P, P, P, SZ] + [I64] * 9 + [P, P, INT, P]),
+    "diga_conv2d_wgrad_winograd_f32_ab": (INT, [P, P, P, P, P, P, SZ] + [I64] * 9 + [P, P]),
+    "diga_conv2d_winograd_f32_keep": (INT, [P, P, P, P, P, P, SZ] + [I64] * 9 + [P, P, INT, P]),
     "diga_conv2d_nhwc_bf16x3_epi": (INT, [P, P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_conv2d_nhwc_twin_epi": (INT, [P, P, P] + [I64] * 16 + [P, INT, P]),
     "diga_gn_fwd": (INT, [P, I64, P, I64, P, P, P, P, P, I64, I64, I64, I64, INT, F32, P, SZ, P]),

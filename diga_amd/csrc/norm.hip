@@ -594,7 +594,10 @@ __global__ __launch_bounds__(256) void bn_finalize2_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                           float* __restrict__ ab, float momentum, float eps) {
+                                                           float* __restrict__ ab, float momentum, float eps,
+                                                           const float* __restrict__ counts = nullptr) {
+    // counts (nullable): rows of every record when they are not g.chunk_rows-sized row chunks (the Winograd output transform's
+    // per-tile-group records, diga_bn_fwd_records); a record may be empty (count 0)
     __shared__ double red[kFinLn][kFinCh];
     const int cl = threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
     const int c = blockIdx.x * kFinCh + cl;
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(256) void bn_finalize2_kernel(const float* __restri
 #pragma unroll 4
         for (int k = lane; k < K; k += kFinLn) {
             const float* p = partial + (int64_t)k * 3 * g.C;
-            const double nk = ((k % g.nchunk) == g.nchunk - 1) ? ci.n_last : ci.n_full;
+            const double nk = counts != nullptr ? (double)counts[k] : ((k % g.nchunk) == g.nchunk - 1) ? ci.n_last : ci.n_full;
             s += nk * (double)p[2 * g.C + c] + (double)p[c];
         }
     red[lane][cl] = s;
@@ -623,7 +626,11 @@ __global__ __launch_bounds__(256) void bn_finalize2_kernel(const float* __restri
         for (int k = lane; k < K; k += kFinLn) {
             const float* p = partial + (int64_t)k * 3 * g.C;
             const bool last = (k % g.nchunk) == g.nchunk - 1;
-            const double nk = last ? ci.n_last : ci.n_full, ik = last ? ci.inv_last : ci.inv_full;
+            double nk = last ? ci.n_last : ci.n_full, ik = last ? ci.inv_last : ci.inv_full;
+            if (counts != nullptr) {
+                nk = (double)counts[k];
+                ik = nk > 0.0 ? 1.0 / nk : 0.0;
+            }
             const double sd = p[c], sd2 = p[g.C + c], sh = p[2 * g.C + c];
             const double d = sh + sd * ik - mean;
             m2 += sd2 - sd * sd * ik + nk * d * d;
@@ -653,7 +660,9 @@ __global__ __launch_bounds__(256) void bn_finalize2_kernel(const float* __restri
 // one ragged) into one partial per group, re-based on the shift of the group's first chunk.  Block = 4 chunk
 // lanes x 64 channels, so every load is a coalesced 256-byte row piece; sums are formed in double.
 __global__ __launch_bounds__(256) void merge_partials_kernel(const float* __restrict__ partial, ColGeom g, int group,
-                                                             float* __restrict__ merged) {
+                                                             float* __restrict__ merged, const float* __restrict__ counts = nullptr,
+                                                             float* __restrict__ mcounts = nullptr) {
+    // counts / mcounts (nullable): per-record row counts in, per-group sums out (records of unequal size, see bn_finalize2_kernel)
     __shared__ double red[2][4][64];
     const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
@@ -663,11 +672,16 @@ __global__ __launch_bounds__(256) void merge_partials_kernel(const float* __rest
     const ChunkInv ci = chunk_inv(g);
     double s1 = 0.0, s2 = 0.0;
     float base = 0.f;
+    if (counts != nullptr && threadIdx.x == 0 && blockIdx.y == 0) {
+        float tot = 0.f;                                   // (integers < 2^24: exact in fp32)
+        for (int k = k0; k < k1; ++k) tot += counts[k];
+        mcounts[blockIdx.x] = tot;
+    }
     if (live) {
         base = partial[((int64_t)k0 * 3 + 2) * g.C + c];
         for (int k = k0 + lane; k < k1; k += 4) {
             const float* p = partial + (int64_t)k * 3 * g.C;
-            const double nk = (k == g.nchunk - 1) ? ci.n_last : ci.n_full;
+            const double nk = counts != nullptr ? (double)counts[k] : (k == g.nchunk - 1) ? ci.n_last : ci.n_full;
             const double sd = p[c], sd2 = p[g.C + c], dl = (double)p[2 * g.C + c] - (double)base;
             s1 += sd + nk * dl;
             s2 += sd2 + 2.0 * dl * sd + nk * dl * dl;
@@ -966,18 +980,18 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     return launch_status("diga_bn_fwd");
 }
 
-extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
-                                    int64_t ld_r, const float* gamma, const float* beta, float* running_mean,
-                                    float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
-                                    int64_t C, int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps,
-                                    const float* partial, int64_t chunk_rows,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-    DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "bn_fwd_partials: relu_bits needs relu and C % 32 == 0");
-    DIGA_REQUIRE(x && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0 && chunk_rows > 0,
-                 DIGA_EINVAL, "bn_fwd_partials: bad argument");
+static int bn_fwd_from_partials(const char* who, const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
+                                int64_t ld_r, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
+                                int64_t C, int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps,
+                                const float* partial, int64_t chunk_rows, const float* counts, int64_t n_records,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "%s: relu_bits needs relu and C %% 32 == 0", who);
+    DIGA_REQUIRE(x && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0, DIGA_EINVAL, "%s: bad argument", who);
+    DIGA_REQUIRE(counts ? (n_records > 0 && n_records < (1 << 30)) : chunk_rows > 0, DIGA_EINVAL, "%s: bad chunk_rows / record count", who);
     // y == nullptr: statistics and coefficients only (save_ab required) -- the consumer applies relu(fma(x, a, b)) on load
-    DIGA_REQUIRE(y || (save_ab && !y_twin), DIGA_EINVAL, "bn_fwd_partials: y = null (statistics and coefficients only) needs save_ab");
-    int rc = check_norm("bn_fwd_partials", C, {ld_x, y ? ld_y : C, residual ? ld_r : C}, {x, y ? (const void*)y : (const void*)x, residual});
+    DIGA_REQUIRE(y || (save_ab && !y_twin), DIGA_EINVAL, "%s: y = null (statistics and coefficients only) needs save_ab", who);
+    int rc = check_norm(who, C, {ld_x, y ? ld_y : C, residual ? ld_r : C}, {x, y ? (const void*)y : (const void*)x, residual});
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * (8.0 + (residual ? 4.0 : 0.0)));   // read x [+ residual], write y
@@ -985,31 +999,55 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
     g.rows_per_seg = M;
     g.nseg = 1;
     g.C = (int)C;
-    g.chunk_rows = (int)chunk_rows;
-    g.nchunk = (int)ceil_div(M, chunk_rows);
+    g.chunk_rows = counts ? 1 : (int)chunk_rows;
+    g.nchunk = counts ? (int)n_records : (int)ceil_div(M, chunk_rows);
     // the finaliser walks all chunks of a channel with 16 lanes: beyond a few hundred chunks fold them first
     // (fold to <= 96 groups: the finaliser's 16 lanes per channel then walk 6 partials each instead of 24+;
     //  merge + finalise of a 1176-chunk layer: 5.9 + 16.4 us before)
     const int group = g.nchunk > 128 ? (int)ceil_div(g.nchunk, 96) : 1;
     const int ngroup = (int)ceil_div(g.nchunk, group);
-    const size_t need = ((group > 1 ? (size_t)ngroup * 3 * C : 0) + (size_t)2 * C) * sizeof(float);
-    DIGA_REQUIRE(workspace_bytes >= need, DIGA_EWORKSPACE, "bn_fwd_partials: workspace too small (%zu < %zu)",
-                 workspace_bytes, need);
+    const size_t need = ((group > 1 ? (size_t)ngroup * 3 * C + (counts ? ngroup : 0) : 0) + (size_t)2 * C) * sizeof(float);
+    DIGA_REQUIRE(workspace_bytes >= need, DIGA_EWORKSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, need);
     float* ab = save_ab != nullptr ? save_ab : (float*)workspace;
     if (group > 1) {
         float* merged = (float*)workspace + 2 * C;
+        float* mcounts = counts ? merged + (size_t)ngroup * 3 * C : nullptr;
         hipLaunchKernelGGL(merge_partials_kernel, dim3(ngroup, (unsigned)ceil_div(C, 64)), dim3(256), 0, st, partial, g, group,
-                           merged);
+                           merged, counts, mcounts);
         partial = merged;
-        g.chunk_rows = (int)(chunk_rows * group);
+        counts = mcounts;
+        g.chunk_rows = counts ? 1 : (int)(chunk_rows * group);
         g.nchunk = ngroup;
     }
     hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
-                       running_mean, running_var, save_mean, save_invstd, ab, momentum, eps);
+                       running_mean, running_var, save_mean, save_invstd, ab, momentum, eps, counts);
     if (y != nullptr)
         hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
                            ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
-    return launch_status("diga_bn_fwd_partials");
+    return launch_status(who);
+}
+
+extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
+                                    int64_t ld_r, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
+                                    int64_t C, int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps,
+                                    const float* partial, int64_t chunk_rows,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_fwd_from_partials("diga_bn_fwd_partials", x, ld_x, y, ld_y, residual, ld_r, gamma, beta, running_mean, running_var, save_mean,
+                                save_invstd, save_ab, M, C, relu, y_twin, relu_bits, momentum, eps, partial, chunk_rows, nullptr, 0,
+                                workspace, workspace_bytes, stream);
+}
+
+extern "C" int diga_bn_fwd_records(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
+                                   int64_t ld_r, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
+                                   int64_t C, int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps,
+                                   const float* partial, const float* counts, int64_t n_records,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    DIGA_REQUIRE(counts != nullptr, DIGA_EINVAL, "diga_bn_fwd_records: null counts");
+    return bn_fwd_from_partials("diga_bn_fwd_records", x, ld_x, y, ld_y, residual, ld_r, gamma, beta, running_mean, running_var, save_mean,
+                                save_invstd, save_ab, M, C, relu, y_twin, relu_bits, momentum, eps, partial, 0, counts, n_records,
+                                workspace, workspace_bytes, stream);
 }
 
 extern "C" int diga_bn_apply(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r, const float* ab,

@@ -84,6 +84,12 @@ __global__ __launch_bounds__(256) void wino_tiles_kernel(int4* __restrict__ tab,
     tab[t] = make_int4(n, a + g.m * R * g.d, b + g.m * Cc * g.d, 0);
 }
 
+// blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous range of blocks (conv.hip's xcd_remap)
+__device__ __forceinline__ int wino_xcd_remap(int orig, int nwg) {
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 using f32x4nt = __attribute__((ext_vector_type(4))) float;
 // V and M are written once and read once by another kernel, hundreds of MB to GB each: keep them out of L2
 __device__ __forceinline__ void nt_store4(float* p, float4 v) {
@@ -538,7 +544,13 @@ __global__ __launch_bounds__(256) void winoM_input_kernel(const float* __restric
     constexpr int A = M + 2;
     constexpr int VW = sizeof(V) / 4;
     const int c4n = C / VW;
+    // XCD x walks a contiguous range of tiles: the (M + 2)^2 patches of neighbouring tiles overlap (a pixel is read by 1.78 tiles
+    // at M = 6), and with the round-robin block -> XCD dispatch every one of those reads came from a different L2 (round 5)
+#ifndef DIGA_WINO_NO_XCD
+    const int64_t idx = (int64_t)wino_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+#else
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+#endif
     if (idx >= Tp * c4n) return;
     const int64_t t = idx / c4n;
     const int c = (int)(idx - t * c4n) * VW;
@@ -588,11 +600,21 @@ __global__ __launch_bounds__(256) void winoM_input_kernel(const float* __restric
 template <int M, typename V>
 __device__ __forceinline__ void winoM_load_rows(const float* __restrict__ src, int64_t plane, V (*s)[M + 2]) {
     constexpr int A = M + 2;
+    // One running pointer per product row, advanced by a plane per column.  Callers that walk SEVERAL tiles in a loop hand in a pointer
+    // the compiler cannot take apart (asm barrier at the call site): written as Mb + t * K + k + (A * i + j) * plane, the A * A
+    // per-lane plane addresses are loop-invariant up to t * K, get hoisted out of the tile loop as 64 VGPR pairs and the kernel
+    // lands at 240-256 VGPRs / one wave per SIMD (what round 4's winoM_output_epi_kernel suffered from: 2.0 TB/s).
+    const float* p[A];
+#pragma unroll
+    for (int i = 0; i < A; ++i) p[i] = src + (int64_t)(A * i) * plane;
 #pragma unroll
     for (int j = 0; j < A; ++j) {
         V m[A];
 #pragma unroll
-        for (int i = 0; i < A; ++i) m[i] = nt_loadv<V>(src + (A * i + j) * plane);
+        for (int i = 0; i < A; ++i) {
+            m[i] = nt_loadv<V>(p[i]);
+            p[i] += plane;
+        }
         V col[M];
         Xf<M>::at(m, col);
 #pragma unroll
@@ -761,6 +783,188 @@ __global__ __launch_bounds__(256) void winoM_output_epi_kernel(const float* __re
     }
 }
 
+// winoM_output_kernel that also leaves the BatchNorm behind the layer its column statistics (round 5: the Winograd layers used to take a
+// separate statistics pass over y, 80 launches and ~9.5 GB per C2 step).  Block b = tiles [b * tpb, (b + 1) * tpb) x CG channel
+// groups of VW channels; thread (tl, q) walks tiles t0 + tl, t0 + tl + TL, ... (TL = 256 / CG tile lanes; a wave never spans two
+// lanes: CG >= 64) and keeps {sum (y - s), sum (y - s)^2, s = its first pixel, n = its pixels} -- record r = b * TL + tl of
+// `stats` ([R][3][K]) and `counts` ([R]): the format of diga_bn_fwd_records (records of unequal, possibly zero, size).
+template <int M, typename V>
+__global__ __launch_bounds__(256, 4) void winoM_output_stats_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+                                                                 const float* __restrict__ bias, float* __restrict__ y, int64_t ld,
+                                                                 int64_t T, int64_t Tp, int K, int H, int W, int d, int tpb, int CG,
+                                                                 float* __restrict__ stats, float* __restrict__ counts) {
+    constexpr int A = M + 2;
+    constexpr int VW = sizeof(V) / 4;
+    const int q = threadIdx.x % CG, tl = threadIdx.x / CG, TL = 256 / CG;
+    const int k = (blockIdx.y * CG + q) * VW;
+    if (k >= K) return;
+    const int64_t t0 = (int64_t)blockIdx.x * tpb;
+    int64_t t1 = t0 + tpb;
+    if (t1 > T) t1 = T;
+    float b[VW], s0[VW], sd[VW], sd2[VW];
+#pragma unroll
+    for (int c = 0; c < VW; ++c) b[c] = s0[c] = sd[c] = sd2[c] = 0.f;
+    if (bias != nullptr) *reinterpret_cast<V*>(b) = *reinterpret_cast<const V*>(bias + k);
+    float n = 0.f;
+#pragma unroll 1
+    for (int64_t t = t0 + tl; t < t1; t += TL) {
+        const int4 e = tab[t];
+        V s[M][A];
+        const float* srcp = Mb + t * K + k;
+        asm volatile("" : "+v"(srcp));
+        winoM_load_rows<M, V>(srcp, Tp * K, s);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const int yy = e.y + i * d;
+            if (yy >= H) continue;
+            V o[M];
+            Xf<M>::at(s[i], o);
+            float* row = y + ((int64_t)(e.x * H + yy) * W) * ld + k;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                if (e.z + j * d >= W) continue;
+                float v[VW];
+                *reinterpret_cast<V*>(v) = o[j];
+#pragma unroll
+                for (int c = 0; c < VW; ++c) v[c] += b[c];
+                *reinterpret_cast<V*>(row + (int64_t)(e.z + j * d) * ld) = *reinterpret_cast<const V*>(v);
+                if (n == 0.f) {
+#pragma unroll
+                    for (int c = 0; c < VW; ++c) s0[c] = v[c];
+                }
+                n += 1.f;
+#pragma unroll
+                for (int c = 0; c < VW; ++c) {
+                    const float dv = v[c] - s0[c];
+                    sd[c] += dv;
+                    sd2[c] = __builtin_fmaf(dv, dv, sd2[c]);
+                }
+            }
+        }
+    }
+    const int64_t r = (int64_t)blockIdx.x * TL + tl;
+    float* o = stats + r * 3 * K + k;
+    *reinterpret_cast<V*>(o) = *reinterpret_cast<const V*>(sd);
+    *reinterpret_cast<V*>(o + K) = *reinterpret_cast<const V*>(sd2);
+    *reinterpret_cast<V*>(o + 2 * K) = *reinterpret_cast<const V*>(s0);
+    if (q == 0 && blockIdx.y == 0) counts[r] = n;
+}
+
+// Round 5: winoM_output_epi_kernel again, built for OCCUPANCY.  The kernel above it holds a tile's A * A products and the M * M pixels'
+// epilogue operands (addend, x, mask: up to 3 * 36 values) in registers at once -- 256 VGPRs, one wave per SIMD, 2.0 TB/s on l3.conv2
+// (626 MB in 316 us) where the plain output transform (95 VGPRs, five waves per SIMD) moves its bytes at 5.7 TB/s.  Here a thread
+// column-transforms the products as they arrive (A * M values stay), then walks the tile's rows: the epilogue operands of ONE row are
+// loaded, used and dropped, the next row's loads are in flight behind the current row's arithmetic only through the other resident
+// waves (four to five per SIMD).  The operand combination is a template parameter (addend?, mask kind) -- no per-element pointer
+// tests.  Same arithmetic per element, same partial-row layout (block (g, s) = tile group x channel slab, TL tile lanes reduced
+// through LDS in lane order): bit-identical results.
+template <int M, typename V, int TL, bool ADD, int MASK /* 0 none, 1 y > 0, 2 bits, 3 fma(x, a, b) > 0 */, bool SUMS>
+__global__ __launch_bounds__(256, 4) void winoM_output_epi2_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+                                                                float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
+                                                                int H, int W, int d, int tpb, WinoEpi ep) {
+    constexpr int A = M + 2;
+    constexpr int VW = sizeof(V) / 4;
+    constexpr int CG = 256 / TL;
+    __shared__ float red[2][TL][CG * VW];
+    const int q = threadIdx.x % CG, tl = threadIdx.x / CG;
+    const int k = (blockIdx.y * CG + q) * VW;
+    const bool kok = k < K;
+    const int64_t t0 = (int64_t)blockIdx.x * tpb;
+    int64_t t1 = t0 + tpb;
+    if (t1 > T) t1 = T;
+    const int64_t plane = Tp * K;
+    float ra[VW], rb[VW], mu[VW], is[VW], sd[VW], sd2[VW];
+#pragma unroll
+    for (int c = 0; c < VW; ++c) ra[c] = rb[c] = mu[c] = is[c] = sd[c] = sd2[c] = 0.f;
+    if (kok && MASK == 3) {
+        *reinterpret_cast<V*>(ra) = *reinterpret_cast<const V*>(ep.relu_ab + k);
+        *reinterpret_cast<V*>(rb) = *reinterpret_cast<const V*>(ep.relu_ab + K + k);
+    }
+    if (kok && SUMS) {
+        *reinterpret_cast<V*>(mu) = *reinterpret_cast<const V*>(ep.mean + k);
+        *reinterpret_cast<V*>(is) = *reinterpret_cast<const V*>(ep.invstd + k);
+    }
+    if (kok) {
+#pragma unroll 1
+        for (int64_t t = t0 + tl; t < t1; t += TL) {
+            const int4 e = tab[t];
+            V s[M][A];
+            const float* srcp = Mb + t * K + k;
+            asm volatile("" : "+v"(srcp));
+            winoM_load_rows<M, V>(srcp, plane, s);
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const int yy = e.y + i * d;
+                if (yy >= H) continue;
+                const int64_t rowbase = (int64_t)(e.x * H + yy) * W + e.z;
+                // this row's epilogue operands (clamped column: loads are unconditional, results of dead pixels unused)
+                V va[M], vx[M], vy[M];
+                unsigned vb[M];
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    const int64_t row = rowbase + min(j * d, W - 1 - e.z);
+                    if (ADD) va[j] = *reinterpret_cast<const V*>(ep.add + row * ep.add_ld + k);
+                    if (MASK == 3 || SUMS) vx[j] = *reinterpret_cast<const V*>(ep.x + row * ep.x_ld + k);
+                    if (MASK == 1) vy[j] = *reinterpret_cast<const V*>(ep.masky + row * ep.masky_ld + k);
+                    if (MASK == 2) vb[j] = (unsigned)ep.maskbits[row * ep.maskbits_ld + (k >> 3)] >> (k & 7);
+                }
+                V o[M];
+                Xf<M>::at(s[i], o);
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    if (e.z + j * d >= W) continue;
+                    float v[VW], xv[VW], a4[VW], y4[VW];
+                    *reinterpret_cast<V*>(v) = o[j];
+                    if (ADD) {
+                        *reinterpret_cast<V*>(a4) = va[j];
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) v[c] += a4[c];
+                    }
+                    if (MASK == 3 || SUMS) *reinterpret_cast<V*>(xv) = vx[j];
+                    if (MASK == 1) {
+                        *reinterpret_cast<V*>(y4) = vy[j];
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) v[c] = y4[c] > 0.f ? v[c] : 0.f;
+                    } else if (MASK == 2) {
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) v[c] = ((vb[j] >> c) & 1u) ? v[c] : 0.f;
+                    } else if (MASK == 3) {
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) v[c] = __builtin_fmaf(xv[c], ra[c], rb[c]) > 0.f ? v[c] : 0.f;
+                    }
+                    *reinterpret_cast<V*>(y + (rowbase + j * d) * ld + k) = *reinterpret_cast<const V*>(v);
+                    if (SUMS) {
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) {
+                            sd[c] += v[c];
+                            sd2[c] += v[c] * ((xv[c] - mu[c]) * is[c]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!SUMS) return;
+#pragma unroll
+    for (int c = 0; c < VW; ++c) {
+        red[0][tl][q * VW + c] = sd[c];
+        red[1][tl][q * VW + c] = sd2[c];
+    }
+    __syncthreads();
+    const int ch = blockIdx.y * CG * VW + threadIdx.x;
+    if (threadIdx.x < CG * VW && ch < K) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int l = 0; l < TL; ++l) {
+            a0 += red[0][l][threadIdx.x];
+            a1 += red[1][l][threadIdx.x];
+        }
+        float* sp = ep.partials + (int64_t)blockIdx.x * 2 * K + ch;
+        sp[0] = a0;
+        sp[K] = a1;
+    }
+}
+
 // Z[k = A i + j][t][co] = (A dY A^T)[i][j] of the M x M output-gradient tile t
 template <int M, typename V>
 __global__ __launch_bounds__(256) void winoM_dy_kernel(const float* __restrict__ dy, int64_t ld, const int4* __restrict__ tab,
@@ -863,14 +1067,75 @@ static void launch_output_m(const float* Mb, const int4* tab, const float* bias,
     hipLaunchKernelGGL((winoM_output_kernel<M, VT>), dim3((unsigned)ceil_div(g.T * (Cout / VW), 256)), dim3(256), 0, st, Mb, tab, bias, out,
                        out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d);
 }
+// statistics records of the forward output transform: tiles per block and channel groups per block (see winoM_output_stats_kernel)
+struct WinoStatsPlan {
+    int tpb, CG, TL;
+    int64_t blocks, records;
+};
+template <int M>
+static WinoStatsPlan stats_plan_m(const WinoGeom& g, int64_t Cout) {
+    using VT = typename Vec<M>::Out;
+    constexpr int VW = sizeof(VT) / 4;
+    WinoStatsPlan p;
+    const int64_t groups = Cout / VW;
+    p.CG = groups >= 256 ? 256 : groups >= 128 ? 128 : 64;
+    p.TL = 256 / p.CG;
+    p.tpb = 4 * p.TL;
+    p.blocks = ceil_div(g.T, p.tpb);
+    p.records = p.blocks * p.TL;
+    return p;
+}
+static WinoStatsPlan stats_plan(const WinoGeom& g, int64_t Cout) {
+    return g.m == 6 ? stats_plan_m<6>(g, Cout) : stats_plan_m<4>(g, Cout);
+}
+template <int M>
+static void launch_output_stats_m(const float* Mb, const int4* tab, const float* bias, float* out, int64_t out_ld, const WinoGeom& g,
+                                  int64_t Cout, float* stats, hipStream_t st) {
+    using VT = typename Vec<M>::Out;
+    constexpr int VW = sizeof(VT) / 4;
+    const WinoStatsPlan p = stats_plan_m<M>(g, Cout);
+    float* counts = stats + p.records * 3 * Cout;
+    hipLaunchKernelGGL((winoM_output_stats_kernel<M, VT>), dim3((unsigned)p.blocks, (unsigned)ceil_div(Cout, (int64_t)p.CG * VW)), dim3(256), 0, st,
+                       Mb, tab, bias, out, out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d, p.tpb, p.CG, stats, counts);
+}
+
+#ifndef DIGA_WINO_EPI_TL
+#define DIGA_WINO_EPI_TL 2          /* tile lanes of the backward-data output transform (round 4: 11.5 / 10.1 / 9.8 ms per step with 4 / 2 / 1) */
+#endif
+template <int M, bool ADD, int MASK>
+static void launch_output_epi2_sums(const float* Mb, const int4* tab, float* out, int64_t out_ld, const WinoGeom& g, int64_t Cout, int64_t G,
+                                    int tpb, const WinoEpi& ep, hipStream_t st) {
+    using VT = typename Vec<M>::Out;
+    constexpr int VW = sizeof(VT) / 4;
+    constexpr int TL = DIGA_WINO_EPI_TL;
+    const dim3 grid((unsigned)G, (unsigned)ceil_div(Cout, (256 / TL) * VW));
+    if (ep.partials != nullptr)
+        hipLaunchKernelGGL((winoM_output_epi2_kernel<M, VT, TL, ADD, MASK, true>), grid, dim3(256), 0, st, Mb, tab, out, out_ld, g.T, g.Tp,
+                           (int)Cout, g.H, g.W, g.d, tpb, ep);
+    else
+        hipLaunchKernelGGL((winoM_output_epi2_kernel<M, VT, TL, ADD, MASK, false>), grid, dim3(256), 0, st, Mb, tab, out, out_ld, g.T, g.Tp,
+                           (int)Cout, g.H, g.W, g.d, tpb, ep);
+}
+template <int M, bool ADD>
+static void launch_output_epi2_mask(const float* Mb, const int4* tab, float* out, int64_t out_ld, const WinoGeom& g, int64_t Cout, int64_t G,
+                                    int tpb, const WinoEpi& ep, hipStream_t st) {
+    if (ep.masky != nullptr) launch_output_epi2_sums<M, ADD, 1>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+    else if (ep.maskbits != nullptr) launch_output_epi2_sums<M, ADD, 2>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+    else if (ep.relu_ab != nullptr) launch_output_epi2_sums<M, ADD, 3>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+    else launch_output_epi2_sums<M, ADD, 0>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+}
+template <int M>
+static void launch_output_epi2_m(const float* Mb, const int4* tab, float* out, int64_t out_ld, const WinoGeom& g, int64_t Cout, int64_t G,
+                                 int tpb, const WinoEpi& ep, hipStream_t st) {
+    if (ep.add != nullptr) launch_output_epi2_mask<M, true>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+    else launch_output_epi2_mask<M, false>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+}
+
 template <int M>
 static void launch_output_epi_m(const float* Mb, const int4* tab, float* out, int64_t out_ld, const WinoGeom& g, int64_t Cout, int64_t G,
                                 int tpb, const WinoEpi& ep, hipStream_t st) {
     using VT = typename Vec<M>::Out;
     constexpr int VW = sizeof(VT) / 4;
-#ifndef DIGA_WINO_EPI_TL
-#define DIGA_WINO_EPI_TL 2          /* measured on the C2 step: 11.5 / 10.1 / 9.8 ms per step with 4 / 2 / 1 tile lanes */
-#endif
     constexpr int TL = DIGA_WINO_EPI_TL;
     hipLaunchKernelGGL((winoM_output_epi_kernel<M, VT, TL>), dim3((unsigned)G, (unsigned)ceil_div(Cout, (256 / TL) * VW)), dim3(256), 0, st, Mb,
                        tab, out, out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d, tpb, ep);
@@ -930,7 +1195,8 @@ extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int
 static int winograd_impl(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                          size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
                          int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int flip, const diga_bwd_epilogue_t* epi, int prof_tag,
-                         void* stream, float* v_keep = nullptr, const float* in_ab = nullptr) {
+                         void* stream, float* v_keep = nullptr, const float* in_ab = nullptr, float* stats = nullptr,
+                         const void* tile_table = nullptr) {
     DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
     DIGA_REQUIRE(tile_ok(tile), DIGA_EINVAL, "conv2d_winograd: tile must be 2, 4 or 6 (F(2x2,3x3) / F(4x4,3x3) / F(6x6,3x3))");
@@ -944,8 +1210,11 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     DIGA_REQUIRE(P * g.Tp / 256 < 32768, DIGA_EINVAL, "conv2d_winograd: too many tiles for one launch");
     const WinoLayout l = wino_layout(g, Cin, Cout);
     DIGA_REQUIRE(workspace_bytes >= l.total, DIGA_EWORKSPACE, "conv2d_winograd: workspace too small (%zu < %zu)", workspace_bytes, l.total);
+    DIGA_REQUIRE(!stats || (epi == nullptr && tile != 2 && aligned16(stats)), DIGA_EINVAL,
+                 "conv2d_winograd: statistics come with the forward output transform of 4x4 / 6x6 tiles (16-byte aligned buffer)");
+    DIGA_REQUIRE(!tile_table || aligned16(tile_table), DIGA_EALIGN, "conv2d_winograd: tile_table must be 16-byte aligned");
     char* ws = static_cast<char*>(workspace);
-    int4* tab = reinterpret_cast<int4*>(ws + l.tab);
+    const int4* tab = tile_table != nullptr ? static_cast<const int4*>(tile_table) : reinterpret_cast<const int4*>(ws + l.tab);
     float* U = reinterpret_cast<float*>(ws + l.U);
     float* V = v_keep != nullptr ? v_keep : reinterpret_cast<float*>(ws + l.V);
     float* Mb = reinterpret_cast<float*>(ws + l.M);
@@ -953,7 +1222,9 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     // priced as the direct convolution it replaces (the algorithmic FLOPs of the layer)
     ProfScope prof(prof_tag == DIGA_PROF_CONV_BWD_DATA ? DIGA_PROF_CONV_BWD_DATA : DIGA_PROF_CONV_FWD, st,
                    2.0 * (double)(N * H * W) * (double)Cout * 9.0 * (double)Cin);
-    hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
+    // (the table depends on the geometry only: a caller that keeps one per geometry -- diga_conv2d_winograd_tile_table -- saves the launch)
+    if (tile_table == nullptr)
+        hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, reinterpret_cast<int4*>(ws + l.tab), g);
     if (tile == 6) launch_weight_m<6>(wgt, U, Cout, Cin, flip, st);
     else if (tile == 4) launch_weight_m<4>(wgt, U, Cout, Cin, flip, st);
     else
@@ -963,7 +1234,10 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     launch_input(tile, in, in_ld, tab, V, g.Tp, Cin, H, W, dilation, in_ab, st);
     int rc = gemm_batched_f32_dma(V, g.Tp, P, Cin, U, Cout, Mb, st);
     if (rc) return rc;
-    if (epi == nullptr) {
+    if (epi == nullptr && stats != nullptr) {
+        if (tile == 6) launch_output_stats_m<6>(Mb, tab, bias, out, out_ld, g, Cout, stats, st);
+        else launch_output_stats_m<4>(Mb, tab, bias, out, out_ld, g, Cout, stats, st);
+    } else if (epi == nullptr) {
         if (tile == 6) launch_output_m<6>(Mb, tab, bias, out, out_ld, g, Cout, st);
         else if (tile == 4) launch_output_m<4>(Mb, tab, bias, out, out_ld, g, Cout, st);
         else
@@ -978,8 +1252,13 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
         ep.relu_ab = epi->relu_ab; ep.mean = epi->mean; ep.invstd = epi->invstd; ep.partials = epi->partials;
         const int64_t G = ceil_div(N * H * W, 128);
         const int tpb = (int)ceil_div(g.T, G);
+#ifdef DIGA_WINO_EPI_OLD
         if (tile == 6) launch_output_epi_m<6>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
         else if (tile == 4) launch_output_epi_m<4>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+#else
+        if (tile == 6) launch_output_epi2_m<6>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+        else if (tile == 4) launch_output_epi2_m<4>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
+#endif
         else
             hipLaunchKernelGGL(wino_output_epi_kernel, dim3((unsigned)G, (unsigned)ceil_div(Cout, 256)), dim3(256), 0, st, Mb, tab, out,
                                out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
@@ -987,21 +1266,46 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     return launch_status("diga_conv2d_winograd_f32");
 }
 
+extern "C" size_t diga_conv2d_winograd_tile_table_bytes(int64_t N, int64_t H, int64_t W, int64_t dilation, int64_t tile) {
+    if (N <= 0 || H <= 0 || W <= 0 || dilation <= 0 || !tile_ok(tile)) return 0;
+    return (size_t)make_wino(N, H, W, dilation, tile).Tp * sizeof(int4);
+}
+
+extern "C" int diga_conv2d_winograd_tile_table(void* table, int64_t N, int64_t H, int64_t W, int64_t dilation, int64_t tile, void* stream) {
+    DIGA_REQUIRE(table && aligned16(table), DIGA_EINVAL, "conv2d_winograd_tile_table: null / unaligned table");
+    DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && tile_ok(tile) && N * H * W < (1ll << 31), DIGA_EINVAL,
+                 "conv2d_winograd_tile_table: bad shape / tile");
+    const WinoGeom g = make_wino(N, H, W, dilation, tile);
+    hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, (hipStream_t)stream, static_cast<int4*>(table), g);
+    return launch_status("diga_conv2d_winograd_tile_table");
+}
+
+extern "C" size_t diga_conv2d_winograd_stats_records(int64_t N, int64_t H, int64_t W, int64_t Cout, int64_t dilation, int64_t tile) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation <= 0 || (tile != 4 && tile != 6)) return 0;
+    return (size_t)stats_plan(make_wino(N, H, W, dilation, tile), Cout).records;
+}
+
+extern "C" size_t diga_conv2d_winograd_stats_floats(int64_t N, int64_t H, int64_t W, int64_t Cout, int64_t dilation, int64_t tile) {
+    const size_t r = diga_conv2d_winograd_stats_records(N, H, W, Cout, dilation, tile);
+    return r * 3 * (size_t)Cout + r;
+}
+
 extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                                         size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
-                                        int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int flip, int prof_tag, void* stream) {
+                                        int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int flip, float* stats_partial,
+                                        const void* tile_table, int prof_tag, void* stream) {
     return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, flip, nullptr,
-                         prof_tag, stream);
+                         prof_tag, stream, nullptr, nullptr, stats_partial, tile_table);
 }
 
 extern "C" int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out,
                                            float* v_keep, void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W,
-                                           int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int prof_tag,
-                                           void* stream) {
+                                           int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile,
+                                           float* stats_partial, const void* tile_table, int prof_tag, void* stream) {
     DIGA_REQUIRE(in_ab != nullptr, DIGA_EINVAL, "conv2d_winograd_ab: null coefficients");
     DIGA_REQUIRE(!v_keep || aligned16(v_keep), DIGA_EALIGN, "conv2d_winograd_ab: v_keep must be 16-byte aligned");
     return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, 0, nullptr,
-                         prof_tag, stream, v_keep, in_ab);
+                         prof_tag, stream, v_keep, in_ab, stats_partial, tile_table);
 }
 
 extern "C" size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation, int64_t tile) {
@@ -1011,17 +1315,17 @@ extern "C" size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W,
 
 extern "C" int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, const float* bias, float* out, float* v_keep,
                                              void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                             int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int prof_tag,
-                                             void* stream) {
+                                             int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile,
+                                             float* stats_partial, const void* tile_table, int prof_tag, void* stream) {
     DIGA_REQUIRE(v_keep != nullptr && aligned16(v_keep), DIGA_EINVAL, "conv2d_winograd_keep: v_keep must be a 16-byte aligned buffer");
     return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, 0, nullptr,
-                         prof_tag, stream, v_keep);
+                         prof_tag, stream, v_keep, nullptr, stats_partial, tile_table);
 }
 
 extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes,
                                             int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
-                                            int64_t out_ld, int64_t dilation, int64_t tile, int flip, const diga_bwd_epilogue_t* e, int prof_tag,
-                                            void* stream) {
+                                            int64_t out_ld, int64_t dilation, int64_t tile, int flip, const diga_bwd_epilogue_t* e,
+                                            const void* tile_table, int prof_tag, void* stream) {
     DIGA_REQUIRE(e != nullptr, DIGA_EINVAL, "conv2d_winograd_epi: null epilogue descriptor");
     DIGA_REQUIRE(e->addend || e->mask_y || e->mask_bits || e->x, DIGA_EINVAL, "conv2d_winograd_epi: empty epilogue descriptor");
     DIGA_REQUIRE(!e->addend || (aligned16(e->addend) && e->addend_ld >= Cout && e->addend_ld % 4 == 0), DIGA_EINVAL, "conv2d_winograd_epi: bad addend");
@@ -1034,7 +1338,7 @@ extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, f
     DIGA_REQUIRE(!e->partials || (e->x && e->mean && e->invstd && aligned16(e->mean) && aligned16(e->invstd)), DIGA_EINVAL,
                  "conv2d_winograd_epi: partials need x, mean and invstd");
     return winograd_impl(in, wgt, nullptr, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, flip, e, prof_tag,
-                         stream);
+                         stream, nullptr, nullptr, nullptr, tile_table);
 }
 
 extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
@@ -1045,7 +1349,8 @@ extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t 
 
 static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw, void* workspace,
                                size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
-                               int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream) {
+                               int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, const void* tile_table, void* stream) {
+    DIGA_REQUIRE(!tile_table || aligned16(tile_table), DIGA_EALIGN, "conv2d_wgrad_winograd: tile_table must be 16-byte aligned");
     DIGA_REQUIRE(dy && (x || v_kept) && dw && workspace, DIGA_EINVAL, "conv2d_wgrad_winograd: null pointer");
     DIGA_REQUIRE(!v_kept || aligned16(v_kept), DIGA_EALIGN, "conv2d_wgrad_winograd: v_kept must be 16-byte aligned");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096 && N * H * W < (1ll << 31) && tile_ok(tile),
@@ -1059,14 +1364,15 @@ static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_a
     DIGA_REQUIRE(workspace_bytes >= l.total, DIGA_EWORKSPACE, "conv2d_wgrad_winograd: workspace too small (%zu < %zu)", workspace_bytes,
                  l.total);
     char* ws = static_cast<char*>(workspace);
-    int4* tab = reinterpret_cast<int4*>(ws + l.tab);
+    const int4* tab = tile_table != nullptr ? static_cast<const int4*>(tile_table) : reinterpret_cast<const int4*>(ws + l.tab);
     const float* V = v_kept != nullptr ? v_kept : reinterpret_cast<float*>(ws + l.V);
     float* Z = reinterpret_cast<float*>(ws + l.Z);
     float* dU = reinterpret_cast<float*>(ws + l.dU);
     float* slab = reinterpret_cast<float*>(ws + l.slab);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_CONV_BWD_WEIGHT, st, 2.0 * (double)(N * H * W) * (double)Cout * 9.0 * (double)Cin);
-    hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, tab, g);
+    if (tile_table == nullptr)
+        hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, reinterpret_cast<int4*>(ws + l.tab), g);
     if (v_kept == nullptr)
         launch_input(tile, x, x_ld, tab, reinterpret_cast<float*>(ws + l.V), g.Tp, Cin, H, W, dilation, x_ab, st);
     if (tile == 6) launch_dy_m<6>(dy, dy_ld, tab, Z, g, Cout, st);
@@ -1085,13 +1391,17 @@ static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_a
 
 extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
                                               size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
-                                              int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream) {
-    return wgrad_winograd_impl(dy, x, nullptr, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile, stream);
+                                              int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, const void* tile_table,
+                                              void* stream) {
+    return wgrad_winograd_impl(dy, x, nullptr, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile,
+                               tile_table, stream);
 }
 
 extern "C" int diga_conv2d_wgrad_winograd_f32_ab(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw,
                                                  void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                                 int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream) {
+                                                 int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile,
+                                                 const void* tile_table, void* stream) {
     DIGA_REQUIRE(x_ab != nullptr && aligned16(x_ab), DIGA_EINVAL, "conv2d_wgrad_winograd_ab: null / unaligned coefficients");
-    return wgrad_winograd_impl(dy, x, x_ab, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile, stream);
+    return wgrad_winograd_impl(dy, x, x_ab, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile,
+                               tile_table, stream);
 }

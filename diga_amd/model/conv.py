@@ -112,6 +112,7 @@ WINOGRAD_RATIO = float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62"))
 WINOGRAD_DEFAULT_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "6"))
 WINOGRAD_MAX_TILE = WINOGRAD_DEFAULT_MAX_TILE           # (_lib.set_conv_math(0, exact=True) sets 2)
 WINOGRAD_KEEP_V = os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
+WINOGRAD_STATS = os.environ.get("DIGA_WINOGRAD_STATS", "1") != "0"       # BatchNorm statistics from the Winograd output transform
 # the keep-V policy is a function of the layer's shape and of STATIC device properties only (round 5; it used to ask the driver how
 # much memory was free at a layer's first forward, so the same binary took different paths -- and speeds -- next to another process):
 KEEP_V_MAX_BYTES = int(float(os.environ.get("DIGA_WINOGRAD_KEEP_V_MAX_GB", "8")) * (1 << 30))         # per layer
@@ -175,6 +176,42 @@ def _wino_plan(hi, wi, d):
     return plan
 
 
+_TILE_TABLES = {}
+
+
+def _tile_table(n, hi, wi, d, tile, device):
+    """The Winograd tile table of a geometry (a function of (N, H, W, dilation, tile) only: image and top-left output pixel of every
+    tile), built once per device and reused by every call on that geometry -- forward, backward-data and backward-weight of all
+    layers that share it (layer3's 23 conv2 layers: 4 calls each per step) -- instead of one wino_tiles_kernel launch per call (136
+    per C2 step).  The one-time build is followed by a stream synchronisation: the table is read from several streams (student,
+    teacher, weight-gradient side stream).  Not inside a stream capture (no sync there): the call then builds its own."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, n, hi, wi, d, tile)
+    tab = _TILE_TABLES.get(key)
+    if tab is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        tab = torch.empty(_lib.lib.diga_conv2d_winograd_tile_table_bytes(n, hi, wi, d, tile), dtype=torch.uint8, device=device)
+        _lib.call("diga_conv2d_winograd_tile_table", _lib.ptr(tab), n, hi, wi, d, tile, _lib.stream())
+        torch.cuda.current_stream(device).synchronize()
+        if len(_TILE_TABLES) > 256:
+            _TILE_TABLES.clear()
+        _TILE_TABLES[key] = tab
+    return tab
+
+
+def winograd_stats_plan(n, hi, wi, cin_padded, k, r, s, stride, padding, dilation, ho, wo):
+    """(floats, records) of the statistics buffer a forward DigaConv2d on the fp32 Winograd path with 4x4 / 6x6 tiles fills for the
+    BatchNorm behind it (diga_conv2d_winograd_stats_floats / _records), or None when the layer is not on that path."""
+    if _lib.get_conv_math() != 0 or not _winograd_ok(n, hi, wi, cin_padded, k, r, s, stride, (-padding[0], -padding[1]), tuple(dilation), ho, wo):
+        return None
+    tile = _wino_plan(hi, wi, dilation[0])[0]
+    if tile < 4 or k % 4 != 0:
+        return None
+    return (_lib.lib.diga_conv2d_winograd_stats_floats(n, hi, wi, k, dilation[0], tile),
+            _lib.lib.diga_conv2d_winograd_stats_records(n, hi, wi, k, dilation[0], tile))
+
+
 def _wino_ratio(hi, wi, d):
     return _wino_plan(hi, wi, d)[1]
 
@@ -196,7 +233,7 @@ def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
 
 
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
-                 opts=None, keep_v=None, in_ab=None, junction=None):
+                 opts=None, keep_v=None, in_ab=None, junction=None, wino_stats=False):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x.
     epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue.
@@ -274,16 +311,20 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                   n * hi * wi, cin, k, _lib.stream())
         junction["filled"] = True
         return None
-    if (_lib.get_conv_math() == 0 and copt is None and stats is None
+    if (_lib.get_conv_math() == 0 and copt is None and (stats is None or wino_stats)
             and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):
         d = abs(doff[0])
         tile, ratio = _wino_plan(hi, wi, d)
+        if stats is not None and (tile < 4 or epi is not None or doff[0] < 0):
+            raise RuntimeError("DigaConv2d: Winograd statistics come with the forward output transform of 4x4 / 6x6 tiles")
         _log_flops(name, direct, direct * ratio)
         nbytes = _lib.lib.diga_conv2d_winograd_workspace_bytes(n, hi, wi, cin, k, d, tile)
         ws = _lib.workspace(nbytes, x.device, "winograd")
+        tab = _tile_table(n, hi, wi, d, tile, x.device)
         if epi is not None:
             _lib.call("diga_conv2d_winograd_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                      n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, 1 if doff[0] < 0 else 0, ctypes.byref(epi), tag, _lib.stream())
+                      n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, 1 if doff[0] < 0 else 0, ctypes.byref(epi), _lib.ptr(tab), tag,
+                      _lib.stream())
             return None
         if in_ab is not None:
             # x holds the pre-activation values of a BatchNorm + ReLU: the input transform applies relu(fma(x, a, b)) on load
@@ -293,17 +334,19 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                 keep_v[0] = _alloc_keep_v(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), x.device)
             _lib.call("diga_conv2d_winograd_f32_ab", _lib.ptr(x), _lib.ptr(in_ab), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out),
                       _lib.ptr(keep_v[0]) if keep_v is not None else None, _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k,
-                      out.stride(2), d, tile, tag, _lib.stream())
+                      out.stride(2), d, tile, _lib.ptr(stats), _lib.ptr(tab), tag, _lib.stream())
             return None
         if keep_v is not None and doff[0] > 0:
             # keep_v: a one-element list -- the transformed input stays alive for this layer's weight gradient
             keep_v[0] = _alloc_keep_v(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), x.device)
         if keep_v is not None and doff[0] > 0 and keep_v[0] is not None:
             _lib.call("diga_conv2d_winograd_f32_keep", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(keep_v[0]),
-                      _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, tag, _lib.stream())
+                      _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, _lib.ptr(stats), _lib.ptr(tab), tag,
+                      _lib.stream())
             return None
         _lib.call("diga_conv2d_winograd_f32", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                  n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, 1 if doff[0] < 0 else 0, tag, _lib.stream())
+                  n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, 1 if doff[0] < 0 else 0, _lib.ptr(stats), _lib.ptr(tab), tag,
+                  _lib.stream())
         return None
     if in_ab is not None:
         raise RuntimeError("DigaConv2d: the input carries a deferred BatchNorm apply (_diga_lazy_ab) but this call is not on the "
@@ -433,14 +476,17 @@ class _Conv2dFn(torch.autograd.Function):
         # exact-fp32 Winograd layers whose weight gradient is wanted keep their transformed input (4x the input's bytes, HBM
         # is 288 GB): the backward-weight pass then skips a bandwidth pass of 5x the input (DIGA_WINOGRAD_KEEP_V=0: recompute)
         keep_v = None
-        if (ctx.needs_input_grad[1] and _lib.get_conv_math() == 0 and k % 256 == 0 and cp % 128 == 0 and stats is None
+        wino_stats = isinstance(stats, tuple)         # (buffer, "records"): the Winograd output transform fills it (DigaConv2d.forward)
+        if wino_stats:
+            stats = stats[0]
+        if (ctx.needs_input_grad[1] and _lib.get_conv_math() == 0 and k % 256 == 0 and cp % 128 == 0 and (stats is None or wino_stats)
                 and (opts is None or not any(opts)) and WINOGRAD_KEEP_V
                 and _winograd_ok(n, hi, wi, cp, k, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
             keep_v = [None]
         if lazy_ab is not None and cp != c:
             raise RuntimeError("DigaConv2d: a deferred BatchNorm input needs Cin % 32 == 0")
         x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box,
-                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v, in_ab=lazy_ab, junction=junction)
+                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v, in_ab=lazy_ab, junction=junction, wino_stats=wino_stats)
         ctx.wino_v = keep_v[0] if keep_v is not None else None
         ctx.in_ab = lazy_ab                 # (the saved xn then holds pre-activation values: the weight gradient applies them too)
         ctx.save_for_backward(xn, w)
@@ -632,13 +678,14 @@ class _Conv2dFn(torch.autograd.Function):
                     _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * 9 * cp, 2.0 * n * ho * wo * kp * 9 * cp * ratio)
                     nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0], tile, 1 if wino_v is not None else 0)
                     wsw = _lib.workspace(nb, w.device, "winograd_wgrad")
+                    tab = _tile_table(n, hi, wi, dilation[0], tile, w.device)
                     if in_ab is not None:
                         _lib.call("diga_conv2d_wgrad_winograd_f32_ab", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(in_ab), _lib.ptr(wino_v),
                                   _lib.ptr(dwp), _lib.ptr(wsw), wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0],
-                                  tile, _lib.stream())
+                                  tile, _lib.ptr(tab), _lib.stream())
                     else:
                         _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(wino_v), _lib.ptr(dwp), _lib.ptr(wsw),
-                                  wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], tile, _lib.stream())
+                                  wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], tile, _lib.ptr(tab), _lib.stream())
                     if not alias:
                         dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
                     return
@@ -703,13 +750,22 @@ class DigaConv2d(nn.Conv2d):
             n, _, h, w = x.shape
             ho = (h + 2 * self.padding[0] - self.dilation[0] * (self.kernel_size[0] - 1) - 1) // self.stride[0] + 1
             wo = (w + 2 * self.padding[1] - self.dilation[1] * (self.kernel_size[1] - 1) - 1) // self.stride[1] + 1
-        if (self.emit_bn_stats and self.training and self.out_channels % 4 == 0
-                and not (_lib.get_conv_math() == 0 and fn is _Conv2dFn and (opts is None or not any(opts))
-                         and _winograd_ok(n, h, w, _pad_to(self.in_channels), self.out_channels, self.kernel_size[0], self.kernel_size[1],
-                                          self.stride, (-self.padding[0], -self.padding[1]), tuple(self.dilation), ho, wo))):
-            # (a Winograd forward has no statistics epilogue: the BatchNorm reads y for them, one pass of a 3x3 layer's output)
-            stats = torch.empty(_lib.lib.diga_conv2d_stats_floats(n, ho, wo, self.out_channels), dtype=torch.float32,
-                                device=x.device)
+        wino_records = None
+        if self.emit_bn_stats and self.training and self.out_channels % 4 == 0:
+            on_wino = (_lib.get_conv_math() == 0 and fn is _Conv2dFn and (opts is None or not any(opts))
+                       and _winograd_ok(n, h, w, _pad_to(self.in_channels), self.out_channels, self.kernel_size[0], self.kernel_size[1],
+                                        self.stride, (-self.padding[0], -self.padding[1]), tuple(self.dilation), ho, wo))
+            if not on_wino:
+                stats = torch.empty(_lib.lib.diga_conv2d_stats_floats(n, ho, wo, self.out_channels), dtype=torch.float32,
+                                    device=x.device)
+            elif WINOGRAD_STATS:
+                # round 5: the Winograd output transform (4x4 / 6x6 tiles) leaves the statistics as records of unequal size
+                # (diga_bn_fwd_records); F(2x2)-only runs keep the BatchNorm's own statistics pass
+                plan = winograd_stats_plan(n, h, w, _pad_to(self.in_channels), self.out_channels, self.kernel_size[0], self.kernel_size[1],
+                                           self.stride, self.padding, self.dilation, ho, wo)
+                if plan is not None:
+                    wino_records = int(plan[1])
+                    stats = (torch.empty(plan[0], dtype=torch.float32, device=x.device), "records")
         uses = None
         if torch.is_grad_enabled() and self.weight.requires_grad:
             if self._bw_seen[0] > 0:          # a backward pass has consumed the previous graph(s)
@@ -763,7 +819,9 @@ class DigaConv2d(nn.Conv2d):
         else:
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
                          twin_box)
-        if stats is not None:
+        if wino_records is not None:
+            y._diga_bn_partials = (stats[0], ("records", wino_records))
+        elif stats is not None:
             chunk = _lib.lib.diga_conv2d_stats_chunk_rows(n, h, w, _pad_to(self.in_channels), ho, wo, self.out_channels,
                                                           self.kernel_size[0], self.kernel_size[1], self.stride[0], self.stride[1],
                                                           -self.padding[0], -self.padding[1], _lib.get_conv_math())

@@ -132,7 +132,16 @@ class _BnFn(torch.autograd.Function):
         bits = None
         if (box is not None and relu and residual is not None and c % 32 == 0 and _relu_bits_enabled()):
             bits = torch.empty((m, c // 8), dtype=torch.uint8, device=xn.device)
-        if partials is not None and training:
+        if partials is not None and training and isinstance(partials[1], tuple):
+            # ... as records of unequal size (the Winograd output transform's tile groups): [R][3][C] sums, then [R] counts
+            recs = int(partials[1][1])
+            wsr = _lib.workspace(max(_lib.lib.diga_norm_workspace_bytes(m, 1, c), (96 * 3 * c + 2 * c + 128) * 4), xn.device, "norm_rec")
+            _lib.call("diga_bn_fwd_records", _lib.ptr(xn), c, None if (defer or junc) else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
+                      _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
+                      _lib.ptr(save_invstd), _lib.ptr(junc_ab if junc else save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
+                      None if junc else _lib.ptr(bits), float(momentum), float(eps), _lib.ptr(partials[0]),
+                      _lib.C.c_void_p(partials[0].data_ptr() + recs * 3 * c * 4), recs, _lib.ptr(wsr), wsr.numel(), _lib.stream())
+        elif partials is not None and training:
             # the producing conv already reduced its output tile by tile: finalise + apply only
             _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, None if (defer or junc) else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),

@@ -368,15 +368,30 @@ int diga_conv2d_junction_f32(const float* y3, int64_t y3_ld, const float* skip, 
  * epilogue.  Cin % 32 == 0, Cout % 4 == 0, Cout > 64.  Replaces the cuDNN call behind nn.Conv2d(3x3, dilation = padding) of
  * G5/model/seg_model_noaux.py:66-70,143-150,166-170.  workspace: diga_conv2d_winograd_workspace_bytes (16-byte aligned). */
 size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t dilation, int64_t tile);
+/* Round 5, two optional arguments of every Winograd entry point:
+ *   tile_table (nullable): the layer's tile table -- a function of (N, H, W, dilation, tile) only -- built ONCE by
+ *     diga_conv2d_winograd_tile_table into a caller-owned buffer of diga_conv2d_winograd_tile_table_bytes bytes and reused by every
+ *     call on that geometry (forward, backward-data, backward-weight of all layers that share it); NULL: the call builds it in its
+ *     workspace, one more launch (136 per C2 step before).
+ *   stats_partial (nullable; forward of 4x4 / 6x6 tiles only): diga_conv2d_winograd_stats_floats floats; the output transform then
+ *     also leaves the BatchNorm behind the layer its column statistics as diga_conv2d_winograd_stats_records RECORDS of unequal
+ *     size -- [R][3][Cout] {sum (y - s), sum (y - s)^2, s} followed by [R] pixel counts -- for diga_bn_fwd_records
+ *     (counts = stats_partial + R * 3 * Cout): no statistics pass over y. */
+size_t diga_conv2d_winograd_tile_table_bytes(int64_t N, int64_t H, int64_t W, int64_t dilation, int64_t tile);
+int diga_conv2d_winograd_tile_table(void* table, int64_t N, int64_t H, int64_t W, int64_t dilation, int64_t tile, void* stream);
+size_t diga_conv2d_winograd_stats_records(int64_t N, int64_t H, int64_t W, int64_t Cout, int64_t dilation, int64_t tile);
+size_t diga_conv2d_winograd_stats_floats(int64_t N, int64_t H, int64_t W, int64_t Cout, int64_t dilation, int64_t tile);
 int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                              size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
-                             int64_t out_ld, int64_t dilation, int64_t tile, int flip, int prof_tag, void* stream);
+                             int64_t out_ld, int64_t dilation, int64_t tile, int flip, float* stats_partial, const void* tile_table,
+                             int prof_tag, void* stream);
 /* ... with the backward-data epilogue of diga_bwd_epilogue_t (declared above; same arithmetic per element as the `_epi` forms
  * of the direct kernels; `partials` rows are filled per group of tiles instead of per 128 pixel rows -- the finaliser
  * diga_bn_bwd_partials only adds the rows up). */
 int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes, int64_t N,
                                  int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation,
-                                 int64_t tile, int flip, const diga_bwd_epilogue_t* epi, int prof_tag, void* stream);
+                                 int64_t tile, int flip, const diga_bwd_epilogue_t* epi, const void* tile_table, int prof_tag,
+                                 void* stream);
 /* Backward-weight of the same layer through Winograd (dw [Cout][3][3][Cin] = G^T [sum over tiles (A dY A^T) (.) (B^T d B)] G):
  * transforms of dy and x, the 16 (tile 2) / 36 (tile 4) products contracted over the tiles in one launch of the fp32 LDS-DMA
  * backward-weight kernel (fixed-order split-K: bit-reproducible), the transform back to 3x3.  Cout % 256 == 0, Cin % 128 == 0. */
@@ -384,7 +399,7 @@ size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t 
                                                   int64_t tile, int v_kept /* 1: the call will pass the forward's kept V */);
 int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
                                    size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld, int64_t Cout,
-                                   int64_t dy_ld, int64_t dilation, int64_t tile, void* stream);
+                                   int64_t dy_ld, int64_t dilation, int64_t tile, const void* tile_table, void* stream);
 /* Forward that leaves its transformed input V (diga_conv2d_winograd_v_floats floats, 4x the input tensor) in `v_keep` for the
  * weight gradient of the same layer: pass it as `v_kept` above (x may then be null) and the backward skips the input transform
  * -- HBM is 288 GB: the transform is a bandwidth pass of 5x the input's bytes per 3x3 layer. */
@@ -395,13 +410,16 @@ size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Ci
  * statistics and coefficients only) -- the activated tensor is never written.  v_keep nullable. */
 int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out, float* v_keep,
                                 void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
-                                int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int prof_tag, void* stream);
+                                int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, float* stats_partial, const void* tile_table,
+                                int prof_tag, void* stream);
 int diga_conv2d_wgrad_winograd_f32_ab(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw,
                                       void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                      int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, void* stream);
+                                      int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, const void* tile_table,
+                                      void* stream);
 int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, const float* bias, float* out, float* v_keep, void* workspace,
                                   size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
-                                  int64_t out_ld, int64_t dilation, int64_t tile, int prof_tag, void* stream);
+                                  int64_t out_ld, int64_t dilation, int64_t tile, float* stats_partial, const void* tile_table, int prof_tag,
+                                  void* stream);
 
 /* diga_conv2d_nhwc_f32 / _bf16x3 / _twin with a diga_conv_options_t (non-null; inference-only: no statistics output). */
 int diga_conv2d_nhwc_f32_opts(const float* in, const float* wgt, const float* bias, float* out, int64_t N, int64_t Hi, int64_t Wi,
@@ -477,6 +495,15 @@ int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, c
                          float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
                          int y_twin, unsigned char* relu_bits, float momentum, float eps, const float* partial,
                          int64_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ... replaced by RECORDS of unequal size: partial [n_records][3][C] {sum (x - s), sum (x - s)^2, s}, counts [n_records] = the rows
+ * behind each record (0 allowed), sum of counts = M -- what the Winograd forward's output transform writes (stats_partial of
+ * diga_conv2d_winograd_f32: its tile groups hold different numbers of in-image pixels).  workspace as diga_bn_fwd_partials + 96 floats. */
+int diga_bn_fwd_records(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
+                        int y_twin, unsigned char* relu_bits, float momentum, float eps, const float* partial,
+                        const float* counts, int64_t n_records, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The apply pass of diga_bn_fwd* on its own: y = [relu](fma(x, a, b) [+ residual]) with ab = the [2][C] coefficients a call with
  * y = NULL left in save_ab (+ the ReLU mask bits).  For a consumer that was handed a deferred BatchNorm output and cannot apply it

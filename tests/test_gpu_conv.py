@@ -358,6 +358,61 @@ WINO_CASES = [("d1_ragged", 3, 128, 33, 29, 160, 1), ("d1_wide", 2, 384, 31, 37,
               ("d3_tiny", 2, 128, 5, 7, 128, 3)]
 
 
+@pytest.mark.parametrize("tile", [4, 6], ids=["F4x4", "F6x6"])
+@pytest.mark.parametrize("case", WINO_CASES + [("d2_4img", 4, 128, 49, 53, 128, 2), ("d1_k512", 2, 128, 40, 40, 512, 1)], ids=lambda c: c[0])
+def test_winograd_output_transform_bn_statistics(case, tile, monkeypatch):
+    """Round 5: the forward Winograd output transform (4x4 / 6x6 tiles) leaves the BatchNorm behind the layer its column statistics as
+    RECORDS of unequal size (tile groups hold different numbers of in-image pixels; diga_bn_fwd_records) -- the BatchNorm's own
+    statistics pass over y is gone.  Train-mode BN fed by the records equals BN that re-reads the conv output and a float64
+    reference, running statistics included; the input carries a large mean; the conv output itself is bit-identical either way."""
+    from diga_amd.model import conv as dc
+    from diga_amd.model.conv import DigaConv2d
+    from diga_amd.model.norm import DigaBatchNorm2d
+    name, n, cin, h, w, cout, dil = case
+    if cout % 4 != 0:
+        pytest.skip("statistics need Cout % 4 == 0")
+    monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", tile)
+    monkeypatch.setattr(dc, "WINOGRAD_RATIO", 10.0)
+    if winograd_tile(n, cin, h, w, cout, 3, 1, dil, dil) != tile:
+        pytest.skip("this geometry does not take this tile")
+    g = synth.gen(zlib.crc32(name.encode()) % 10000 + 11 + tile)
+    x = torch.randn((n, cin, h, w), generator=g) + 2.0
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    conv = DigaConv2d(cin, cout, 3, stride=1, padding=dil, dilation=dil, bias=False)
+    bn_a, bn_b = DigaBatchNorm2d(cout), DigaBatchNorm2d(cout)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, cout))
+            for p in bn.parameters():
+                p.requires_grad = False
+    conv, bn_a, bn_b = conv.to(DEV).train(), bn_a.to(DEV).train(), bn_b.to(DEV).train()
+    conv.emit_bn_stats = True
+    xd = x.to(DEV)
+    y = conv(xd)
+    part = getattr(y, "_diga_bn_partials", None)
+    assert part is not None and part[1][0] == "records" and part[1][1] > 0
+    fused = bn_a(y, relu=True)
+    monkeypatch.setattr(dc, "WINOGRAD_STATS", False)
+    y2 = conv(xd)
+    assert not hasattr(y2, "_diga_bn_partials") and torch.equal(y2, y)
+    plain = bn_b(y2, relu=True)
+    yd = y.detach().double().cpu()
+    mean, var = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
+    ref = torch.relu((yd - mean[None, :, None, None]) / torch.sqrt(var + bn_a.eps)[None, :, None, None]
+                     * bn_a.weight.double().cpu()[None, :, None, None] + bn_a.bias.double().cpu()[None, :, None, None])
+    assert_close(fused.cpu(), ref, rtol=2e-5, atol=2e-5, what=f"{name} BN on records")
+    assert_close(fused.cpu(), plain.cpu(), rtol=1e-5, atol=1e-5, what=f"{name} records vs statistics pass")
+    cnt = yd.numel() // cout
+    assert_close(bn_a.running_mean.cpu(), 0.1 * mean, rtol=1e-5, atol=1e-6, what="running_mean")
+    assert_close(bn_a.running_var.cpu(), 0.9 + 0.1 * var * cnt / (cnt - 1), rtol=1e-5, atol=1e-6, what="running_var")
+    # the counts of the records add up to the layer's pixels
+    recs = int(part[1][1])
+    counts = part[0][recs * 3 * cout: recs * 3 * cout + recs]
+    assert float(counts.sum()) == n * h * w
+
+
 @pytest.mark.parametrize("tile", [2, 4, 6], ids=["F2x2", "F4x4", "F6x6"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
 def test_winograd_f32_vs_float64(case, tile, monkeypatch):

@@ -209,9 +209,18 @@ def test_trainable_batchnorm_vs_torch():
         assert_close(mine.bias.grad, ref.bias.grad, 1e-4, 1e-4, "dbeta")
     assert_close(mine.running_mean, ref.running_mean, 1e-5, 1e-6, "running_mean")
     assert_close(mine.running_var, ref.running_var, 1e-5, 1e-6, "running_var")
+    # eval mode (running statistics; BN-frozen fine-tuning of a head in .eval()): what nn.BatchNorm2d returns, no exception (round 5)
     mine.eval()
-    with pytest.raises(RuntimeError):
-        mine(x.to(DEV).requires_grad_(), relu=True).sum().backward()
+    ref.eval()
+    xr = x.double().requires_grad_()
+    ref.zero_grad()
+    (torch.relu(ref(xr)) * probe.double()).sum().backward()
+    xm = x.to(DEV).requires_grad_()
+    mine.zero_grad()
+    (mine(xm, relu=True) * probe.to(DEV)).sum().backward()
+    assert_close(xm.grad, xr.grad, 1e-4, 1e-5, "eval dx")
+    assert_close(mine.weight.grad, ref.weight.grad, 1e-4, 1e-4, "eval dgamma")
+    assert_close(mine.bias.grad, ref.bias.grad, 1e-4, 1e-4, "eval dbeta")
 
 
 def test_small_embed_ragged_vs_oracle(conv_math):
