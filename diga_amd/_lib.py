@@ -91,6 +91,7 @@ SIGNATURES = {
     "diga_conv2d_winograd_stats_records": (SZ, [I64] * 6),
     "diga_conv2d_winograd_stats_floats": (SZ, [I64] * 6),
     "diga_conv2d_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [INT, P, P, INT, P]),
+    "diga_conv2d_winograd_f32_opts": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [P, P, INT, P]),
     "diga_conv2d_winograd_f32_epi": (INT, [P, P, P, P, SZ] + [I64] * 9 + [INT, P, P, INT, P]),
     "diga_conv2d_wgrad_winograd_workspace_bytes": (SZ, [I64] * 7 + [INT]),
     "diga_conv2d_wgrad_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [P, P]),

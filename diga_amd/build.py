@@ -44,7 +44,13 @@ def _compile(src, obj, extra):
     return r.stderr
 
 
-def build(force=False, jobs=None, verbose=True, extra=()):
+def build(force=False, jobs=None, verbose=True, extra=(), variant=None):
+    """variant: A/B builds of the library -- objects under build_<variant>/, result libdiga_hip_<variant>.so (load it with
+    DIGA_LIB=...); `extra` = additional hipcc flags (-D switches of the diagnostic / tuning macros in csrc/)."""
+    global OBJ, LIB
+    if variant:
+        OBJ = os.path.join(HERE, "build_" + variant)
+        LIB = os.path.join(HERE, f"libdiga_hip_{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -84,6 +90,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--variant", default=None, help="A/B build: objects in build_<variant>/, library libdiga_hip_<variant>.so")
+    ap.add_argument("--define", "-D", action="append", default=[], help="extra -D macro(s) for the variant")
     a = ap.parse_args()
-    build(force=a.force, jobs=a.jobs)
+    build(force=a.force, jobs=a.jobs, extra=["-D" + d for d in a.define], variant=a.variant)
     sys.exit(0)

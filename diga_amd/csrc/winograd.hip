@@ -67,7 +67,19 @@ __global__ __launch_bounds__(256) void wino_tiles_kernel(int4* __restrict__ tab,
     }
     const int timg = g.tys * g.txs;
     const int n = (int)(t / timg), r = (int)(t - (int64_t)n * timg);
-    int R = r / g.txs, Cc = r - R * g.txs;
+    // Order of an image's tiles (any order works: the table IS the order of the GEMM's rows and of every transform): bands of
+    // kBand tile rows, column-major inside a band -- vertically adjacent tiles are neighbours in t, horizontally adjacent ones
+    // kBand apart -- so that the (m + 2)^2 input patches of neighbouring tiles, which overlap by two rows / columns, are read by
+    // neighbouring blocks while the lines are still in the XCD's L2 (row-major order put vertical neighbours a whole tile row =
+    // ~1 MB of reads + 2 MB of V stores apart: the r04 PMC pass counted 3x the input's bytes fetched).
+#ifdef DIGA_WINO_ROWMAJOR
+    constexpr int kBand = 1;               /* (A/B build: the row-major order of rounds 3-4) */
+#else
+    constexpr int kBand = 4;
+#endif
+    const int band = r / (kBand * g.txs), rem = r - band * kBand * g.txs;
+    const int rows_in_band = min(kBand, g.tys - kBand * band);
+    int Cc = rem / rows_in_band, R = kBand * band + (rem - Cc * rows_in_band);
     int a = 0, b = 0;
     for (; a < g.d; ++a) {
         const int cnt = g.H > a ? (g.H - a + g.d - 1) / g.d : 0;
@@ -540,7 +552,9 @@ __global__ __launch_bounds__(256) void winoM_weight_kernel(const float* __restri
 template <int M, typename V>
 __global__ __launch_bounds__(256) void winoM_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
                                                           float* __restrict__ Vo, int64_t Tp, int C, int H, int W, int d,
-                                                          const float* __restrict__ ab) {
+                                                          const float* __restrict__ ab, int reflect) {
+    // reflect != 0: taps outside the image read the MIRRORED pixel (nn.ReflectionPad2d(d) in front of the conv: the translator's
+    // ResBlocks, G5/model/model_util.py:21-61) instead of zero; coordinates beyond the mirror's reach only feed discarded outputs
     constexpr int A = M + 2;
     constexpr int VW = sizeof(V) / 4;
     const int c4n = C / VW;
@@ -567,14 +581,22 @@ __global__ __launch_bounds__(256) void winoM_input_kernel(const float* __restric
     for (int j = 0; j < A; ++j) {
         // branch-free: every tap is loaded from a clamped (valid) address and zeroed afterwards when it lies outside the image,
         // so the A * A loads of a thread issue back to back (measured on 4x4 tiles: 151 -> 109 us)
-        const int xx = e.z + (j - 1) * d;
-        const bool xok = e.x >= 0 && (unsigned)xx < (unsigned)W;
+        int xx = e.z + (j - 1) * d;
+        if (reflect) {
+            xx = xx < 0 ? -xx : xx;
+            xx = xx >= W ? 2 * (W - 1) - xx : xx;
+        }
+        const bool xok = e.x >= 0 && (reflect || (unsigned)xx < (unsigned)W);
         const int xc = min(max(xx, 0), W - 1);
         V p[A];
 #pragma unroll
         for (int i = 0; i < A; ++i) {
-            const int y = e.y + (i - 1) * d;
-            const bool ok = xok && (unsigned)y < (unsigned)H;
+            int y = e.y + (i - 1) * d;
+            if (reflect) {
+                y = y < 0 ? -y : y;
+                y = y >= H ? 2 * (H - 1) - y : y;
+            }
+            const bool ok = xok && (reflect || (unsigned)y < (unsigned)H);
             const int yc = min(max(y, 0), H - 1);
             V v = *reinterpret_cast<const V*>(x + ((int64_t)(img * H + yc) * W + xc) * ld + c);
             if (ab != nullptr) v = relu_fma(v, av, bv);
@@ -1041,16 +1063,16 @@ __global__ __launch_bounds__(256) void winoM_dw_kernel(const float* __restrict__
 // ---- launches by tile size (2: the hand-written F(2x2) kernels above)
 template <int M>
 static void launch_input_m(const float* x, int64_t ld, const int4* tab, float* V, int64_t Tp, int64_t C, int64_t H, int64_t W, int64_t d,
-                           const float* ab, hipStream_t st) {
+                           const float* ab, hipStream_t st, int reflect) {
     using VT = typename Vec<M>::In;
     constexpr int VW = sizeof(VT) / 4;
     hipLaunchKernelGGL((winoM_input_kernel<M, VT>), dim3((unsigned)ceil_div(Tp * (C / VW), 256)), dim3(256), 0, st, x, ld, tab, V, Tp, (int)C,
-                       (int)H, (int)W, (int)d, ab);
+                       (int)H, (int)W, (int)d, ab, reflect);
 }
 static void launch_input(int64_t tile, const float* x, int64_t ld, const int4* tab, float* V, int64_t Tp, int64_t C, int64_t H, int64_t W,
-                         int64_t d, const float* ab, hipStream_t st) {
-    if (tile == 6) launch_input_m<6>(x, ld, tab, V, Tp, C, H, W, d, ab, st);
-    else if (tile == 4) launch_input_m<4>(x, ld, tab, V, Tp, C, H, W, d, ab, st);
+                         int64_t d, const float* ab, hipStream_t st, int reflect = 0) {
+    if (tile == 6) launch_input_m<6>(x, ld, tab, V, Tp, C, H, W, d, ab, st, reflect);
+    else if (tile == 4) launch_input_m<4>(x, ld, tab, V, Tp, C, H, W, d, ab, st, reflect);
     else
         hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(Tp * (C / 4), 256)), dim3(256), 0, st, x, ld, tab, V, Tp, (int)C,
                            (int)H, (int)W, (int)d, ab);
@@ -1196,7 +1218,9 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
                          size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
                          int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int flip, const diga_bwd_epilogue_t* epi, int prof_tag,
                          void* stream, float* v_keep = nullptr, const float* in_ab = nullptr, float* stats = nullptr,
-                         const void* tile_table = nullptr) {
+                         const void* tile_table = nullptr, int reflect = 0) {
+    DIGA_REQUIRE(!reflect || (tile != 2 && !flip && !epi && !in_ab && dilation < H && dilation < W), DIGA_EINVAL,
+                 "conv2d_winograd: reflection padding comes with the forward of 4x4 / 6x6 tiles (pad < H, W)");
     DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
     DIGA_REQUIRE(tile_ok(tile), DIGA_EINVAL, "conv2d_winograd: tile must be 2, 4 or 6 (F(2x2,3x3) / F(4x4,3x3) / F(6x6,3x3))");
@@ -1231,7 +1255,7 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
         hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, wgt, U, (int)Cout, (int)Cin,
                            flip);
     DIGA_REQUIRE(!in_ab || aligned16(in_ab), DIGA_EALIGN, "conv2d_winograd: in_ab must be 16-byte aligned");
-    launch_input(tile, in, in_ld, tab, V, g.Tp, Cin, H, W, dilation, in_ab, st);
+    launch_input(tile, in, in_ld, tab, V, g.Tp, Cin, H, W, dilation, in_ab, st, reflect);
     int rc = gemm_batched_f32_dma(V, g.Tp, P, Cin, U, Cout, Mb, st);
     if (rc) return rc;
     if (epi == nullptr && stats != nullptr) {
@@ -1296,6 +1320,17 @@ extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const
                                         const void* tile_table, int prof_tag, void* stream) {
     return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, flip, nullptr,
                          prof_tag, stream, nullptr, nullptr, stats_partial, tile_table);
+}
+
+extern "C" int diga_conv2d_winograd_f32_opts(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
+                                             size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
+                                             int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, const diga_conv_options_t* opts,
+                                             const void* tile_table, int prof_tag, void* stream) {
+    DIGA_REQUIRE(opts != nullptr, DIGA_EINVAL, "conv2d_winograd_opts: null options");
+    DIGA_REQUIRE(opts->upsample_shift == 0 && opts->activation == 0, DIGA_EINVAL,
+                 "conv2d_winograd_opts: only reflect_pad is folded on the Winograd path (upsampling / tanh: the direct `_opts` kernels)");
+    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, 0, nullptr,
+                         prof_tag, stream, nullptr, nullptr, nullptr, tile_table, opts->reflect_pad ? 1 : 0);
 }
 
 extern "C" int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out,

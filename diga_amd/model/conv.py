@@ -65,10 +65,11 @@ def _use_twin(cin, k, taps, shared):
 def bn1_defer_ok(conv, x, need_wgrad):
     """True when the BatchNorm + ReLU in front of `conv` (a DigaConv2d, the 3x3 conv2 of a bottleneck reading x [N,C,H,W]) may
     skip its apply pass: fp32 arithmetic, the forward on the Winograd path and -- if the weight gradient is wanted -- that one
-    too (it reads the kept transform, or re-applies the coefficients).  Off by default (DIGA_FUSE_BN1=1 enables it): bit-identical
-    and 3 ms of BatchNorm passes less per serialised step, but the two-stream step did not get faster (same-box A/B 542.0 / 538.4 ms
-    with, 538.5 / 540.1 ms without: the pass it removes was already hidden, the transform pays the coefficients' loads)."""
-    if os.environ.get("DIGA_FUSE_BN1", "0") != "1" or _lib.get_conv_math() != 0 or conv.bias is not None:
+    too (it reads the kept transform, or re-applies the coefficients).  On by default since round 5 (FUSE_BN1; DIGA_FUSE_BN1=0
+    switches it off): bit-identical, one BatchNorm apply pass per bottleneck less.  Measured neutral in round 3 (542.0 / 538.4 ms
+    with, 538.5 / 540.1 ms without), 2.2 ms faster now (same-box A/B 428.1 / 429.9 vs 431.0 / 431.4 ms): the round-5 kernel trace
+    shows the forward's apply passes running with no matrix-core kernel in flight (31 ms exposed), so removing one pays."""
+    if not FUSE_BN1 or _lib.get_conv_math() != 0 or conv.bias is not None:
         return False
     n, c, h, w = x.shape
     k = conv.out_channels
@@ -112,6 +113,7 @@ WINOGRAD_RATIO = float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62"))
 WINOGRAD_DEFAULT_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "6"))
 WINOGRAD_MAX_TILE = WINOGRAD_DEFAULT_MAX_TILE           # (_lib.set_conv_math(0, exact=True) sets 2)
 WINOGRAD_KEEP_V = os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
+FUSE_BN1 = os.environ.get("DIGA_FUSE_BN1", "1") != "0"                  # bn1's apply pass inside conv2's Winograd input transform
 WINOGRAD_STATS = os.environ.get("DIGA_WINOGRAD_STATS", "1") != "0"       # BatchNorm statistics from the Winograd output transform
 # the keep-V policy is a function of the layer's shape and of STATIC device properties only (round 5; it used to ask the driver how
 # much memory was free at a layer's first forward, so the same binary took different paths -- and speeds -- next to another process):
@@ -310,6 +312,18 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                   _lib.ptr(x), x.stride(2), _lib.ptr(junction["bits"]), _lib.ptr(w_krsc), _lib.ptr(out), out.stride(2), _lib.ptr(stats),
                   n * hi * wi, cin, k, _lib.stream())
         junction["filled"] = True
+        return None
+    if (_lib.get_conv_math() == 0 and copt is not None and copt.upsample_shift == 0 and copt.activation == 0 and copt.reflect_pad
+            and doff[0] > 0 and doff[0] < min(hi, wi) and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)
+            and _wino_plan(hi, wi, doff[0])[0] >= 4):
+        # reflection padding folded into the Winograd input transform (the translator's 3x3 ResBlock convs; round 5)
+        d = doff[0]
+        tile, ratio = _wino_plan(hi, wi, d)
+        _log_flops(name, direct, direct * ratio)
+        ws = _lib.workspace(_lib.lib.diga_conv2d_winograd_workspace_bytes(n, hi, wi, cin, k, d, tile), x.device, "winograd")
+        _lib.call("diga_conv2d_winograd_f32_opts", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                  n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, ctypes.byref(copt), _lib.ptr(_tile_table(n, hi, wi, d, tile, x.device)),
+                  tag, _lib.stream())
         return None
     if (_lib.get_conv_math() == 0 and copt is None and (stats is None or wino_stats)
             and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)):

@@ -243,7 +243,9 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
         # defer_apply (ReLU, no residual): statistics and coefficients only; the returned tensor holds the PRE-activation values
         # and carries the coefficients (`_diga_lazy_ab`) -- only a DigaConv2d on the Winograd path may read it (it applies
         # relu(fma(x, a, b)) in its input transform, diga_conv2d_winograd_f32_ab)
-        lazy = {} if (defer_apply and relu and residual is None and not twin_out) else None
+        # (never with forward hooks on this module: they would be handed the pre-activation values)
+        lazy = {} if (defer_apply and relu and residual is None and not twin_out and not self._forward_hooks
+                      and not torch.nn.modules.module._global_forward_hooks) else None
         # defer_junction (ReLU with residual, inside a whole-network forward): the apply pass is left to conv1 of the next bottleneck;
         # the returned tensor is allocated but NOT YET FILLED and carries `_diga_lazy_junction` -- a DigaConv2d that reads it fills it
         # (fused, or with the stand-alone pass when it cannot fuse).  Never with forward hooks on this module: they would see garbage.

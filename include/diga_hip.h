@@ -385,6 +385,13 @@ int diga_conv2d_winograd_f32(const float* in, const float* wgt, const float* bia
                              size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
                              int64_t out_ld, int64_t dilation, int64_t tile, int flip, float* stats_partial, const void* tile_table,
                              int prof_tag, void* stream);
+/* Forward with a diga_conv_options_t (inference-only, as the `_opts` forms of the direct kernels): reflect_pad folds
+ * nn.ReflectionPad2d(dilation) into the input transform's tap addressing (the translator's 3x3 ResBlock convs,
+ * G5/model/model_util.py:21-61: 54 % of its FLOPs); upsample_shift / activation must be 0 here (direct kernels).  tile = 4 or 6. */
+int diga_conv2d_winograd_f32_opts(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
+                                  size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
+                                  int64_t out_ld, int64_t dilation, int64_t tile, const diga_conv_options_t* opts, const void* tile_table,
+                                  int prof_tag, void* stream);
 /* ... with the backward-data epilogue of diga_bwd_epilogue_t (declared above; same arithmetic per element as the `_epi` forms
  * of the direct kernels; `partials` rows are filled per group of tiles instead of per 128 pixel rows -- the finaliser
  * diga_bn_bwd_partials only adds the rows up). */

@@ -112,7 +112,7 @@ def test_deferred_bn1_apply_is_bit_identical(monkeypatch):
     try:
         res = []
         for fuse, keep in (("0", "1"), ("1", "1"), ("1", "0")):
-            monkeypatch.setenv("DIGA_FUSE_BN1", fuse)
+            monkeypatch.setattr(_dconv, "FUSE_BN1", fuse == "1")
             monkeypatch.setattr(_dconv, "WINOGRAD_KEEP_V", keep == "1")
             for p_ in blk.parameters():
                 p_.grad = None

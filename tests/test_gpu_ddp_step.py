@@ -138,3 +138,28 @@ def test_bench_two_ranks_over_rccl():
     assert len(lines[0]) < 4000
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "nccl" and d["ranks_agree"] is True
     assert d["config"]["global_batch"] == 16 and d["value"] > 0 and d["cpu_baseline"] is None
+
+
+@pytest.mark.timeout(1500)
+def test_bench_launcher_eight_ranks_gloo_toy():
+    """Launcher smoke for the 8-GPU node the driver measures on, with what a 1-GPU box has: `bench.py --gpus 8` starts EIGHT worker
+    processes (spawned before anything touches the GPU; LOCAL_WORLD_SIZE / OMP_NUM_THREADS set, every rank pinned to its own slice of
+    the host's cores) over gloo, all sharing the one device, on the small backbone at 64 x 64: the process group comes up as 8 ranks,
+    the hook-driven gradient buckets (gradients living in the buckets: ddp.GradReducer) all-reduce, every rank ends with the same
+    student bit for bit (bench.py's own all-gather of a parameter checksum), rank 0 prints the one compact line, exit code 0."""
+    import json
+    env = dict(os.environ, DIGA_DDP_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--lean", "--config", "c1", "--batch", "1", "--size", "64", "64",
+                        "--steps", "2", "--warmup", "1", "--no-graph"], capture_output=True, text=True, timeout=1400, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["backend"] == "gloo" and d["ranks_agree"] is True
+    assert d["config"]["global_batch"] == 8 and d["value"] > 0
+    detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
+    host = detail["host"]
+    assert host["local_world"] == 8 and host["omp_num_threads"] >= 1
+    if (os.cpu_count() or 1) >= 8:
+        assert host["pinned"] and host["n_cores"] >= 1
