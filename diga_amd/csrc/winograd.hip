@@ -508,10 +508,16 @@ template <> struct Vec<4> { using In = float4; using Out = float2; using Dy = fl
 #ifndef DIGA_WINO6_OUT_VEC
 #define DIGA_WINO6_OUT_VEC float
 #endif
+// round 5: the 6x6 input transform on float4 (108 vs 163 us on l3.conv2, 16 images: with the taps branch-free and the plane stores
+// 1 KB per wave the wider accesses win, although the 8 x 8 patch no longer fits the register file without scratch); dy stays on pairs
+// (84 vs 88 us)
 #ifndef DIGA_WINO6_IN_VEC
-#define DIGA_WINO6_IN_VEC float2
+#define DIGA_WINO6_IN_VEC float4
 #endif
-template <> struct Vec<6> { using In = DIGA_WINO6_IN_VEC; using Out = DIGA_WINO6_OUT_VEC; using Dy = DIGA_WINO6_IN_VEC; };
+#ifndef DIGA_WINO6_DY_VEC
+#define DIGA_WINO6_DY_VEC float2
+#endif
+template <> struct Vec<6> { using In = DIGA_WINO6_IN_VEC; using Out = DIGA_WINO6_OUT_VEC; using Dy = DIGA_WINO6_DY_VEC; };
 
 // U[k = A i + j][co][c] = (G g G^T)[i][j], A = M + 2
 template <int M>
@@ -549,8 +555,18 @@ __global__ __launch_bounds__(256) void winoM_weight_kernel(const float* __restri
 
 // V[k = A i + j][t][c] = (B^T d B)[i][j] of the A x A patch of tile t (zero outside the image / for padding tiles); `ab` as in
 // wino_input_kernel
+#ifndef DIGA_WINO_IN_OCC
+#define DIGA_WINO_IN_OCC 1            /* (A/B knob: minimum blocks per CU the input transform is compiled for) */
+#endif
+template <typename V> __device__ __forceinline__ void wino_in_store(float* p, V v) {
+#ifdef DIGA_WINO_IN_PLAIN_STORE
+    *reinterpret_cast<V*>(p) = v;
+#else
+    nt_store4(p, v);
+#endif
+}
 template <int M, typename V>
-__global__ __launch_bounds__(256) void winoM_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
+__global__ __launch_bounds__(256, DIGA_WINO_IN_OCC) void winoM_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
                                                           float* __restrict__ Vo, int64_t Tp, int C, int H, int W, int d,
                                                           const float* __restrict__ ab, int reflect) {
     // reflect != 0: taps outside the image read the MIRRORED pixel (nn.ReflectionPad2d(d) in front of the conv: the translator's
@@ -614,7 +630,7 @@ __global__ __launch_bounds__(256) void winoM_input_kernel(const float* __restric
         V row[A];
         Xf<M>::bt(m[i], row);
 #pragma unroll
-        for (int j = 0; j < A; ++j) nt_store4(o + (A * i + j) * plane, row[j]);
+        for (int j = 0; j < A; ++j) wino_in_store<V>(o + (A * i + j) * plane, row[j]);
     }
 }
 

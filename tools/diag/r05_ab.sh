@@ -8,7 +8,7 @@ for round in 1 2; do
   for spec in "$@"; do
     name=${spec%%=*}; envs=${spec#*=}
     if [ "$name" = "$spec" ]; then envs=""; fi
-    ms=$(env $envs python $R/bench.py --lean --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    ms=$(env $envs python $R/bench.py --lean --steps 12 --warmup 2 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
     echo "$round $name $ms" | tee -a $OUT
   done
 done
