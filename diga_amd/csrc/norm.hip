@@ -369,7 +369,14 @@ __global__ void gn_param_grad_kernel(const float* __restrict__ chan_sums, int N,
 }
 
 // dx = k1*g - k2 - xhat*k3 ; dres = g   (g = dy*[y>0])
-__global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ dy, int64_t ld_dy,
+// (A/B knob: minimum blocks per CU bwd_apply_kernel is compiled for -- its register cap; measured in the step, round 5: 6 / 7 blocks
+// = caps of 80 / 72 registers: +2..4 ms; the default stays the compiler's own choice, 92 registers)
+#ifdef DIGA_BWD_APPLY_OCC
+#define DIGA_BWD_APPLY_BOUNDS __launch_bounds__(256, DIGA_BWD_APPLY_OCC)
+#else
+#define DIGA_BWD_APPLY_BOUNDS __launch_bounds__(256)
+#endif
+__global__ DIGA_BWD_APPLY_BOUNDS void bwd_apply_kernel(const float* __restrict__ dy, int64_t ld_dy,
                                                         const float* __restrict__ x, int64_t ld_x,
                                                         const float* __restrict__ y, int64_t ld_y,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,

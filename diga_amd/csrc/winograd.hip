@@ -67,16 +67,15 @@ __global__ __launch_bounds__(256) void wino_tiles_kernel(int4* __restrict__ tab,
     }
     const int timg = g.tys * g.txs;
     const int n = (int)(t / timg), r = (int)(t - (int64_t)n * timg);
-    // Order of an image's tiles (any order works: the table IS the order of the GEMM's rows and of every transform): bands of
-    // kBand tile rows, column-major inside a band -- vertically adjacent tiles are neighbours in t, horizontally adjacent ones
-    // kBand apart -- so that the (m + 2)^2 input patches of neighbouring tiles, which overlap by two rows / columns, are read by
-    // neighbouring blocks while the lines are still in the XCD's L2 (row-major order put vertical neighbours a whole tile row =
-    // ~1 MB of reads + 2 MB of V stores apart: the r04 PMC pass counted 3x the input's bytes fetched).
-#ifdef DIGA_WINO_ROWMAJOR
-    constexpr int kBand = 1;               /* (A/B build: the row-major order of rounds 3-4) */
-#else
-    constexpr int kBand = 4;
+    // Order of an image's tiles (any order works: the table IS the order of the GEMM's rows and of every transform).  Row-major
+    // (DIGA_WINO_BAND = 1, the default): horizontally adjacent tiles are neighbours in t and read the same 8 image rows as contiguous
+    // ~14 KB row pieces.  Round 5 tried bands of 4 tile rows, column-major inside a band (vertical neighbours adjacent in t, to keep
+    // the two shared patch rows in L2): FETCH_SIZE unchanged (100 062 vs 100 283 KB raw per launch on l3.conv2) and the input transform
+    // SLOWER inside the step, 177 vs 141 us per launch -- vertically adjacent patches touch separate DRAM pages.
+#ifndef DIGA_WINO_BAND
+#define DIGA_WINO_BAND 1
 #endif
+    constexpr int kBand = DIGA_WINO_BAND;
     const int band = r / (kBand * g.txs), rem = r - band * kBand * g.txs;
     const int rows_in_band = min(kBand, g.tys - kBand * band);
     int Cc = rem / rows_in_band, R = kBand * band + (rem - Cc * rows_in_band);
@@ -508,11 +507,12 @@ template <> struct Vec<4> { using In = float4; using Out = float2; using Dy = fl
 #ifndef DIGA_WINO6_OUT_VEC
 #define DIGA_WINO6_OUT_VEC float
 #endif
-// round 5: the 6x6 input transform on float4 (108 vs 163 us on l3.conv2, 16 images: with the taps branch-free and the plane stores
-// 1 KB per wave the wider accesses win, although the 8 x 8 patch no longer fits the register file without scratch); dy stays on pairs
-// (84 vs 88 us)
+// round 5 re-measured the 6x6 input transform on float4: 108 vs 163 us per launch in a warm micro-benchmark (tools/bench_conv.py), but
+// INSIDE the step (cold operands, serialised: tools/diag/r05_regress.sh) 195 vs 177 us per launch, and the two-stream step 427.7 vs
+// 424.7 ms (three interleaved runs each on one box) -- the float4 form needs the whole register file (one wave per SIMD) and
+// co-resides with nothing.  Pairs stay; dy on pairs as well (84 vs 88 us).
 #ifndef DIGA_WINO6_IN_VEC
-#define DIGA_WINO6_IN_VEC float4
+#define DIGA_WINO6_IN_VEC float2
 #endif
 #ifndef DIGA_WINO6_DY_VEC
 #define DIGA_WINO6_DY_VEC float2
@@ -555,8 +555,12 @@ __global__ __launch_bounds__(256) void winoM_weight_kernel(const float* __restri
 
 // V[k = A i + j][t][c] = (B^T d B)[i][j] of the A x A patch of tile t (zero outside the image / for padding tiles); `ab` as in
 // wino_input_kernel
-#ifndef DIGA_WINO_IN_OCC
-#define DIGA_WINO_IN_OCC 1            /* (A/B knob: minimum blocks per CU the input transform is compiled for) */
+// (A/B knob: minimum blocks per CU the input transform is compiled for.  NOT `__launch_bounds__(256, 1)` by default: an explicit 1 makes
+// the compiler plan for one wave per SIMD -- the float2 form went from 161 to > 200 VGPRs and from 130 to 220 us per launch)
+#ifdef DIGA_WINO_IN_OCC
+#define DIGA_WINO_IN_BOUNDS __launch_bounds__(256, DIGA_WINO_IN_OCC)
+#else
+#define DIGA_WINO_IN_BOUNDS __launch_bounds__(256)
 #endif
 template <typename V> __device__ __forceinline__ void wino_in_store(float* p, V v) {
 #ifdef DIGA_WINO_IN_PLAIN_STORE
@@ -565,18 +569,24 @@ template <typename V> __device__ __forceinline__ void wino_in_store(float* p, V 
     nt_store4(p, v);
 #endif
 }
-template <int M, typename V>
-__global__ __launch_bounds__(256, DIGA_WINO_IN_OCC) void winoM_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
+template <int M, typename V, bool REFLECT = false>
+__global__ DIGA_WINO_IN_BOUNDS void winoM_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
                                                           float* __restrict__ Vo, int64_t Tp, int C, int H, int W, int d,
-                                                          const float* __restrict__ ab, int reflect) {
-    // reflect != 0: taps outside the image read the MIRRORED pixel (nn.ReflectionPad2d(d) in front of the conv: the translator's
-    // ResBlocks, G5/model/model_util.py:21-61) instead of zero; coordinates beyond the mirror's reach only feed discarded outputs
+                                                          const float* __restrict__ ab) {
+    // REFLECT: taps outside the image read the MIRRORED pixel (nn.ReflectionPad2d(d) in front of the conv: the translator's
+    // ResBlocks, G5/model/model_util.py:21-61) instead of zero; coordinates beyond the mirror's reach only feed discarded outputs.
+    // A template parameter, not a kernel argument: as a run-time flag the two `if (reflect)` per tap cost the zero-padding form
+    // its back-to-back loads (130 -> 220 us per launch on l3.conv2; found by the per-kernel diff against the round-4 tree,
+    // tools/diag/r05_regress.sh)
+    constexpr bool reflect = REFLECT;
     constexpr int A = M + 2;
     constexpr int VW = sizeof(V) / 4;
     const int c4n = C / VW;
-    // XCD x walks a contiguous range of tiles: the (M + 2)^2 patches of neighbouring tiles overlap (a pixel is read by 1.78 tiles
-    // at M = 6), and with the round-robin block -> XCD dispatch every one of those reads came from a different L2 (round 5)
-#ifndef DIGA_WINO_NO_XCD
+    // Round 5 tried an XCD-aware block order here (XCD x walks a contiguous range of tiles: the (M + 2)^2 patches of neighbouring tiles
+    // overlap, a pixel is read by 1.78 tiles at M = 6, and the round-robin block -> XCD dispatch sends those reads through eight
+    // different L2s): FETCH_SIZE per launch 117 611 -> 100 062 KB raw on l3.conv2 (-15 %), but the kernel no faster (141 vs 132 us in
+    // the serialised step) and the two-stream step 1.5 ms slower (425.6 vs 424.1 ms, three interleaved runs).  -DDIGA_WINO_XCD builds it.
+#ifdef DIGA_WINO_XCD
     const int64_t idx = (int64_t)wino_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
 #else
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -827,7 +837,10 @@ __global__ __launch_bounds__(256) void winoM_output_epi_kernel(const float* __re
 // lanes: CG >= 64) and keeps {sum (y - s), sum (y - s)^2, s = its first pixel, n = its pixels} -- record r = b * TL + tl of
 // `stats` ([R][3][K]) and `counts` ([R]): the format of diga_bn_fwd_records (records of unequal, possibly zero, size).
 template <int M, typename V>
-__global__ __launch_bounds__(256, 4) void winoM_output_stats_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+#ifndef DIGA_WINO_OUT_OCC
+#define DIGA_WINO_OUT_OCC 4           /* (A/B knob: register cap of the two looping output transforms, 512 / (4 * OCC) per wave) */
+#endif
+__global__ __launch_bounds__(256, DIGA_WINO_OUT_OCC) void winoM_output_stats_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
                                                                  const float* __restrict__ bias, float* __restrict__ y, int64_t ld,
                                                                  int64_t T, int64_t Tp, int K, int H, int W, int d, int tpb, int CG,
                                                                  float* __restrict__ stats, float* __restrict__ counts) {
@@ -897,7 +910,7 @@ __global__ __launch_bounds__(256, 4) void winoM_output_stats_kernel(const float*
 // tests.  Same arithmetic per element, same partial-row layout (block (g, s) = tile group x channel slab, TL tile lanes reduced
 // through LDS in lane order): bit-identical results.
 template <int M, typename V, int TL, bool ADD, int MASK /* 0 none, 1 y > 0, 2 bits, 3 fma(x, a, b) > 0 */, bool SUMS>
-__global__ __launch_bounds__(256, 4) void winoM_output_epi2_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+__global__ __launch_bounds__(256, DIGA_WINO_OUT_OCC) void winoM_output_epi2_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
                                                                 float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
                                                                 int H, int W, int d, int tpb, WinoEpi ep) {
     constexpr int A = M + 2;
@@ -1082,8 +1095,11 @@ static void launch_input_m(const float* x, int64_t ld, const int4* tab, float* V
                            const float* ab, hipStream_t st, int reflect) {
     using VT = typename Vec<M>::In;
     constexpr int VW = sizeof(VT) / 4;
-    hipLaunchKernelGGL((winoM_input_kernel<M, VT>), dim3((unsigned)ceil_div(Tp * (C / VW), 256)), dim3(256), 0, st, x, ld, tab, V, Tp, (int)C,
-                       (int)H, (int)W, (int)d, ab, reflect);
+    const dim3 grid((unsigned)ceil_div(Tp * (C / VW), 256));
+    if (reflect)
+        hipLaunchKernelGGL((winoM_input_kernel<M, VT, true>), grid, dim3(256), 0, st, x, ld, tab, V, Tp, (int)C, (int)H, (int)W, (int)d, ab);
+    else
+        hipLaunchKernelGGL((winoM_input_kernel<M, VT, false>), grid, dim3(256), 0, st, x, ld, tab, V, Tp, (int)C, (int)H, (int)W, (int)d, ab);
 }
 static void launch_input(int64_t tile, const float* x, int64_t ld, const int4* tab, float* V, int64_t Tp, int64_t C, int64_t H, int64_t W,
                          int64_t d, const float* ab, hipStream_t st, int reflect = 0) {

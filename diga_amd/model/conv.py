@@ -65,10 +65,12 @@ def _use_twin(cin, k, taps, shared):
 def bn1_defer_ok(conv, x, need_wgrad):
     """True when the BatchNorm + ReLU in front of `conv` (a DigaConv2d, the 3x3 conv2 of a bottleneck reading x [N,C,H,W]) may
     skip its apply pass: fp32 arithmetic, the forward on the Winograd path and -- if the weight gradient is wanted -- that one
-    too (it reads the kept transform, or re-applies the coefficients).  On by default since round 5 (FUSE_BN1; DIGA_FUSE_BN1=0
-    switches it off): bit-identical, one BatchNorm apply pass per bottleneck less.  Measured neutral in round 3 (542.0 / 538.4 ms
-    with, 538.5 / 540.1 ms without), 2.2 ms faster now (same-box A/B 428.1 / 429.9 vs 431.0 / 431.4 ms): the round-5 kernel trace
-    shows the forward's apply passes running with no matrix-core kernel in flight (31 ms exposed), so removing one pays."""
+    too (it reads the kept transform, or re-applies the coefficients).  Off by default (FUSE_BN1; DIGA_FUSE_BN1=1 enables it):
+    bit-identical and one BatchNorm apply pass per bottleneck less, but the coefficients' loads and the fma + max per tap make the
+    input transform slower by more than the pass it removes (serialised step: input transform +4.6 ms, apply passes -3.0 ms) and the
+    two-stream step is 5 ms SLOWER with it (round 5, three interleaved same-box runs: 425.6 vs 420.6 ms; round 3 had measured 542.0 /
+    538.4 vs 538.5 / 540.1 ms).  An early round-5 A/B that showed -2.5 ms was taken while the input transform carried a run-time
+    `reflect` flag that had slowed it down by 70 % (csrc/winograd.hip) -- every switch was re-measured after that was found."""
     if not FUSE_BN1 or _lib.get_conv_math() != 0 or conv.bias is not None:
         return False
     n, c, h, w = x.shape
@@ -113,7 +115,7 @@ WINOGRAD_RATIO = float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62"))
 WINOGRAD_DEFAULT_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "6"))
 WINOGRAD_MAX_TILE = WINOGRAD_DEFAULT_MAX_TILE           # (_lib.set_conv_math(0, exact=True) sets 2)
 WINOGRAD_KEEP_V = os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
-FUSE_BN1 = os.environ.get("DIGA_FUSE_BN1", "1") != "0"                  # bn1's apply pass inside conv2's Winograd input transform
+FUSE_BN1 = os.environ.get("DIGA_FUSE_BN1", "0") == "1"                  # bn1's apply pass inside conv2's Winograd input transform
 WINOGRAD_STATS = os.environ.get("DIGA_WINOGRAD_STATS", "1") != "0"       # BatchNorm statistics from the Winograd output transform
 # the keep-V policy is a function of the layer's shape and of STATIC device properties only (round 5; it used to ask the driver how
 # much memory was free at a layer's first forward, so the same binary took different paths -- and speeds -- next to another process):
