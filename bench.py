@@ -49,7 +49,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak
 SERIAL_STEPS = 2          # steps of the serialised-stream pass that times kernels for the roofline
 FWD_GFLOP_768 = 1232.9           # model forward, one 768x768 image
 FWD_GFLOP_256 = 142.6
-PROFILE_TAGS = ("r04", "r03", "r02")    # profiles/<tag>_<precision>_serial_pmc_summary.json feeds roofline.traffic (newest first)
+PROFILE_TAGS = ("r05", "r04", "r03", "r02")    # profiles/<tag>_<precision>_serial_pmc_summary.json feeds roofline.traffic (newest first)
 
 CONFIGS = {
     # name: (arch, batch per GPU, H, W, label block, BASELINE.json entry, description)
@@ -508,7 +508,8 @@ def rooflines(config, precision, families, counts, geom):
     pmc = None
     for tag in PROFILE_TAGS:
         try:
-            with open(os.path.join(ROOT, "profiles", f"{tag}_{precision}_serial_pmc_summary.json")) as fh:
+            # (the self-training leg has its own passes since round 5: profiles/r05_c4_f32_serial_pmc_summary.json)
+            with open(os.path.join(ROOT, "profiles", f"{tag}_{'c4_' if config == 'c4' else ''}{precision}_serial_pmc_summary.json")) as fh:
                 pmc = json.load(fh)["kernels"]
             break
         except (OSError, ValueError, KeyError):
@@ -532,11 +533,11 @@ def rooflines(config, precision, families, counts, geom):
         kname = ("gemm_f32_persistent_kernel + conv_fwd_dma_kernel + Winograd transforms" if precision == "f32"
                  else "conv_fwd_x3w_kernel + conv_fwd_x3t8_kernel")
         traffic = None
-        if pmc and (B, H, W) == (8, 768, 768) and config == "c2":
+        if pmc and ((B, H, W) == (8, 768, 768) and config == "c2" or (B, H, W) == (8, 512, 1024) and config == "c4"):
             # launch-weighted mean over the family's kernels (the 128-column instantiations carry > 95 % of its time;
             # the same kernels also serve backward-data, whose launches are in the PMC averages)
             names = ("diga::gemm_f32_persistent_kernel", "diga::conv_fwd_dma_kernel", "diga::conv_fwd_kernel<2", "diga::wino::winoM_input_kernel",
-                     "diga::wino::winoM_output_kernel") if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t8_kernel<2", "diga::conv_fwd_x3t_kernel<2")
+                     "diga::wino::winoM_output_kernel", "diga::wino::winoM_output_stats_kernel") if precision == "f32" else ("diga::conv_fwd_x3w_kernel<2", "diga::conv_fwd_x3t8_kernel<2", "diga::conv_fwd_x3t_kernel<2")
             ent = [v for k, v in pmc.items() if k.startswith(names)]
             nl = sum(v["launches"] for v in ent)
             traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in ent) / nl if nl else None
@@ -591,8 +592,24 @@ def translator_leg(dev, precision):
             torch.cuda.synchronize()
             res[name + "_ms"] = 1e3 * (time.perf_counter() - t0) / 3
         del y
-    res.update(images_per_s=8.0 / (res["folded_ms"] * 1e-3), dtype=precision,
-               workload="dec_s2t(enc_s(x)), x [8,3,768,768], random-init weights, inference")
+    # roofline of the folded pass: FLOPs of its convolutions as direct convolutions (algorithmic) and as executed (the sixteen 3x3
+    # 256 -> 256 ResBlock convs run on F(6x6,3x3) Winograd with the reflection padding folded into the input transform since round 5)
+    from diga_amd.model import conv as _dconv
+    _dconv.flop_log = {}
+    with torch.no_grad():
+        dec(enc(x))
+    torch.cuda.synchronize()
+    direct = sum(v[0] for v in _dconv.flop_log.values())
+    executed = sum(v[1] for v in _dconv.flop_log.values())
+    _dconv.flop_log = None
+    peak = F32_MFMA_PEAK_TFLOPS if precision == "f32" else BF16_MFMA_PEAK_TFLOPS / 3.0
+    sec = res["folded_ms"] * 1e-3
+    res.update(images_per_s=8.0 / sec, dtype=precision,
+               workload="dec_s2t(enc_s(x)), x [8,3,768,768], random-init weights, inference",
+               roofline={"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": executed / sec / 1e12, "frac": executed / sec / 1e12 / peak,
+                         "achieved_algorithmic": direct / sec / 1e12, "frac_algorithmic": direct / sec / 1e12 / peak,
+                         "direct_tflop": direct / 1e12, "executed_tflop": executed / 1e12,
+                         "note": "whole pass (convolutions + InstanceNorm passes) timed; FLOPs = its convolutions only"})
     del enc, dec, x
     torch.cuda.empty_cache()
     return res
@@ -733,7 +750,9 @@ def main():
                 "kernel_families": cfam if cfg in ("c5", "c4") else None,
                 "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea},
                 "hip_graph": bool(use_graph), **({"head": a.c5_head} if cfg == "c5" else {}),
-                "roofline_conv_fwd": None if croof is None else {k: croof.get(k) for k in ("achieved", "peak", "unit", "frac", "frac_algorithmic")},
+                **({"note": "SegFormer head: linear_fuse (mmcv ConvModule) is pinned to a stand-in conv(bias=False) -> BN -> ReLU = mmcv 1.x's documented "
+                            "behaviour, not its code (mmcv absent); MiT encoder pinned to the reference module"} if cfg == "c5" and a.c5_head == "segformer" else {}),
+                "roofline_conv_fwd": None if croof is None else {k: croof.get(k) for k in ("achieved", "peak", "unit", "frac", "frac_algorithmic", "traffic")},
                 "roofline_other_kernels": cother if cfg == "c4" else None,
                 "losses_last_step": {k: v for k, v in closs.items() if not k.startswith("_")}}
             if cfg == "c5":
@@ -820,6 +839,7 @@ def compact(line):
         return {"value": num(d["value"]), "unit": d["unit"], "ms_per_step": num(d["ms_per_step"]), "steps": d["steps"],
                 "warmup": d["warmup"], "dtype": d["dtype"].split(" (")[0], "frac": num(r.get("frac")),
                 "peak_mem_gb": num((d.get("peak_mem_gb") or {}).get("allocated"), 4),
+                **({"traffic": num(r.get("traffic"), 4)} if r.get("traffic") else {}),
                 **({"head": d["head"]} if "head" in d else {})}
 
     oc = line.get("other_configs") or {}

@@ -131,7 +131,13 @@ class DigaTrainer:
         persistent GEMM of one stream holds every CU while the other stream's bandwidth passes run under it, and the two
         alternate from then on.  Returns (student outputs, pending teacher outputs for `_teacher_join`)."""
         where = os.environ.get("DIGA_TEACHER_OFFSET", "layer1")
-        stage = getattr(self.student, where, None) if where not in ("", "0") else None
+        stage = None
+        if where not in ("", "0"):
+            stage = self.student
+            for part in where.split("."):                       # a stage ("layer1") or a block inside one ("layer1.1", "layer2.0")
+                stage = getattr(stage, part, None) if not part.isdigit() else (stage[int(part)] if stage is not None and int(part) < len(stage) else None)
+                if stage is None:
+                    break
         if not isinstance(stage, torch.nn.Module) or os.environ.get("DIGA_TEACHER_STREAM", "1") == "0" or not student_in.is_cuda:
             pending = self._teacher_async(*teacher_in)
             return self.student(student_in), pending

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r05_ab.txt
 : > $OUT
-for round in 1 2; do
+for round in 1 2 3; do
   for spec in "$@"; do
     name=${spec%%=*}; envs=${spec#*=}
     if [ "$name" = "$spec" ]; then envs=""; fi

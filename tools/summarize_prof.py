@@ -40,6 +40,7 @@ def pmc(dirname):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    config = sys.argv[5] if len(sys.argv) > 5 else ("c4" if "_c4_" in tag else "c2")
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     ks = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)
@@ -59,7 +60,7 @@ def main():
                       "hbm_bytes_per_launch_corrected": (2.0 * f_kb + w_kb) * 1024.0}
     with open(os.path.join(out, f"{tag}_pmc_summary.json"), "w") as fh:
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
-                           "bench.py --steps 1 --warmup 1 --serial-streams (config c2); FETCH_SIZE doubled per MI355X_MICROARCH.md",
+                           "bench.py --steps 1 --warmup 1 --serial-streams (config " + config + "); FETCH_SIZE doubled per MI355X_MICROARCH.md",
                    "kernels": summary}, fh, indent=1)
     print("wrote", out)
 
