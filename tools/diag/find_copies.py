@@ -22,7 +22,7 @@ def main():
     student, teacher = SegModel(arch=sm.RESNET101).to(dev), SegModel(arch=sm.RESNET101).to(dev)
     teacher.train()
     tr = train_step.DigaTrainer(student, teacher, rng=random.Random(1))
-    batch = synthetic.warmup_batch(1234, 2, 256, 256, block=32, device=dev)
+    batch = synthetic.warmup_batch(1234, int(os.environ.get("FC_B", "2")), int(os.environ.get("FC_HW", "256")), int(os.environ.get("FC_HW", "256")), block=32, device=dev)
     for it in range(2):
         tr.warmup_step(it, *batch)
     torch.cuda.synchronize()
