@@ -66,8 +66,18 @@ def test_abi_argument_errors_without_gpu():
     ws = {t: _lib.lib.diga_conv2d_winograd_workspace_bytes(16, 97, 97, 256, 256, 2, t) for t in (2, 4, 6)}
     assert ws[2] > ws[4] > ws[6] > 0 and _lib.lib.diga_conv2d_winograd_workspace_bytes(16, 97, 97, 256, 256, 2, 3) == 0
     assert _lib.lib.diga_conv2d_winograd_v_floats(16, 97, 97, 256, 2, 6) == 64 * 4864 * 256      # 16 x 17^2 tiles -> 4864 rows, 64 products
-    rc = _lib.lib.diga_conv2d_winograd_f32(1, 1, None, 1, 1, 1 << 30, 1, 8, 8, 128, 128, 128, 128, 1, 5, 0, 0, None)
+    rc = _lib.lib.diga_conv2d_winograd_f32(1, 1, None, 1, 1, 1 << 30, 1, 8, 8, 128, 128, 128, 128, 1, 5, 0, None, None, 0, None)
     assert rc == -1 and "tile" in _lib.last_error()
+    # round-5 entry points: tile tables and the statistics records of the forward output transform are sized by query; F(2x2) has no
+    # statistics form; the reflect-padded forward refuses upsampling / tanh (those stay on the direct `_opts` kernels)
+    assert _lib.lib.diga_conv2d_winograd_tile_table_bytes(16, 97, 97, 2, 6) == 4864 * 16
+    assert _lib.lib.diga_conv2d_winograd_stats_records(16, 97, 97, 256, 2, 6) == 1156 and _lib.lib.diga_conv2d_winograd_stats_records(16, 97, 97, 256, 2, 2) == 0
+    assert _lib.lib.diga_conv2d_winograd_stats_floats(16, 97, 97, 256, 2, 6) == 1156 * 3 * 256 + 1156
+    import ctypes
+    opt = _lib.ConvOptions(1, 1, 0)
+    rc = _lib.lib.diga_conv2d_winograd_f32_opts(16, 16, None, 16, 16, 1 << 30, 1, 8, 8, 128, 128, 128, 128, 1, 6, ctypes.byref(opt), None, 0, None)
+    assert rc == -1 and "reflect_pad" in _lib.last_error()
+    assert _lib.lib.diga_bn_fwd_records(16, 4, 16, 4, None, 4, 16, 16, None, None, 16, 16, None, 8, 4, 0, 0, None, 0.1, 1e-5, 16, None, 4, 16, 1 << 20, None) == -1
     assert _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 1024, 256) == 1 and _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 1024, 64) == 0
     assert _lib.lib.diga_conv2d_junction_ok(4 * 97 * 97, 1024, 256) == 0 and _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 4096, 256) == 0
     assert _lib.lib.diga_small_linear_fwd(None, None, None, None, 1, 1, 1, 0, None) == -1
