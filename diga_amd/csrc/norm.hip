@@ -206,12 +206,15 @@ __device__ __forceinline__ void norm_split4(const float4 v, uint2& hi, uint2& lo
 
 // twin_out: y receives the split twin of the result ([row][C/8][hi8 | lo8], dense rows of 4*C bytes) instead of fp32 --
 // for a tensor whose only readers are convolutions on the twin kernels
+// Round 5: the operand combination (residual?, ReLU?, mask bits?, twin output?, per-segment coefficients?) is a TEMPLATE parameter --
+// with run-time flags every instantiation carried the registers of its heaviest path (the split-twin output: 54) and the flag tests per
+// row; the forms the fp32 step runs need 30-40.  Same expression per element, bit for bit.
+template <bool RES, bool RELU, bool BITS, bool TWIN, bool SEG>
 __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, int64_t ld_x, float* __restrict__ y,
                                                            int64_t ld_y, const float* __restrict__ res, int64_t ld_r,
                                                            const float* __restrict__ a, const float* __restrict__ b,
                                                            int64_t ab_seg_stride, int64_t rows_per_seg, int64_t rows,
-                                                           int C, int relu, int twin_out,
-                                                           unsigned char* __restrict__ relu_bits = nullptr) {
+                                                           int C, unsigned char* __restrict__ relu_bits) {
     // a thread keeps its channel quad(s) and walks rows: no per-element division, coefficients in registers
     const int tq = C >> 2;
     const int tpr = tq < 256 ? tq : 256;          // threads per row
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
         float4 bv = b != nullptr ? *reinterpret_cast<const float4*>(b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         int cur_seg = 0;
         for (int r = blockIdx.x * rpb + rl; r < nrows; r += rstep) {
-            if (ab_seg_stride != 0) {
+            if (SEG) {
                 const int seg = r / rps;
                 if (seg != cur_seg) {
                     cur_seg = seg;
@@ -240,12 +243,12 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
             // same expression instead of re-reading y
             o.x = __builtin_fmaf(xv.x, av.x, bv.x); o.y = __builtin_fmaf(xv.y, av.y, bv.y);
             o.z = __builtin_fmaf(xv.z, av.z, bv.z); o.w = __builtin_fmaf(xv.w, av.w, bv.w);
-            if (res != nullptr) {
+            if (RES) {
                 const float4 rv = ld4s(res + (int64_t)r * ld_r + c);
                 o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
             }
-            if (relu) {
-                if (relu_bits != nullptr) {
+            if (RELU) {
+                if (BITS) {
                     // the ReLU mask as one bit per channel (C % 32 == 0): 8 lanes = 32 consecutive channels of one row OR
                     // their nibbles together (two quad permutes + a half-row mirror) and the first lane stores the word
                     unsigned v = ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u))
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
                 }
                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
-            if (twin_out) {
+            if (TWIN) {
                 uint2 hi, lo;
                 norm_split4(o, hi, lo);
                 unsigned char* tw = reinterpret_cast<unsigned char*>(y) + ((int64_t)r * (C >> 3) + (c >> 3)) * 32 + ((c >> 2) & 1) * 8;
@@ -269,6 +272,38 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
             }
         }
     }
+}
+
+template <bool RES, bool RELU, bool BITS, bool TWIN>
+static void launch_affine_seg(dim3 grid, hipStream_t st, const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* res, int64_t ld_r,
+                              const float* a, const float* b, int64_t ab_seg_stride, int64_t rows_per_seg, int64_t rows, int C,
+                              unsigned char* relu_bits) {
+    if (ab_seg_stride != 0)
+        hipLaunchKernelGGL((affine_apply_kernel<RES, RELU, BITS, TWIN, true>), grid, dim3(256), 0, st, x, ld_x, y, ld_y, res, ld_r, a, b, ab_seg_stride,
+                           rows_per_seg, rows, C, relu_bits);
+    else
+        hipLaunchKernelGGL((affine_apply_kernel<RES, RELU, BITS, TWIN, false>), grid, dim3(256), 0, st, x, ld_x, y, ld_y, res, ld_r, a, b, ab_seg_stride,
+                           rows_per_seg, rows, C, relu_bits);
+}
+// the run-time flags of the entry points -> the instantiation (relu_bits only with relu; a twin output only without mask bits)
+static void launch_affine(dim3 grid, hipStream_t st, const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* res, int64_t ld_r,
+                          const float* a, const float* b, int64_t ab_seg_stride, int64_t rows_per_seg, int64_t rows, int C, int relu,
+                          int twin_out, unsigned char* relu_bits = nullptr) {
+#define DIGA_AFF(RES, RELU, BITS, TWIN) \
+    launch_affine_seg<RES, RELU, BITS, TWIN>(grid, st, x, ld_x, y, ld_y, res, ld_r, a, b, ab_seg_stride, rows_per_seg, rows, C, relu_bits)
+    const bool bits = relu && relu_bits != nullptr;
+    if (res != nullptr) {
+        if (relu) {
+            if (bits) { if (twin_out) DIGA_AFF(true, true, true, true); else DIGA_AFF(true, true, true, false); }
+            else { if (twin_out) DIGA_AFF(true, true, false, true); else DIGA_AFF(true, true, false, false); }
+        } else { if (twin_out) DIGA_AFF(true, false, false, true); else DIGA_AFF(true, false, false, false); }
+    } else {
+        if (relu) {
+            if (bits) { if (twin_out) DIGA_AFF(false, true, true, true); else DIGA_AFF(false, true, true, false); }
+            else { if (twin_out) DIGA_AFF(false, true, false, true); else DIGA_AFF(false, true, false, false); }
+        } else { if (twin_out) DIGA_AFF(false, false, false, true); else DIGA_AFF(false, false, false, false); }
+    }
+#undef DIGA_AFF
 }
 
 // partial[(seg*nchunk+chunk)][2][C] = { sum g, sum g*xhat },  g = dy * [y > 0] (relu) , xhat = (x-mean)*invstd
@@ -369,14 +404,11 @@ __global__ void gn_param_grad_kernel(const float* __restrict__ chan_sums, int N,
 }
 
 // dx = k1*g - k2 - xhat*k3 ; dres = g   (g = dy*[y>0])
-// (A/B knob: minimum blocks per CU bwd_apply_kernel is compiled for -- its register cap; measured in the step, round 5: 6 / 7 blocks
-// = caps of 80 / 72 registers: +2..4 ms; the default stays the compiler's own choice, 92 registers)
-#ifdef DIGA_BWD_APPLY_OCC
-#define DIGA_BWD_APPLY_BOUNDS __launch_bounds__(256, DIGA_BWD_APPLY_OCC)
-#else
-#define DIGA_BWD_APPLY_BOUNDS __launch_bounds__(256)
-#endif
-__global__ DIGA_BWD_APPLY_BOUNDS void bwd_apply_kernel(const float* __restrict__ dy, int64_t ld_dy,
+// Round 5: as affine_apply_kernel, the operand combination is a template parameter (MASK: 0 the gradient arrives masked / no ReLU,
+// 1 mask = y > 0, 2 mask = fma(x, a, b) > 0; DRES: also store the masked gradient; TWIN: dx as the split twin; SEG: per-segment
+// coefficients = GroupNorm) -- 92 registers with run-time flags, 44-64 per instantiation; same arithmetic per element.
+template <int MASK, bool DRES, bool TWIN, bool SEG>
+__global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ dy, int64_t ld_dy,
                                                         const float* __restrict__ x, int64_t ld_x,
                                                         const float* __restrict__ y, int64_t ld_y,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -384,8 +416,8 @@ __global__ DIGA_BWD_APPLY_BOUNDS void bwd_apply_kernel(const float* __restrict__
                                                         int64_t kk_seg_stride, int64_t kk_plane, float* __restrict__ dx,
                                                         int64_t ld_dx, float* __restrict__ dres, int64_t ld_dr,
                                                         int64_t rows_per_seg, int64_t rows, int C,
-                                                        const float* __restrict__ relu_ab, int twin_out) {
-    // twin_out: dx receives the split twin ([row][C/8][hi8 | lo8]) instead of fp32 (its only readers are twin kernels)
+                                                        const float* __restrict__ relu_ab) {
+    // TWIN: dx receives the split twin ([row][C/8][hi8 | lo8]) instead of fp32 (its only readers are twin kernels)
     const int tq = C >> 2;
     const int tpr = tq < 256 ? tq : 256;
     const int rpb = 256 / tpr;
@@ -393,12 +425,11 @@ __global__ DIGA_BWD_APPLY_BOUNDS void bwd_apply_kernel(const float* __restrict__
     if (rl >= rpb) return;
     const int nrows = (int)rows, rps = (int)rows_per_seg;
     const int rstep = gridDim.x * rpb;
-    const bool per_seg = kk_seg_stride != 0 || st_seg_stride != 0;
     for (int q = q0; q < tq; q += tpr) {
         const int c = q * 4;
         float k1a[4], k2a[4], k3a[4], mu[4], is[4];
         float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (relu_ab != nullptr) {
+        if (MASK == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 ra[e] = relu_ab[c + e];
@@ -423,7 +454,7 @@ __global__ DIGA_BWD_APPLY_BOUNDS void bwd_apply_kernel(const float* __restrict__
         load_coeff(0);
         int cur_seg = 0;
         for (int r = blockIdx.x * rpb + rl; r < nrows; r += rstep) {
-            if (per_seg) {
+            if (SEG) {
                 const int seg = r / rps;
                 if (seg != cur_seg) {
                     cur_seg = seg;
@@ -434,12 +465,12 @@ __global__ DIGA_BWD_APPLY_BOUNDS void bwd_apply_kernel(const float* __restrict__
             const float4 xv = ld4s(x + (int64_t)r * ld_x + c);
             float gg[4] = {gv.x, gv.y, gv.z, gv.w};
             const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
-            if (y != nullptr) {
+            if (MASK == 1) {
                 const float4 yv = ld4s(y + (int64_t)r * ld_y + c);
                 const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
-            } else if (relu_ab != nullptr) {
+            } else if (MASK == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gg[e] = __builtin_fmaf(xx[e], ra[e], rb[e]) > 0.f ? gg[e] : 0.f;
             }
@@ -449,7 +480,7 @@ __global__ DIGA_BWD_APPLY_BOUNDS void bwd_apply_kernel(const float* __restrict__
                 const float xh = (xx[e] - mu[e]) * is[e];
                 o[e] = k1a[e] * gg[e] - k2a[e] - xh * k3a[e];
             }
-            if (twin_out) {
+            if (TWIN) {
                 uint2 hi, lo;
                 norm_split4(make_float4(o[0], o[1], o[2], o[3]), hi, lo);
                 unsigned char* tw = reinterpret_cast<unsigned char*>(dx) + ((int64_t)r * (C >> 3) + (c >> 3)) * 32 + ((c >> 2) & 1) * 8;
@@ -458,10 +489,39 @@ __global__ DIGA_BWD_APPLY_BOUNDS void bwd_apply_kernel(const float* __restrict__
             } else {
                 st4s(dx + (int64_t)r * ld_dx + c, make_float4(o[0], o[1], o[2], o[3]));
             }
-            if (dres != nullptr)
-                st4s(dres + (int64_t)r * ld_dr + c, make_float4(gg[0], gg[1], gg[2], gg[3]));
+            if (DRES) st4s(dres + (int64_t)r * ld_dr + c, make_float4(gg[0], gg[1], gg[2], gg[3]));
         }
     }
+}
+
+template <int MASK, bool DRES, bool TWIN>
+static void launch_bwd_apply_seg(dim3 grid, hipStream_t st, const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y,
+                                 int64_t ld_y, const float* mean, const float* invstd, int st_seg_stride, int cdiv, const float* kk,
+                                 int64_t kk_seg_stride, int64_t kk_plane, float* dx, int64_t ld_dx, float* dres, int64_t ld_dr,
+                                 int64_t rows_per_seg, int64_t rows, int C, const float* relu_ab) {
+    if (kk_seg_stride != 0 || st_seg_stride != 0)
+        hipLaunchKernelGGL((bwd_apply_kernel<MASK, DRES, TWIN, true>), grid, dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y, mean, invstd, st_seg_stride,
+                           cdiv, kk, kk_seg_stride, kk_plane, dx, ld_dx, dres, ld_dr, rows_per_seg, rows, C, relu_ab);
+    else
+        hipLaunchKernelGGL((bwd_apply_kernel<MASK, DRES, TWIN, false>), grid, dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y, mean, invstd, st_seg_stride,
+                           cdiv, kk, kk_seg_stride, kk_plane, dx, ld_dx, dres, ld_dr, rows_per_seg, rows, C, relu_ab);
+}
+static void launch_bwd_apply(dim3 grid, hipStream_t st, const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
+                             const float* mean, const float* invstd, int st_seg_stride, int cdiv, const float* kk, int64_t kk_seg_stride,
+                             int64_t kk_plane, float* dx, int64_t ld_dx, float* dres, int64_t ld_dr, int64_t rows_per_seg, int64_t rows, int C,
+                             const float* relu_ab, int twin_out) {
+#define DIGA_BA(MASK, DRES, TWIN)                                                                                                          \
+    launch_bwd_apply_seg<MASK, DRES, TWIN>(grid, st, dy, ld_dy, x, ld_x, y, ld_y, mean, invstd, st_seg_stride, cdiv, kk, kk_seg_stride, kk_plane, \
+                                           dx, ld_dx, dres, ld_dr, rows_per_seg, rows, C, relu_ab)
+    const int mk = y != nullptr ? 1 : relu_ab != nullptr ? 2 : 0;
+    if (dres != nullptr) {
+        if (twin_out) { if (mk == 1) DIGA_BA(1, true, true); else if (mk == 2) DIGA_BA(2, true, true); else DIGA_BA(0, true, true); }
+        else { if (mk == 1) DIGA_BA(1, true, false); else if (mk == 2) DIGA_BA(2, true, false); else DIGA_BA(0, true, false); }
+    } else {
+        if (twin_out) { if (mk == 1) DIGA_BA(1, false, true); else if (mk == 2) DIGA_BA(2, false, true); else DIGA_BA(0, false, true); }
+        else { if (mk == 1) DIGA_BA(1, false, false); else if (mk == 2) DIGA_BA(2, false, false); else DIGA_BA(0, false, false); }
+    }
+#undef DIGA_BA
 }
 
 // out[seg][c] = mean over the segment's rows (SE global average pool) from colstats partials
@@ -982,7 +1042,7 @@ extern "C" int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
                            running_var, save_mean, save_invstd, ab, (int)C, eps);
     }
     if (y != nullptr)
-        hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
+        launch_affine(dim3(ew_blocks(M * C / 4)), st, x, ld_x, y, ld_y, residual, ld_r, ab,
                            ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
     return launch_status("diga_bn_fwd");
 }
@@ -1029,7 +1089,7 @@ static int bn_fwd_from_partials(const char* who, const float* x, int64_t ld_x, f
     hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
                        running_mean, running_var, save_mean, save_invstd, ab, momentum, eps, counts);
     if (y != nullptr)
-        hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab,
+        launch_affine(dim3(ew_blocks(M * C / 4)), st, x, ld_x, y, ld_y, residual, ld_r, ab,
                            ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
     return launch_status(who);
 }
@@ -1065,7 +1125,7 @@ extern "C" int diga_bn_apply(const float* x, int64_t ld_x, float* y, int64_t ld_
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * (8.0 + (residual ? 4.0 : 0.0)));
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y, residual, ld_r, ab, ab + C,
+    launch_affine(dim3(ew_blocks(M * C / 4)), st, x, ld_x, y, ld_y, residual, ld_r, ab, ab + C,
                        (int64_t)0, M, M, (int)C, relu, 0, relu_bits);
     return launch_status("diga_bn_apply");
 }
@@ -1093,7 +1153,7 @@ static int bn_bwd_impl(const float* dy, int64_t ld_dy, const float* x, int64_t l
                            save_mean, save_invstd, 0, 1, g, partial, relu_ab);
     hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma,
                        save_invstd, kk, training, dgamma, dbeta);
-    hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y, save_mean,
+    launch_bwd_apply(dim3(ew_blocks(M * C / 4)), st, dy, ld_dy, x, ld_x, y, ld_y, save_mean,
                        save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, dres, ld_dr, M, M, (int)C, relu_ab, dx_twin);
     return launch_status(dgamma ? "diga_bn_bwd_affine" : "diga_bn_bwd");
 }
@@ -1147,7 +1207,7 @@ extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x
     }
     hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, geo, gamma,
                        save_invstd, kk, 1);
-    hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(M * C / 4)), dim3(256), 0, st, g, ld_g, x, ld_x, (const float*)nullptr,
+    launch_bwd_apply(dim3(ew_blocks(M * C / 4)), st, g, ld_g, x, ld_x, (const float*)nullptr,
                        (int64_t)0, save_mean, save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, (float*)nullptr,
                        (int64_t)0, M, M, (int)C, (const float*)nullptr, dx_twin);
     return launch_status("diga_bn_bwd_partials");
@@ -1174,7 +1234,7 @@ extern "C" int diga_gn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y,
     else
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)ceil_div(N * G, 64)), dim3(64), 0, st, partial, g, (int)G, gamma,
                            beta, chan_scale, save_mean, save_invstd, ab, eps);
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y,
+    launch_affine(dim3(ew_blocks(N * HW * C / 4)), st, x, ld_x, y, ld_y,
                        (const float*)nullptr, (int64_t)0, ab, ab + N * C, C, HW, N * HW, (int)C, relu, 0);
     return launch_status("diga_gn_fwd");
 }
@@ -1206,7 +1266,7 @@ extern "C" int diga_gn_bwd(const float* dy, int64_t ld_dy, const float* x, int64
                            gamma, chan_scale, save_invstd, kk, chan_sums);
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, chan_sums, (int)N, (int)C,
                        dgamma, dbeta);
-    hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, dy, ld_dy, x, ld_x, y, ld_y,
+    launch_bwd_apply(dim3(ew_blocks(N * HW * C / 4)), st, dy, ld_dy, x, ld_x, y, ld_y,
                        save_mean, save_invstd, (int)G, cpg, kk, C, N * C, dx, ld_dx, (float*)nullptr, (int64_t)0, HW, N * HW,
                        (int)C, (const float*)nullptr, 0);
     return launch_status("diga_gn_bwd");
@@ -1307,7 +1367,7 @@ extern "C" int diga_channel_affine(const float* x, int64_t ld_x, float* y, int64
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(DIGA_PROF_ELEMENTWISE, st, (double)N * HW * C * 8.0);
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(ew_blocks(N * HW * C / 4)), dim3(256), 0, st, x, ld_x, y, ld_y,
+    launch_affine(dim3(ew_blocks(N * HW * C / 4)), st, x, ld_x, y, ld_y,
                        (const float*)nullptr, (int64_t)0, a, b, C, HW, N * HW, (int)C, 0, 0);
     return launch_status("diga_channel_affine");
 }
