@@ -1280,8 +1280,11 @@ __device__ unsigned long long g_probe_stamps[8192 * 6];
 #define DIGA_STAMP(slot_) do { } while (0)
 #endif
 
+#ifndef DIGA_FWD_DMA_MINW
+#define DIGA_FWD_DMA_MINW 3           /* (A/B knob: 4 = a 128-register cap, so that apply-pass waves of the other stream fit next to it) */
+#endif
 template <bool EPI = false>
-__global__ __launch_bounds__(768, 3) void conv_fwd_dma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(768, DIGA_FWD_DMA_MINW) void conv_fwd_dma_kernel(ConvArgs a) {
     constexpr int BM = 256, BN = 128;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __align__(16) unsigned char smem_b[];
@@ -2695,30 +2698,34 @@ __global__ __launch_bounds__(JUNC ? 1024 : 768, JUNC ? 4 : 3) void gemm_f32_pers
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int li = lane & 31, lh = lane >> 5;
     const int fsw = (li >> 1) & 7;
-    int foff[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) foff[t] = li * 128 + (((2 * t + lh) ^ fsw) << 4);
-    const int abase = wm * 64 * 128, bbase = A_BYTES + wn * 64 * 128;
+    // k-group t of row li sits at byte li * 128 + (((2 t + lh) ^ fsw) << 4) = F ^ (t << 5), F = li * 128 + ((lh ^ fsw) << 4): ONE
+    // per-lane base per operand and an XOR immediate per k-group instead of four offset registers and eight per-step addresses
+    // (round 5: 117 -> 112 VGPRs with the 32-bit output offsets below -- 176 instead of 152 registers per SIMD stay free for the
+    // other stream's bandwidth kernels; same reads, same MFMA order)
+    const int F = li * 128 + ((lh ^ fsw) << 4);
+    const int FA = F + wm * 64 * 128, FB = F + A_BYTES + wn * 64 * 128;
+#define DIGA_FOFF(t) ((t) << 5)
 
     __builtin_amdgcn_s_barrier();                                // stage 0 has landed
     int cur = 0, it = 0, ks_in_tile = 0;
     for (int gs = 0; gs < total_steps; ++gs) {
-        const unsigned char* As = smem_b + cur * STAGE + abase;
-        const unsigned char* Bs = smem_b + cur * STAGE + bbase;
+        const int sa = cur * STAGE + FA, sb = cur * STAGE + FB;      // (stage and wave bases are multiples of 8 KB: bits 5-6 stay F's)
+#define As_AT(t) (smem_b + (sa ^ DIGA_FOFF(t)))
+#define Bs_AT(t) (smem_b + (sb ^ DIGA_FOFF(t)))
         float4 fa[2][2], fb[2][2];
-        fa[0][0] = *reinterpret_cast<const float4*>(As + foff[0]);
-        fa[0][1] = *reinterpret_cast<const float4*>(As + foff[0] + 32 * 128);
-        fb[0][0] = *reinterpret_cast<const float4*>(Bs + foff[0]);
-        fb[0][1] = *reinterpret_cast<const float4*>(Bs + foff[0] + 32 * 128);
+        fa[0][0] = *reinterpret_cast<const float4*>(As_AT(0));
+        fa[0][1] = *reinterpret_cast<const float4*>(As_AT(0) + 32 * 128);
+        fb[0][0] = *reinterpret_cast<const float4*>(Bs_AT(0));
+        fb[0][1] = *reinterpret_cast<const float4*>(Bs_AT(0) + 32 * 128);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int p = t & 1;
             if (t + 1 < 4) {
-                fa[p ^ 1][0] = *reinterpret_cast<const float4*>(As + foff[t + 1]);
-                fa[p ^ 1][1] = *reinterpret_cast<const float4*>(As + foff[t + 1] + 32 * 128);
-                fb[p ^ 1][0] = *reinterpret_cast<const float4*>(Bs + foff[t + 1]);
-                fb[p ^ 1][1] = *reinterpret_cast<const float4*>(Bs + foff[t + 1] + 32 * 128);
+                fa[p ^ 1][0] = *reinterpret_cast<const float4*>(As_AT(t + 1));
+                fa[p ^ 1][1] = *reinterpret_cast<const float4*>(As_AT(t + 1) + 32 * 128);
+                fb[p ^ 1][0] = *reinterpret_cast<const float4*>(Bs_AT(t + 1));
+                fb[p ^ 1][1] = *reinterpret_cast<const float4*>(Bs_AT(t + 1) + 32 * 128);
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             }
 #pragma unroll
@@ -2742,7 +2749,10 @@ __global__ __launch_bounds__(JUNC ? 1024 : 768, JUNC ? 4 : 3) void gemm_f32_pers
             const int tile_n = t % g.tiles_n, tile_m = t / g.tiles_n;
             const int row_w = tile_m * 256 + wm * 64;                          // first row of this wave's 64 x 64 piece
             const int col_w = tile_n * 128 + wn * 64 + li;
-            float* o = g.out + (int64_t)(row_w + 4 * lh) * g.out_ld + col_w;
+            // 32-bit element offsets from the uniform output pointer (M * out_ld < 2^32: checked where the kernel is chosen): one
+            // offset register instead of a 64-bit pointer per lane
+            const unsigned ob = (unsigned)(row_w + 4 * lh) * (unsigned)g.out_ld + (unsigned)col_w;
+#define DIGA_O_AT(r, j) (g.out + (size_t)(ob + (unsigned)(r) * (unsigned)g.out_ld + (unsigned)((j) * 32)))
             const int rows_left = g.M - (row_w + 4 * lh);                      // row offset r is valid iff r < rows_left
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -2760,7 +2770,7 @@ __global__ __launch_bounds__(JUNC ? 1024 : 768, JUNC ? 4 : 3) void gemm_f32_pers
                         for (int e = 0; e < 16; ++e) {
                             const int r = i * 32 + (e & 3) + 8 * (e >> 2);
                             const float v = acc[i][j][e] + bv;
-                            __builtin_nontemporal_store(v, o + (int64_t)r * g.out_ld + j * 32);
+                            __builtin_nontemporal_store(v, DIGA_O_AT(r, j));
                             const float d = v - sh;
                             sd += d;
                             sd2 += d * d;
@@ -2774,7 +2784,7 @@ __global__ __launch_bounds__(JUNC ? 1024 : 768, JUNC ? 4 : 3) void gemm_f32_pers
                             const int r = i * 32 + (e & 3) + 8 * (e >> 2);
                             const float v = acc[i][j][e] + bv;
                             if (r < rows_left) {
-                                __builtin_nontemporal_store(v, o + (int64_t)r * g.out_ld + j * 32);
+                                __builtin_nontemporal_store(v, DIGA_O_AT(r, j));
                                 const float d = v - sh;
                                 sd += d;
                                 sd2 += d * d;
@@ -2822,7 +2832,7 @@ int gemm_batched_f32_dma(const float* A, int64_t rows_per_batch, int batches, in
     a.wb_stride = Cout * K;
     const unsigned grid = (unsigned)((M / 256) * a.tiles_n);
     const size_t sh = 3 * (256 + 128) * 128;
-    if (Cout % 128 == 0 && grid >= 512) {        // (at least two rounds of tiles: the persistent walk)
+    if (Cout % 128 == 0 && grid >= 512 && M * Cout < (1ll << 32)) {        // (at least two rounds of tiles: the persistent walk; 32-bit output offsets)
         GemmArgs g;
         g.A = A; g.W = W; g.out = out; g.M = (int)M; g.K = (int)K; g.Cout = (int)Cout;
         g.tiles_m = (int)(M / 256); g.tiles_n = a.tiles_n; g.wb_tiles = a.wb_tiles; g.wb_stride = a.wb_stride;
@@ -2895,6 +2905,8 @@ static int conv2d_f32_impl(const float* in, const float* wgt, const float* bias,
     if (pointwise_persistent_ok(N * Ho * Wo, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride_y, stride_x, off_y0, off_x0) &&
         epi == nullptr && !(opts && (opts->reflect_pad || opts->upsample_shift || opts->activation))) {
         // 1x1, stride 1: the persistent GEMM (statistics per 64-row chunk: diga_conv2d_stats_chunk_rows)
+        DIGA_REQUIRE((int64_t)a.M * out_ld < (1ll << 32), DIGA_EINVAL, "conv2d_nhwc_f32: output beyond 2^32 elements (the pointwise kernel "
+                     "addresses it with 32-bit element offsets)");
         GemmArgs g;
         g.A = in; g.W = wgt; g.out = out; g.M = a.M; g.K = (int)Cin; g.Cout = (int)Cout;
         g.tiles_m = (int)ceil_div(a.M, 256); g.tiles_n = (int)(Cout / 128); g.wb_tiles = 0; g.wb_stride = 0;
