@@ -21,6 +21,8 @@ from diga_amd.util import utils as U
 
 
 _STREAMS = {}
+# self-training step: backward of the student(cat) graph overlapped with the forward + backward of the student(cross_mix) graph
+C4_OVERLAP = os.environ.get("DIGA_C4_OVERLAP", "1") != "0"
 
 
 def _shared_stream(device, role):
@@ -301,9 +303,61 @@ class DigaTrainer:
                     continue
                 sums, counts = ddp.gather_class_sums(sums, counts)
                 class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
+        if self.world == 1 and x.is_cuda and C4_OVERLAP:
+            return self._selftrain_tail_overlapped(s_lr, t_lr, labels, cross_mix, cross_lab, lambda_seg, lambda_distil)
         _, _, c_lr, _ = self.student(cross_mix)
         total_s, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
         ce_mix = L.upsample_ce(c_lr, cross_lab, lambda_seg)
         total = total_s + ce_mix
         self._finish(total)
         return {"total": total.detach(), "ce": ce, "distil": di, "ce_mix": ce_mix.detach()}
+
+    def _selftrain_tail_overlapped(self, s_lr, t_lr, labels, cross_mix, cross_lab, lambda_seg, lambda_distil):
+        """The last third of the self-training step with its two student graphs on two streams (round 5, one process per GPU only):
+        the reference forms total = CE + distill (graph of student(cat)) + CE_mix (graph of student(cross_mix)) and calls one
+        backward; the cross-mixed forward can only start after the teacher's target pass, the consensus filter and ClassMix #2, so in
+        the one-backward form it runs ALONE on the GPU (single stream: every bandwidth pass exposed) before the backward pass starts.
+        Here the backward of the first graph starts as soon as its loss exists, on the main stream (+ the weight-gradient side
+        stream), while the cross-mixed forward and then ITS backward (torch.autograd.grad: gradients in tensors of their own) run on a
+        third stream; one multi-tensor add joins the two gradient sets.  Same terms: grad = g_cat + g_cross, a two-term sum either way
+        (fp addition commutes), every kernel and its arithmetic unchanged -- bit-identical to the one-backward form
+        (tests/test_gpu_selftrain.py::test_selftrain_overlapped_tail_is_bit_identical).  DIGA_C4_OVERLAP=0 switches it off."""
+        dev = s_lr.device
+        main = torch.cuda.current_stream(dev)
+        sb = _shared_stream(dev, "cross")
+        total_s, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
+        sb.wait_stream(main)                                    # cross_mix / cross_lab (ClassMix #2) and the EMA'd state are ready
+        with torch.cuda.stream(sb):
+            _, _, c_lr, _ = self.student(cross_mix)
+            ce_mix = L.upsample_ce(c_lr, cross_lab, lambda_seg)
+        for t in (cross_mix, cross_lab):
+            t.record_stream(sb)
+        params = [p for p in self.student.parameters() if p.requires_grad]
+        self.opt.zero_grad(set_to_none=True)
+        _lib.side_overlap = True
+        try:
+            total_s.backward()                                  # main stream; weight gradients on the side stream
+            with torch.cuda.stream(sb):
+                g2 = torch.autograd.grad(ce_mix, params, allow_unused=True)
+        finally:
+            _lib.side_overlap = False
+            _lib.join_side()
+        main.wait_stream(sb)
+        pg, gg = [], []
+        for p, g in zip(params, g2):
+            if g is None:
+                continue
+            g.record_stream(main)
+            if p.grad is None:
+                p.grad = g
+            else:
+                pg.append(p.grad)
+                gg.append(g)
+        if pg:
+            torch._foreach_add_(pg, gg)
+        ce_mix_d = ce_mix.detach()
+        ce_mix_d.record_stream(main)
+        total = total_s.detach() + ce_mix_d
+        self.reducer.reduce()
+        self._opt_step()
+        return {"total": total, "ce": ce, "distil": di, "ce_mix": ce_mix_d}

@@ -76,3 +76,42 @@ def cf_consensus(cf, teacher, batch, g):
     same = (fp.cpu() == g.t("feat_pseudo"))[safe]
     # the teacher has taken one more train-mode forward since the capture (running stats only), features equal
     return bool(same.float().mean() > 0.995), fp
+
+
+@pytest.mark.gpu
+def test_selftrain_overlapped_tail_is_bit_identical(golden, conv_math, monkeypatch):
+    """Round 5: the self-training step's two student graphs on two streams (backward of student(cat) started as soon as its loss
+    exists, forward + backward of student(cross_mix) on a third stream, one multi-tensor add of the two gradient sets) against the
+    one-backward form: losses, every student parameter after the step, BatchNorm running statistics and the centroid bank are equal
+    BIT FOR BIT -- the gradient of a shared weight is a two-term sum either way."""
+    from diga_amd import train_step as ts
+    from diga_amd.calc_centroids import Class_Features
+    from diga_amd.model.model_noaux import SegModel
+    g = golden("selftrain")
+
+    def run(overlap):
+        monkeypatch.setattr(ts, "C4_OVERLAP", overlap)
+        def make():
+            m = SegModel()
+            m.load_state_dict(detweights.state_dict(od.RESNET101))
+            m.final.head[0].p = 0.0
+            return m.to("cuda")
+        student, teacher = make(), make()
+        teacher.train()
+        tr = ts.DigaTrainer(student, teacher, rng=random)
+        cf = Class_Features(numbers=19)
+        cf.objective_vectors = g.t("cents0").clone().to("cuda")
+        logs = []
+        for it in (3, 4):                                    # two steps: the second runs on momentum buffers and a moved teacher
+            batch = [t.to("cuda") for t in synth.selftrain_batch(3000 + it, 2, 128, 128, block=16)]
+            random.seed(78 + it)
+            logs.append({k: float(v) for k, v in tr.selftrain_step(it, *batch, cf).items()})
+        torch.cuda.synchronize()
+        return logs, {k: v.clone() for k, v in student.state_dict().items()}, cf.objective_vectors.clone()
+
+    la, sa, ca = run(False)
+    lb, sb, cb = run(True)
+    assert la == lb, (la, lb)
+    assert torch.equal(ca, cb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
