@@ -22,7 +22,9 @@ from diga_amd.util import utils as U
 
 _STREAMS = {}
 # self-training step: backward of the student(cat) graph overlapped with the forward + backward of the student(cross_mix) graph
-C4_OVERLAP = os.environ.get("DIGA_C4_OVERLAP", "1") != "0"
+# (0: one backward pass as the reference writes it; 1: only the cross-mixed forward / backward on a third stream; 2: the whole target
+#  branch -- consensus, ClassMix #2, centroid updates, cross-mixed forward / backward -- next to the backward of the student(cat) graph)
+C4_OVERLAP = int(os.environ.get("DIGA_C4_OVERLAP", "2"))
 
 
 def _shared_stream(device, role):
@@ -117,8 +119,14 @@ class DigaTrainer:
             self._side = _shared_stream(dev, "teacher")
         main = torch.cuda.current_stream(dev)
         self._side.wait_stream(main)                 # EMA update of the teacher and the inputs are ready
+        self._teacher_events = []
         with torch.cuda.stream(self._side), torch.no_grad():
-            outs = [self.teacher(x)[2:4] for x in inputs]
+            outs = []
+            for x in inputs:
+                outs.append(self.teacher(x)[2:4])
+                ev = torch.cuda.Event()
+                ev.record(self._side)                # (the overlapped self-training step waits for the passes one by one)
+                self._teacher_events.append(ev)
         for x in inputs:
             x.record_stream(self._side)
         self._pending_join = True
@@ -288,6 +296,10 @@ class DigaTrainer:
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng, present=present)
             cat = torch.cat([x, mix])
         (_, _, s_lr, _), pending = self._student_and_teacher(cat, cat, t_img)
+        if (self.world == 1 and x.is_cuda and C4_OVERLAP >= 2 and getattr(self, "_pending_join", False)
+                and len(getattr(self, "_teacher_events", ())) == 2):
+            return self._selftrain_rest_overlapped(s_lr, pending, x, labels, t_aug, pseudo_prob, class_features, present, B,
+                                                   lambda_seg, lambda_distil)
         (t_lr, t_feat), (tt_lr, tt_feat) = self._teacher_join(pending)
         with torch.no_grad():
             # bilateral consensus: keep the offline pseudo-label where the centroid label agrees
@@ -303,7 +315,7 @@ class DigaTrainer:
                     continue
                 sums, counts = ddp.gather_class_sums(sums, counts)
                 class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
-        if self.world == 1 and x.is_cuda and C4_OVERLAP:
+        if self.world == 1 and x.is_cuda and C4_OVERLAP >= 1:
             return self._selftrain_tail_overlapped(s_lr, t_lr, labels, cross_mix, cross_lab, lambda_seg, lambda_distil)
         _, _, c_lr, _ = self.student(cross_mix)
         total_s, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
@@ -311,6 +323,78 @@ class DigaTrainer:
         total = total_s + ce_mix
         self._finish(total)
         return {"total": total.detach(), "ce": ce, "distil": di, "ce_mix": ce_mix.detach()}
+
+    def _selftrain_rest_overlapped(self, s_lr, pending, x, labels, t_aug, pseudo_prob, class_features, present, B, lambda_seg, lambda_distil):
+        """C4_OVERLAP = 2 (default): everything behind the student(cat) / teacher(cat) forwards as TWO concurrent branches.
+        Main stream: wait for the teacher's pass over `cat` only (an event between its two passes), form CE + distill and start the
+        backward pass of the student(cat) graph (weight gradients on their side stream).  Third stream: wait for the teacher's pass
+        over the target images, then the consensus filter, ClassMix #2, the two centroid updates, the forward of student(cross_mix),
+        CE_mix and its backward (torch.autograd.grad) -- which used to run with the GPU to themselves, one stream, between the
+        forwards and the one backward pass.  Host order of every ClassMix draw, BatchNorm running-statistics update
+        (student(cat) before student(cross_mix): an event) and centroid update is the reference's; the gradient of a shared weight is
+        g_cat + g_cross either way: bit-identical to the one-backward form (tests/test_selftrain.py)."""
+        dev = s_lr.device
+        main = torch.cuda.current_stream(dev)
+        sb = _shared_stream(dev, "cross")
+        (t_lr, t_feat), (tt_lr, tt_feat) = pending
+        ev_cat, ev_tgt = self._teacher_events
+        main.wait_event(ev_cat)
+        for t in (t_lr, t_feat):
+            t.record_stream(main)
+        total_s, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
+        ev_main = torch.cuda.Event()
+        ev_main.record(main)                                    # student(cat)'s forward (its BatchNorm statistics updates) is enqueued
+        params = [p for p in self.student.parameters() if p.requires_grad]
+        self.opt.zero_grad(set_to_none=True)
+        _lib.side_overlap = True
+        try:
+            total_s.backward()                                  # main stream; weight gradients on the side stream
+            sb.wait_event(ev_tgt)
+            sb.wait_event(ev_main)
+            for t in (t_lr, t_feat, tt_lr, tt_feat):
+                t.record_stream(sb)
+            with torch.cuda.stream(sb):
+                with torch.no_grad():
+                    pseudo = class_features.consensus_pseudo_labels(tt_feat, pseudo_prob)
+                    cross_mix, cross_lab, _ = U.classmix(t_aug, x, labels, self.rng, bg_labels=pseudo, present=present)
+                    for feat, out, lab in ((tt_feat, tt_lr, pseudo), (t_feat[B:], t_lr[B:], labels)):
+                        sums, counts = class_features._class_sums(feat, out, labels_full=lab)[:2]
+                        if self.centroid_exchange == "allreduce":
+                            ms, nv = ddp.allreduce_class_means(sums, counts, class_features.min_pixels)
+                            cents, nums = class_features._state_on(sums.device)
+                            ddp.apply_mean_of_vectors(cents, nums, ms, nv, class_features.centroid_momentum)
+                            continue
+                        class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
+                _, _, c_lr, _ = self.student(cross_mix)
+                ce_mix = L.upsample_ce(c_lr, cross_lab, lambda_seg)
+                g2 = torch.autograd.grad(ce_mix, params, allow_unused=True)
+        finally:
+            _lib.side_overlap = False
+            _lib.join_side()
+        self._pending_join = False
+        main.wait_stream(sb)
+        main.wait_stream(self._side)
+        return self._join_gradients(params, g2, total_s, ce, di, ce_mix, main)
+
+    def _join_gradients(self, params, g2, total_s, ce, di, ce_mix, main):
+        pg, gg = [], []
+        for p, g in zip(params, g2):
+            if g is None:
+                continue
+            g.record_stream(main)
+            if p.grad is None:
+                p.grad = g
+            else:
+                pg.append(p.grad)
+                gg.append(g)
+        if pg:
+            torch._foreach_add_(pg, gg)
+        ce_mix_d = ce_mix.detach()
+        ce_mix_d.record_stream(main)
+        total = total_s.detach() + ce_mix_d
+        self.reducer.reduce()
+        self._opt_step()
+        return {"total": total, "ce": ce, "distil": di, "ce_mix": ce_mix_d}
 
     def _selftrain_tail_overlapped(self, s_lr, t_lr, labels, cross_mix, cross_lab, lambda_seg, lambda_distil):
         """The last third of the self-training step with its two student graphs on two streams (round 5, one process per GPU only):
@@ -343,21 +427,4 @@ class DigaTrainer:
             _lib.side_overlap = False
             _lib.join_side()
         main.wait_stream(sb)
-        pg, gg = [], []
-        for p, g in zip(params, g2):
-            if g is None:
-                continue
-            g.record_stream(main)
-            if p.grad is None:
-                p.grad = g
-            else:
-                pg.append(p.grad)
-                gg.append(g)
-        if pg:
-            torch._foreach_add_(pg, gg)
-        ce_mix_d = ce_mix.detach()
-        ce_mix_d.record_stream(main)
-        total = total_s.detach() + ce_mix_d
-        self.reducer.reduce()
-        self._opt_step()
-        return {"total": total, "ce": ce, "distil": di, "ce_mix": ce_mix_d}
+        return self._join_gradients(params, g2, total_s, ce, di, ce_mix, main)

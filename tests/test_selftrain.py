@@ -109,9 +109,10 @@ def test_selftrain_overlapped_tail_is_bit_identical(golden, conv_math, monkeypat
         torch.cuda.synchronize()
         return logs, {k: v.clone() for k, v in student.state_dict().items()}, cf.objective_vectors.clone()
 
-    la, sa, ca = run(False)
-    lb, sb, cb = run(True)
-    assert la == lb, (la, lb)
-    assert torch.equal(ca, cb)
-    for k in sa:
-        assert torch.equal(sa[k], sb[k]), k
+    la, sa, ca = run(0)
+    for mode in (1, 2):                                        # 1: cross-mixed forward / backward only; 2: the whole target branch
+        lb, sb, cb = run(mode)
+        assert la == lb, (mode, la, lb)
+        assert torch.equal(ca, cb), mode
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (mode, k)
