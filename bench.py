@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
                     help="file the full tables go to (kernel families, every roofline, bandwidth kernels, mIoU parity)")
     ap.add_argument("--no-graph", action="store_true", help="run the launch-bound legs (c1, c5) eagerly instead of from a HIP graph")
+    ap.add_argument("--graph", action="store_true", help="run the MAIN configuration's step from a HIP graph (A/B runs of c5 / c1 as --config)")
     ap.add_argument("--no-bandwidth-kernels", action="store_true")
     ap.add_argument("--no-miou", action="store_true", help="skip the fixed-seed validation-mIoU parity leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -713,7 +714,7 @@ def main():
     if a.serial_streams:
         os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
     dt, (families, families_ov), losses, counts, geom = run_steps(a, a.config, a.precision, a.steps, a.warmup, rank, world,
-                                                                  dev, prof)
+                                                                  dev, prof, graph=bool(a.graph and world == 1))
     B, H, W, _ = geom
     other_line = None
     if not a.no_other_precision:

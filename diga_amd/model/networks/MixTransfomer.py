@@ -138,10 +138,27 @@ class _Ops:
                   float(alpha), m, n, k, _lib.stream())
         return out
 
-    def wgrad(self, dy, x, scale, bias=False):
+    def wgrad(self, dy, x, scale, bias=False, side_ok=True):
         """dW [n,k] = scale * dy^T x (fp32); with bias=True also the bias gradient (column sums of dy) from the same pass."""
         m, n = dy.shape
         k = x.shape[1]
+        # Weight gradients are leaves of the stage's backward: under the step driver (`_lib.side_overlap`, as the DeepLab convolutions'
+        # weight gradients) they run on the side stream next to the backward-data / attention chain -- in a captured HIP graph that is a
+        # forked branch per weight gradient, joined before the optimizer (round 5: the MiT kernels are short and fill a fraction of the
+        # chip each).  dy and x are never written again after they were produced (every in-place accumulation of the backward pass
+        # goes into the residual-stream buffers, which no weight gradient reads).
+        # side_ok=False: the caller post-processes the result on the CURRENT stream right away (a slice + reshape copy, the overflow check)
+        side = _lib.side_stream(self.dev) if (dy.is_cuda and side_ok) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                res = self._wgrad_launch(dy, x, scale, bias, m, n, k)
+            for t in (dy, x):
+                t.record_stream(side)
+            return res
+        return self._wgrad_launch(dy, x, scale, bias, m, n, k)
+
+    def _wgrad_launch(self, dy, x, scale, bias, m, n, k):
         dw = self.empty((n, k), torch.float32)
         db = self.empty((n,), torch.float32) if bias else None
         nbytes = _lib.lib.diga_mit_gemm_tn_workspace_bytes(m, n, k)
@@ -387,7 +404,7 @@ class _MitStageFn(torch.autograd.Function):
                     grads[bp + ".attn.norm.weight"], grads[bp + ".attn.norm.bias"] = dg, db
                     kps = bs["kps"]
                     d_pc = ops.gemm(d_s, bs["wsrt"], None, kps)
-                    dwsr, grads[bp + ".attn.sr.bias"] = ops.wgrad(d_s, bs["pc"], inv, bias=True)
+                    dwsr, grads[bp + ".attn.sr.bias"] = ops.wgrad(d_s, bs["pc"], inv, bias=True, side_ok=False)
                     grads[bp + ".attn.sr.weight"] = dwsr[:, :sr * sr * C].reshape(C, sr, sr, C).permute(0, 3, 1, 2)
                     ops.col2im(d_pc, d_a, False, B, ho, wo, C, sr, sr, 0, bs["hk"], bs["wk"], kps)
                 else:
@@ -408,7 +425,7 @@ class _MitStageFn(torch.autograd.Function):
             _, d_y, dg, db = ops.ln_bwd(dx32, ss["y32"], par[pre + ".norm.weight"], ss["e_mean"], ss["e_rstd"], None, False, True, inv)
             grads[pre + ".norm.weight"], grads[pre + ".norm.bias"] = dg, db
             k = st["patch"]
-            dwp, grads[pre + ".proj.bias"] = ops.wgrad(d_y, ss["cols"], inv, bias=True)
+            dwp, grads[pre + ".proj.bias"] = ops.wgrad(d_y, ss["cols"], inv, bias=True, side_ok=False)
             if cfg.get("overflow_flag") is not None:
                 # (d_y is fp16 under the loss scale as well: an overflow born in the patch embedding's LayerNorm backward shows in
                 #  its projection's weight gradient -- a few thousand fp32 values; covers stage 1, which no later check sees)

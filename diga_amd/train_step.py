@@ -25,6 +25,9 @@ _STREAMS = {}
 # (0: one backward pass as the reference writes it; 1: only the cross-mixed forward / backward on a third stream; 2: the whole target
 #  branch -- consensus, ClassMix #2, centroid updates, cross-mixed forward / backward -- next to the backward of the student(cat) graph)
 C4_OVERLAP = int(os.environ.get("DIGA_C4_OVERLAP", "2"))
+# HIP-graph step (the launch-bound legs: c1, c5): capture the teacher's forward on a forked stream
+GRAPH_FORK_TEACHER = os.environ.get("DIGA_GRAPH_FORK_TEACHER", "1") != "0"
+GRAPH_FORK_WGRAD = os.environ.get("DIGA_GRAPH_FORK_WGRAD", "1") != "0"
 
 
 def _shared_stream(device, role):
@@ -233,11 +236,32 @@ class DigaTrainer:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    with torch.no_grad():
-                        t_lr = self.teacher(g["cat"])[2]
-                    s_lr = self.student(g["cat"])[2]
+                    if GRAPH_FORK_TEACHER:
+                        # round 5: the teacher's forward on a stream FORKED from the capture stream and joined before the loss -- in the
+                        # replayed graph the two networks' forwards are independent branches and run concurrently (the MiT student's
+                        # kernels are short and fill a fraction of the chip each)
+                        cap = torch.cuda.current_stream(x.device)
+                        fork = _shared_stream(x.device, "capture_fork")
+                        fork.wait_stream(cap)
+                        with torch.cuda.stream(fork), torch.no_grad():
+                            t_lr = self.teacher(g["cat"])[2]
+                        s_lr = self.student(g["cat"])[2]
+                        cap.wait_stream(fork)
+                    else:
+                        with torch.no_grad():
+                            t_lr = self.teacher(g["cat"])[2]
+                        s_lr = self.student(g["cat"])[2]
                     total, ce, di = L.upsample_ce_distill(s_lr, t_lr, g["labels"], lambda_seg, lambda_distil, self.distill_scale)
-                    total.backward()
+                    if GRAPH_FORK_WGRAD and saved["DIGA_WGRAD_STREAM"] != "0":
+                        os.environ.pop("DIGA_WGRAD_STREAM", None)      # weight gradients as forked branches of the captured graph
+                        _lib.side_overlap = True
+                        try:
+                            total.backward()
+                        finally:
+                            _lib.side_overlap = False
+                            _lib.join_side()
+                    else:
+                        total.backward()
             finally:
                 for k, v in saved.items():
                     if v is None:
