@@ -21,6 +21,7 @@ from diga_amd.util import utils as U
 
 
 _STREAMS = {}
+_MISMATCH_WARNING_OFF = False
 # self-training step: backward of the student(cat) graph overlapped with the forward + backward of the student(cross_mix) graph
 # (0: one backward pass as the reference writes it; 1: only the cross-mixed forward / backward on a third stream; 2: the whole target
 #  branch -- consensus, ClassMix #2, centroid updates, cross-mixed forward / backward -- next to the backward of the student(cat) graph)
@@ -28,6 +29,19 @@ C4_OVERLAP = int(os.environ.get("DIGA_C4_OVERLAP", "2"))
 # HIP-graph step (the launch-bound legs: c1, c5): capture the teacher's forward on a forked stream
 GRAPH_FORK_TEACHER = os.environ.get("DIGA_GRAPH_FORK_TEACHER", "1") != "0"
 GRAPH_FORK_WGRAD = os.environ.get("DIGA_GRAPH_FORK_WGRAD", "1") != "0"
+
+
+def _accumulate_on_other_streams_is_intended():
+    """The overlapped self-training step runs the backward passes of two student graphs on two streams, so a parameter's
+    AccumulateGrad node (created by whichever forward touched the parameter first) may sit on another stream than the node that
+    hands it a gradient.  The autograd engine orders the two with events and joins every leaf stream with the caller's at the end
+    of backward(); torch only warns that this costs a synchronisation.  Say that it is intended (once per process)."""
+    global _MISMATCH_WARNING_OFF
+    if not _MISMATCH_WARNING_OFF:
+        fn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if fn is not None:
+            fn(False)
+        _MISMATCH_WARNING_OFF = True
 
 
 def _shared_stream(device, role):
@@ -357,6 +371,7 @@ class DigaTrainer:
         forwards and the one backward pass.  Host order of every ClassMix draw, BatchNorm running-statistics update
         (student(cat) before student(cross_mix): an event) and centroid update is the reference's; the gradient of a shared weight is
         g_cat + g_cross either way: bit-identical to the one-backward form (tests/test_selftrain.py)."""
+        _accumulate_on_other_streams_is_intended()
         dev = s_lr.device
         main = torch.cuda.current_stream(dev)
         sb = _shared_stream(dev, "cross")
@@ -430,6 +445,7 @@ class DigaTrainer:
         third stream; one multi-tensor add joins the two gradient sets.  Same terms: grad = g_cat + g_cross, a two-term sum either way
         (fp addition commutes), every kernel and its arithmetic unchanged -- bit-identical to the one-backward form
         (tests/test_gpu_selftrain.py::test_selftrain_overlapped_tail_is_bit_identical).  DIGA_C4_OVERLAP=0 switches it off."""
+        _accumulate_on_other_streams_is_intended()
         dev = s_lr.device
         main = torch.cuda.current_stream(dev)
         sb = _shared_stream(dev, "cross")

@@ -116,3 +116,25 @@ def test_selftrain_overlapped_tail_is_bit_identical(golden, conv_math, monkeypat
         assert torch.equal(ca, cb), mode
         for k in sa:
             assert torch.equal(sa[k], sb[k]), (mode, k)
+
+
+@pytest.mark.timeout(900)
+def test_oracle_selftrain_trajectory_first_steps(golden):
+    """The oracle's self-training step against the 10-step capture of the reference's loop (tests/golden/selftraj10.npz,
+    tools/gen_golden.py::_gen_selftraj): the first three steps -- losses within 3x the capture's own rounding floor (reference vs
+    reference, oneDNN off; the floor of CE_mix contains single consensus pixels flipping), the kept share within two pixels, the
+    centroid bank's change to 1e-3 of itself."""
+    g = golden("selftraj10")
+    B, H, W, steps, seed0, block, mix_seed = (int(v) for v in g["geometry"])
+    tr = ost.Trainer(detweights.state_dict(), detweights.state_dict())
+    cents, nums = g.t("cents0").clone(), torch.zeros(19)
+    random.seed(mix_seed)
+    assert steps == 10 and bool(g["floor_nums_equal"])
+    for it in range(3):
+        batch = synth.selftrain_batch(seed0 + it, B, H, W, block=block)
+        log = tr.selftrain_step(it, *batch, cents, nums, random)
+        for k, extra in (("ce", 2e-6), ("distil", 2e-6), ("ce_mix", 3e-5)):
+            assert log[k] == pytest.approx(float(g[k][it]), rel=3 * (float(g["floor_" + k + "_dev"].max()) + extra)), (it, k)
+        assert log["kept"] == pytest.approx(float(g["kept"][it]), abs=2.5 / (B * H * W)), it
+        cd = float((cents.double() - g.t("cents0").double()).norm())
+        assert cd == pytest.approx(float(g["cents_delta"][it]), rel=1e-3), it

@@ -942,6 +942,145 @@ def gen_selftrain():
           "ids_t", id_t, "ids_s", id_s)
 
 
+# ------------------------------------------------------------------ G-selftraj (self-training trajectory, round 5)
+def _gen_selftraj(name, B, H, W, steps, seed0, block, mix_seed, variant=None):
+    """The reference's self-training loop body (train_DiGA_gta2city_self_training.py:214-387: learning-rate schedule, EMA teacher,
+    ClassMix #1, student(cat) / teacher(cat), bilateral consensus of the offline pseudo-labels with the centroid pseudo-labeler,
+    ClassMix #2 with label paste, the two centroid-bank updates, student(cross_mix), CE + CE_mix + 0.25 * distillation, SGD) run for
+    `steps` iterations on the reference's own classes (SegModel, Class_Features, cross_entropy2d, distillation_loss, ...), every batch
+    regenerated from its seed (seed0 + it).  Per step: the three losses, the share of pseudo-labels the consensus keeps, the
+    norm of the centroid bank and of its change; at the end: the bank and its counts, the student head and its change, BatchNorm
+    running statistics, eval-mode probe logits.  `floor_*`: the same loop a second time with oneDNN off (see _gen_traj)."""
+    import torch.optim as optim
+    student, teacher = _ref_model(), _ref_model()
+    for mdl in (student, teacher):
+        mdl.final.head[0].p = 0.0
+    opt = optim.SGD(student.optim_parameters(2.5e-4), lr=2.5e-4, momentum=0.9, weight_decay=0.0005)
+    up = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+    teacher = create_teacher_params(teacher, student)
+    cf = Class_Features(numbers=19)
+    cents0 = torch.randn((19, 256), generator=synth.gen(7)) * 0.3
+    cf.objective_vectors = cents0.clone()
+    w0 = student.state_dict()["final.head.1.weight"].clone()
+    random.seed(mix_seed)
+    log = {k: [] for k in ("ce", "distil", "ce_mix", "total", "kept", "cents_norm", "cents_delta", "head_delta")}
+    ids_log = []
+
+    def pick_classes(lab_i):
+        present = torch.unique(lab_i).tolist()
+        pick = random.sample(present, len(present) // 2)
+        if 255 not in pick:
+            pick.append(255)
+        return pick
+
+    for it in range(steps):
+        student.train()
+        adjust_learning_rate([opt], base_lr=2.5e-4, i_iter=it, max_iter=80000, power=0.9)
+        with torch.no_grad():
+            teacher = update_teacher_params(teacher, student, it)
+        x, x_aug, rec, lab, t_img, t_aug, pseudo_prob = synth.selftrain_batch(seed0 + it, B, H, W, block=block)
+        mask = torch.zeros(lab.size())                                   # :259-275 ClassMix #1
+        for i in range(B):
+            for c in pick_classes(lab[i]):
+                mask[i][lab[i] == c] = 1
+        mix = torch.zeros(rec.size())
+        for i in range(B):
+            mix[i] = torch.mul(rec[i], 1 - mask[i]) + torch.mul(x_aug[i], mask[i])
+        cat = torch.cat([x, mix])
+        _, _, s_cat, _ = student(cat)
+        with torch.no_grad():
+            _, _, t_cat_lr, t_feat_cat = teacher(cat)
+        t_aug_raw = t_cat_lr[B:]
+        t_cat = up(t_cat_lr)
+        s_feat_tea_aug = t_feat_cat[B:]
+        with torch.no_grad():                                            # :298-304 bilateral consensus
+            pseudo = pseudo_prob.clone()
+            _, _, tt_pred, tt_feat = teacher(t_img)
+            fw = up(cf.get_centroid_weight(tt_feat.detach()))
+            feat_pseudo = fw.max(1, keepdim=True)[1].squeeze(1)
+            pseudo[pseudo_prob != feat_pseudo] = 255
+        cross_lab = pseudo.clone()                                       # :306-325 ClassMix #2 with label paste
+        mask = torch.zeros(lab.size())
+        for i in range(B):
+            for c in pick_classes(lab[i]):
+                cross_lab[i][lab[i] == c] = c
+                mask[i][lab[i] == c] = 1
+        cross_mix = torch.zeros(t_aug.size())
+        for i in range(B):
+            cross_mix[i] = torch.mul(t_aug[i], 1 - mask[i]) + torch.mul(x[i], mask[i])
+        cross_lab = cross_lab.long()
+        with torch.no_grad():                                            # :327-341 centroid updates (target, then source)
+            nl_t = F.interpolate(pseudo.clone().reshape([B, 1, H, W]).float(), size=tt_feat.size()[2:], mode="nearest")
+            v_t, id_t = cf.calculate_mean_vector(tt_feat, tt_pred.detach(), nl_t)
+            for k in range(len(id_t)):
+                cf.update_objective_SingleVector(id_t[k], v_t[k].detach(), start_mean=False)
+            nl_s = F.interpolate(lab.clone().reshape([B, 1, H, W]).float(), size=s_feat_tea_aug.size()[2:], mode="nearest")
+            v_s, id_s = cf.calculate_mean_vector(s_feat_tea_aug, t_aug_raw.detach(), nl_s)
+            for k in range(len(id_s)):
+                cf.update_objective_SingleVector(id_s[k], v_s[k].detach(), start_mean=False)
+        _, _, c_pred, _ = student(cross_mix)
+        c_pred = up(c_pred)
+        s_up = up(s_cat)
+        ce = cross_entropy2d(s_up[:B], lab)
+        di = distillation_loss(t_cat, s_up)
+        ce_mix = cross_entropy2d(c_pred, cross_lab)
+        total = 1.0 * (ce + ce_mix) + 0.25 * di
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        hw = student.state_dict()["final.head.1.weight"]
+        cents = torch.as_tensor(cf.objective_vectors)
+        for k, v in (("ce", ce), ("distil", di), ("ce_mix", ce_mix), ("total", total), ("kept", (pseudo != 255).float().mean()),
+                     ("cents_norm", cents.double().norm()), ("cents_delta", (cents - cents0).double().norm()),
+                     ("head_delta", (hw - w0).double().norm())):
+            log[k].append(float(v))
+        ids_log.append([len(id_t), len(id_s)])
+        print(name, "step", it, log["ce"][-1], log["distil"][-1], log["ce_mix"][-1], "kept", log["kept"][-1], "cents", log["cents_delta"][-1],
+              flush=True)
+    student.eval()
+    teacher.eval()
+    xp = synth.warmup_batch(seed0 + 1000, 1, H, W, block=block)[0]
+    with torch.no_grad():
+        _, _, so, _ = student(xp)
+        _, _, to, _ = teacher(xp)
+    res = {k: np.array(v, dtype=np.float64) for k, v in log.items()}
+    res["geometry"] = np.array([B, H, W, steps, seed0, block, mix_seed])
+    res["n_ids"] = np.array(ids_log)
+    sd, td = student.state_dict(), teacher.state_dict()
+    res.update(cents0=cents0, cents=torch.as_tensor(cf.objective_vectors).clone(), nums=torch.as_tensor(cf.objective_vectors_num).clone().float(),
+               student_head=sd["final.head.1.weight"], student_head_delta=sd["final.head.1.weight"] - w0,
+               teacher_head=td["final.head.1.weight"], probe_student=so, probe_teacher=to)
+    for n in ["layer1.0.bn1.running_mean", "layer3.22.bn3.running_mean", "layer4.2.bn3.running_var", "layer2.3.bn2.running_var"]:
+        res["stu_" + n.replace(".", "_")] = sd[n]
+        res["tea_" + n.replace(".", "_")] = td[n]
+    if variant is not None:
+        return res
+    with torch.backends.mkldnn.flags(enabled=False):
+        alt = _gen_selftraj(name + "/no-onednn", B, H, W, steps, seed0, block, mix_seed, variant="no_onednn")
+
+    def rel(a, b):
+        a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+        return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+    for k in ("ce", "distil", "ce_mix"):
+        res["floor_" + k + "_dev"] = np.abs(alt[k] - res[k]) / np.abs(res[k])
+    res["floor_kept"] = np.abs(alt["kept"] - res["kept"])
+    res["floor_cents"] = np.array(rel(alt["cents"] - alt["cents0"], res["cents"] - res["cents0"]))
+    res["floor_head_delta"] = np.array(rel(alt["student_head_delta"], res["student_head_delta"]))
+    res["floor_probe"] = np.array([float((alt[k] - res[k]).abs().max() / res[k].abs().max()) for k in ("probe_student", "probe_teacher")])
+    res["floor_bn"] = np.array([float((alt[k] - res[k]).abs().max() / res[k].abs().max()) for k in sorted(res)
+                                if k.startswith(("stu_layer", "tea_layer"))])
+    res["floor_nums_equal"] = np.array(bool(torch.equal(torch.as_tensor(alt["nums"]), torch.as_tensor(res["nums"]))))
+    print(name, "rounding floor: losses", [float(res["floor_" + k + "_dev"].max()) for k in ("ce", "distil", "ce_mix")], "kept",
+          float(res["floor_kept"].max()), "centroid change", float(res["floor_cents"]), "head change", float(res["floor_head_delta"]),
+          "probe", res["floor_probe"].tolist(), "bn", float(res["floor_bn"].max()), "counts equal", bool(res["floor_nums_equal"]), flush=True)
+    save(name, **res)
+
+
+def gen_selftraj10():
+    _gen_selftraj("selftraj10", 2, 128, 128, 10, 8000, 16, 81)
+
+
 # ------------------------------------------------------------------ translator (SURVEY 8f "next" #1)
 def gen_translator():
     from model.model_noaux import ImgDecoder, ImgEncoder  # reference
@@ -1057,7 +1196,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(traj25=gen_traj25, traj768=gen_traj768, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(traj25=gen_traj25, traj768=gen_traj768, selftraj10=gen_selftraj10, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
