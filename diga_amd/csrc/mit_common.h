@@ -80,21 +80,37 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
 // phases per block (phase p adds chunks p, p + 8, ... sequentially, then the phases are added 0..7).
 //   MAP 0: out0[i]      MAP 1 (LayerNorm): i < C -> out0[i] (dgamma), else out1[i - C] (dbeta)
 //   MAP 2 (depthwise 3x3): t = i / C, c = i % C: t < 9 -> out0[c * 9 + t] (dw [C][9]), t == 9 -> out1[c] (db)
-template <int MAP>
+//   COLS x (256 / COLS) phases per block: 32 x 8 for the weight-sized sums; 8 x 32 where n is a few hundred values and the chunks are
+//   hundreds (LayerNorm dgamma / dbeta of a 300 000-row token matrix: 20 blocks of 144-deep chains otherwise -- 18 us of latency).
+//   (partial2, n2 > 0): a SECOND sum of the same chunk count handled by the blocks behind the first one's (MAP 0 only: the bias slab of
+//   a weight-gradient GEMM, written to out1) -- one launch instead of two.
+template <int MAP, int COLS = 32>
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int chunks, int n, float* __restrict__ out0,
-                                                             float* __restrict__ out1, int C, float scale, int accumulate) {
-    __shared__ float red[8][33];
-    const int col = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + col;
+                                                             float* __restrict__ out1, int C, float scale, int accumulate,
+                                                             const float* __restrict__ partial2 = nullptr, int n2 = 0) {
+    constexpr int PH = 256 / COLS;
+    __shared__ float red[PH][COLS + 1];
+    const int col = threadIdx.x % COLS, ph = threadIdx.x / COLS;
+    int blk = blockIdx.x;
+    if constexpr (MAP == 0) {
+        const int nb0 = (n + COLS - 1) / COLS;
+        if (blk >= nb0) {                                   // the second sum (block-uniform branch)
+            blk -= nb0;
+            partial = partial2;
+            n = n2;
+            out0 = out1;
+        }
+    }
+    const int i = blk * COLS + col;
     float s = 0.f;
     if (i < n)
-        for (int k = ph; k < chunks; k += 8) s += partial[(int64_t)k * n + i];
+        for (int k = ph; k < chunks; k += PH) s += partial[(int64_t)k * n + i];
     red[ph][col] = s;
     __syncthreads();
     if (ph == 0 && i < n) {
         float tot = red[0][col];
 #pragma unroll
-        for (int p = 1; p < 8; ++p) tot += red[p][col];
+        for (int p = 1; p < PH; ++p) tot += red[p][col];
         tot *= scale;
         float* dst;
         if constexpr (MAP == 0) {

@@ -513,11 +513,9 @@ extern "C" int diga_mit_gemm_tn(const void* A, int64_t lda, const void* B, int64
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_n * p.tiles_k * p.splits), dim3(256), SH, st, a);
     const int64_t n = N * K;
     // fixed-order sum of the split slabs (32 columns x 8 split phases per block: short latency chains even for 500 splits)
-    hipLaunchKernelGGL(partial_reduce_kernel<0>, dim3((unsigned)ceil_div(n, 32)), dim3(256), 0, st, a.slab, p.splits, (int)n, dw,
-                       (float*)nullptr, (int)n, scale, accumulate);
-    if (dbias != nullptr)
-        hipLaunchKernelGGL(partial_reduce_kernel<0>, dim3((unsigned)ceil_div(N, 32)), dim3(256), 0, st, a.bias_slab, p.splits, (int)N, dbias,
-                           (float*)nullptr, (int)N, scale, accumulate);
+    // (the bias slab, when there is one, by the blocks behind the weight's: one launch)
+    hipLaunchKernelGGL((partial_reduce_kernel<0, 32>), dim3((unsigned)(ceil_div(n, 32) + (dbias != nullptr ? ceil_div(N, 32) : 0))), dim3(256), 0, st,
+                       a.slab, p.splits, (int)n, dw, dbias, (int)n, scale, accumulate, (const float*)a.bias_slab, dbias != nullptr ? (int)N : 0);
     return launch_status("mit_gemm_tn");
 }
 
@@ -547,8 +545,12 @@ extern "C" int diga_mit_colsum(const void* x, int64_t ld, float* out, float scal
     ProfScope prof(DIGA_PROF_MIT_MISC, st, 2.0 * (double)M * (double)C);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks), dim3(256), 0, st, static_cast<const _Float16*>(x), ld,
                        static_cast<float*>(workspace), (int)M, (int)C, rpb);
-    hipLaunchKernelGGL(partial_reduce_kernel<0>, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), chunks,
-                       (int)C, out, (float*)nullptr, (int)C, scale, accumulate);
+    if (chunks >= 64)
+        hipLaunchKernelGGL((partial_reduce_kernel<0, 8>), dim3((unsigned)ceil_div(C, 8)), dim3(256), 0, st, static_cast<const float*>(workspace), chunks,
+                           (int)C, out, (float*)nullptr, (int)C, scale, accumulate, (const float*)nullptr, 0);
+    else
+        hipLaunchKernelGGL((partial_reduce_kernel<0, 32>), dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), chunks,
+                           (int)C, out, (float*)nullptr, (int)C, scale, accumulate, (const float*)nullptr, 0);
     return launch_status("mit_colsum");
 }
 

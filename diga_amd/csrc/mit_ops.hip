@@ -697,8 +697,12 @@ extern "C" int diga_mit_layernorm_bwd(const void* dy, int dy_is_f32, int64_t ldg
     else DIGA_LN_BWD_T(_Float16);
 #undef DIGA_LN_BWD_T
 #undef DIGA_LN_BWD
-    hipLaunchKernelGGL(partial_reduce_kernel<1>, dim3((unsigned)ceil_div(2 * C, 32)), dim3(256), 0, st, part, blocks, (int)(2 * C), dgamma, dbeta,
-                       (int)C, param_scale, accumulate);
+    if (blocks >= 64)             // few values, many chunks: 8 columns x 32 chunk phases per block
+        hipLaunchKernelGGL((partial_reduce_kernel<1, 8>), dim3((unsigned)ceil_div(2 * C, 8)), dim3(256), 0, st, part, blocks, (int)(2 * C), dgamma, dbeta,
+                           (int)C, param_scale, accumulate, (const float*)nullptr, 0);
+    else
+        hipLaunchKernelGGL((partial_reduce_kernel<1, 32>), dim3((unsigned)ceil_div(2 * C, 32)), dim3(256), 0, st, part, blocks, (int)(2 * C), dgamma, dbeta,
+                           (int)C, param_scale, accumulate, (const float*)nullptr, 0);
     return launch_status("mit_layernorm_bwd");
 }
 
@@ -893,8 +897,12 @@ extern "C" int diga_mit_dwconv_gelu_bwd(const void* dh, const void* u, const voi
                            static_cast<const _Float16*>(dh), static_cast<const _Float16*>(u), static_cast<const _Float16*>(x),
                            static_cast<_Float16*>(du16), static_cast<float*>(workspace), (int)B, (int)H, (int)W, (int)C, rpb, gw, phases);
     }
-    hipLaunchKernelGGL(partial_reduce_kernel<2>, dim3((unsigned)ceil_div(10 * C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), blocks,
-                       (int)(10 * C), dw, db, (int)C, param_scale, accumulate);
+    if (blocks >= 64)
+        hipLaunchKernelGGL((partial_reduce_kernel<2, 8>), dim3((unsigned)ceil_div(10 * C, 8)), dim3(256), 0, st, static_cast<const float*>(workspace), blocks,
+                           (int)(10 * C), dw, db, (int)C, param_scale, accumulate, (const float*)nullptr, 0);
+    else
+        hipLaunchKernelGGL((partial_reduce_kernel<2, 32>), dim3((unsigned)ceil_div(10 * C, 32)), dim3(256), 0, st, static_cast<const float*>(workspace), blocks,
+                           (int)(10 * C), dw, db, (int)C, param_scale, accumulate, (const float*)nullptr, 0);
     const int64_t items = B * H * ceil_div(W, kDwPX) * (C / 8);
     const int R = dw_rows_per_thread(B, H, W, C);
     if (R > 0) {

@@ -21,7 +21,7 @@ sgd = [i for i, r in enumerate(rows) if "sgd_multi_kernel" in r[2]]
 a, b = sgd[-2] + 1, sgd[-1] + 1
 step = rows[a:b]
 t0, t1 = step[0][0], max(r[1] for r in step)
-MFMA = ("conv_fwd", "conv_wgrad", "gemm_f32_persistent")
+MFMA = ("conv_fwd", "conv_wgrad", "gemm_f32_persistent", "gemm_nt_kernel", "gemm_tn_kernel", "attn_fwd", "attn_bwd")   # (the last four: the MiT leg)
 ev = []
 for s, e, n in step:
     k = 0 if any(m in n for m in MFMA) else 1
