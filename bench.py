@@ -427,6 +427,8 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
         # with the streams serialised time every kernel on its own (all ranks, the step has a collective).
         saved = {k: os.environ.get(k) for k in ("DIGA_TEACHER_STREAM", "DIGA_WGRAD_STREAM")}
         os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
+        from diga_amd import train_step as _ts
+        saved_overlap, _ts.C4_OVERLAP = _ts.C4_OVERLAP, 0        # (c4: the one-backward form, no third stream, while kernels are timed)
         try:
             one_step(it)
             it += 1
@@ -448,6 +450,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
                     families[tag]["executed_flops_per_step"] = executed / SERIAL_STEPS
             _dconv.flop_log = None
         finally:
+            _ts.C4_OVERLAP = saved_overlap
             for k, v in saved.items():
                 if v is None:
                     os.environ.pop(k, None)
@@ -713,6 +716,8 @@ def main():
 
     if a.serial_streams:
         os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
+        from diga_amd import train_step as _ts
+        _ts.C4_OVERLAP = 0                   # (the self-training step's third stream as well)
     dt, (families, families_ov), losses, counts, geom = run_steps(a, a.config, a.precision, a.steps, a.warmup, rank, world,
                                                                   dev, prof, graph=bool(a.graph and world == 1))
     B, H, W, _ = geom
