@@ -115,6 +115,7 @@ class GradReducer:
         self._ready = [0] * len(self.buckets)
         self._copy_back = [None] * len(self.buckets)
         self._hooks = []
+        self._held = 0
         self._where = {}                      # id(param) -> (bucket, element offset)
         for i, bucket in enumerate(self.buckets):
             off = 0
@@ -141,8 +142,25 @@ class GradReducer:
             if getattr(p, "_diga_grad_view", None) is not None:
                 del p._diga_grad_view
 
+    def hold(self):
+        """Context: gradients produced inside are NOT counted or sent by the hooks (the self-training step's two-graph form: the
+        first backward() leaves partial sums in p.grad, the second graph's gradients are added by hand, then `reduce()` sends every
+        bucket at once)."""
+        reducer = self
+
+        class _Hold:
+            def __enter__(self):
+                reducer._held += 1
+
+            def __exit__(self, *exc):
+                reducer._held -= 1
+                return False
+        return _Hold()
+
     def _make_hook(self, i):
         def hook(_param):
+            if self._held:
+                return
             self._ready[i] += 1
             if self._ready[i] > len(self.buckets[i]):
                 # a second backward() accumulated into p.grad after the bucket was packed and sent: its contribution

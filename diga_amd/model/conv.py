@@ -94,6 +94,9 @@ def takes_twin_only_input(conv, pointwise_ok=False):
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
 
 
+# False while a forward builds a graph whose weight gradients must land in tensors of their own (the step driver's second student
+# graph, differentiated with torch.autograd.grad next to the first one's backward(): the bucket slice holds the FIRST graph's gradient)
+GRAD_VIEWS = True
 INLINE_WGRAD = "inline"       # `uses` of a functional _Conv2dFn call whose weight is a non-leaf tensor (see backward)
 _WINO_CACHE = {}
 # bench.py sets this to a dict to learn what the convolutions of a step multiply: name -> [FLOPs of the direct
@@ -516,7 +519,7 @@ class _Conv2dFn(torch.autograd.Function):
                                "(check takes_twin_only_input before asking the producer for a twin)")
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         ctx.uses = uses
-        ctx.grad_view = getattr(weight, "_diga_grad_view", None) if isinstance(weight, nn.Parameter) else None
+        ctx.grad_view = getattr(weight, "_diga_grad_view", None) if (GRAD_VIEWS and isinstance(weight, nn.Parameter)) else None
         # the arithmetic / twin decisions of this forward bind its backward: saved tensors may hold twin bytes
         ctx.math = _lib.get_conv_math()
         ctx.x_is_twin = bool(x_is_twin)

@@ -334,7 +334,7 @@ class DigaTrainer:
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng, present=present)
             cat = torch.cat([x, mix])
         (_, _, s_lr, _), pending = self._student_and_teacher(cat, cat, t_img)
-        if (self.world == 1 and x.is_cuda and C4_OVERLAP >= 2 and getattr(self, "_pending_join", False)
+        if (x.is_cuda and C4_OVERLAP >= 2 and getattr(self, "_pending_join", False)
                 and len(getattr(self, "_teacher_events", ())) == 2):
             return self._selftrain_rest_overlapped(s_lr, pending, x, labels, t_aug, pseudo_prob, class_features, present, B,
                                                    lambda_seg, lambda_distil)
@@ -353,7 +353,7 @@ class DigaTrainer:
                     continue
                 sums, counts = ddp.gather_class_sums(sums, counts)
                 class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
-        if self.world == 1 and x.is_cuda and C4_OVERLAP >= 1:
+        if x.is_cuda and C4_OVERLAP >= 1:
             return self._selftrain_tail_overlapped(s_lr, t_lr, labels, cross_mix, cross_lab, lambda_seg, lambda_distil)
         _, _, c_lr, _ = self.student(cross_mix)
         total_s, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
@@ -371,6 +371,7 @@ class DigaTrainer:
         forwards and the one backward pass.  Host order of every ClassMix draw, BatchNorm running-statistics update
         (student(cat) before student(cross_mix): an event) and centroid update is the reference's; the gradient of a shared weight is
         g_cat + g_cross either way: bit-identical to the one-backward form (tests/test_selftrain.py)."""
+        from diga_amd.model import conv as _dconv
         _accumulate_on_other_streams_is_intended()
         dev = s_lr.device
         main = torch.cuda.current_stream(dev)
@@ -387,7 +388,8 @@ class DigaTrainer:
         self.opt.zero_grad(set_to_none=True)
         _lib.side_overlap = True
         try:
-            total_s.backward()                                  # main stream; weight gradients on the side stream
+            with self.reducer.hold():                           # (N > 1: these are partial sums -- the buckets leave after the join)
+                total_s.backward()                              # main stream; weight gradients on the side stream
             sb.wait_event(ev_tgt)
             sb.wait_event(ev_main)
             for t in (t_lr, t_feat, tt_lr, tt_feat):
@@ -403,8 +405,15 @@ class DigaTrainer:
                             cents, nums = class_features._state_on(sums.device)
                             ddp.apply_mean_of_vectors(cents, nums, ms, nv, class_features.centroid_momentum)
                             continue
+                        sums, counts = ddp.gather_class_sums(sums, counts)
                         class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
-                _, _, c_lr, _ = self.student(cross_mix)
+                # (N > 1: this graph is built AFTER the first one's backward ran, so its convolutions would take themselves for the
+                #  first users of their weights and write into the all-reduce bucket slices that hold the first graph's gradients)
+                _dconv.GRAD_VIEWS = False
+                try:
+                    _, _, c_lr, _ = self.student(cross_mix)
+                finally:
+                    _dconv.GRAD_VIEWS = True
                 ce_mix = L.upsample_ce(c_lr, cross_lab, lambda_seg)
                 g2 = torch.autograd.grad(ce_mix, params, allow_unused=True)
         finally:
@@ -460,7 +469,8 @@ class DigaTrainer:
         self.opt.zero_grad(set_to_none=True)
         _lib.side_overlap = True
         try:
-            total_s.backward()                                  # main stream; weight gradients on the side stream
+            with self.reducer.hold():                           # (N > 1: partial sums -- the buckets leave after the join)
+                total_s.backward()                              # main stream; weight gradients on the side stream
             with torch.cuda.stream(sb):
                 g2 = torch.autograd.grad(ce_mix, params, allow_unused=True)
         finally:

@@ -22,6 +22,11 @@ def main(out_dir):
     from oracle import deeplab as od
     from oracle import detweights, synth
     rank, world, local = ddp.init_from_env()
+    if os.environ.get("DIGA_TEST_FORCE_STREAMS") == "1":
+        # init_from_env puts gloo runs on one stream (gloo's host-synchronous GPU collectives make the side streams slow, not
+        # wrong); the parent asks for them anyway to drive the three-stream self-training step under data parallelism
+        os.environ["DIGA_TEACHER_STREAM"] = "1"
+        os.environ["DIGA_WGRAD_STREAM"] = "1"
     dev = torch.device("cuda", local)
     _lib.set_conv_math(int(os.environ.get("DIGA_TEST_MATH", "0")))
 
@@ -42,6 +47,14 @@ def main(out_dir):
         sent.append((sums.cpu().clone(), counts.cpu().clone()))
         return orig(sums, counts, group)
     ddp.gather_class_sums = spy
+    forms = []
+    for name in ("_selftrain_rest_overlapped", "_selftrain_tail_overlapped"):
+        def wrap(fn, name=name):
+            def run(*a, **k):
+                forms.append(name)
+                return fn(*a, **k)
+            return run
+        setattr(tr, name, wrap(getattr(tr, name)))
     wb = [t.to(dev) for t in synth.warmup_batch(900 + rank, 2, 96, 128, block=16)]
     log1 = tr.warmup_step(0, *wb)
     torch.cuda.synchronize()
@@ -55,7 +68,7 @@ def main(out_dir):
     after2 = {k: v.detach().cpu().clone() for k, v in student.named_parameters()}
     torch.save({"after1": after1, "after2": after2, "log1": {k: float(v) for k, v in log1.items()},
                 "log2": {k: float(v) for k, v in log2.items()}, "cents": cf.objective_vectors.cpu(),
-                "nums": cf.objective_vectors_num.cpu(), "sent": sent}, os.path.join(out_dir, f"rank{rank}.pt"))
+                "nums": cf.objective_vectors_num.cpu(), "sent": sent, "forms": forms}, os.path.join(out_dir, f"rank{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

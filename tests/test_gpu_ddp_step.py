@@ -25,14 +25,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda"
 
 
-def _run_workers(tmp, math):
+def _run_workers(tmp, math, **extra_env):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   DIGA_TEST_MATH=str(math))
+                   DIGA_TEST_MATH=str(math), **extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_step_worker.py"), str(tmp)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -120,6 +120,31 @@ def test_two_rank_steps_equal_single_process_emulation(tmp_path, conv_math):
     cf = Class_Features(numbers=19)                                 # and hw above is the map size the library used
     f = torch.zeros((1, 256, 13, 17), device=DEV)
     assert cf._class_sums(f, torch.zeros((1, 19, 13, 17), device=DEV), labels_full=torch.zeros((1, 96, 128), dtype=torch.int64, device=DEV))[2] == hw
+
+
+@pytest.mark.timeout(1500)
+def test_two_rank_selftraining_step_same_in_all_three_forms(tmp_path, conv_math):
+    """The self-training step under data parallelism in its three forms -- one backward pass with hook-driven buckets (the
+    reference's form), cross-mixed forward / backward on a third stream, the whole target branch on a third stream (round 5; the two
+    overlapped forms hold the hooks back: the first backward() leaves partial sums, the buckets leave after the join) -- gives
+    the same student, centroid bank and losses on both ranks, bit for bit."""
+    runs = {}
+    for tag, env in (("one_backward", dict(DIGA_C4_OVERLAP="0")), ("tail", dict(DIGA_C4_OVERLAP="2")),
+                     ("target_branch", dict(DIGA_C4_OVERLAP="2", DIGA_TEST_FORCE_STREAMS="1"))):
+        d = tmp_path / tag
+        d.mkdir()
+        runs[tag] = _run_workers(d, conv_math, **env)
+    assert runs["one_backward"][0]["forms"] == [] and runs["tail"][0]["forms"] == ["_selftrain_tail_overlapped"]
+    assert runs["target_branch"][0]["forms"] == ["_selftrain_rest_overlapped"]
+    ref = runs["one_backward"]
+    for tag in ("tail", "target_branch"):
+        for r in range(2):
+            assert runs[tag][r]["log2"] == ref[r]["log2"], (tag, r, runs[tag][r]["log2"], ref[r]["log2"])
+            assert torch.equal(runs[tag][r]["cents"], ref[r]["cents"]) and torch.equal(runs[tag][r]["nums"], ref[r]["nums"])
+            for k in ref[r]["after2"]:
+                assert torch.equal(runs[tag][r]["after2"][k], ref[r]["after2"][k]), (tag, r, k)
+        for k in runs[tag][0]["after2"]:
+            assert torch.equal(runs[tag][0]["after2"][k], runs[tag][1]["after2"][k]), (tag, k)
 
 
 @pytest.mark.timeout(1500)
