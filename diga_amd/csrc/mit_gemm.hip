@@ -35,6 +35,7 @@ struct GemmArgs {
     int tiles_n;
     int out_f32;
     int accumulate;           // out += result (fp16 out only; read-modify-write)
+    int plain16;              // host: fp16 output, no residual / segment scale / accumulate, 16-byte rows -> the whole-tile fp16 epilogue
     float alpha;
 };
 
@@ -126,10 +127,40 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_kernel(GemmArgs a) {
         nx = nx == 2 ? 0 : nx + 1;
     }
 
-    // epilogue: 64-row halves through LDS, whole row segments out with 16-byte (fp32) / 8-byte (fp16) accesses
+    const int t = threadIdx.x;
+    // epilogue, plain fp16 output (q / kv / fc1 and the backward-data GEMMs: no residual, no read-modify-write): alpha and bias in
+    // registers, the WHOLE block tile staged as fp16 (BM x (BN + 8) halves fit the operand ring), one barrier, 16-byte row segments
+    // out.  (The general path below stages fp32 in 64-row quarters: 2 WM barriers, 8-byte stores.)
+    if (a.plain16 && n0 + BN <= a.N) {                     // uniform over the block
+        constexpr int LDH = BN + 8;
+        _Float16* st16 = reinterpret_cast<_Float16*>(smem);
+        static_assert(BM * LDH * 2 <= 3 * STAGE, "fp16 tile image must fit the operand ring");
+        float bv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = a.bias != nullptr ? a.bias[n0 + wn * 32 * TN + j * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    st16[(wm * 64 + i * 16 + (lane >> 4) * 4 + e) * LDH + wn * 32 * TN + j * 16 + (lane & 15)] =
+                        (_Float16)(acc[i][j][e] * a.alpha + bv[j]);
+        __syncthreads();
+        constexpr int OCT = BN / 8;                        // 16-byte groups per row
+        for (int idx = t; idx < BM * OCT; idx += 64 * NW) {
+            const int r = idx / OCT, q = idx - r * OCT;
+            const int m = m0 + r;
+            if (m >= a.M) continue;
+            *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(a.out) + (int64_t)m * a.ldc + n0 + q * 8) =
+                *reinterpret_cast<const f16x8*>(st16 + r * LDH + q * 8);
+        }
+        return;
+    }
+    // epilogue (general: fp32 output, residual, segment scale, read-modify-write): 64-row halves through LDS as fp32, whole row
+    // segments out with 16-byte (fp32) / 8-byte (fp16) accesses.  (Two wave rows per pass where the ring holds them: measured neutral.)
     constexpr int LDS_LD = BN + 4;
     float* stage = reinterpret_cast<float*>(smem);
-    const int t = threadIdx.x;
 #pragma unroll
     for (int h = 0; h < WM; ++h) {
         if (m0 + h * 64 >= a.M) break;                     // uniform over the block
@@ -439,6 +470,7 @@ extern "C" int diga_mit_gemm_nt(const void* A, int64_t lda, const void* B, int64
     a.bias = bias; a.out = out; a.ldc = ldc; a.res = residual; a.ldr = ldr;
     a.seg_scale = seg_scale; a.rows_per_seg = (int)rows_per_seg;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.out_f32 = out_f32; a.accumulate = accumulate; a.alpha = alpha;
+    a.plain16 = !out_f32 && residual == nullptr && seg_scale == nullptr && !accumulate && ldc % 8 == 0 && aligned16(out);
     ProfScope prof(DIGA_PROF_MIT_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
     if (N > 64) {
         a.tiles_n = (int)ceil_div(N, 128);
