@@ -875,13 +875,25 @@ extern "C" int diga_mit_dwconv_gelu_bwd(const void* dh, const void* u, const voi
     ProfScope prof(DIGA_PROF_MIT_DWCONV, st, (double)B * H * W * C * 12.0);
     // row-sliding form where the tensor is large enough for >= 512 blocks of (32 or 64 channel groups) x (8 or 4 strip lanes) x R rows;
     // R >= rpb keeps the partial sums inside the workspace the caller sized with diga_mit_dwconv_bwd_workspace_bytes
+    // (gw, R) by a cost model of the launch: two blocks per CU (206 registers) = 512 slots per round; a block's work is its threads'
+    // strips x (R rows + the halo / prologue share of a walk); dead lanes of the last channel-group block and a mostly empty last round
+    // are what the model avoids -- the stage-3 tensor (160 channel groups, 48 rows x 16 images) went 3 x 64 groups x 4 rows = 576 blocks
+    // (two rounds for 1.1 rounds of work, a quarter of the third block's lanes dead) -> 5 x 32 groups x 8 rows = 480 blocks, one round
     const int cgn = (int)(C / 8);
-    const int gwr = cgn % 64 == 0 || cgn > 96 ? 64 : 32;
-    int Rr = 0;
-    for (int r = 8; r >= 1; r >>= 1)
-        if (r >= rpb && ceil_div(cgn, gwr) * B * ceil_div(H, r) >= 512) {
-            Rr = r;
-            break;
+    const int strips = (int)ceil_div(W, mit::kPrepPX);
+    int gwr = 32, Rr = 0;
+    double best = 0.0;
+    for (int gw = 64; gw >= 32; gw >>= 1)
+        for (int r = 8; r >= 1; r >>= 1) {
+            if (r < rpb) continue;
+            const int64_t nb = ceil_div(cgn, gw) * B * ceil_div(H, r);
+            if (nb < 256) continue;                               // less than half a round: the other kernel form
+            const double cost = (double)ceil_div(nb, 512) * (double)ceil_div(strips, 256 / gw) * ((double)r + 0.4);
+            if (Rr == 0 || cost < best) {
+                best = cost;
+                gwr = gw;
+                Rr = r;
+            }
         }
     if (Rr > 0 && cgn >= 32) {
         blocks = (int)(B * ceil_div(H, Rr));
