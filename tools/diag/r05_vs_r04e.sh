@@ -1,4 +1,6 @@
 #!/bin/bash
+# This tree against the round-4 tree on ONE box, interleaved.  The round-4 tree is a scratch copy next to this one (git-ignored, removed
+# at the end of the round):  mkdir .r04_tree && git archive 2992702 | tar -x -C .r04_tree && (cd .r04_tree && python -m diga_amd.build)
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r05_vs_r04e.txt
 : > $OUT
