@@ -235,7 +235,26 @@ def _worker(rank, world, port, out):
         tot = sum(rr + 1 + step for rr in range(world))
         ok_hooks &= all(torch.allclose(p.grad, torch.full_like(p, float(tot * (i + 1)))) for i, p in enumerate(params))
         ok_hooks &= all(w_ is None for w_ in red._work)
-    ok_grads = ok_grads and ok_hooks
+    # two graphs differentiated before one exchange (the overlapped self-training step): the first backward() runs under hold() -- the
+    # hooks neither count nor send its partial sums --, the second graph's gradients are added by hand, reduce() sends every bucket
+    for p in params:
+        p.grad = None
+    with red.hold():
+        sum(float((rank + 1) * (i + 1)) * p.sum() for i, p in enumerate(params)).backward()
+    ok_hold = all(w_ is None for w_ in red._work) and all(n_ == 0 for n_ in red._ready)
+    g2 = torch.autograd.grad(sum(float(10 * (rank + 1)) * p.sum() for p in params), params)
+    torch._foreach_add_([p.grad for p in params], list(g2))
+    red.reduce()
+    tot1, tot2 = sum(rr + 1 for rr in range(world)), sum(10 * (rr + 1) for rr in range(world))
+    ok_hold &= all(torch.allclose(p.grad, torch.full_like(p, float(tot1 * (i + 1) + tot2))) for i, p in enumerate(params))
+    # ... and the hook-driven form works again right after it
+    for p in params:
+        p.grad = None
+    sum(float(i + 1) * p.sum() for i, p in enumerate(params)).backward()
+    ok_hold &= all(w_ is not None for w_ in red._work)
+    red.reduce()
+    ok_hold &= all(torch.allclose(p.grad, torch.full_like(p, float(world * (i + 1)))) for i, p in enumerate(params))
+    ok_grads = ok_grads and ok_hooks and ok_hold
     # centroid sums: rank-major concatenation
     sums = torch.full((2, 19, 4), float(rank))
     sums[1] += 0.5
