@@ -283,9 +283,9 @@ class _MitStageFn(torch.autograd.Function):
             for bi, bp in enumerate(st["blocks"]):
                 seg_a = seg_m = None
                 if cfg["training"] and st["drop_path"][bi] > 0.0:
-                    # timm DropPath (:156,176-177): per sample keep / drop, rescaled by 1 / keep; one draw per branch
-                    keep = 1.0 - st["drop_path"][bi]
-                    seg_a, seg_m = ((torch.rand((2, B), device=dev) < keep).float() / keep).unbind(0)
+                    # timm DropPath (:156,176-177): per sample keep / drop, rescaled by 1 / keep; one draw per branch -- all blocks' draws
+                    # of a forward pass come from ONE rand call (forward_features: four launches per pass instead of four per block)
+                    seg_a, seg_m = cfg["drop_scales"][si][bi].unbind(0)
                 wq, wqt, _ = prep[bp + ".attn.q.weight"]
                 wkv, wkvt, _ = prep[bp + ".attn.kv.weight"]
                 wpr, wprt, _ = prep[bp + ".attn.proj.weight"]
@@ -595,6 +595,27 @@ class MixVisionTransformer(nn.Module):
                 self._clean_steps = 0
         return new
 
+    def _drop_path_scales(self, cfg, B, dev):
+        """Per stage a [blocks][2][B] tensor of DropPath scales (0 or 1 / keep; branch 0 = attention, 1 = Mix-FFN) for this forward pass,
+        or None outside training / without DropPath: one uniform draw for the whole encoder against the per-block keep probabilities
+        (a cached device vector) -- the per-block form cost four tiny launches per block and network, ~400 per training step."""
+        dps = [st["drop_path"] for st in cfg["stages"]]
+        if not cfg["training"] or not any(d > 0.0 for dp in dps for d in dp):
+            return [None] * len(dps)
+        flat = [1.0 - d for dp in dps for d in dp]
+        key = (str(dev), tuple(flat))
+        cached = getattr(self, "_keep_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, torch.tensor(flat, dtype=torch.float32).view(-1, 1, 1).to(dev))
+            object.__setattr__(self, "_keep_cache", cached)
+        keep = cached[1]
+        scales = (torch.rand((len(flat), 2, B), device=dev) < keep).float() / keep
+        out, at = [], 0
+        for dp in dps:
+            out.append(scales[at:at + len(dp)])
+            at += len(dp)
+        return out
+
     def forward_features(self, x):
         params = [p for _, p in self.named_parameters()]
         cfg = self._cfg()
@@ -604,6 +625,7 @@ class MixVisionTransformer(nn.Module):
             self.grad_overflow[0:1].zero_()
             cfg["overflow_flag"] = self.grad_overflow
         cfg["prep"] = self._prepare_weights() if x.is_cuda else None
+        cfg["drop_scales"] = self._drop_path_scales(cfg, x.shape[0], x.device) if x.is_cuda else None
         named = dict(self.named_parameters())
         outs, src = [], x
         for si in range(4):
