@@ -334,7 +334,12 @@ class DigaTrainer:
             mix, _ = U.classmix(rec_s2t, x_aug, labels, self.rng, present=present)
             cat = torch.cat([x, mix])
         (_, _, s_lr, _), pending = self._student_and_teacher(cat, cat, t_img)
-        if (x.is_cuda and C4_OVERLAP >= 2 and getattr(self, "_pending_join", False)
+        # (gloo is the smoke-test backend: its host-synchronous GPU collectives next to extra streams degenerate to seconds per step --
+        #  ddp.init_from_env switches the side streams off for it, and the overlapped forms stay off too unless a test asks for them)
+        overlap = C4_OVERLAP
+        if self.world > 1 and torch.distributed.get_backend() == "gloo" and os.environ.get("DIGA_C4_OVERLAP_GLOO") != "1":
+            overlap = 0
+        if (x.is_cuda and overlap >= 2 and getattr(self, "_pending_join", False)
                 and len(getattr(self, "_teacher_events", ())) == 2):
             return self._selftrain_rest_overlapped(s_lr, pending, x, labels, t_aug, pseudo_prob, class_features, present, B,
                                                    lambda_seg, lambda_distil)
@@ -353,7 +358,7 @@ class DigaTrainer:
                     continue
                 sums, counts = ddp.gather_class_sums(sums, counts)
                 class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
-        if x.is_cuda and C4_OVERLAP >= 1:
+        if x.is_cuda and overlap >= 1:
             return self._selftrain_tail_overlapped(s_lr, t_lr, labels, cross_mix, cross_lab, lambda_seg, lambda_distil)
         _, _, c_lr, _ = self.student(cross_mix)
         total_s, ce, di = L.upsample_ce_distill(s_lr, t_lr, labels, lambda_seg, lambda_distil, self.distill_scale)
