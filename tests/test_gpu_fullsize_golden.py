@@ -39,27 +39,37 @@ def exact_tiles(request, conv_math):
         _lib.set_conv_math(0, exact=False)
 
 
-@pytest.mark.parametrize("name", ["full768", "full512x1024"])
+@pytest.mark.parametrize("name", ["full768", "full512x1024", "full768b8"])
 def test_benchmark_geometry_vs_reference(golden, conv_math, exact_tiles, name):
+    """full768b8 (round 5): EIGHT images of 768 x 768 -- half the benchmark's student batch, 75 272 rows per pointwise GEMM (beyond 2^15
+    and 2^16 rows; four times the tile count, other split-K boundaries than the two-image captures); its logits are stored as a
+    strided sample."""
     from diga_amd import _lib
     g = golden(name)
-    _, H, W = (int(v) for v in g["geometry"])
+    batch, H, W = (int(v) for v in g["geometry"])
     gen = synth.gen(int(g["seed"]))
-    x = torch.rand((2, 3, H, W), generator=gen) * 2 - 1
+    x = torch.rand((batch, 3, H, W), generator=gen) * 2 - 1
     m = _model().train()
     m.final.head[0].p = 0.0                                       # Dropout2d off, as in the capture
     sh, dp, out, feat = m(x.to(DEV))
-    want = g.t("out")
-    assert tuple(out.shape) == tuple(want.shape)
+    if "out" in g:
+        want = g.t("out")
+        assert tuple(out.shape) == tuple(want.shape)
+        got = out.detach().cpu()
+    else:
+        want = g.t("out_sample")
+        got = out.detach().cpu().reshape(-1)[::7]
+        assert tuple(got.shape) == tuple(want.shape) and tuple(out.shape[:2]) == (batch, 19)
+        assert float(out.detach().abs().sum()) == pytest.approx(float(g["out_sum"][1]), rel=1e-4)
     scale = float(want.abs().max())
-    err = float((out.detach().cpu() - want).abs().max())
+    err = float((got - want).abs().max())
     # north_star: logits within 1e-3 relative of the reference's CPU path -- in BOTH arithmetics ...
     assert err < 1e-3 * scale, (name, err, scale)
     # ... and within 3x of what the kernels measure (exact fp32 with 6x6 / 4x4 Winograd tiles: 2.5e-5 / 4.3e-5 of scale at 768x768 /
     # 512x1024; split bf16: 1.6e-4): a regression of the arithmetic shows long before it reaches the contract's bound
     assert err < ((4e-5 if exact_tiles else 1.5e-4) if conv_math == 0 else 5e-4) * scale, (name, err, scale)
     if conv_math == 0:
-        assert_close(out, want, 1e-3, 3e-4 * scale, "train logits (fp32 mode, elementwise)")
+        assert_close(got, want, 1e-3, 3e-4 * scale, "train logits (fp32 mode, elementwise)")
     # features / trunk outputs: strided samples and L1 sums of the reference
     featc = feat.detach().cpu()
     fs = g.t("feat_sample")
@@ -72,7 +82,7 @@ def test_benchmark_geometry_vs_reference(golden, conv_math, exact_tiles, name):
     assert float(sh.detach().abs().sum()) == pytest.approx(float(g["shallow_sum"][1]), rel=1e-4)
     del featc, dpc
 
-    probe = torch.randn(want.shape, generator=gen)
+    probe = torch.randn(tuple(out.shape), generator=gen)
     _lib.side_overlap = True                                      # as bench.py runs it: weight gradients on the side stream
     try:
         (out * probe.to(DEV)).sum().backward()
@@ -120,11 +130,12 @@ def test_benchmark_geometry_vs_reference(golden, conv_math, exact_tiles, name):
     assert_close(sd["layer3.22.bn3.running_mean"], g.t("rm_layer3"), 1e-3, 1e-5, "running mean layer3")
     assert_close(sd["layer4.2.bn3.running_var"], g.t("rv_layer4"), 1e-3, 1e-6, "running var layer4")
     # eval mode (running statistics as updated by the pass above, like the capture)
-    m.eval()
-    with torch.no_grad():
-        oe = m(x.to(DEV))[2]
-    we = g.t("out_eval")
-    assert float((oe.cpu() - we).abs().max()) < 1e-3 * float(we.abs().max())
+    if "out_eval" in g:
+        m.eval()
+        with torch.no_grad():
+            oe = m(x.to(DEV))[2]
+        we = g.t("out_eval")
+        assert float((oe.cpu() - we).abs().max()) < 1e-3 * float(we.abs().max())
     print(f"{name} math={conv_math} exact={exact_tiles}: logits max err {err / scale:.2e} of scale, worst gradient-sample relative L2 {worst:.2e}")
 
 

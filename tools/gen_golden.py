@@ -431,7 +431,7 @@ FULLSIZE_GRADS = ["layer0.0.weight", "layer1.0.conv1.weight", "layer1.0.downsamp
                   "final.bottleneck.2.weight"]
 
 
-def _gen_fullsize(name, H, W, seed):
+def _gen_fullsize(name, H, W, seed, batch=2):
     """Reference SegModel (model_noaux.py:28-46), train mode (batch-statistics BN), Dropout2d off, deterministic
     weights, on TWO crops of the benchmark geometry: 768x768 -> 97x97 map (BASELINE configs[1]) and 512x1024 -> 65x129
     (configs[3]).  The input and the gradient probe are regenerated from their seeds by the test; stored are the
@@ -441,11 +441,14 @@ def _gen_fullsize(name, H, W, seed):
     m.train()
     m.final.head[0].p = 0.0
     g = synth.gen(seed)
-    x = torch.rand((2, 3, H, W), generator=g) * 2 - 1
+    x = torch.rand((batch, 3, H, W), generator=g) * 2 - 1
     sh, dp, out, feat = m(x)
     probe = torch.randn(out.shape, generator=g)
     (out * probe).sum().backward()
-    res = dict(seed=np.array(seed), geometry=np.array([2, H, W]), out=out, feat_sample=feat.detach().reshape(-1)[::61].clone(),
+    # (batch > 2 -- the half-benchmark-batch capture: 8 images, 75 272 rows per GEMM --: logits as a strided sample + sums, no eval pass)
+    outs = dict(out=out) if batch <= 2 else dict(out_sample=out.detach().reshape(-1)[::7].clone(),
+                                                 out_sum=np.array([synth.checksum(out), float(out.detach().abs().sum()), float(out.detach().abs().max())]))
+    res = dict(seed=np.array(seed), geometry=np.array([batch, H, W]), **outs, feat_sample=feat.detach().reshape(-1)[::61].clone(),
                feat_sum=np.array([synth.checksum(feat), float(feat.detach().abs().sum())]),
                shallow_sum=np.array([synth.checksum(sh), float(sh.detach().abs().sum())]),
                deep_sum=np.array([synth.checksum(dp), float(dp.detach().abs().sum())]),
@@ -463,10 +466,17 @@ def _gen_fullsize(name, H, W, seed):
     res["rm_layer1"] = sd["layer1.0.bn1.running_mean"]
     res["rv_layer4"] = sd["layer4.2.bn3.running_var"]
     res["rm_layer3"] = sd["layer3.22.bn3.running_mean"]
-    m.eval()
-    with torch.no_grad():
-        res["out_eval"] = m(x)[2]
+    if batch <= 2:
+        m.eval()
+        with torch.no_grad():
+            res["out_eval"] = m(x)[2]
     save(name, **res)
+
+
+def gen_full768b8():
+    """Half the benchmark's student batch (8 of 16 images: the reference's 8-image pass peaks at 36 GB resident, 16 images do not fit this
+    container's 62 GB): 75 272 rows per pointwise GEMM -- beyond 2^15 and 2^16 rows, four times the tile count of the 2-image capture."""
+    _gen_fullsize("full768b8", 768, 768, 8769, batch=8)
 
 
 def gen_full768():
@@ -1196,7 +1206,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(traj25=gen_traj25, traj768=gen_traj768, selftraj10=gen_selftraj10, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(full768b8=gen_full768b8, traj25=gen_traj25, traj768=gen_traj768, selftraj10=gen_selftraj10, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
