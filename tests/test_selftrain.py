@@ -87,6 +87,8 @@ def test_selftrain_overlapped_tail_is_bit_identical(golden, conv_math, monkeypat
     from diga_amd import train_step as ts
     from diga_amd.calc_centroids import Class_Features
     from diga_amd.model.model_noaux import SegModel
+    if conv_math != 0:
+        pytest.skip("stream structure, not arithmetic: once (fp32) is enough -- three two-step runs of the ResNet-101 step")
     g = golden("selftrain")
 
     def run(overlap):
