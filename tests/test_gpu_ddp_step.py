@@ -128,6 +128,8 @@ def test_two_rank_selftraining_step_same_in_all_three_forms(tmp_path, conv_math)
     reference's form), cross-mixed forward / backward on a third stream, the whole target branch on a third stream (round 5; the two
     overlapped forms hold the hooks back: the first backward() leaves partial sums, the buckets leave after the join) -- gives
     the same student, centroid bank and losses on both ranks, bit for bit."""
+    if conv_math != 0:
+        pytest.skip("stream / reducer structure, not arithmetic: once (fp32) is enough -- three pairs of worker processes")
     runs = {}
     # (DIGA_C4_OVERLAP_GLOO: the overlapped forms are off under gloo by default -- slow there, not wrong)
     for tag, env in (("one_backward", dict(DIGA_C4_OVERLAP="0")), ("tail", dict(DIGA_C4_OVERLAP="2", DIGA_C4_OVERLAP_GLOO="1")),
