@@ -39,11 +39,11 @@ def exact_tiles(request, conv_math):
         _lib.set_conv_math(0, exact=False)
 
 
-@pytest.mark.parametrize("name", ["full768", "full512x1024", "full768b8"])
+@pytest.mark.parametrize("name", ["full768", "full512x1024", "full768b8", "full512x1024b8"])
 def test_benchmark_geometry_vs_reference(golden, conv_math, exact_tiles, name):
     """full768b8 (round 5): EIGHT images of 768 x 768 -- half the benchmark's student batch, 75 272 rows per pointwise GEMM (beyond 2^15
     and 2^16 rows; four times the tile count, other split-K boundaries than the two-image captures); its logits are stored as a
-    strided sample."""
+    strided sample.  full512x1024b8: the self-training geometry at the per-GPU batch of its student(cat) pass (4 + 4 crops, 67 080 rows)."""
     from diga_amd import _lib
     g = golden(name)
     batch, H, W = (int(v) for v in g["geometry"])

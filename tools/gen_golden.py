@@ -479,6 +479,12 @@ def gen_full768b8():
     _gen_fullsize("full768b8", 768, 768, 8769, batch=8)
 
 
+def gen_full512x1024b8():
+    """The self-training geometry (configs[3]) at the per-GPU batch of its student(cat) pass: 4 + 4 crops of 512x1024 = 8 images,
+    67 080 rows per pointwise GEMM."""
+    _gen_fullsize("full512x1024b8", 512, 1024, 8513, batch=8)
+
+
 def gen_full768():
     _gen_fullsize("full768", 768, 768, 8768)
 
@@ -1206,7 +1212,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(full768b8=gen_full768b8, traj25=gen_traj25, traj768=gen_traj768, selftraj10=gen_selftraj10, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(full768b8=gen_full768b8, full512x1024b8=gen_full512x1024b8, traj25=gen_traj25, traj768=gen_traj768, selftraj10=gen_selftraj10, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
