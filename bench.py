@@ -310,11 +310,17 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
     ranks, kernel families, last losses, parameter counts, geometry)."""
     import torch
     from diga_amd import _lib, ddp, synthetic
+    from diga_amd import config as dcfg
     from diga_amd.model import seg_model_noaux as sm
     from diga_amd.model.model_noaux import SegModel
     from diga_amd.train_step import DigaTrainer
 
-    _lib.set_conv_math(1 if precision == "bf16x3" else 0)
+    # the step's configuration is explicit (diga_amd/config.py): the process defaults (environment read once at import; gloo runs
+    # have had their side streams switched off by ddp.init_from_env) with this leg's arithmetic and stream policy
+    step_cfg = dcfg.DEFAULTS.replace(conv_math=1 if precision == "bf16x3" else 0)
+    if a.serial_streams:
+        step_cfg = step_cfg.serial_streams()
+    _lib.set_conv_math(step_cfg.conv_math)       # (model construction and anything outside a step follow the same arithmetic)
     arch_name, B, H, W, block = geometry(a, config)
     torch.manual_seed(0)                       # identical random-init weights on every rank
     if arch_name.startswith("MIT_"):
@@ -329,7 +335,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
     rng = random.Random(1234 + rank)           # ClassMix class choice differs per rank, reproducibly
     # graph=True (the launch-bound legs c1 / c5): the static part of the step is captured into a HIP graph and replayed
     # (diga_amd/train_step.py); kernel-family timings then come from extra eager steps after the timed region
-    tr = DigaTrainer(student, teacher, rng=rng, graph=graph)
+    tr = DigaTrainer(student, teacher, rng=rng, graph=graph, config=step_cfg)
     if config == "c4":
         from diga_amd.calc_centroids import Class_Features
         batch = synthetic.selftrain_batch(1234 + rank, B, H, W, block=block, device=dev)
@@ -425,10 +431,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
         # Kernel durations for the roofline: the timed region runs the teacher forward and the weight gradients on a
         # second stream, so the HIP events of a launch there span other kernels sharing the GPU.  Two more steps
         # with the streams serialised time every kernel on its own (all ranks, the step has a collective).
-        saved = {k: os.environ.get(k) for k in ("DIGA_TEACHER_STREAM", "DIGA_WGRAD_STREAM")}
-        os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
-        from diga_amd import train_step as _ts
-        saved_overlap, _ts.C4_OVERLAP = _ts.C4_OVERLAP, 0        # (c4: the one-backward form, no third stream, while kernels are timed)
+        tr.cfg = step_cfg.serial_streams()       # (c4: the one-backward form, no third stream, while kernels are timed)
         try:
             one_step(it)
             it += 1
@@ -450,12 +453,7 @@ def run_steps(a, config, precision, steps, warmup, rank, world, dev, prof, graph
                     families[tag]["executed_flops_per_step"] = executed / SERIAL_STEPS
             _dconv.flop_log = None
         finally:
-            _ts.C4_OVERLAP = saved_overlap
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            tr.cfg = step_cfg
         barrier()
     if prof:
         _lib.call("diga_prof_reset")
@@ -714,10 +712,6 @@ def main():
     backend = torch.distributed.get_backend() if world > 1 else None
     prof = not a.no_prof
 
-    if a.serial_streams:
-        os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
-        from diga_amd import train_step as _ts
-        _ts.C4_OVERLAP = 0                   # (the self-training step's third stream as well)
     dt, (families, families_ov), losses, counts, geom = run_steps(a, a.config, a.precision, a.steps, a.warmup, rank, world,
                                                                   dev, prof, graph=bool(a.graph and world == 1))
     B, H, W, _ = geom

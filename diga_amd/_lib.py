@@ -8,6 +8,8 @@ import os
 
 import torch
 
+from diga_amd import config
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIGA_LIB") or os.path.join(_HERE, "libdiga_hip.so")      # DIGA_LIB: A/B builds of the library
 
@@ -82,9 +84,6 @@ SIGNATURES = {
     "diga_pyramid_sum_bwd3": (INT, [P, I64, I64, P, P, P, I64, I64, P]),
     "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
     "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
-    "diga_bn_apply": (INT, [P, I64, P, I64, P, I64, P, I64, I64, INT, P, P]),
-    "diga_conv2d_junction_ok": (INT, [I64, I64, I64]),
-    "diga_conv2d_junction_f32": (INT, [P, I64, P, I64, P, P, I64, P, P, P, I64, P, I64, I64, I64, P]),
     "diga_conv2d_winograd_workspace_bytes": (SZ, [I64] * 7),
     "diga_conv2d_winograd_tile_table_bytes": (SZ, [I64] * 5),
     "diga_conv2d_winograd_tile_table": (INT, [P] + [I64] * 5 + [P]),
@@ -96,8 +95,6 @@ SIGNATURES = {
     "diga_conv2d_wgrad_winograd_workspace_bytes": (SZ, [I64] * 7 + [INT]),
     "diga_conv2d_wgrad_winograd_f32": (INT, [P, P, P, P, P, SZ] + [I64] * 9 + [P, P]),
     "diga_conv2d_winograd_v_floats": (SZ, [I64] * 6),
-    "diga_conv2d_winograd_f32_ab": (INT, [P, P, P, P, P, P, P, SZ] + [I64] * 9 + [P, P, INT, P]),
-    "diga_conv2d_wgrad_winograd_f32_ab": (INT, [P, P, P, P, P, P, SZ] + [I64] * 9 + [P, P]),
     "diga_conv2d_winograd_f32_keep": (INT, [P, P, P, P, P, P, SZ] + [I64] * 9 + [P, P, INT, P]),
     "diga_conv2d_nhwc_bf16x3_epi": (INT, [P, P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_conv2d_nhwc_twin_epi": (INT, [P, P, P] + [I64] * 16 + [P, INT, P]),
@@ -184,7 +181,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 # ---- conv arithmetic: host-side policy (the library keeps no process-wide mode; include/diga_hip.h, DIGA_CONV_MATH_*)
 CONV_MATH_F32, CONV_MATH_BF16X3 = 0, 1
-_conv_math = CONV_MATH_BF16X3 if os.environ.get("DIGA_CONV_MATH", "") in ("bf16x3", "1") else CONV_MATH_F32
+# (the mode is a field of the active configuration, diga_amd/config.py; DIGA_CONV_MATH gives its default)
 
 
 def set_conv_math(mode, exact=None):
@@ -195,20 +192,18 @@ def set_conv_math(mode, exact=None):
     the direct kernels' error level (7e-7), at ~25 % more step time; `exact=False` restores the default tiles; None leaves the
     tile cap alone.  Selects which entry points DigaConv2d calls from now on; graphs already built keep the arithmetic of their
     forward pass only where they hold split-twin tensors (DigaConv2d checks and raises otherwise)."""
-    global _conv_math
     mode = {"f32": 0, "bf16x3": 1}.get(mode, mode)
     if mode not in (CONV_MATH_F32, CONV_MATH_BF16X3):
         raise ValueError(f"conv math must be 0 / 'f32' or 1 / 'bf16x3', not {mode!r}")
     if exact is not None:
         if exact and mode != CONV_MATH_F32:
             raise ValueError("exact=True belongs to the fp32 arithmetic")
-        from diga_amd.model import conv as _conv
-        _conv.WINOGRAD_MAX_TILE = 2 if exact else _conv.WINOGRAD_DEFAULT_MAX_TILE
-    _conv_math = int(mode)
+        config.active().winograd_max_tile = 2 if exact else config.active().winograd_default_max_tile
+    config.active().conv_math = int(mode)
 
 
 def get_conv_math():
-    return _conv_math
+    return config.active().conv_math
 
 
 def last_error():
@@ -248,6 +243,24 @@ def contiguous(t, dtype=None):
 
 _workspaces = {}
 
+# ---- overflow flags (the fp16 MiT backward's device flag) that an optimizer step has read since their model last cleared them
+_consumed_flags = set()
+
+
+def flag_consumed(flag):
+    """Called by DigaSGD.step(found_inf=flag): the step has been enqueued behind everything that could set the flag."""
+    _consumed_flags.add((flag.device.index, flag.data_ptr()))
+
+
+def take_consumed_flag(flag):
+    """True once per optimizer step that read `flag` (the model clears the flag then); False for a forward that runs between a
+    backward pass and the optimizer step that has yet to read its verdict."""
+    key = (flag.device.index, flag.data_ptr())
+    if key in _consumed_flags:
+        _consumed_flags.discard(key)
+        return True
+    return False
+
 
 # ---- optional second stream for work that is off the critical path (weight gradients during backward)
 _side_streams = {}
@@ -257,7 +270,7 @@ side_overlap = False          # switched on by the step driver around backward()
 
 def side_stream(device):
     """The per-device side stream when overlap is switched on, else None."""
-    if not side_overlap or os.environ.get("DIGA_WGRAD_STREAM", "1") == "0":
+    if not side_overlap or not config.active().wgrad_stream:
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _side_streams.get(idx)

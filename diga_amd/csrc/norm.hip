@@ -1117,19 +1117,6 @@ extern "C" int diga_bn_fwd_records(const float* x, int64_t ld_x, float* y, int64
                                 workspace, workspace_bytes, stream);
 }
 
-extern "C" int diga_bn_apply(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r, const float* ab,
-                             int64_t M, int64_t C, int relu, unsigned char* relu_bits, void* stream) {
-    DIGA_REQUIRE(x && y && ab && M > 0, DIGA_EINVAL, "bn_apply: bad argument");
-    DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "bn_apply: relu_bits needs relu and C % 32 == 0");
-    int rc = check_norm("bn_apply", C, {ld_x, ld_y, residual ? ld_r : C}, {x, y, residual});
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    ProfScope prof(DIGA_PROF_NORM, st, (double)M * C * (8.0 + (residual ? 4.0 : 0.0)));
-    launch_affine(dim3(ew_blocks(M * C / 4)), st, x, ld_x, y, ld_y, residual, ld_r, ab, ab + C,
-                       (int64_t)0, M, M, (int)C, relu, 0, relu_bits);
-    return launch_status("diga_bn_apply");
-}
-
 static int bn_bwd_impl(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
                            const float* relu_ab, const float* gamma, const float* save_mean, const float* save_invstd,
                            float* dx, int64_t ld_dx,

@@ -68,14 +68,11 @@ __global__ __launch_bounds__(256) void wino_tiles_kernel(int4* __restrict__ tab,
     const int timg = g.tys * g.txs;
     const int n = (int)(t / timg), r = (int)(t - (int64_t)n * timg);
     // Order of an image's tiles (any order works: the table IS the order of the GEMM's rows and of every transform).  Row-major
-    // (DIGA_WINO_BAND = 1, the default): horizontally adjacent tiles are neighbours in t and read the same 8 image rows as contiguous
-    // ~14 KB row pieces.  Round 5 tried bands of 4 tile rows, column-major inside a band (vertical neighbours adjacent in t, to keep
-    // the two shared patch rows in L2): FETCH_SIZE unchanged (100 062 vs 100 283 KB raw per launch on l3.conv2) and the input transform
-    // SLOWER inside the step, 177 vs 141 us per launch -- vertically adjacent patches touch separate DRAM pages.
-#ifndef DIGA_WINO_BAND
-#define DIGA_WINO_BAND 1
-#endif
-    constexpr int kBand = DIGA_WINO_BAND;
+    // (kBand = 1): horizontally adjacent tiles are neighbours in t and read the same 8 image rows as contiguous ~14 KB row pieces.
+    // Round 5 tried bands of 4 tile rows, column-major inside a band (vertical neighbours adjacent in t, to keep the two shared patch
+    // rows in L2): FETCH_SIZE unchanged (100 062 vs 100 283 KB raw per launch on l3.conv2) and the input transform SLOWER inside the
+    // step, 177 vs 141 us per launch -- vertically adjacent patches touch separate DRAM pages.
+    constexpr int kBand = 1;
     const int band = r / (kBand * g.txs), rem = r - band * kBand * g.txs;
     const int rows_in_band = min(kBand, g.tys - kBand * band);
     int Cc = rem / rows_in_band, R = kBand * band + (rem - Cc * rows_in_band);
@@ -93,12 +90,6 @@ __global__ __launch_bounds__(256) void wino_tiles_kernel(int4* __restrict__ tab,
         Cc -= tl;
     }
     tab[t] = make_int4(n, a + g.m * R * g.d, b + g.m * Cc * g.d, 0);
-}
-
-// blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous range of blocks (conv.hip's xcd_remap)
-__device__ __forceinline__ int wino_xcd_remap(int orig, int nwg) {
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
 using f32x4nt = __attribute__((ext_vector_type(4))) float;
@@ -151,12 +142,8 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 }
 
 // V[k][t][c] = (B^T d B)[i][j] of the 4x4 patch of tile t, channel c (zero outside the image / for padding tiles)
-// ab != nullptr: the input is the PRE-activation tensor of a train-mode BatchNorm + ReLU without residual; the transform reads
-// relu(fma(x, a[c], b[c])) (ab = [2][C], the BatchNorm's forward coefficients, the expression affine_apply_kernel evaluates) --
-// the activated tensor is never written or re-read (out-of-image taps stay exact zeros).
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
-                                                         float* __restrict__ V, int64_t Tp, int C, int H, int W, int d,
-                                                         const float* __restrict__ ab) {
+                                                         float* __restrict__ V, int64_t Tp, int C, int H, int W, int d) {
     const int c4n = C / 4;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= Tp * c4n) return;
@@ -164,11 +151,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const int c = (int)(idx - t * c4n) * 4;
     const int4 e = tab[t];
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = z;
-    if (ab != nullptr) {
-        av = *reinterpret_cast<const float4*>(ab + c);
-        bv = *reinterpret_cast<const float4*>(ab + C + c);
-    }
     // branch-free: every tap is loaded from a clamped (valid) address and zeroed afterwards when it lies outside the image, so the
     // 16 loads of a thread issue back to back (measured on the 4x4-tile twin of this kernel: 151 -> 109 us)
     const int img = max(e.x, 0);
@@ -182,11 +164,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) {
             const int xx = e.z + (j - 1) * d;
             const bool ok = yok && (unsigned)xx < (unsigned)W;
-            float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(img * H + yc) * W + min(max(xx, 0), W - 1)) * ld + c);
-            if (ab != nullptr) {
-                v.x = fmaxf(__builtin_fmaf(v.x, av.x, bv.x), 0.f); v.y = fmaxf(__builtin_fmaf(v.y, av.y, bv.y), 0.f);
-                v.z = fmaxf(__builtin_fmaf(v.z, av.z, bv.z), 0.f); v.w = fmaxf(__builtin_fmaf(v.w, av.w, bv.w), 0.f);
-            }
+            const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(img * H + yc) * W + min(max(xx, 0), W - 1)) * ld + c);
             p[i][j] = ok ? v : z;
         }
     }
@@ -474,14 +452,6 @@ template <typename V> __device__ __forceinline__ V vzero();
 template <> __device__ __forceinline__ float vzero<float>() { return 0.f; }
 template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <> __device__ __forceinline__ float2 vzero<float2>() { return make_float2(0.f, 0.f); }
-__device__ __forceinline__ float4 relu_fma(float4 v, float4 a, float4 b) {
-    return make_float4(fmaxf(__builtin_fmaf(v.x, a.x, b.x), 0.f), fmaxf(__builtin_fmaf(v.y, a.y, b.y), 0.f),
-                       fmaxf(__builtin_fmaf(v.z, a.z, b.z), 0.f), fmaxf(__builtin_fmaf(v.w, a.w, b.w), 0.f));
-}
-__device__ __forceinline__ float relu_fma(float v, float a, float b) { return fmaxf(__builtin_fmaf(v, a, b), 0.f); }
-__device__ __forceinline__ float2 relu_fma(float2 v, float2 a, float2 b) {
-    return make_float2(fmaxf(__builtin_fmaf(v.x, a.x, b.x), 0.f), fmaxf(__builtin_fmaf(v.y, a.y, b.y), 0.f));
-}
 
 #include "winograd_xforms.h"      // (inside namespace diga::wino: the generated transforms use the helpers above)
 
@@ -504,20 +474,11 @@ template <> struct Xf<6> {
 // instead of 215 VGPRs; input / dy: no difference; the 8x8-patch passes of 6x6 tiles hold 64 vectors per thread: pairs throughout)
 template <int M> struct Vec;
 template <> struct Vec<4> { using In = float4; using Out = float2; using Dy = float4; };
-#ifndef DIGA_WINO6_OUT_VEC
-#define DIGA_WINO6_OUT_VEC float
-#endif
 // round 5 re-measured the 6x6 input transform on float4: 108 vs 163 us per launch in a warm micro-benchmark (tools/bench_conv.py), but
 // INSIDE the step (cold operands, serialised: tools/diag/r05_regress.sh) 195 vs 177 us per launch, and the two-stream step 427.7 vs
 // 424.7 ms (three interleaved runs each on one box) -- the float4 form needs the whole register file (one wave per SIMD) and
 // co-resides with nothing.  Pairs stay; dy on pairs as well (84 vs 88 us).
-#ifndef DIGA_WINO6_IN_VEC
-#define DIGA_WINO6_IN_VEC float2
-#endif
-#ifndef DIGA_WINO6_DY_VEC
-#define DIGA_WINO6_DY_VEC float2
-#endif
-template <> struct Vec<6> { using In = DIGA_WINO6_IN_VEC; using Out = DIGA_WINO6_OUT_VEC; using Dy = DIGA_WINO6_DY_VEC; };
+template <> struct Vec<6> { using In = float2; using Out = float; using Dy = float2; };
 
 // U[k = A i + j][co][c] = (G g G^T)[i][j], A = M + 2
 template <int M>
@@ -553,26 +514,13 @@ __global__ __launch_bounds__(256) void winoM_weight_kernel(const float* __restri
     }
 }
 
-// V[k = A i + j][t][c] = (B^T d B)[i][j] of the A x A patch of tile t (zero outside the image / for padding tiles); `ab` as in
-// wino_input_kernel
-// (A/B knob: minimum blocks per CU the input transform is compiled for.  NOT `__launch_bounds__(256, 1)` by default: an explicit 1 makes
-// the compiler plan for one wave per SIMD -- the float2 form went from 161 to > 200 VGPRs and from 130 to 220 us per launch)
-#ifdef DIGA_WINO_IN_OCC
-#define DIGA_WINO_IN_BOUNDS __launch_bounds__(256, DIGA_WINO_IN_OCC)
-#else
-#define DIGA_WINO_IN_BOUNDS __launch_bounds__(256)
-#endif
-template <typename V> __device__ __forceinline__ void wino_in_store(float* p, V v) {
-#ifdef DIGA_WINO_IN_PLAIN_STORE
-    *reinterpret_cast<V*>(p) = v;
-#else
-    nt_store4(p, v);
-#endif
-}
+// V[k = A i + j][t][c] = (B^T d B)[i][j] of the A x A patch of tile t (zero outside the image / for padding tiles).
+// (NOT `__launch_bounds__(256, 1)`: an explicit 1 makes the compiler plan for one wave per SIMD -- the float2 form went from 161 to
+//  > 200 VGPRs and from 130 to 220 us per launch)
+template <typename V> __device__ __forceinline__ void wino_in_store(float* p, V v) { nt_store4(p, v); }
 template <int M, typename V, bool REFLECT = false>
-__global__ DIGA_WINO_IN_BOUNDS void winoM_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
-                                                          float* __restrict__ Vo, int64_t Tp, int C, int H, int W, int d,
-                                                          const float* __restrict__ ab) {
+__global__ __launch_bounds__(256) void winoM_input_kernel(const float* __restrict__ x, int64_t ld, const int4* __restrict__ tab,
+                                                          float* __restrict__ Vo, int64_t Tp, int C, int H, int W, int d) {
     // REFLECT: taps outside the image read the MIRRORED pixel (nn.ReflectionPad2d(d) in front of the conv: the translator's
     // ResBlocks, G5/model/model_util.py:21-61) instead of zero; coordinates beyond the mirror's reach only feed discarded outputs.
     // A template parameter, not a kernel argument: as a run-time flag the two `if (reflect)` per tap cost the zero-padding form
@@ -585,22 +533,13 @@ __global__ DIGA_WINO_IN_BOUNDS void winoM_input_kernel(const float* __restrict__
     // Round 5 tried an XCD-aware block order here (XCD x walks a contiguous range of tiles: the (M + 2)^2 patches of neighbouring tiles
     // overlap, a pixel is read by 1.78 tiles at M = 6, and the round-robin block -> XCD dispatch sends those reads through eight
     // different L2s): FETCH_SIZE per launch 117 611 -> 100 062 KB raw on l3.conv2 (-15 %), but the kernel no faster (141 vs 132 us in
-    // the serialised step) and the two-stream step 1.5 ms slower (425.6 vs 424.1 ms, three interleaved runs).  -DDIGA_WINO_XCD builds it.
-#ifdef DIGA_WINO_XCD
-    const int64_t idx = (int64_t)wino_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-#else
+    // the serialised step) and the two-stream step 1.5 ms slower (425.6 vs 424.1 ms, three interleaved runs): not kept.
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-#endif
     if (idx >= Tp * c4n) return;
     const int64_t t = idx / c4n;
     const int c = (int)(idx - t * c4n) * VW;
     const int4 e = tab[t];
     const V z = vzero<V>();
-    V av = z, bv = z;
-    if (ab != nullptr) {
-        av = *reinterpret_cast<const V*>(ab + c);
-        bv = *reinterpret_cast<const V*>(ab + C + c);
-    }
     const int img = max(e.x, 0);
     V m[A][A];
 #pragma unroll
@@ -624,8 +563,7 @@ __global__ DIGA_WINO_IN_BOUNDS void winoM_input_kernel(const float* __restrict__
             }
             const bool ok = xok && (reflect || (unsigned)y < (unsigned)H);
             const int yc = min(max(y, 0), H - 1);
-            V v = *reinterpret_cast<const V*>(x + ((int64_t)(img * H + yc) * W + xc) * ld + c);
-            if (ab != nullptr) v = relu_fma(v, av, bv);
+            const V v = *reinterpret_cast<const V*>(x + ((int64_t)(img * H + yc) * W + xc) * ld + c);
             p[i] = ok ? v : z;
         }
         V col[A];
@@ -699,148 +637,14 @@ __global__ __launch_bounds__(256) void winoM_output_kernel(const float* __restri
     }
 }
 
-// one output pixel (VW = 4, 2 or 1 channels) of a backward-data convolution through the epilogue of diga_bwd_epilogue_t (the arithmetic
-// of wino_output_epi_kernel / drain_stage<EPI>, element for element), its operands already in registers
-template <typename V>
-__device__ __forceinline__ void wino_epi_pixel_regs(V o, V add, V xin, V ym, unsigned bits, int64_t row, int k, float* __restrict__ y,
-                                                    int64_t ld, const WinoEpi& ep, const float* ra, const float* rb, const float* mu,
-                                                    const float* is, float* sd, float* sd2) {
-    constexpr int VW = sizeof(V) / 4;
-    float v[VW], xv[VW], a4[VW], y4[VW];
-    *reinterpret_cast<V*>(v) = o;
-    *reinterpret_cast<V*>(a4) = add;
-    *reinterpret_cast<V*>(xv) = xin;
-    *reinterpret_cast<V*>(y4) = ym;
-    if (ep.add != nullptr) {
-#pragma unroll
-        for (int c = 0; c < VW; ++c) v[c] += a4[c];
-    }
-    if (ep.masky != nullptr) {
-#pragma unroll
-        for (int c = 0; c < VW; ++c) v[c] = y4[c] > 0.f ? v[c] : 0.f;
-    } else if (ep.maskbits != nullptr) {
-#pragma unroll
-        for (int c = 0; c < VW; ++c) v[c] = ((bits >> c) & 1u) ? v[c] : 0.f;
-    } else if (ep.relu_ab != nullptr) {
-#pragma unroll
-        for (int c = 0; c < VW; ++c) v[c] = __builtin_fmaf(xv[c], ra[c], rb[c]) > 0.f ? v[c] : 0.f;
-    }
-    *reinterpret_cast<V*>(y + row * ld + k) = *reinterpret_cast<const V*>(v);
-#pragma unroll
-    for (int c = 0; c < VW; ++c) {
-        sd[c] += v[c];
-        sd2[c] += v[c] * ((xv[c] - mu[c]) * is[c]);
-    }
-}
-
-// winoM_output_kernel with the backward-data epilogue: block (g, s) = tiles [g * tpb, (g + 1) * tpb) x channels [64 VW s, 64 VW (s + 1)),
-// 256 / TL channel groups x TL tile lanes; partial-row layout of wino_output_epi_kernel (the finaliser only adds the rows up).
-template <int M, typename V, int TL>
-__global__ __launch_bounds__(256) void winoM_output_epi_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
-                                                               float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
-                                                               int H, int W, int d, int tpb, WinoEpi ep) {
-    constexpr int A = M + 2;
-    constexpr int VW = sizeof(V) / 4;
-    constexpr int CG = 256 / TL;                 // channel groups per block; TL tile lanes
-    __shared__ float red[2][TL][CG * VW];
-    const int q = threadIdx.x % CG, tl = threadIdx.x / CG;
-    const int k = (blockIdx.y * CG + q) * VW;
-    const bool kok = k < K;
-    const int64_t t0 = (int64_t)blockIdx.x * tpb;
-    int64_t t1 = t0 + tpb;
-    if (t1 > T) t1 = T;
-    const int64_t plane = Tp * K;
-    float ra[VW], rb[VW], mu[VW], is[VW], sd[VW], sd2[VW];
-#pragma unroll
-    for (int c = 0; c < VW; ++c) ra[c] = rb[c] = mu[c] = is[c] = sd[c] = sd2[c] = 0.f;
-    if (kok && ep.relu_ab != nullptr) {
-        *reinterpret_cast<V*>(ra) = *reinterpret_cast<const V*>(ep.relu_ab + k);
-        *reinterpret_cast<V*>(rb) = *reinterpret_cast<const V*>(ep.relu_ab + K + k);
-    }
-    if (kok && ep.partials != nullptr) {
-        *reinterpret_cast<V*>(mu) = *reinterpret_cast<const V*>(ep.mean + k);
-        *reinterpret_cast<V*>(is) = *reinterpret_cast<const V*>(ep.invstd + k);
-    }
-    if (kok) {
-        for (int64_t t = t0 + tl; t < t1; t += TL) {
-            const int4 e = tab[t];
-            // ONE round trip per tile: the A * A product loads and, right behind them, the epilogue operands (addend, x, mask) of the
-            // tile's M * M pixels are all issued before anything is used (the pixel loads used to start only after the transform:
-            // two dependent latencies per tile at one or two waves per SIMD -- 2.3 TB/s)
-            V mt[A][A];
-#pragma unroll
-            for (int j = 0; j < A; ++j)
-#pragma unroll
-                for (int i = 0; i < A; ++i) mt[i][j] = nt_loadv<V>(Mb + t * K + k + (A * i + j) * plane);
-            V va[M][M], vx[M][M], vy[M][M];
-            unsigned vb[M][M];
-            bool ok[M][M];
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    const int yy = e.y + i * d, xx = e.z + j * d;
-                    ok[i][j] = yy < H && xx < W;
-                    const int64_t row = (int64_t)(e.x * H + min(yy, H - 1)) * W + min(xx, W - 1);     // (clamped: loads are unconditional)
-                    va[i][j] = ep.add != nullptr ? *reinterpret_cast<const V*>(ep.add + row * ep.add_ld + k) : vzero<V>();
-                    vx[i][j] = ep.x != nullptr ? *reinterpret_cast<const V*>(ep.x + row * ep.x_ld + k) : vzero<V>();
-                    vy[i][j] = ep.masky != nullptr ? *reinterpret_cast<const V*>(ep.masky + row * ep.masky_ld + k) : vzero<V>();
-                    vb[i][j] = ep.maskbits != nullptr ? (unsigned)ep.maskbits[row * ep.maskbits_ld + (k >> 3)] >> (k & 7) : 0u;
-                }
-            V s[M][A];
-#pragma unroll
-            for (int j = 0; j < A; ++j) {
-                V col_in[A], col[M];
-#pragma unroll
-                for (int i = 0; i < A; ++i) col_in[i] = mt[i][j];
-                Xf<M>::at(col_in, col);
-#pragma unroll
-                for (int i = 0; i < M; ++i) s[i][j] = col[i];
-            }
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                V o[M];
-                Xf<M>::at(s[i], o);
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    if (!ok[i][j]) continue;
-                    const int64_t row = (int64_t)(e.x * H + e.y + i * d) * W + e.z + j * d;
-                    wino_epi_pixel_regs<V>(o[j], va[i][j], vx[i][j], vy[i][j], vb[i][j], row, k, y, ld, ep, ra, rb, mu, is, sd, sd2);
-                }
-            }
-        }
-    }
-    if (ep.partials == nullptr) return;
-#pragma unroll
-    for (int c = 0; c < VW; ++c) {
-        red[0][tl][q * VW + c] = sd[c];
-        red[1][tl][q * VW + c] = sd2[c];
-    }
-    __syncthreads();
-    const int ch = blockIdx.y * CG * VW + threadIdx.x;
-    if (threadIdx.x < CG * VW && ch < K) {
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int l = 0; l < TL; ++l) {
-            a0 += red[0][l][threadIdx.x];
-            a1 += red[1][l][threadIdx.x];
-        }
-        float* sp = ep.partials + (int64_t)blockIdx.x * 2 * K + ch;
-        sp[0] = a0;
-        sp[K] = a1;
-    }
-}
-
 // winoM_output_kernel that also leaves the BatchNorm behind the layer its column statistics (round 5: the Winograd layers used to take a
 // separate statistics pass over y, 80 launches and ~9.5 GB per C2 step).  Block b = tiles [b * tpb, (b + 1) * tpb) x CG channel
 // groups of VW channels; thread (tl, q) walks tiles t0 + tl, t0 + tl + TL, ... (TL = 256 / CG tile lanes; a wave never spans two
 // lanes: CG >= 64) and keeps {sum (y - s), sum (y - s)^2, s = its first pixel, n = its pixels} -- record r = b * TL + tl of
 // `stats` ([R][3][K]) and `counts` ([R]): the format of diga_bn_fwd_records (records of unequal, possibly zero, size).
 template <int M, typename V>
-#ifndef DIGA_WINO_OUT_OCC
-#define DIGA_WINO_OUT_OCC 4           /* (A/B knob: register cap of the two looping output transforms, 512 / (4 * OCC) per wave) */
-#endif
-__global__ __launch_bounds__(256, DIGA_WINO_OUT_OCC) void winoM_output_stats_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+// (register cap of the two looping output transforms: 4 blocks per CU = 128 VGPRs per wave)
+__global__ __launch_bounds__(256, 4) void winoM_output_stats_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
                                                                  const float* __restrict__ bias, float* __restrict__ y, int64_t ld,
                                                                  int64_t T, int64_t Tp, int K, int H, int W, int d, int tpb, int CG,
                                                                  float* __restrict__ stats, float* __restrict__ counts) {
@@ -910,7 +714,7 @@ __global__ __launch_bounds__(256, DIGA_WINO_OUT_OCC) void winoM_output_stats_ker
 // tests.  Same arithmetic per element, same partial-row layout (block (g, s) = tile group x channel slab, TL tile lanes reduced
 // through LDS in lane order): bit-identical results.
 template <int M, typename V, int TL, bool ADD, int MASK /* 0 none, 1 y > 0, 2 bits, 3 fma(x, a, b) > 0 */, bool SUMS>
-__global__ __launch_bounds__(256, DIGA_WINO_OUT_OCC) void winoM_output_epi2_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
+__global__ __launch_bounds__(256, 4) void winoM_output_epi2_kernel(const float* __restrict__ Mb, const int4* __restrict__ tab,
                                                                 float* __restrict__ y, int64_t ld, int64_t T, int64_t Tp, int K,
                                                                 int H, int W, int d, int tpb, WinoEpi ep) {
     constexpr int A = M + 2;
@@ -1092,22 +896,22 @@ __global__ __launch_bounds__(256) void winoM_dw_kernel(const float* __restrict__
 // ---- launches by tile size (2: the hand-written F(2x2) kernels above)
 template <int M>
 static void launch_input_m(const float* x, int64_t ld, const int4* tab, float* V, int64_t Tp, int64_t C, int64_t H, int64_t W, int64_t d,
-                           const float* ab, hipStream_t st, int reflect) {
+                           hipStream_t st, int reflect) {
     using VT = typename Vec<M>::In;
     constexpr int VW = sizeof(VT) / 4;
     const dim3 grid((unsigned)ceil_div(Tp * (C / VW), 256));
     if (reflect)
-        hipLaunchKernelGGL((winoM_input_kernel<M, VT, true>), grid, dim3(256), 0, st, x, ld, tab, V, Tp, (int)C, (int)H, (int)W, (int)d, ab);
+        hipLaunchKernelGGL((winoM_input_kernel<M, VT, true>), grid, dim3(256), 0, st, x, ld, tab, V, Tp, (int)C, (int)H, (int)W, (int)d);
     else
-        hipLaunchKernelGGL((winoM_input_kernel<M, VT, false>), grid, dim3(256), 0, st, x, ld, tab, V, Tp, (int)C, (int)H, (int)W, (int)d, ab);
+        hipLaunchKernelGGL((winoM_input_kernel<M, VT, false>), grid, dim3(256), 0, st, x, ld, tab, V, Tp, (int)C, (int)H, (int)W, (int)d);
 }
 static void launch_input(int64_t tile, const float* x, int64_t ld, const int4* tab, float* V, int64_t Tp, int64_t C, int64_t H, int64_t W,
-                         int64_t d, const float* ab, hipStream_t st, int reflect = 0) {
-    if (tile == 6) launch_input_m<6>(x, ld, tab, V, Tp, C, H, W, d, ab, st, reflect);
-    else if (tile == 4) launch_input_m<4>(x, ld, tab, V, Tp, C, H, W, d, ab, st, reflect);
+                         int64_t d, hipStream_t st, int reflect = 0) {
+    if (tile == 6) launch_input_m<6>(x, ld, tab, V, Tp, C, H, W, d, st, reflect);
+    else if (tile == 4) launch_input_m<4>(x, ld, tab, V, Tp, C, H, W, d, st, reflect);
     else
         hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(Tp * (C / 4), 256)), dim3(256), 0, st, x, ld, tab, V, Tp, (int)C,
-                           (int)H, (int)W, (int)d, ab);
+                           (int)H, (int)W, (int)d);
 }
 template <int M>
 static void launch_weight_m(const float* w, float* U, int64_t Cout, int64_t Cin, int flip, hipStream_t st) {
@@ -1153,15 +957,13 @@ static void launch_output_stats_m(const float* Mb, const int4* tab, const float*
                        Mb, tab, bias, out, out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d, p.tpb, p.CG, stats, counts);
 }
 
-#ifndef DIGA_WINO_EPI_TL
-#define DIGA_WINO_EPI_TL 2          /* tile lanes of the backward-data output transform (round 4: 11.5 / 10.1 / 9.8 ms per step with 4 / 2 / 1) */
-#endif
+constexpr int kEpiTileLanes = 2;    // tile lanes of the backward-data output transform (round 4: 11.5 / 10.1 / 9.8 ms per step with 4 / 2 / 1)
 template <int M, bool ADD, int MASK>
 static void launch_output_epi2_sums(const float* Mb, const int4* tab, float* out, int64_t out_ld, const WinoGeom& g, int64_t Cout, int64_t G,
                                     int tpb, const WinoEpi& ep, hipStream_t st) {
     using VT = typename Vec<M>::Out;
     constexpr int VW = sizeof(VT) / 4;
-    constexpr int TL = DIGA_WINO_EPI_TL;
+    constexpr int TL = kEpiTileLanes;
     const dim3 grid((unsigned)G, (unsigned)ceil_div(Cout, (256 / TL) * VW));
     if (ep.partials != nullptr)
         hipLaunchKernelGGL((winoM_output_epi2_kernel<M, VT, TL, ADD, MASK, true>), grid, dim3(256), 0, st, Mb, tab, out, out_ld, g.T, g.Tp,
@@ -1185,15 +987,6 @@ static void launch_output_epi2_m(const float* Mb, const int4* tab, float* out, i
     else launch_output_epi2_mask<M, false>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
 }
 
-template <int M>
-static void launch_output_epi_m(const float* Mb, const int4* tab, float* out, int64_t out_ld, const WinoGeom& g, int64_t Cout, int64_t G,
-                                int tpb, const WinoEpi& ep, hipStream_t st) {
-    using VT = typename Vec<M>::Out;
-    constexpr int VW = sizeof(VT) / 4;
-    constexpr int TL = DIGA_WINO_EPI_TL;
-    hipLaunchKernelGGL((winoM_output_epi_kernel<M, VT, TL>), dim3((unsigned)G, (unsigned)ceil_div(Cout, (256 / TL) * VW)), dim3(256), 0, st, Mb,
-                       tab, out, out_ld, g.T, g.Tp, (int)Cout, g.H, g.W, g.d, tpb, ep);
-}
 template <int M>
 static void launch_dy_m(const float* dy, int64_t dy_ld, const int4* tab, float* Z, const WinoGeom& g, int64_t Cout, hipStream_t st) {
     using VT = typename Vec<M>::Dy;
@@ -1249,9 +1042,9 @@ extern "C" size_t diga_conv2d_winograd_workspace_bytes(int64_t N, int64_t H, int
 static int winograd_impl(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
                          size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
                          int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int flip, const diga_bwd_epilogue_t* epi, int prof_tag,
-                         void* stream, float* v_keep = nullptr, const float* in_ab = nullptr, float* stats = nullptr,
+                         void* stream, float* v_keep = nullptr, float* stats = nullptr,
                          const void* tile_table = nullptr, int reflect = 0) {
-    DIGA_REQUIRE(!reflect || (tile != 2 && !flip && !epi && !in_ab && dilation < H && dilation < W), DIGA_EINVAL,
+    DIGA_REQUIRE(!reflect || (tile != 2 && !flip && !epi && dilation < H && dilation < W), DIGA_EINVAL,
                  "conv2d_winograd: reflection padding comes with the forward of 4x4 / 6x6 tiles (pad < H, W)");
     DIGA_REQUIRE(in && wgt && out && workspace, DIGA_EINVAL, "conv2d_winograd: null pointer");
     DIGA_REQUIRE(N > 0 && H > 0 && W > 0 && dilation > 0 && dilation < 4096, DIGA_EINVAL, "conv2d_winograd: bad shape");
@@ -1286,8 +1079,7 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
     else
         hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(Cout * (Cin / 4), 256)), dim3(256), 0, st, wgt, U, (int)Cout, (int)Cin,
                            flip);
-    DIGA_REQUIRE(!in_ab || aligned16(in_ab), DIGA_EALIGN, "conv2d_winograd: in_ab must be 16-byte aligned");
-    launch_input(tile, in, in_ld, tab, V, g.Tp, Cin, H, W, dilation, in_ab, st, reflect);
+    launch_input(tile, in, in_ld, tab, V, g.Tp, Cin, H, W, dilation, st, reflect);
     int rc = gemm_batched_f32_dma(V, g.Tp, P, Cin, U, Cout, Mb, st);
     if (rc) return rc;
     if (epi == nullptr && stats != nullptr) {
@@ -1308,13 +1100,8 @@ static int winograd_impl(const float* in, const float* wgt, const float* bias, f
         ep.relu_ab = epi->relu_ab; ep.mean = epi->mean; ep.invstd = epi->invstd; ep.partials = epi->partials;
         const int64_t G = ceil_div(N * H * W, 128);
         const int tpb = (int)ceil_div(g.T, G);
-#ifdef DIGA_WINO_EPI_OLD
-        if (tile == 6) launch_output_epi_m<6>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
-        else if (tile == 4) launch_output_epi_m<4>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
-#else
         if (tile == 6) launch_output_epi2_m<6>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
         else if (tile == 4) launch_output_epi2_m<4>(Mb, tab, out, out_ld, g, Cout, G, tpb, ep, st);
-#endif
         else
             hipLaunchKernelGGL(wino_output_epi_kernel, dim3((unsigned)G, (unsigned)ceil_div(Cout, 256)), dim3(256), 0, st, Mb, tab, out,
                                out_ld, g.T, g.Tp, (int)Cout, (int)H, (int)W, (int)dilation, tpb, ep);
@@ -1351,7 +1138,7 @@ extern "C" int diga_conv2d_winograd_f32(const float* in, const float* wgt, const
                                         int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, int flip, float* stats_partial,
                                         const void* tile_table, int prof_tag, void* stream) {
     return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, flip, nullptr,
-                         prof_tag, stream, nullptr, nullptr, stats_partial, tile_table);
+                         prof_tag, stream, nullptr, stats_partial, tile_table);
 }
 
 extern "C" int diga_conv2d_winograd_f32_opts(const float* in, const float* wgt, const float* bias, float* out, void* workspace,
@@ -1362,17 +1149,7 @@ extern "C" int diga_conv2d_winograd_f32_opts(const float* in, const float* wgt, 
     DIGA_REQUIRE(opts->upsample_shift == 0 && opts->activation == 0, DIGA_EINVAL,
                  "conv2d_winograd_opts: only reflect_pad is folded on the Winograd path (upsampling / tanh: the direct `_opts` kernels)");
     return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, 0, nullptr,
-                         prof_tag, stream, nullptr, nullptr, nullptr, tile_table, opts->reflect_pad ? 1 : 0);
-}
-
-extern "C" int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out,
-                                           float* v_keep, void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W,
-                                           int64_t Cin, int64_t in_ld, int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile,
-                                           float* stats_partial, const void* tile_table, int prof_tag, void* stream) {
-    DIGA_REQUIRE(in_ab != nullptr, DIGA_EINVAL, "conv2d_winograd_ab: null coefficients");
-    DIGA_REQUIRE(!v_keep || aligned16(v_keep), DIGA_EALIGN, "conv2d_winograd_ab: v_keep must be 16-byte aligned");
-    return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, 0, nullptr,
-                         prof_tag, stream, v_keep, in_ab, stats_partial, tile_table);
+                         prof_tag, stream, nullptr, nullptr, tile_table, opts->reflect_pad ? 1 : 0);
 }
 
 extern "C" size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation, int64_t tile) {
@@ -1386,7 +1163,7 @@ extern "C" int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, 
                                              float* stats_partial, const void* tile_table, int prof_tag, void* stream) {
     DIGA_REQUIRE(v_keep != nullptr && aligned16(v_keep), DIGA_EINVAL, "conv2d_winograd_keep: v_keep must be a 16-byte aligned buffer");
     return winograd_impl(in, wgt, bias, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, 0, nullptr,
-                         prof_tag, stream, v_keep, nullptr, stats_partial, tile_table);
+                         prof_tag, stream, v_keep, stats_partial, tile_table);
 }
 
 extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, float* out, void* workspace, size_t workspace_bytes,
@@ -1405,7 +1182,7 @@ extern "C" int diga_conv2d_winograd_f32_epi(const float* in, const float* wgt, f
     DIGA_REQUIRE(!e->partials || (e->x && e->mean && e->invstd && aligned16(e->mean) && aligned16(e->invstd)), DIGA_EINVAL,
                  "conv2d_winograd_epi: partials need x, mean and invstd");
     return winograd_impl(in, wgt, nullptr, out, workspace, workspace_bytes, N, H, W, Cin, in_ld, Cout, out_ld, dilation, tile, flip, e, prof_tag,
-                         stream, nullptr, nullptr, nullptr, tile_table);
+                         stream, nullptr, nullptr, tile_table);
 }
 
 extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
@@ -1414,7 +1191,7 @@ extern "C" size_t diga_conv2d_wgrad_winograd_workspace_bytes(int64_t N, int64_t 
     return wino_wgrad_layout(make_wino(N, H, W, dilation, tile), Cin, Cout, v_kept == 0).total;
 }
 
-static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw, void* workspace,
+static int wgrad_winograd_impl(const float* dy, const float* x, const float* v_kept, float* dw, void* workspace,
                                size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
                                int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, const void* tile_table, void* stream) {
     DIGA_REQUIRE(!tile_table || aligned16(tile_table), DIGA_EALIGN, "conv2d_wgrad_winograd: tile_table must be 16-byte aligned");
@@ -1441,7 +1218,7 @@ static int wgrad_winograd_impl(const float* dy, const float* x, const float* x_a
     if (tile_table == nullptr)
         hipLaunchKernelGGL(wino_tiles_kernel, dim3((unsigned)ceil_div(g.Tp, 256)), dim3(256), 0, st, reinterpret_cast<int4*>(ws + l.tab), g);
     if (v_kept == nullptr)
-        launch_input(tile, x, x_ld, tab, reinterpret_cast<float*>(ws + l.V), g.Tp, Cin, H, W, dilation, x_ab, st);
+        launch_input(tile, x, x_ld, tab, reinterpret_cast<float*>(ws + l.V), g.Tp, Cin, H, W, dilation, st);
     if (tile == 6) launch_dy_m<6>(dy, dy_ld, tab, Z, g, Cout, st);
     else if (tile == 4) launch_dy_m<4>(dy, dy_ld, tab, Z, g, Cout, st);
     else
@@ -1460,15 +1237,6 @@ extern "C" int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, c
                                               size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t x_ld,
                                               int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, const void* tile_table,
                                               void* stream) {
-    return wgrad_winograd_impl(dy, x, nullptr, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile,
-                               tile_table, stream);
-}
-
-extern "C" int diga_conv2d_wgrad_winograd_f32_ab(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw,
-                                                 void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                                 int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile,
-                                                 const void* tile_table, void* stream) {
-    DIGA_REQUIRE(x_ab != nullptr && aligned16(x_ab), DIGA_EINVAL, "conv2d_wgrad_winograd_ab: null / unaligned coefficients");
-    return wgrad_winograd_impl(dy, x, x_ab, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile,
+    return wgrad_winograd_impl(dy, x, v_kept, dw, workspace, workspace_bytes, N, H, W, Cin, x_ld, Cout, dy_ld, dilation, tile,
                                tile_table, stream);
 }

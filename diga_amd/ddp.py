@@ -18,14 +18,18 @@ import os
 import torch
 import torch.distributed as dist
 
+from diga_amd import config
 
-def init_from_env(backend=None):
+
+def init_from_env(backend=None, cfg=None, single_rank_group=False):
     """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun contract).
-    Returns (rank, world, local_rank).  World size 1 needs no process group."""
+    Returns (rank, world, local_rank).  World size 1 needs no process group (single_rank_group=True creates one anyway: the
+    1-rank RCCL test).  Under the gloo smoke-test backend on a GPU the side streams are switched off IN `cfg` (default: the
+    process defaults, diga_amd.config.DEFAULTS) -- a field write, not an environment variable."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -55,13 +59,22 @@ def init_from_env(backend=None):
             # side streams (teacher forward, weight gradients) that degenerates to seconds per step on this stack
             # (measured: 2 ranks on one GPU 15 s vs 0.13 s).  gloo is the smoke-test backend only -- run it on one
             # stream.  The RCCL path is stream-ordered and keeps the side streams (tools/nccl_1rank_proxy.py).
-            os.environ["DIGA_TEACHER_STREAM"] = "0"
-            os.environ["DIGA_WGRAD_STREAM"] = "0"
+            cfg = cfg if cfg is not None else config.DEFAULTS
+            cfg.teacher_stream = False
+            cfg.wgrad_stream = False
     return rank, world, local
 
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def reducer_active():
+    """Do gradients travel?  More than one rank -- or ONE rank of an initialised group with config.ddp_single_rank (the 1-rank
+    RCCL test: hooks, bucket views and collectives run exactly as with N ranks, the sum over one rank is the identity)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or config.active().ddp_single_rank
 
 
 def rank():
@@ -93,7 +106,7 @@ class GradReducer:
             # still running and only the last one (stem .. first layer-1 blocks, produced at the very end) is exposed; with
             # the 128 MB buckets of round 2 the exposed tail was a third of the payload.  Per-link xGMI time of a 25 MB
             # ring all-reduce on 8 GPUs: 2*(7/8)*25 MB / ~50 GB/s effective ~ 0.9 ms -- far above launch latency.
-            bucket_bytes = int(os.environ.get("DIGA_DDP_BUCKET_MB", "25")) << 20
+            bucket_bytes = int(config.active().ddp_bucket_mb) << 20
         seen, uniq = set(), []
         for p in params:
             if p.requires_grad and id(p) not in seen:
@@ -122,9 +135,9 @@ class GradReducer:
             for p in bucket:
                 self._where[id(p)] = (i, off)
                 off += p.numel()
-        active = world_size() > 1
-        self.as_views = (overlap if as_views is None else bool(as_views)) and active and os.environ.get("DIGA_DDP_GRAD_VIEWS", "1") != "0"
-        if overlap and active and os.environ.get("DIGA_DDP_OVERLAP", "1") != "0":
+        active = self.active = reducer_active()
+        self.as_views = (overlap if as_views is None else bool(as_views)) and active and config.active().ddp_grad_views
+        if overlap and active and config.active().ddp_overlap:
             for i, bucket in enumerate(self.buckets):
                 for p in bucket:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -239,9 +252,16 @@ class GradReducer:
                 torch._foreach_copy_(dst, src)
             self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def launch_bucket(self, i):
+        """Start bucket i's all-reduce now (its gradients are final): the overlapped self-training forms add the second graph's
+        gradients bucket by bucket, in the order the buckets were formed, and send each bucket as soon as its sum exists instead of
+        all of them after the last add."""
+        if self.active and self._work[i] is None:
+            self._launch(i)
+
     def reduce(self):
-        """Sum gradients over all ranks in place.  No-op for world size 1."""
-        if world_size() == 1:
+        """Sum gradients over all ranks in place.  No-op for world size 1 (unless config.ddp_single_rank built the reducer active)."""
+        if not self.active:
             return
         for i in range(len(self.buckets)):
             if self._work[i] is None:
@@ -262,7 +282,7 @@ def gather_class_sums(sums, counts, group=None):
     batch).  ONE collective per call: sums and counts travel packed as [N,K,D+1] fp32 (a count is at most h*w < 2^24,
     exact in fp32)."""
     w = world_size()
-    if w == 1:
+    if w == 1 and not reducer_active():
         return sums, counts
     n, k, d = sums.shape
     packed = torch.empty((n, k, d + 1), dtype=torch.float32, device=sums.device)
@@ -287,7 +307,7 @@ def allreduce_class_means(sums, counts, min_pixels, group=None):
     packed = torch.empty((k, d + 1), dtype=torch.float32, device=sums.device)
     packed[:, :d] = (means * valid[..., None]).sum(0)
     packed[:, d] = valid.sum(0).to(torch.float32)
-    if world_size() > 1:
+    if reducer_active():
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return packed[:, :d].contiguous(), packed[:, d].contiguous()
 

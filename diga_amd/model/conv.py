@@ -16,7 +16,7 @@ import torch.nn as nn
 _pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.path.dirname(_pkg) not in sys.path:
     sys.path.append(os.path.dirname(_pkg))
-from diga_amd import _lib  # noqa: E402
+from diga_amd import _lib, config  # noqa: E402
 
 _TAG_FWD, _TAG_BWD_DATA = _lib.PROF_TAGS.index("conv_fwd"), _lib.PROF_TAGS.index("conv_bwd_data")
 
@@ -56,30 +56,10 @@ def _use_twin(cin, k, taps, shared):
     their split twin (read 4 B + write 4 B per element).  That pays when the tensor is read by many tiles: convs with
     more than one tap, or several convs on one input (`shared`, the ASPP branches).  DIGA_CONV_TWIN=0 switches the
     path off, =1 forces it for every eligible conv."""
-    mode = os.environ.get("DIGA_CONV_TWIN", "3")
+    mode = config.active().conv_twin
     if mode == "0" or cin % 32 != 0 or k <= 64:
         return False
     return mode == "1" or taps > 1 or shared
-
-
-def bn1_defer_ok(conv, x, need_wgrad):
-    """True when the BatchNorm + ReLU in front of `conv` (a DigaConv2d, the 3x3 conv2 of a bottleneck reading x [N,C,H,W]) may
-    skip its apply pass: fp32 arithmetic, the forward on the Winograd path and -- if the weight gradient is wanted -- that one
-    too (it reads the kept transform, or re-applies the coefficients).  Off by default (FUSE_BN1; DIGA_FUSE_BN1=1 enables it):
-    bit-identical and one BatchNorm apply pass per bottleneck less, but the coefficients' loads and the fma + max per tap make the
-    input transform slower by more than the pass it removes (serialised step: input transform +4.6 ms, apply passes -3.0 ms) and the
-    two-stream step is 5 ms SLOWER with it (round 5, three interleaved same-box runs: 425.6 vs 420.6 ms; round 3 had measured 542.0 /
-    538.4 vs 538.5 / 540.1 ms).  An early round-5 A/B that showed -2.5 ms was taken while the input transform carried a run-time
-    `reflect` flag that had slowed it down by 70 % (csrc/winograd.hip) -- every switch was re-measured after that was found."""
-    if not FUSE_BN1 or _lib.get_conv_math() != 0 or conv.bias is not None:
-        return False
-    n, c, h, w = x.shape
-    k = conv.out_channels
-    if c != conv.in_channels or c % 32 != 0 or tuple(conv.kernel_size) != (3, 3) or conv.groups != 1:
-        return False
-    if need_wgrad and not (k % 256 == 0 and c % 128 == 0):
-        return False
-    return _winograd_ok(n, h, w, c, k, 3, 3, tuple(conv.stride), (-conv.padding[0], -conv.padding[1]), tuple(conv.dilation), h, w)
 
 
 def takes_twin_only_input(conv, pointwise_ok=False):
@@ -88,15 +68,12 @@ def takes_twin_only_input(conv, pointwise_ok=False):
     pointwise_ok: also for 1x1 layers (worth it only when both of its twins are free, i.e. under autograd where the
     weight gradient gains 35-39 %; the forward kernel alone gains nothing on 8-step tiles)."""
     taps = conv.kernel_size[0] * conv.kernel_size[1]
-    return (_lib.get_conv_math() == 1 and os.environ.get("DIGA_CONV_TWIN", "3") != "0"
-            and os.environ.get("DIGA_TWIN_ONLY", "1") != "0"
+    cfg = config.active()
+    return (cfg.conv_math == 1 and cfg.conv_twin != "0" and cfg.twin_only
             and (taps > 1 or pointwise_ok) and conv.in_channels % 32 == 0 and conv.in_channels > 64 and conv.out_channels >= 256 and conv.out_channels % 8 == 0
             and tuple(conv.stride) == (1, 1) and conv.groups == 1)
 
 
-# False while a forward builds a graph whose weight gradients must land in tensors of their own (the step driver's second student
-# graph, differentiated with torch.autograd.grad next to the first one's backward(): the bucket slice holds the FIRST graph's gradient)
-GRAD_VIEWS = True
 INLINE_WGRAD = "inline"       # `uses` of a functional _Conv2dFn call whose weight is a non-leaf tensor (see backward)
 _WINO_CACHE = {}
 # bench.py sets this to a dict to learn what the convolutions of a step multiply: name -> [FLOPs of the direct
@@ -111,19 +88,9 @@ def _log_flops(name, direct, executed):
         e[1] += executed
 
 
-# Path switches, read ONCE at import (not per call: a convolution call makes no environment or driver query); tests and
-# A/B runs set the module attributes.  WINOGRAD_MAX_TILE 2 keeps every layer on F(2x2,3x3).
-WINOGRAD = os.environ.get("DIGA_CONV_WINOGRAD", "1") != "0"
-WINOGRAD_RATIO = float(os.environ.get("DIGA_CONV_WINOGRAD_RATIO", "0.62"))
-WINOGRAD_DEFAULT_MAX_TILE = int(os.environ.get("DIGA_CONV_WINOGRAD_TILE", "6"))
-WINOGRAD_MAX_TILE = WINOGRAD_DEFAULT_MAX_TILE           # (_lib.set_conv_math(0, exact=True) sets 2)
-WINOGRAD_KEEP_V = os.environ.get("DIGA_WINOGRAD_KEEP_V", "1") != "0"
-FUSE_BN1 = os.environ.get("DIGA_FUSE_BN1", "0") == "1"                  # bn1's apply pass inside conv2's Winograd input transform
-WINOGRAD_STATS = os.environ.get("DIGA_WINOGRAD_STATS", "1") != "0"       # BatchNorm statistics from the Winograd output transform
-# the keep-V policy is a function of the layer's shape and of STATIC device properties only (round 5; it used to ask the driver how
-# much memory was free at a layer's first forward, so the same binary took different paths -- and speeds -- next to another process):
-KEEP_V_MAX_BYTES = int(float(os.environ.get("DIGA_WINOGRAD_KEEP_V_MAX_GB", "8")) * (1 << 30))         # per layer
-KEEP_V_MIN_DEVICE_BYTES = int(float(os.environ.get("DIGA_WINOGRAD_KEEP_V_MIN_DEVICE_GB", "160")) * (1 << 30))
+# Path switches live in diga_amd/config.py (StepConfig: winograd, winograd_ratio, winograd_max_tile, winograd_keep_v, winograd_stats,
+# keep_v_max_gb, keep_v_min_device_gb; environment variables give their DEFAULTS, read once at import); a convolution call reads the
+# active configuration, makes no environment or driver query.  winograd_max_tile = 2 keeps every layer on F(2x2,3x3).
 _DEVICE_TOTAL = {}
 _KEEP_OFF = set()             # devices on which a keep-V allocation failed: the recompute path from then on (reset_keep_decisions())
 
@@ -136,17 +103,18 @@ def reset_keep_decisions():
 def _room_for(nbytes, device):
     """Keeping a layer's transformed input V alive until its weight gradient is a memory-for-bandwidth trade (the backward-weight
     pass skips one input transform: a bandwidth pass over the input + V; 26 layers, ~4 ms of a 424 ms C2 step).  Decision:
-    DIGA_WINOGRAD_KEEP_V on (default), the layer's V <= KEEP_V_MAX_BYTES (8 GiB; the largest C2 layer keeps 2.2 GB) and the device
-    has >= KEEP_V_MIN_DEVICE_BYTES of memory in total (160 GiB: an MI355X has 288 GB; the C2 step keeps ~21 GB of V and peaks at
+    `winograd_keep_v` on (default), the layer's V <= `keep_v_max_gb` (8 GiB; the largest C2 layer keeps 2.2 GB) and the device
+    has >= `keep_v_min_device_gb` of memory in total (160 GiB: an MI355X has 288 GB; the C2 step keeps ~21 GB of V and peaks at
     the figure bench.py reports as peak_mem_gb) -- shape and static device properties only, no free-memory query.  If the
     allocation itself fails, `_alloc_keep_v` switches the device to the recompute path."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    if not WINOGRAD_KEEP_V or idx in _KEEP_OFF or nbytes > KEEP_V_MAX_BYTES:
+    cfg = config.active()
+    if not cfg.winograd_keep_v or idx in _KEEP_OFF or nbytes > int(cfg.keep_v_max_gb * (1 << 30)):
         return False
     total = _DEVICE_TOTAL.get(idx)
     if total is None:
         total = _DEVICE_TOTAL[idx] = torch.cuda.get_device_properties(idx).total_memory
-    return total >= KEEP_V_MIN_DEVICE_BYTES
+    return total >= int(cfg.keep_v_min_device_gb * (1 << 30))
 
 
 def _alloc_keep_v(nfloats, device):
@@ -167,14 +135,15 @@ def _wino_plan(hi, wi, d):
     (m + 2)^2 products each: F(2x2,3x3) 16 per 4 outputs, F(4x4,3x3) 36 per 16, F(6x6,3x3) 64 per 36; the smallest count wins, the
     smaller tile on a tie (97 x 97 map: dilation 1 / 2 / 4 / 18 -> 0.218 / 0.218 / 0.218 / 0.245 with 6x6 tiles, where 4x4 tiles
     give 0.266 / 0.266 / 0.266 / 0.551; dilation 12 / 24 -> 0.266 with 4x4 tiles, 0.435 with 6x6; direct = 1)."""
-    key = (hi, wi, d, WINOGRAD_MAX_TILE)
+    max_tile = config.active().winograd_max_tile
+    key = (hi, wi, d, max_tile)
     plan = _WINO_CACHE.get(key)
     if plan is None:
         def tiles(length, m):
             return sum((((length - a + d - 1) // d if length > a else 0) + m - 1) // m for a in range(d))
         plan = None
         for m in (2, 4, 6):
-            if m > WINOGRAD_MAX_TILE:
+            if m > max_tile:
                 continue
             ratio = float((m + 2) ** 2) * tiles(hi, m) * tiles(wi, m) / (9.0 * hi * wi)
             if plan is None or ratio < plan[1] - 1e-9:
@@ -201,8 +170,8 @@ def _tile_table(n, hi, wi, d, tile, device):
         tab = torch.empty(_lib.lib.diga_conv2d_winograd_tile_table_bytes(n, hi, wi, d, tile), dtype=torch.uint8, device=device)
         _lib.call("diga_conv2d_winograd_tile_table", _lib.ptr(tab), n, hi, wi, d, tile, _lib.stream())
         torch.cuda.current_stream(device).synchronize()
-        if len(_TILE_TABLES) > 256:
-            _TILE_TABLES.clear()
+        # never evicted: a table is a few KB, its device pointer may be baked into captured HIP graphs and kernels on the side /
+        # teacher streams may still be reading it (clearing the cache at 256 geometries freed tables in use)
         _TILE_TABLES[key] = tab
     return tab
 
@@ -226,9 +195,10 @@ def _wino_ratio(hi, wi, d):
 def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
     """Exact-fp32 mode: stride-1 'same' 3x3 layers (dilation d = padding, forward or backward-data geometry) go through
     Winograd (csrc/winograd.hip; tile from _wino_plan) when cutting the d*d sub-images into tiles leaves few enough
-    multiplications: share of the direct convolution <= WINOGRAD_RATIO (default 0.62; dilation 24 on a 97x97 map has 5x5
-    sub-images -> 0.98 and stays direct, where the kernel also skips the dead taps).  WINOGRAD = False switches the path off."""
-    if not WINOGRAD:
+    multiplications: share of the direct convolution <= `winograd_ratio` (default 0.62; dilation 24 on a 97x97 map has 5x5
+    sub-images -> 0.98 and stays direct, where the kernel also skips the dead taps).  `winograd = False` switches the path off."""
+    cfg = config.active()
+    if not cfg.winograd:
         return False
     d = abs(doff[0])
     if not (r == 3 and s == 3 and tuple(stride) == (1, 1) and doff[0] == doff[1] and d >= 1 and off0[0] == -doff[0]
@@ -236,11 +206,11 @@ def _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo):
         return False
     ratio = _wino_ratio(hi, wi, d)
     # (the batched GEMM indexes its products * tiles rows as a [rows / 256][256] image with 15-bit row coordinates)
-    return ratio <= WINOGRAD_RATIO and n * hi * wi * ratio * 9.0 / 256.0 < 32000
+    return ratio <= cfg.winograd_ratio and n * hi * wi * ratio * 9.0 / 256.0 < 32000
 
 
 def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin_box=None, must_twin=False, epi=None,
-                 opts=None, keep_v=None, in_ab=None, junction=None, wino_stats=False):
+                 opts=None, keep_v=None, wino_stats=False):
     """x [N,Hi,Wi,Cin] (contiguous or a channel slice of a contiguous tensor), w_krsc [K,R,S,Cin],
     out [N,Ho,Wo,K] (same rule).  twin_box: a one-element list shared by the convs that read the very same x.
     epi: a _lib.BwdEpilogue (backward-data only, bias-free): the `_epi` entry points finish the gradient in the epilogue.
@@ -256,8 +226,6 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
     n, hi, wi, cin = x.shape
     _, ho, wo, k = out.shape
     _, r, s, _ = w_krsc.shape
-    if in_ab is not None and _lib.get_conv_math() != 0:
-        raise RuntimeError("DigaConv2d: a deferred BatchNorm input needs the fp32 arithmetic")
     if (_lib.get_conv_math() == 1 and _use_twin(cin, k, r * s, twin_box is not None)
             and n * hi * wi * cin * 4 < (1 << 40)):
         # split-bf16 arithmetic without register staging: both operands pre-split, copied global -> LDS by LDS-DMA
@@ -285,7 +253,7 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         return twin
     if must_twin:
         raise RuntimeError("DigaConv2d: the input holds split-twin bytes but the twin kernel is not selected "
-                           "(conv math or DIGA_CONV_TWIN changed since the producer ran)")
+                           "(conv math or config.conv_twin changed since the producer ran)")
     if _lib.get_conv_math() == 1:
         # split-bf16 arithmetic: the weights are split once here (two bf16 arrays), the activations inside the kernel
         nel = w_krsc.numel()
@@ -308,16 +276,6 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
         return None
     direct = 2.0 * n * ho * wo * k * r * s * cin
     name = "conv_bwd_data" if tag == _TAG_BWD_DATA else "conv_fwd"
-    if junction is not None and not junction["filled"]:
-        # x is the not-yet-filled output of a residual junction (norm.py: defer_junction): this GEMM's loader waves compute it from
-        # (y3, skip, coefficients) on the way into LDS, its column-tile-0 blocks store x and the ReLU mask bits (DigaConv2d.forward
-        # made sure the shape is eligible)
-        _log_flops(name, direct, direct)
-        _lib.call("diga_conv2d_junction_f32", _lib.ptr(junction["y3"]), cin, _lib.ptr(junction["skip"]), cin, _lib.ptr(junction["ab"]),
-                  _lib.ptr(x), x.stride(2), _lib.ptr(junction["bits"]), _lib.ptr(w_krsc), _lib.ptr(out), out.stride(2), _lib.ptr(stats),
-                  n * hi * wi, cin, k, _lib.stream())
-        junction["filled"] = True
-        return None
     if (_lib.get_conv_math() == 0 and copt is not None and copt.upsample_shift == 0 and copt.activation == 0 and copt.reflect_pad
             and doff[0] > 0 and doff[0] < min(hi, wi) and _winograd_ok(n, hi, wi, cin, k, r, s, stride, off0, doff, ho, wo)
             and _wino_plan(hi, wi, doff[0])[0] >= 4):
@@ -345,16 +303,6 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                       n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, 1 if doff[0] < 0 else 0, ctypes.byref(epi), _lib.ptr(tab), tag,
                       _lib.stream())
             return None
-        if in_ab is not None:
-            # x holds the pre-activation values of a BatchNorm + ReLU: the input transform applies relu(fma(x, a, b)) on load
-            if epi is not None or doff[0] < 0:
-                raise RuntimeError("DigaConv2d: a deferred BatchNorm input only feeds a forward convolution")
-            if keep_v is not None:
-                keep_v[0] = _alloc_keep_v(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), x.device)
-            _lib.call("diga_conv2d_winograd_f32_ab", _lib.ptr(x), _lib.ptr(in_ab), _lib.ptr(w_krsc), _lib.ptr(bias), _lib.ptr(out),
-                      _lib.ptr(keep_v[0]) if keep_v is not None else None, _lib.ptr(ws), ws.numel(), n, hi, wi, cin, x.stride(2), k,
-                      out.stride(2), d, tile, _lib.ptr(stats), _lib.ptr(tab), tag, _lib.stream())
-            return None
         if keep_v is not None and doff[0] > 0:
             # keep_v: a one-element list -- the transformed input stays alive for this layer's weight gradient
             keep_v[0] = _alloc_keep_v(_lib.lib.diga_conv2d_winograd_v_floats(n, hi, wi, cin, d, tile), x.device)
@@ -367,9 +315,6 @@ def _conv_launch(x, w_krsc, bias, out, stride, off0, doff, tag, stats=None, twin
                   n, hi, wi, cin, x.stride(2), k, out.stride(2), d, tile, 1 if doff[0] < 0 else 0, _lib.ptr(stats), _lib.ptr(tab), tag,
                   _lib.stream())
         return None
-    if in_ab is not None:
-        raise RuntimeError("DigaConv2d: the input carries a deferred BatchNorm apply (_diga_lazy_ab) but this call is not on the "
-                           "fp32 Winograd path that can apply it (check bn1_defer_ok before deferring)")
     _log_flops(name, direct, direct)
     if epi is not None:
         _lib.call("diga_conv2d_nhwc_f32_epi", _lib.ptr(x), _lib.ptr(w_krsc), _lib.ptr(out), n, hi, wi, cin,
@@ -466,7 +411,7 @@ def _set_mask(epi, box, xn, cp):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, stats=None, uses=None, twin_box=None, x_is_twin=False,
-                dy_is_twin=False, bn_box=None, opts=None, chain=None, lazy_ab=None, junction=None):
+                dy_is_twin=False, bn_box=None, opts=None, chain=None):
         # x: NCHW-shaped; weight: [K,C,R,S] (any dense layout); returns an NCHW-shaped channels_last tensor
         _lib.require_gpu(x, weight)
         if x_is_twin:          # the producer wrote the split twin instead of fp32 (same bytes per element): hand it on
@@ -493,21 +438,19 @@ class _Conv2dFn(torch.autograd.Function):
         out = torch.empty((n, ho, wo, k), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
         # exact-fp32 Winograd layers whose weight gradient is wanted keep their transformed input (4x the input's bytes, HBM
-        # is 288 GB): the backward-weight pass then skips a bandwidth pass of 5x the input (DIGA_WINOGRAD_KEEP_V=0: recompute)
+        # is 288 GB): the backward-weight pass then skips a bandwidth pass of 5x the input (config.winograd_keep_v = False: recompute)
         keep_v = None
         wino_stats = isinstance(stats, tuple)         # (buffer, "records"): the Winograd output transform fills it (DigaConv2d.forward)
         if wino_stats:
             stats = stats[0]
         if (ctx.needs_input_grad[1] and _lib.get_conv_math() == 0 and k % 256 == 0 and cp % 128 == 0 and (stats is None or wino_stats)
-                and (opts is None or not any(opts)) and WINOGRAD_KEEP_V
+                and (opts is None or not any(opts)) and config.active().winograd_keep_v
                 and _winograd_ok(n, hi, wi, cp, k, r, s, stride, (-padding[0], -padding[1]), dilation, ho, wo)):
             keep_v = [None]
-        if lazy_ab is not None and cp != c:
-            raise RuntimeError("DigaConv2d: a deferred BatchNorm input needs Cin % 32 == 0")
         x_twin = _conv_launch(xn, w, b, out, stride, (-padding[0], -padding[1]), dilation, _TAG_FWD, stats, twin_box,
-                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v, in_ab=lazy_ab, junction=junction, wino_stats=wino_stats)
+                              must_twin=bool(x_is_twin), opts=opts, keep_v=keep_v, wino_stats=wino_stats)
         ctx.wino_v = keep_v[0] if keep_v is not None else None
-        ctx.in_ab = lazy_ab                 # (the saved xn then holds pre-activation values: the weight gradient applies them too)
+        ctx.max_tile = config.active().winograd_max_tile      # (the kept transform's layout is the forward's tile: checked in backward)
         ctx.save_for_backward(xn, w)
         # the split twin of the input serves the weight gradient too (multi-tap / shared-input layers, Cout >= 256)
         ctx.x_twin = x_twin if (ctx.needs_input_grad[1] and k >= 256 and k % 8 == 0 and cp == c) else None
@@ -519,7 +462,9 @@ class _Conv2dFn(torch.autograd.Function):
                                "(check takes_twin_only_input before asking the producer for a twin)")
         ctx.geom = (stride, padding, dilation, c, bias is not None, weight.stride())
         ctx.uses = uses
-        ctx.grad_view = getattr(weight, "_diga_grad_view", None) if (GRAD_VIEWS and isinstance(weight, nn.Parameter)) else None
+        # data-parallel runs: the parameter offers its slice of the all-reduce bucket as the gradient's home (ddp.GradReducer.grad_view)
+        ctx.grad_view = getattr(weight, "_diga_grad_view", None) if isinstance(weight, nn.Parameter) else None
+        ctx.weight_param = weight if ctx.grad_view is not None else None
         # the arithmetic / twin decisions of this forward bind its backward: saved tensors may hold twin bytes
         ctx.math = _lib.get_conv_math()
         ctx.x_is_twin = bool(x_is_twin)
@@ -662,6 +607,14 @@ class _Conv2dFn(torch.autograd.Function):
             # (ddp.GradReducer.grad_view: a fresh tensor of the weight's shape and strides over that slice) -- nothing packs it
             gv = getattr(ctx, "grad_view", None)
             dw = gv() if (gv is not None and not later and not inline and kp == k and cp == c_true) else None
+            if dw is not None:
+                # ... unless the slice already IS the parameter's gradient: a second graph differentiated before reduce() (the
+                # overlapped self-training step's student(cross_mix), gradient accumulation under GradReducer.hold()) would overwrite
+                # the first graph's result and AccumulateGrad would then add the slice to itself (this check replaced a
+                # module-global switch the step driver had to flip around the second forward)
+                held = ctx.weight_param.grad
+                if held is not None and held.data_ptr() == dw.data_ptr():
+                    dw = None
             if dw is None or tuple(dw.stride()) != tuple(w_strides) or dw.device != w.device:
                 dw = torch.empty_strided((k, c_true, r, s), w_strides, dtype=torch.float32, device=w.device)
             # the kernels write [K][R][S][C]: for an unpadded channels_last weight that IS dw's memory (no copy afterwards)
@@ -677,7 +630,10 @@ class _Conv2dFn(torch.autograd.Function):
 
             wino_v = getattr(ctx, "wino_v", None)
             ctx.wino_v = None
-            in_ab = getattr(ctx, "in_ab", None)
+            if wino_v is not None and config.active().winograd_max_tile != ctx.max_tile:
+                raise RuntimeError("DigaConv2d: the Winograd tile cap changed between this layer's forward and its backward "
+                                   f"({ctx.max_tile} -> {config.active().winograd_max_tile}): the kept input transform has the forward's "
+                                   "layout (set_conv_math(..., exact=) belongs between steps, not inside one)")
 
             def run_twin():
                 nbytes = _lib.lib.diga_conv2d_wgrad_twin_workspace_bytes(n, ho, wo, kp, cp, r, s)
@@ -698,18 +654,11 @@ class _Conv2dFn(torch.autograd.Function):
                     nb = _lib.lib.diga_conv2d_wgrad_winograd_workspace_bytes(n, hi, wi, cp, kp, dilation[0], tile, 1 if wino_v is not None else 0)
                     wsw = _lib.workspace(nb, w.device, "winograd_wgrad")
                     tab = _tile_table(n, hi, wi, dilation[0], tile, w.device)
-                    if in_ab is not None:
-                        _lib.call("diga_conv2d_wgrad_winograd_f32_ab", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(in_ab), _lib.ptr(wino_v),
-                                  _lib.ptr(dwp), _lib.ptr(wsw), wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0],
-                                  tile, _lib.ptr(tab), _lib.stream())
-                    else:
-                        _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(wino_v), _lib.ptr(dwp), _lib.ptr(wsw),
-                                  wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], tile, _lib.ptr(tab), _lib.stream())
+                    _lib.call("diga_conv2d_wgrad_winograd_f32", _lib.ptr(gyp), _lib.ptr(xn), _lib.ptr(wino_v), _lib.ptr(dwp), _lib.ptr(wsw),
+                              wsw.numel(), n, hi, wi, cp, xn.stride(2), kp, gyp.stride(2), dilation[0], tile, _lib.ptr(tab), _lib.stream())
                     if not alias:
                         dw.copy_(dwp[:k, :, :, :c_true].permute(0, 3, 1, 2))
                     return
-                if in_ab is not None:
-                    raise RuntimeError("DigaConv2d: weight gradient of a layer with a deferred BatchNorm input off the Winograd path")
                 _log_flops("conv_bwd_weight", 2.0 * n * ho * wo * kp * r * s * cp, 2.0 * n * ho * wo * kp * r * s * cp)
                 nbytes = _lib.lib.diga_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, cp, r, s)
                 ws = _lib.workspace(nbytes, w.device, "wgrad")
@@ -735,7 +684,7 @@ class _Conv2dFn(torch.autograd.Function):
                     tns.record_stream(side)
         if has_bias and ctx.needs_input_grad[2]:
             db = _bias_grad(gy)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 class DigaConv2d(nn.Conv2d):
@@ -777,7 +726,7 @@ class DigaConv2d(nn.Conv2d):
             if not on_wino:
                 stats = torch.empty(_lib.lib.diga_conv2d_stats_floats(n, ho, wo, self.out_channels), dtype=torch.float32,
                                     device=x.device)
-            elif WINOGRAD_STATS:
+            elif config.active().winograd_stats:
                 # round 5: the Winograd output transform (4x4 / 6x6 tiles) leaves the statistics as records of unequal size
                 # (diga_bn_fwd_records); F(2x2)-only runs keep the BatchNorm's own statistics pass
                 plan = winograd_stats_plan(n, h, w, _pad_to(self.in_channels), self.out_channels, self.kernel_size[0], self.kernel_size[1],
@@ -798,26 +747,6 @@ class DigaConv2d(nn.Conv2d):
         x_is_twin = bool(getattr(x, "_diga_is_twin", False))
         if x_is_twin and fn is not _Conv2dFn:
             raise RuntimeError("DigaConv2d: twin-only input on the stem path")
-        # the residual junction in front deferred its apply pass to this conv (norm.py: defer_junction): fuse it when this is a stride-1
-        # pointwise layer the persistent GEMM takes (exact fp32, no bias, >= 512 tiles), else run the stand-alone pass now
-        junction = getattr(x, "_diga_lazy_junction", None)
-        if junction is not None and junction["filled"]:
-            junction = None
-        if junction is not None:
-            nj, cj, hj, wj = x.shape
-            ok = (fn is _Conv2dFn and _lib.get_conv_math() == 0 and tuple(self.kernel_size) == (1, 1) and tuple(self.stride) == (1, 1)
-                  and tuple(self.padding) == (0, 0) and self.bias is None and (opts is None or not any(opts)) and not twin_grad
-                  and cj == self.in_channels and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
-                  and bool(_lib.lib.diga_conv2d_junction_ok(nj * hj * wj, cj, self.out_channels)))
-            from diga_amd.model import norm as _dn
-            if ok and _dn.JUNCTION_FUSION < 2 and self.out_channels != 128:
-                ok = False                    # (measured slower with more than one column tile: norm.junction_fusion)
-            if not ok:
-                _dn.materialize_junction(junction)
-                junction = None
-        lazy_ab = getattr(x, "_diga_lazy_ab", None)       # the BatchNorm in front deferred its apply to this conv's input transform
-        if lazy_ab is not None and (fn is not _Conv2dFn or x_is_twin or twin_grad or chain is not None or (opts is not None and any(opts))):
-            raise RuntimeError("DigaConv2d: a deferred BatchNorm input (_diga_lazy_ab) reached a call that cannot apply it")
         bn_box = getattr(x, "_diga_bn_box", None)
         if bn_box is not None and (self.share_twin or chain is not None or fn is not _Conv2dFn or not torch.is_grad_enabled()):
             bn_box = None                     # several convs read this tensor (the chain carries the box) / no backward
@@ -826,14 +755,14 @@ class DigaConv2d(nn.Conv2d):
                 raise RuntimeError("DigaConv2d: folded padding / upsampling / activation need the implicit-GEMM path without BN statistics")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), None, uses,
                          twin_box, False, False, None, tuple(int(v) for v in opts))
-        elif x_is_twin or twin_grad or bn_box is not None or chain is not None or lazy_ab is not None or junction is not None:
+        elif x_is_twin or twin_grad or bn_box is not None or chain is not None:
             if fn is not _Conv2dFn or (self.bias is not None and twin_grad):
                 if chain is not None:
                     chain["disabled"] = True
                 else:
                     raise RuntimeError("DigaConv2d: twin gradient needs a bias-free conv on the implicit-GEMM path")
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,
-                         twin_box, x_is_twin, bool(twin_grad), bn_box, None, chain, lazy_ab, junction) if fn is _Conv2dFn else \
+                         twin_box, x_is_twin, bool(twin_grad), bn_box, None, chain) if fn is _Conv2dFn else \
                 fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses, twin_box)
         else:
             y = fn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding), tuple(self.dilation), stats, uses,

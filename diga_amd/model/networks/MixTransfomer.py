@@ -30,7 +30,7 @@ import torch.nn as nn
 _pkg = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if os.path.dirname(_pkg) not in sys.path:
     sys.path.append(os.path.dirname(_pkg))
-from diga_amd import _lib  # noqa: E402
+from diga_amd import _lib, config  # noqa: E402
 
 P = _lib.ptr
 _TAGS = ("mit_gemm", "mit_wgrad", "mit_attn_fwd", "mit_attn_bwd", "mit_norm", "mit_dwconv", "mit_misc")
@@ -123,8 +123,9 @@ def _rup(v, q):
 class _Ops:
     """Thin launch helpers over include/diga_mit.h (raw pointers of torch tensors on the current stream)."""
 
-    def __init__(self, device):
+    def __init__(self, device, side_ok=True):
         self.dev = device
+        self.side_ok = side_ok       # False: every weight gradient of this pass stays on the current stream (see _MitStageFn.backward)
 
     def empty(self, shape, dtype=torch.float16):
         return torch.empty(shape, dtype=dtype, device=self.dev)
@@ -148,7 +149,7 @@ class _Ops:
         # chip each).  dy and x are never written again after they were produced (every in-place accumulation of the backward pass
         # goes into the residual-stream buffers, which no weight gradient reads).
         # side_ok=False: the caller post-processes the result on the CURRENT stream right away (a slice + reshape copy, the overflow check)
-        side = _lib.side_stream(self.dev) if (dy.is_cuda and side_ok) else None
+        side = _lib.side_stream(self.dev) if (dy.is_cuda and side_ok and self.side_ok) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
@@ -345,7 +346,18 @@ class _MitStageFn(torch.autograd.Function):
         inv = 1.0 / S
         B = ctx.B
         dev = g.device
-        ops = _Ops(dev)
+        # A stage that entered the graph more than once (the one-backward self-training step runs the student twice) has its
+        # parameters' gradients summed by autograd on the CURRENT stream: only the first contribution of a backward pass may still be
+        # in flight on the side stream when it is handed over; the later ones join the side stream first and run in line
+        # (same rule as DigaConv2d's `uses`, diga_amd/model/conv.py).
+        uses = cfg.get("uses")
+        later = False
+        if uses is not None:
+            later = uses[si][0] > 0
+            uses[si][0] += 1
+        if later:
+            _lib.join_side()
+        ops = _Ops(dev, side_ok=not later)
         grads = {}
         down = None                                            # true (unscaled) fp32 gradient wrt this stage's input
         if True:
@@ -453,9 +465,10 @@ class MixVisionTransformer(nn.Module):
         self.num_classes = num_classes
         self.depths = depths
         self.embed_dims = list(embed_dims)
-        self.loss_scale = float(os.environ.get("DIGA_MIT_LOSS_SCALE", "1024"))
+        self.loss_scale = float(config.active().mit_loss_scale)
         # [0]: this step's backward met an inf / NaN (set on the device, cleared by the next training forward); [1]: such steps so far
         self.register_buffer("grad_overflow", torch.zeros(2, dtype=torch.int32), persistent=False)
+        self._bw_seen = [[0], [0], [0], [0]]
         self._overflow_seen = 0
         self.patch_embed1 = OverlapPatchEmbed(img_size=img_size, patch_size=7, stride=4, in_chans=in_chans, embed_dim=embed_dims[0])
         self.patch_embed2 = OverlapPatchEmbed(img_size=img_size // 4, patch_size=3, stride=2, in_chans=embed_dims[0], embed_dim=embed_dims[1])
@@ -622,8 +635,17 @@ class MixVisionTransformer(nn.Module):
         cfg["need_grad"] = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         cfg["overflow_flag"] = None
         if cfg["need_grad"] and x.is_cuda:
-            self.grad_overflow[0:1].zero_()
+            # The flag means "a backward pass overflowed since the optimizer last looked": it is cleared by the first training
+            # forward AFTER an optimizer step has consumed it (DigaSGD.step(found_inf=flag) -> _lib.flag_consumed), never by a
+            # forward that runs between a backward pass and that step -- the overlapped self-training step runs the forward of
+            # student(cross_mix) next to the backward of student(cat), and a clear there would erase an overflow the step must skip on.
+            if _lib.take_consumed_flag(self.grad_overflow):
+                self.grad_overflow[0:1].zero_()
             cfg["overflow_flag"] = self.grad_overflow
+            if any(u[0] > 0 for u in self._bw_seen):          # a backward pass has consumed the previous graph(s)
+                for u in self._bw_seen:
+                    u[0] = 0
+            cfg["uses"] = self._bw_seen                        # per stage: [weight-gradient passes of the current backward pass]
         cfg["prep"] = self._prepare_weights() if x.is_cuda else None
         cfg["drop_scales"] = self._drop_path_scales(cfg, x.shape[0], x.device) if x.is_cuda else None
         named = dict(self.named_parameters())

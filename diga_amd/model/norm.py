@@ -6,12 +6,10 @@ the following ReLU and the residual add), nn.GroupNorm(32) (fused with ReLU / th
 scale, able to write straight into a channel slice of the ASPP concat buffer), SEBlock pieces and the
 stem max-pool.  Tensors cross module boundaries as NCHW-shaped views of NHWC memory.
 """
-import os
-
 import torch
 import torch.nn as nn
 
-from diga_amd import _lib
+from diga_amd import _lib, config
 
 
 def nhwc(x):
@@ -53,47 +51,6 @@ def _ws(rows_per_seg, nseg, c, device):
     return _lib.workspace(_lib.lib.diga_norm_workspace_bytes(rows_per_seg, nseg, c), device, "norm")
 
 
-# --------------------------------------------------------------------------------------------- residual junctions, fused forward
-_JUNCTION_DEPTH = [0]
-
-
-class junction_fusion:
-    """Context of a WHOLE-network forward (SegModel / ResNetMulti.forward): inside it the last BatchNorm of a bottleneck may leave its
-    apply pass -- relu(fma(y3, a, b) + skip), three tensors of the block's size -- to conv1 of the NEXT bottleneck, whose GEMM applies
-    it while staging its operand (diga_conv2d_junction_f32).  Outside the context (a block or a layer called on its own) every module
-    returns finished tensors.  JUNCTION_FUSION (DIGA_FUSE_JUNCTION, read once at import): 0 (DEFAULT) off; 1 consumers with ONE
-    column tile (128 output channels: layer2 -- stand-alone 0.326 vs 0.369 ms for the pair, but 435.6 / 437.0 vs 432.5 / 435.0 ms on
-    the step); 2 every eligible consumer (layer3: 1.056 vs 1.005 ms, layer4: 3.66 vs 3.25 ms -- each of a row tile's 2 / 4 column-tile
-    blocks loads and transforms y3 and skip again and the GEMM stalls on it; step 437.6 vs 432.6 ms).  Bit-identical in every mode
-    (tests/test_gpu_bn_box.py); measured with tools/diag/junction_probe.py and bench.py --lean; DESIGN section 11."""
-
-    def __enter__(self):
-        _JUNCTION_DEPTH[0] += 1
-
-    def __exit__(self, *exc):
-        _JUNCTION_DEPTH[0] -= 1
-        return False
-
-
-JUNCTION_FUSION = int(os.environ.get("DIGA_FUSE_JUNCTION", "0"))
-
-
-def junction_fusion_active():
-    return JUNCTION_FUSION > 0 and _JUNCTION_DEPTH[0] > 0 and _lib.get_conv_math() == 0
-
-
-def materialize_junction(lj):
-    """The stand-alone apply pass of a deferred junction (the consumer could not fuse it): fills lj['out'] and its mask bits."""
-    if lj["filled"]:
-        return
-    y3, out = lj["y3"], lj["out"]
-    c = y3.shape[-1]
-    m = y3.numel() // c
-    _lib.call("diga_bn_apply", _lib.ptr(y3), c, _lib.ptr(out), c, _lib.ptr(lj["skip"]), c, _lib.ptr(lj["ab"]), m, c, 1, _lib.ptr(lj["bits"]),
-              _lib.stream())
-    lj["filled"] = True
-
-
 # --------------------------------------------------------------------------------------------- BatchNorm
 class _BnFn(torch.autograd.Function):
     """Train-mode BatchNorm (+ReLU, +residual).  `box` (a dict, or None) ties this BN to the convolution that consumes its
@@ -104,28 +61,17 @@ class _BnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, relu, momentum, eps,
-                partials=None, twin_out=False, dx_twin=False, box=None, res_box=None, lazy=None, junction=None):
+                partials=None, twin_out=False, dx_twin=False, box=None, res_box=None):
         _lib.require_gpu(x)
         xn = nhwc(x.detach())
         n, h, w, c = xn.shape
         m = n * h * w
         rn = None if residual is None else nhwc(residual.detach())
-        # lazy (a dict, ReLU without residual only): statistics and coefficients only -- the consumer (the Winograd input
-        # transform of the 3x3 conv behind this BN) applies relu(fma(x, a, b)) on load; the "output" aliases x
-        defer = lazy is not None
-        if defer and not (relu and residual is None and not twin_out):
-            raise RuntimeError("DigaBatchNorm2d: a deferred apply needs ReLU, no residual and an fp32 output")
-        # junction (a dict, ReLU WITH residual): statistics and coefficients only as well, but the output tensor exists (uninitialised):
-        # conv1 of the next bottleneck fills it -- and the mask bits -- while staging its operand (model/conv.py, `junction`)
-        junc = junction is not None
-        if junc and not (relu and residual is not None and not twin_out and c % 32 == 0):
-            raise RuntimeError("DigaBatchNorm2d: a deferred junction needs ReLU, a residual, an fp32 output and C % 32 == 0")
-        y = xn if defer else torch.empty_like(xn)
+        y = torch.empty_like(xn)
         save_mean = torch.empty(c, dtype=torch.float32, device=xn.device)
         save_invstd = torch.empty_like(save_mean)
         # ReLU without residual: the backward re-derives the mask from x and the forward coefficients (no y read)
         save_ab = torch.empty(2 * c, dtype=torch.float32, device=xn.device) if (relu and residual is None) else None
-        junc_ab = torch.empty(2 * c, dtype=torch.float32, device=xn.device) if junc else None
         ws = _ws(m, 1, c, xn.device)
         # a BN with residual keeps its ReLU mask as one bit per element for the backward epilogue of the conv that reads
         # y (instead of y itself: 1/32 of the bytes); DIGA_RELU_BITS=0 reads y as before
@@ -136,29 +82,25 @@ class _BnFn(torch.autograd.Function):
             # ... as records of unequal size (the Winograd output transform's tile groups): [R][3][C] sums, then [R] counts
             recs = int(partials[1][1])
             wsr = _lib.workspace(max(_lib.lib.diga_norm_workspace_bytes(m, 1, c), (96 * 3 * c + 2 * c + 128) * 4), xn.device, "norm_rec")
-            _lib.call("diga_bn_fwd_records", _lib.ptr(xn), c, None if (defer or junc) else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
+            _lib.call("diga_bn_fwd_records", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
-                      _lib.ptr(save_invstd), _lib.ptr(junc_ab if junc else save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
-                      None if junc else _lib.ptr(bits), float(momentum), float(eps), _lib.ptr(partials[0]),
+                      _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
+                      _lib.ptr(bits), float(momentum), float(eps), _lib.ptr(partials[0]),
                       _lib.C.c_void_p(partials[0].data_ptr() + recs * 3 * c * 4), recs, _lib.ptr(wsr), wsr.numel(), _lib.stream())
         elif partials is not None and training:
             # the producing conv already reduced its output tile by tile: finalise + apply only
-            _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, None if (defer or junc) else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
+            _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
-                      _lib.ptr(save_invstd), _lib.ptr(junc_ab if junc else save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
-                      None if junc else _lib.ptr(bits),
+                      _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
+                      _lib.ptr(bits),
                       float(momentum), float(eps), _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(),
                       _lib.stream())
         else:
-            _lib.call("diga_bn_fwd", _lib.ptr(xn), c, None if (defer or junc) else _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
+            _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
                       _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_invstd),
-                      _lib.ptr(junc_ab if junc else save_ab), m, c, 1 if training else 0, 1 if relu else 0, 1 if twin_out else 0,
-                      None if junc else _lib.ptr(bits),
+                      _lib.ptr(save_ab), m, c, 1 if training else 0, 1 if relu else 0, 1 if twin_out else 0,
+                      _lib.ptr(bits),
                       float(momentum), float(eps), _lib.ptr(ws), ws.numel(), _lib.stream())
-        if defer:
-            lazy["ab"] = save_ab
-        if junc:
-            junction.update(y3=xn, skip=rn, ab=junc_ab, bits=bits, out=y, filled=False)
         ctx.save_for_backward(xn, y if (relu and save_ab is None) else None, weight, save_mean, save_invstd, save_ab)
         ctx.flags = (training, residual is not None)
         ctx.dx_twin = bool(dx_twin and c % 8 == 0)
@@ -187,7 +129,7 @@ class _BnFn(torch.autograd.Function):
                       _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(dx), c, _lib.ptr(dgamma), _lib.ptr(dbeta), m, c,
                       1 if training else 0, _lib.ptr(ws), ws.numel(), _lib.stream())
             return (dx.permute(0, 3, 1, 2), None, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                    None, None, None, None, None, None, None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None, None, None, None, None)
         pre = ctx.box.pop("premasked", None) if ctx.box is not None else None
         # (same buffer AND untouched since the conv wrote it: autograd sums a second gradient into a NEW tensor while the
         #  box holds a reference to this one; the version check also catches an in-place accumulation)
@@ -211,7 +153,7 @@ class _BnFn(torch.autograd.Function):
             ctx.res_box["dres"] = dres
             dres = None
         return (dx.permute(0, 3, 1, 2), None if dres is None else dres.permute(0, 3, 1, 2),
-                dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None, None)
+                dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class DigaBatchNorm2d(nn.BatchNorm2d):
@@ -219,7 +161,7 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
     G5/model/seg_model_noaux.py:64-76) -- gradients flow to the input only.  forward(x, residual, relu)
     computes relu(bn(x) + residual) in one pass."""
 
-    def forward(self, x, residual=None, relu=False, twin_out=False, dx_twin=False, defer_apply=False, defer_junction=False):
+    def forward(self, x, residual=None, relu=False, twin_out=False, dx_twin=False):
         """twin_out (ReLU, no residual, C % 8 == 0): the result is written as the split twin the staging-free conv
         kernels read (same 4 bytes per element, diga_make_twin's format) INSTEAD of fp32; the returned tensor has the
         usual shape and dtype but holds twin bytes (`_diga_is_twin`) -- only a DigaConv2d on the twin path may read it."""
@@ -240,26 +182,8 @@ class DigaBatchNorm2d(nn.BatchNorm2d):
                 if rb is not None and rb.get("consumer_ready") and "res_claimed" not in rb:
                     rb["res_claimed"] = True
                     res_box = rb
-        # defer_apply (ReLU, no residual): statistics and coefficients only; the returned tensor holds the PRE-activation values
-        # and carries the coefficients (`_diga_lazy_ab`) -- only a DigaConv2d on the Winograd path may read it (it applies
-        # relu(fma(x, a, b)) in its input transform, diga_conv2d_winograd_f32_ab)
-        # (never with forward hooks on this module: they would be handed the pre-activation values)
-        lazy = {} if (defer_apply and relu and residual is None and not twin_out and not self._forward_hooks
-                      and not torch.nn.modules.module._global_forward_hooks) else None
-        # defer_junction (ReLU with residual, inside a whole-network forward): the apply pass is left to conv1 of the next bottleneck;
-        # the returned tensor is allocated but NOT YET FILLED and carries `_diga_lazy_junction` -- a DigaConv2d that reads it fills it
-        # (fused, or with the stand-alone pass when it cannot fuse).  Never with forward hooks on this module: they would see garbage.
-        junction = None
-        if (defer_junction and relu and residual is not None and not twin_out and x.shape[1] % 32 == 0 and x.is_cuda
-                and junction_fusion_active() and not self._forward_hooks and not torch.nn.modules.module._global_forward_hooks):
-            junction = {}
         y = _BnFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, training, relu,
-                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin), box, res_box, lazy,
-                        junction)
-        if junction is not None:
-            y._diga_lazy_junction = junction
-        if lazy is not None:
-            y._diga_lazy_ab = lazy["ab"]
+                        self.momentum, self.eps, getattr(x, "_diga_bn_partials", None), twin_out, bool(dx_twin), box, res_box)
         if twin_out:
             y._diga_is_twin = True
         if box is not None:
@@ -279,7 +203,7 @@ class DigaTrainableBatchNorm2d(DigaBatchNorm2d):
         elif self.training and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
         return _BnFn.apply(x, None, self.weight, self.bias, self.running_mean, self.running_var, training, relu, self.momentum, self.eps,
-                           getattr(x, "_diga_bn_partials", None), False, False, None, None, None, None)
+                           getattr(x, "_diga_bn_partials", None), False, False, None, None)
 
 
 def bump_batches_tracked(model):
@@ -314,15 +238,13 @@ def bump_batches_tracked(model):
 
 
 def _relu_bits_enabled():
-    import os
-    return os.environ.get("DIGA_RELU_BITS", "1") != "0"
+    return config.active().relu_bits
 
 
 def fuse_backward_enabled():
-    """DIGA_FUSE_BWD=0 switches the backward-epilogue fusion (residual add + ReLU mask + BN-backward sums inside the
+    """config.fuse_bwd = False switches the backward-epilogue fusion (residual add + ReLU mask + BN-backward sums inside the
     backward-data convolution) off: the A/B switch of the parity tests."""
-    import os
-    return os.environ.get("DIGA_FUSE_BWD", "1") != "0"
+    return config.active().fuse_bwd
 
 
 # --------------------------------------------------------------------------------------------- GroupNorm

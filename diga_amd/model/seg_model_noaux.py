@@ -12,15 +12,15 @@ Semantics kept from the reference: BN uses batch statisti
 train mode (the teacher always is) and updates its running statistics; GroupNorm(32) is trainable; `feat` is
 the post-Dropout2d tensor; all conv weights start as N(0, 0.01).
 """
-import os
 from dataclasses import dataclass
 from typing import Tuple
 
 import torch
 import torch.nn as nn
 
+from diga_amd import config
 from diga_amd.model import norm as dn
-from diga_amd.model.conv import DigaConv2d, bn1_defer_ok, takes_twin_only_input
+from diga_amd.model.conv import DigaConv2d, takes_twin_only_input
 
 
 @dataclass(frozen=True)
@@ -66,10 +66,6 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)          # kept for module-tree parity; the ReLUs run inside the BN kernels
         self.downsample = downsample
         self.stride = stride
-        # set by ResNetMulti on every block whose output goes straight into another bottleneck: bn3 may then leave its apply pass
-        # (relu(bn3(y3) + skip)) to that block's conv1 (norm.junction_fusion; never for a block or layer called on its own)
-        self.defer_out = False
-        self.next_conv1 = None                     # (out_channels, stride) of the conv1 that reads this block's output
         for conv in (self.conv1, self.conv2, self.conv3) + ((downsample[0],) if downsample is not None else ()):
             conv.emit_bn_stats = True              # BN statistics come out of the conv epilogue
 
@@ -87,21 +83,19 @@ class Bottleneck(nn.Module):
             # they meet in an autograd add and that BatchNorm keeps its own mask / reduce passes
             box = getattr(x, "_diga_bn_box", None)
             if (grad and x.requires_grad and dn.fuse_backward_enabled() and tuple(self.conv1.stride) == (1, 1)
-                    and tuple(self.downsample[0].stride) == (1, 1) and os.environ.get("DIGA_JUNCTION_CHAIN", "1") != "0"):
+                    and tuple(self.downsample[0].stride) == (1, 1) and config.active().junction_chain):
                 chain = {"remaining": 2, "acc": None, "box": box}
             elif box is not None:
                 x._diga_bn_box = None
         tw2 = takes_twin_only_input(self.conv2)
         # (round 2: with streaming epilogue stores the twin kernel is also the faster one for pointwise layers without a
-        #  weight gradient -- the no-grad teacher takes it too; DIGA_TWIN_CONV3=2 restricts it to autograd passes as in round 1)
-        c3 = os.environ.get("DIGA_TWIN_CONV3", "1")
+        #  weight gradient -- the no-grad teacher takes it too; config.twin_conv3 = "2" restricts it to autograd passes as in round 1)
+        c3 = config.active().twin_conv3
         tw3 = (grad or c3 != "2") and c3 != "0" and takes_twin_only_input(self.conv3, pointwise_ok=True)
         y1 = self.conv1(x, chain=chain)
-        # fp32: bn1's activated output would be read only by conv2's Winograd input transform (and, through the transform the
-        # forward keeps, by its weight gradient): bn1 then computes statistics and coefficients only and the transform applies
-        # relu(fma(y1, a, b)) on load -- one BatchNorm apply pass per bottleneck less (model/conv.py: bn1_defer_ok)
-        defer1 = (not tw2) and bn1_defer_ok(self.conv2, y1, grad and self.conv2.weight.requires_grad)
-        y = self.bn1(y1, relu=True, twin_out=tw2, defer_apply=defer1)
+        # (two forward fusions were built, measured slower and retired in round 6 -- tools/experiments/: bn1's apply pass inside conv2's
+        #  Winograd input transform, +5 ms per C2 step; bn3's residual junction inside the next block's conv1 GEMM, +5 ms)
+        y = self.bn1(y1, relu=True, twin_out=tw2)
         y = self.bn2(self.conv2(y, twin_grad=tw2 and grad), relu=True, twin_out=tw3, dx_twin=tw2 and grad)
         if self.downsample is None:
             skip = x
@@ -109,10 +103,7 @@ class Bottleneck(nn.Module):
             skip = self.downsample[1](self.downsample[0](x, chain=chain))
         else:
             skip = self.downsample(x)
-        # (only where the consumer will fuse under the current policy: norm.JUNCTION_FUSION 1 = single-column-tile consumers)
-        defer = (self.defer_out and not tw3 and not self._forward_hooks and self.next_conv1 is not None
-                 and self.next_conv1[1] == (1, 1) and (dn.JUNCTION_FUSION >= 2 or self.next_conv1[0] == 128))
-        return self.bn3(self.conv3(y, twin_grad=tw3), residual=skip, relu=True, dx_twin=tw3, defer_junction=defer)
+        return self.bn3(self.conv3(y, twin_grad=tw3), residual=skip, relu=True, dx_twin=tw3)
 
 
 class SEBlock(nn.Module):
@@ -206,10 +197,6 @@ class ResNetMulti(nn.Module):
             self.bn_pretrain = dn.DigaBatchNorm2d(self.inplanes, affine=True)
             for p in self.bn_pretrain.parameters():
                 p.requires_grad = False
-        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
-        for b, nxt in zip(blocks[:-1], blocks[1:]):  # every bottleneck but the last feeds another bottleneck (see Bottleneck.defer_out)
-            b.defer_out = True
-            b.next_conv1 = (nxt.conv1.out_channels, tuple(nxt.conv1.stride))
         for m in self.modules():                     # the reference's global init runs after the head's own
             if isinstance(m, nn.Conv2d):
                 m.weight.data.normal_(0, 0.01)
@@ -233,8 +220,7 @@ class ResNetMulti(nn.Module):
     def forward(self, x):
         if self.training:
             dn.bump_batches_tracked(self)
-        with dn.junction_fusion():
-            x = self.layer4(self.layer3(self.layer2(self.layer1(self.stem(x)))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(self.stem(x)))))
         if self.bn_clr:
             x = self.bn_pretrain(x)
         return self.layer5(x)

@@ -10,25 +10,20 @@ upsampling fused (no [2B,19,H,W] tensors), ClassMix costs one D->H copy per call
 per image, EMA/SGD are single launches, no per-step .cpu()/.item() syncs; the unused
 `student(tdatav)` visualisation forward (warm_up.py:265-266) is not executed.
 """
-import os
 import random
 
 import torch
 
 from diga_amd import _lib, ddp
+from diga_amd import config as _config
 from diga_amd.util import loss as L
 from diga_amd.util import utils as U
 
 
 _STREAMS = {}
 _MISMATCH_WARNING_OFF = False
-# self-training step: backward of the student(cat) graph overlapped with the forward + backward of the student(cross_mix) graph
-# (0: one backward pass as the reference writes it; 1: only the cross-mixed forward / backward on a third stream; 2: the whole target
-#  branch -- consensus, ClassMix #2, centroid updates, cross-mixed forward / backward -- next to the backward of the student(cat) graph)
-C4_OVERLAP = int(os.environ.get("DIGA_C4_OVERLAP", "2"))
-# HIP-graph step (the launch-bound legs: c1, c5): capture the teacher's forward on a forked stream
-GRAPH_FORK_TEACHER = os.environ.get("DIGA_GRAPH_FORK_TEACHER", "1") != "0"
-GRAPH_FORK_WGRAD = os.environ.get("DIGA_GRAPH_FORK_WGRAD", "1") != "0"
+# Stream policy, the self-training step's overlap form (c4_overlap) and graph capture are fields of diga_amd.config.StepConfig:
+# DigaTrainer(config=...) owns one and runs every step under it; nothing here reads or writes the environment.
 
 
 def _accumulate_on_other_streams_is_intended():
@@ -62,7 +57,13 @@ def _prefetch_stream(device):
 
 class DigaTrainer:
     def __init__(self, student, teacher, base_lr=2.5e-4, max_iter=80000, power=0.9, momentum=0.9,
-                 weight_decay=5e-4, rng=random, distill_scale=0.5, centroid_exchange=None, graph=None):
+                 weight_decay=5e-4, rng=random, distill_scale=0.5, centroid_exchange=None, graph=None, config=None):
+        """config: a diga_amd.config.StepConfig (teacher / weight-gradient streams, c4 overlap form, graph capture, conv arithmetic,
+        Winograd tile cap, keep-V policy, data-parallel buckets ...).  None = follow whatever configuration is active when a step is
+        called (the process defaults unless the caller runs the step inside `config.use(...)` / `config.override(...)`).
+        `centroid_exchange` / `graph`, when given, override the corresponding fields."""
+        self.cfg = config
+        cfg = self._cfg()
         self.student, self.teacher = student, teacher
         self.base_lr, self.max_iter, self.power = base_lr, max_iter, power
         self.rng = rng
@@ -71,7 +72,7 @@ class DigaTrainer:
         # self-training, N > 1: "allgather" = exact (every rank applies all ranks' class means in global order, bit-identical
         # to one process on the concatenated batch); "allreduce" = BASELINE configs[3]'s cheaper, approximate exchange
         # (diga_amd/ddp.py::allreduce_class_means).  One collective per centroid pass either way.
-        self.centroid_exchange = centroid_exchange or os.environ.get("DIGA_CENTROID_EXCHANGE", "allgather")
+        self.centroid_exchange = centroid_exchange or cfg.centroid_exchange
         if self.centroid_exchange not in ("allgather", "allreduce"):
             raise ValueError(f"centroid_exchange must be 'allgather' or 'allreduce', not {self.centroid_exchange!r}")
         self.opt = U.DigaSGD(student.optim_parameters(base_lr), lr=base_lr, momentum=momentum,
@@ -81,13 +82,17 @@ class DigaTrainer:
         # the library's launches on torch's capture stream) and replayed every step; what depends on the iteration or on host
         # decisions stays outside (learning rate, EMA coefficient, ClassMix class choice, all-reduce, SGD).  For the launch-bound
         # configurations (small backbone, MiT encoder: hundreds of 5-30 us kernels); the big ResNet-101 step is GPU-bound either way.
-        self.use_graph = bool(int(os.environ.get("DIGA_STEP_GRAPH", "0"))) if graph is None else bool(graph)
+        self.use_graph = cfg.step_graph if graph is None else bool(graph)
         self._g = None
-        self.reducer = ddp.GradReducer([p for p in student.parameters() if p.requires_grad], overlap=not self.use_graph)
+        with _config.use(cfg):
+            self.reducer = ddp.GradReducer([p for p in student.parameters() if p.requires_grad], overlap=not self.use_graph)
         self._side = None
         U.create_teacher_params(teacher, student)
         for p in teacher.parameters():
             p.requires_grad_(False)
+
+    def _cfg(self):
+        return self.cfg if self.cfg is not None else _config.active()
 
     # ------------------------------------------------------------------ ClassMix class lists ahead of time
     def prefetch_classmix(self, labels):
@@ -126,10 +131,10 @@ class DigaTrainer:
     def _teacher_async(self, *inputs):
         """Teacher forward(s) (no grad) on a second HIP stream, concurrent with the student's forward on the current
         one: the passes are independent, and kernels of one fill the CUs that the tile tails of the other leave
-        idle (DIGA_TEACHER_STREAM=0 runs them in line).  Returns one (logits, feat) pair per input; call
+        idle (config.teacher_stream = False runs them in line).  Returns one (logits, feat) pair per input; call
         `_teacher_join` on the result before using it."""
         dev = inputs[0].device
-        if not (inputs[0].is_cuda and os.environ.get("DIGA_TEACHER_STREAM", "1") != "0"):
+        if not (inputs[0].is_cuda and _config.active().teacher_stream):
             with torch.no_grad():
                 return [self.teacher(x)[2:4] for x in inputs]
         if self._side is None:
@@ -151,13 +156,13 @@ class DigaTrainer:
 
     def _student_and_teacher(self, student_in, *teacher_in):
         """Student forward on the current stream, teacher forward(s) on the side stream -- the teacher enqueued from a hook
-        behind the student's first stage (`DIGA_TEACHER_OFFSET`, default `layer1`; `0` = both at once, as before).  Why the
+        behind the student's first stage (config.teacher_offset, default `layer1`; `0` = both at once, as before).  Why the
         offset: student and teacher run the SAME kernel sequence, and two matrix-core kernels launched together share the
         CUs half and half, finish together and leave the BatchNorm / transform passes of both streams to run together with no
         matrix-core kernel in flight (tools/diag/overlap_timeline.py: 52 ms of the forward).  Started one stage apart, a
         persistent GEMM of one stream holds every CU while the other stream's bandwidth passes run under it, and the two
         alternate from then on.  Returns (student outputs, pending teacher outputs for `_teacher_join`)."""
-        where = os.environ.get("DIGA_TEACHER_OFFSET", "layer1")
+        where = _config.active().teacher_offset
         stage = None
         if where not in ("", "0"):
             stage = self.student
@@ -165,7 +170,7 @@ class DigaTrainer:
                 stage = getattr(stage, part, None) if not part.isdigit() else (stage[int(part)] if stage is not None and int(part) < len(stage) else None)
                 if stage is None:
                     break
-        if not isinstance(stage, torch.nn.Module) or os.environ.get("DIGA_TEACHER_STREAM", "1") == "0" or not student_in.is_cuda:
+        if not isinstance(stage, torch.nn.Module) or not _config.active().teacher_stream or not student_in.is_cuda:
             pending = self._teacher_async(*teacher_in)
             return self.student(student_in), pending
         box = {}
@@ -244,13 +249,16 @@ class DigaTrainer:
             g["cat"][B:].copy_(mix)
             g["labels"].copy_(labels)
             self.opt.zero_grad(set_to_none=True)          # the captured backward ASSIGNS the gradients (static buffers of the graph's pool)
-            saved = {k: os.environ.get(k) for k in ("DIGA_TEACHER_STREAM", "DIGA_WGRAD_STREAM")}
-            os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")      # one capture stream
-            try:
+            cfg = _config.active()
+            flag = getattr(self.student, "grad_overflow", None)
+            if flag is not None:
+                _lib.flag_consumed(flag)                  # (the captured forward must contain the flag's clear)
+            # one capture stream: the teacher / weight-gradient side streams are off while capturing, except as FORKED branches
+            with _config.use(cfg.replace(teacher_stream=False, wgrad_stream=False)):
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    if GRAPH_FORK_TEACHER:
+                    if cfg.graph_fork_teacher:
                         # round 5: the teacher's forward on a stream FORKED from the capture stream and joined before the loss -- in the
                         # replayed graph the two networks' forwards are independent branches and run concurrently (the MiT student's
                         # kernels are short and fill a fraction of the chip each)
@@ -266,22 +274,17 @@ class DigaTrainer:
                             t_lr = self.teacher(g["cat"])[2]
                         s_lr = self.student(g["cat"])[2]
                     total, ce, di = L.upsample_ce_distill(s_lr, t_lr, g["labels"], lambda_seg, lambda_distil, self.distill_scale)
-                    if GRAPH_FORK_WGRAD and saved["DIGA_WGRAD_STREAM"] != "0":
-                        os.environ.pop("DIGA_WGRAD_STREAM", None)      # weight gradients as forked branches of the captured graph
-                        _lib.side_overlap = True
-                        try:
-                            total.backward()
-                        finally:
-                            _lib.side_overlap = False
-                            _lib.join_side()
+                    if cfg.graph_fork_wgrad and cfg.wgrad_stream:
+                        # weight gradients as forked branches of the captured graph
+                        with _config.use(cfg.replace(teacher_stream=False, wgrad_stream=True)):
+                            _lib.side_overlap = True
+                            try:
+                                total.backward()
+                            finally:
+                                _lib.side_overlap = False
+                                _lib.join_side()
                     else:
                         total.backward()
-            finally:
-                for k, v in saved.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
             # the captured backward writes into THESE gradient tensors (memory of the graph's pool) on every replay
             g.update(graph=graph, out=(total.detach(), ce, di),
                      grads=[(p, p.grad) for p in self.student.parameters() if p.requires_grad])
@@ -305,9 +308,10 @@ class DigaTrainer:
     # ------------------------------------------------------------------ warm-up step
     def warmup_step(self, it, x, x_aug, rec_s2t, labels, lambda_seg=1.0, lambda_distil=0.5):
         """x, x_aug, rec_s2t [B,3,H,W]; labels [B,H,W] int64.  Returns device scalars (no sync)."""
-        if self.use_graph and x.is_cuda:
-            return self._warmup_step_graphed(it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil)
-        return self._warmup_step_eager(it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil)
+        with _config.use(self._cfg()):
+            if self.use_graph and x.is_cuda:
+                return self._warmup_step_graphed(it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil)
+            return self._warmup_step_eager(it, x, x_aug, rec_s2t, labels, lambda_seg, lambda_distil)
 
     def _warmup_step_eager(self, it, x, x_aug, rec_s2t, labels, lambda_seg=1.0, lambda_distil=0.5):
         self._begin(it)
@@ -325,6 +329,10 @@ class DigaTrainer:
                        lambda_seg=1.0, lambda_distil=0.25):
         """Adds target images `t_img`, their augmented view and offline pseudo-labels; `class_features`
         is a diga_amd.calc_centroids.Class_Features."""
+        with _config.use(self._cfg()):
+            return self._selftrain_step(it, x, x_aug, rec_s2t, labels, t_img, t_aug, pseudo_prob, class_features, lambda_seg, lambda_distil)
+
+    def _selftrain_step(self, it, x, x_aug, rec_s2t, labels, t_img, t_aug, pseudo_prob, class_features, lambda_seg, lambda_distil):
         self._begin(it)
         B = x.shape[0]
         with torch.no_grad():
@@ -336,8 +344,9 @@ class DigaTrainer:
         (_, _, s_lr, _), pending = self._student_and_teacher(cat, cat, t_img)
         # (gloo is the smoke-test backend: its host-synchronous GPU collectives next to extra streams degenerate to seconds per step --
         #  ddp.init_from_env switches the side streams off for it, and the overlapped forms stay off too unless a test asks for them)
-        overlap = C4_OVERLAP
-        if self.world > 1 and torch.distributed.get_backend() == "gloo" and os.environ.get("DIGA_C4_OVERLAP_GLOO") != "1":
+        cfg = _config.active()
+        overlap = cfg.c4_overlap
+        if self.world > 1 and torch.distributed.get_backend() == "gloo" and not cfg.c4_overlap_gloo:
             overlap = 0
         if (x.is_cuda and overlap >= 2 and getattr(self, "_pending_join", False)
                 and len(getattr(self, "_teacher_events", ())) == 2):
@@ -368,7 +377,7 @@ class DigaTrainer:
         return {"total": total.detach(), "ce": ce, "distil": di, "ce_mix": ce_mix.detach()}
 
     def _selftrain_rest_overlapped(self, s_lr, pending, x, labels, t_aug, pseudo_prob, class_features, present, B, lambda_seg, lambda_distil):
-        """C4_OVERLAP = 2 (default): everything behind the student(cat) / teacher(cat) forwards as TWO concurrent branches.
+        """config.c4_overlap = 2 (default): everything behind the student(cat) / teacher(cat) forwards as TWO concurrent branches.
         Main stream: wait for the teacher's pass over `cat` only (an event between its two passes), form CE + distill and start the
         backward pass of the student(cat) graph (weight gradients on their side stream).  Third stream: wait for the teacher's pass
         over the target images, then the consensus filter, ClassMix #2, the two centroid updates, the forward of student(cross_mix),
@@ -376,7 +385,6 @@ class DigaTrainer:
         forwards and the one backward pass.  Host order of every ClassMix draw, BatchNorm running-statistics update
         (student(cat) before student(cross_mix): an event) and centroid update is the reference's; the gradient of a shared weight is
         g_cat + g_cross either way: bit-identical to the one-backward form (tests/test_selftrain.py)."""
-        from diga_amd.model import conv as _dconv
         _accumulate_on_other_streams_is_intended()
         dev = s_lr.device
         main = torch.cuda.current_stream(dev)
@@ -412,13 +420,9 @@ class DigaTrainer:
                             continue
                         sums, counts = ddp.gather_class_sums(sums, counts)
                         class_features._apply(sums, counts, feat.shape[-2] * feat.shape[-1], class_features.min_pixels, 0)
-                # (N > 1: this graph is built AFTER the first one's backward ran, so its convolutions would take themselves for the
-                #  first users of their weights and write into the all-reduce bucket slices that hold the first graph's gradients)
-                _dconv.GRAD_VIEWS = False
-                try:
-                    _, _, c_lr, _ = self.student(cross_mix)
-                finally:
-                    _dconv.GRAD_VIEWS = True
+                # (N > 1: this graph is built AFTER the first one's backward ran; its convolutions see that their bucket slices already
+                #  ARE their parameters' gradients and write into tensors of their own -- model/conv.py, `held`)
+                _, _, c_lr, _ = self.student(cross_mix)
                 ce_mix = L.upsample_ce(c_lr, cross_lab, lambda_seg)
                 g2 = torch.autograd.grad(ce_mix, params, allow_unused=True)
         finally:
@@ -430,18 +434,37 @@ class DigaTrainer:
         return self._join_gradients(params, g2, total_s, ce, di, ce_mix, main)
 
     def _join_gradients(self, params, g2, total_s, ce, di, ce_mix, main):
-        pg, gg = [], []
+        second = {}
         for p, g in zip(params, g2):
-            if g is None:
-                continue
-            g.record_stream(main)
-            if p.grad is None:
-                p.grad = g
-            else:
-                pg.append(p.grad)
-                gg.append(g)
-        if pg:
-            torch._foreach_add_(pg, gg)
+            if g is not None:
+                g.record_stream(main)
+                second[id(p)] = g
+
+        def add(group):
+            pg, gg = [], []
+            for p in group:
+                g = second.get(id(p))
+                if g is None:
+                    continue
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    pg.append(p.grad)
+                    gg.append(g)
+            if pg:
+                torch._foreach_add_(pg, gg)
+
+        if self.reducer.active:
+            # N > 1: bucket by bucket, in the order the buckets leave -- a bucket's all-reduce starts as soon as ITS sum exists and
+            # travels under the adds of the buckets behind it (round 5 added everything, then sent all 260 MB at once)
+            in_buckets = set()
+            for i, bucket in enumerate(self.reducer.buckets):
+                add(bucket)
+                in_buckets.update(id(p) for p in bucket)
+                self.reducer.launch_bucket(i)
+            add([p for p in params if id(p) not in in_buckets])
+        else:
+            add(params)
         ce_mix_d = ce_mix.detach()
         ce_mix_d.record_stream(main)
         total = total_s.detach() + ce_mix_d
@@ -458,7 +481,7 @@ class DigaTrainer:
         stream), while the cross-mixed forward and then ITS backward (torch.autograd.grad: gradients in tensors of their own) run on a
         third stream; one multi-tensor add joins the two gradient sets.  Same terms: grad = g_cat + g_cross, a two-term sum either way
         (fp addition commutes), every kernel and its arithmetic unchanged -- bit-identical to the one-backward form
-        (tests/test_gpu_selftrain.py::test_selftrain_overlapped_tail_is_bit_identical).  DIGA_C4_OVERLAP=0 switches it off."""
+        (tests/test_selftrain.py::test_selftrain_overlapped_tail_is_bit_identical).  config.c4_overlap = 0 switches it off."""
         _accumulate_on_other_streams_is_intended()
         dev = s_lr.device
         main = torch.cuda.current_stream(dev)

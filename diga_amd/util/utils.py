@@ -415,6 +415,8 @@ class DigaSGD(torch.optim.Optimizer):
                   _lib.ptr(tab.chunk_start), tab.n_chunks, CHUNK_ELEMS, float(g0["momentum"]),
                   float(g0["weight_decay"]), 1 if self._first else 0, self.grad_scale,
                   _lib.ptr(found_inf) if found_inf is not None else None, _lib.stream())
+        if found_inf is not None:
+            _lib.flag_consumed(found_inf)          # the owning model clears it at its next training forward, not before
         self._first = False
         return None
 

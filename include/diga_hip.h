@@ -342,19 +342,6 @@ int diga_conv2d_nhwc_twin(const void* in_twin, const void* wgt_img, const float*
                           int64_t stride_y, int64_t stride_x, int64_t off_y0, int64_t off_x0, int64_t off_dy, int64_t off_dx,
                           float* stats_partial, int prof_tag, void* stream);
 
-/* conv1 of a bottleneck fused with the residual junction in front of it (the end of Bottleneck.forward of block b,
- * G5/model/seg_model_noaux.py:96-101 -- out = relu(bn3(conv3(..)) + residual) -- and conv1 of block b + 1, :85-87), exact fp32:
- *   x   [M][x_ld]   = relu(fma(y3, a[k], b[k]) + skip)        a = ab[0..K), b = ab[K..2K): the coefficients diga_bn_fwd* leaves in save_ab
- *   relu_bits [M][K / 8] (nullable) = x > 0, one bit per channel   (what diga_bn_fwd* writes for its consumers' backward epilogues)
- *   out [M][out_ld] = x . W^T,  W [Cout][K];  stats_partial (nullable) as diga_conv2d_nhwc_f32 with 64-row chunks
- * in one launch: the GEMM's loader waves apply the junction while staging their operand and the column-tile-0 blocks store x -- the
- * stand-alone apply pass (3 tensors of M x K) and the GEMM's own read of x disappear.  Same bits as the two separate calls.
- * diga_conv2d_junction_ok: K % 32 == 0, K <= 2048, Cout % 128 == 0, ceil(M / 256) * Cout / 128 >= 512. */
-int diga_conv2d_junction_ok(int64_t M, int64_t K, int64_t Cout);
-int diga_conv2d_junction_f32(const float* y3, int64_t y3_ld, const float* skip, int64_t skip_ld, const float* ab, float* x_out, int64_t x_ld,
-                             unsigned char* relu_bits, const float* wgt, float* out, int64_t out_ld, float* stats_partial, int64_t M,
-                             int64_t K, int64_t Cout, void* stream);
-
 /* Winograd in fp32 for a stride-1 3x3 convolution with padding = dilation (output H x W = input H x W): same result as
  * diga_conv2d_nhwc_f32 with R = S = 3, offsets (-dilation, +dilation) up to fp32 rounding.
  *   tile = 2: F(2x2,3x3), 16 instead of 36 multiplications per 2x2 outputs, transforms with coefficients 0, +-1, +-1/2
@@ -411,18 +398,6 @@ int diga_conv2d_wgrad_winograd_f32(const float* dy, const float* x, const float*
  * weight gradient of the same layer: pass it as `v_kept` above (x may then be null) and the backward skips the input transform
  * -- HBM is 288 GB: the transform is a bandwidth pass of 5x the input's bytes per 3x3 layer. */
 size_t diga_conv2d_winograd_v_floats(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t dilation, int64_t tile);
-/* Forward / backward-weight whose input is the PRE-activation tensor of a train-mode BatchNorm + ReLU without residual
- * (bn1 of a bottleneck in front of its 3x3 conv2, G5/model/seg_model_noaux.py:89-93): the input transform reads
- * relu(fma(in, a[c], b[c])) with in_ab = [2][Cin] = the coefficients diga_bn_fwd* leaves in save_ab (call it with y = NULL:
- * statistics and coefficients only) -- the activated tensor is never written.  v_keep nullable. */
-int diga_conv2d_winograd_f32_ab(const float* in, const float* in_ab, const float* wgt, const float* bias, float* out, float* v_keep,
-                                void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld,
-                                int64_t Cout, int64_t out_ld, int64_t dilation, int64_t tile, float* stats_partial, const void* tile_table,
-                                int prof_tag, void* stream);
-int diga_conv2d_wgrad_winograd_f32_ab(const float* dy, const float* x, const float* x_ab, const float* v_kept, float* dw,
-                                      void* workspace, size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin,
-                                      int64_t x_ld, int64_t Cout, int64_t dy_ld, int64_t dilation, int64_t tile, const void* tile_table,
-                                      void* stream);
 int diga_conv2d_winograd_f32_keep(const float* in, const float* wgt, const float* bias, float* out, float* v_keep, void* workspace,
                                   size_t workspace_bytes, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t in_ld, int64_t Cout,
                                   int64_t out_ld, int64_t dilation, int64_t tile, float* stats_partial, const void* tile_table, int prof_tag,
@@ -512,11 +487,6 @@ int diga_bn_fwd_records(const float* x, int64_t ld_x, float* y, int64_t ld_y, co
                         int y_twin, unsigned char* relu_bits, float momentum, float eps, const float* partial,
                         const float* counts, int64_t n_records, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The apply pass of diga_bn_fwd* on its own: y = [relu](fma(x, a, b) [+ residual]) with ab = the [2][C] coefficients a call with
- * y = NULL left in save_ab (+ the ReLU mask bits).  For a consumer that was handed a deferred BatchNorm output and cannot apply it
- * itself (diga_conv2d_junction_f32 / diga_conv2d_winograd_f32_ab can). */
-int diga_bn_apply(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r, const float* ab, int64_t M,
-                  int64_t C, int relu, unsigned char* relu_bits, void* stream);
 /* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*mask, mask = [y>0] when y is given,
  * [fma(x, a, b) > 0] when relu_ab = save_ab of the forward is given instead (BN without residual), 1 when both are
  * null (no ReLU); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (nullable) = g.  dx_twin != 0: dx (dense,

@@ -51,8 +51,14 @@ class Trainer:
     """Student + EMA teacher + duplicate-aware SGD, all on state dicts."""
 
     def __init__(self, student_sd, teacher_sd, arch=od.RESNET101, base_lr=2.5e-4, max_iter=80000,
-                 power=0.9, momentum=0.9, weight_decay=5e-4, droprate_off=True):
+                 power=0.9, momentum=0.9, weight_decay=5e-4, droprate_off=True, keep_masks=None):
+        """droprate_off=False keeps the head's Dropout2d(arch.droprate) LIVE (seg_model_noaux.py:171,207-208: student and teacher both
+        run it in train mode); its draws then come from `keep_masks(role, n, width)` -> a 0/1 [n, width] tensor, role in
+        ("student", "teacher"), called once per forward pass in the order the passes are listed in the step."""
         self.arch = arch if not droprate_off else od.Arch(**{**arch.__dict__, "droprate": 0.0})
+        if not droprate_off and keep_masks is None:
+            raise ValueError("oracle.step.Trainer: live dropout needs the drawn keep masks (keep_masks=...)")
+        self.keep_masks = None if droprate_off else keep_masks
         self.s, self.t = student_sd, teacher_sd
         self.pkeys, self.tkeys = param_keys(arch), trainable_keys(arch)
         self.bufs = {k: torch.zeros_like(self.s[k]) for k in self.tkeys}
@@ -63,7 +69,10 @@ class Trainer:
             for k in self.pkeys:
                 self.t[k].copy_(self.s[k])
 
-    def _keep(self, n, width=256):
+    def _keep(self, n, width=None, role="student"):
+        width = self.arch.aspp_width if width is None else width
+        if self.keep_masks is not None:
+            return self.keep_masks(role, n, width)
         return torch.ones(n, width)                # dropout forced off (mask of ones, p=0)
 
     def _sgd(self, grads, it):
@@ -86,7 +95,7 @@ class Trainer:
                                    update_stats=True)
         with torch.no_grad():
             _, _, t_lr, _ = od.forward(self.t, cat, self.arch, training=True,
-                                       keep_mask=self._keep(2 * B), update_stats=True)
+                                       keep_mask=self._keep(2 * B, role="teacher"), update_stats=True)
         total, ce, di = ol.warmup_losses_lowres(s_lr, t_lr, labels, lambda_seg, lambda_distil)
         grads = dict(zip(leaves.keys(), torch.autograd.grad(total, list(leaves.values()))))
         lr = self._sgd(grads, it)
@@ -104,9 +113,9 @@ class Trainer:
         _, _, s_lr, _ = od.forward(sd, cat, self.arch, training=True, keep_mask=self._keep(2 * B),
                                    update_stats=True)                            # :281
         with torch.no_grad():
-            _, _, t_lr, t_feat = od.forward(self.t, cat, self.arch, training=True, keep_mask=self._keep(2 * B),
+            _, _, t_lr, t_feat = od.forward(self.t, cat, self.arch, training=True, keep_mask=self._keep(2 * B, role="teacher"),
                                             update_stats=True)                   # :286-287
-            _, _, tt_lr, tt_feat = od.forward(self.t, t_img, self.arch, training=True, keep_mask=self._keep(B),
+            _, _, tt_lr, tt_feat = od.forward(self.t, t_img, self.arch, training=True, keep_mask=self._keep(B, role="teacher"),
                                               update_stats=True)                 # :300
             w = oc.centroid_weight(tt_feat, centroids)                           # :301
             pseudo, _ = oc.consensus_filter(w, pseudo_prob)                      # :302-304

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main(out_dir):
     os.environ["DIGA_DDP_BACKEND"] = "gloo"
-    from diga_amd import _lib, ddp
+    from diga_amd import _lib, config, ddp
     from diga_amd.calc_centroids import Class_Features
     from diga_amd.model import seg_model_noaux as sm
     from diga_amd.model.model_noaux import SegModel
@@ -25,8 +25,8 @@ def main(out_dir):
     if os.environ.get("DIGA_TEST_FORCE_STREAMS") == "1":
         # init_from_env puts gloo runs on one stream (gloo's host-synchronous GPU collectives make the side streams slow, not
         # wrong); the parent asks for them anyway to drive the three-stream self-training step under data parallelism
-        os.environ["DIGA_TEACHER_STREAM"] = "1"
-        os.environ["DIGA_WGRAD_STREAM"] = "1"
+        config.DEFAULTS.teacher_stream = True
+        config.DEFAULTS.wgrad_stream = True
     dev = torch.device("cuda", local)
     _lib.set_conv_math(int(os.environ.get("DIGA_TEST_MATH", "0")))
 

@@ -15,6 +15,8 @@ import random
 import pytest
 import torch
 
+from diga_amd import config
+
 from conftest import assert_close
 from oracle import deeplab as od
 from oracle import detweights, synth
@@ -111,12 +113,12 @@ def test_bottleneck_twin_only_vs_float64_and_bit_identity(case, bf16x3, monkeypa
             hk.remove()
         return out, (seen["m1"].double(), seen["m2"].double(), (out[0] > 0).cpu().double())
 
-    monkeypatch.setenv("DIGA_TWIN_ONLY", "0")
+    monkeypatch.setattr(config.active(), "twin_only", False)
     assert not takes_twin_only_input(blk.conv2)
     g2 = synth.gen(17)
     probe = torch.randn((n, planes * 4, (h - 1) // stride + 1, (w - 1) // stride + 1), generator=g2)
     (y0, dx0, gr0), masks = masks_of(lambda: _run_block(blk, x, probe))
-    monkeypatch.setenv("DIGA_TWIN_ONLY", "1")
+    monkeypatch.setattr(config.active(), "twin_only", True)
     if planes >= 256:
         assert takes_twin_only_input(blk.conv2) and takes_twin_only_input(blk.conv3, pointwise_ok=True)
     y1, dx1, gr1 = _run_block(blk, x, probe)
@@ -191,15 +193,15 @@ def test_resnet101_twin_only_and_side_stream_bit_identity(golden, bf16x3, monkey
     def reset_stats():
         m.load_state_dict(rm0, strict=False)
 
-    monkeypatch.setenv("DIGA_TWIN_ONLY", "1")
+    monkeypatch.setattr(config.active(), "twin_only", True)
     out_a, gr_a = _fwd_bwd(m, x, probe, side=True)
     reset_stats()
     out_b, gr_b = _fwd_bwd(m, x, probe, side=False)
     reset_stats()
-    monkeypatch.setenv("DIGA_TWIN_CONV3", "0")
+    monkeypatch.setattr(config.active(), "twin_conv3", "0")
     out_c, gr_c = _fwd_bwd(m, x, probe, side=False)
     reset_stats()
-    monkeypatch.setenv("DIGA_TWIN_ONLY", "0")
+    monkeypatch.setattr(config.active(), "twin_only", False)
     out_d, gr_d = _fwd_bwd(m, x, probe, side=False)
     assert len(gr_a) == sum(1 for p in m.parameters() if p.requires_grad)
     for tag, out, gr in (("side stream off", out_b, gr_b), ("conv3 off twins", out_c, gr_c), ("twin-only off", out_d, gr_d)):
@@ -319,13 +321,13 @@ def test_residual_junction_fused_backward_vs_float64(planes, inpl, dil, n, h, w,
         calls.append(name)
         return orig(name, *a)
     monkeypatch.setattr(_lib, "call", counting)
-    monkeypatch.setenv("DIGA_TWIN_ONLY", "0")                      # readable BN outputs for the mask hooks
-    monkeypatch.setenv("DIGA_FUSE_BWD", "0")
+    monkeypatch.setattr(config.active(), "twin_only", False)                      # readable BN outputs for the mask hooks
+    monkeypatch.setattr(config.active(), "fuse_bwd", False)
     masks = {}
     y0, dx0, gr0 = run(masks)
     assert not any(c.endswith("_epi") for c in calls) and "diga_bn_bwd_partials" not in calls
-    monkeypatch.delenv("DIGA_TWIN_ONLY")
-    monkeypatch.setenv("DIGA_FUSE_BWD", "1")
+    monkeypatch.setattr(config.active(), "twin_only", True)
+    monkeypatch.setattr(config.active(), "fuse_bwd", True)
     assert dn.fuse_backward_enabled()
     calls.clear()
     y1, dx1, gr1 = run()
@@ -334,10 +336,10 @@ def test_residual_junction_fused_backward_vs_float64(planes, inpl, dil, n, h, w,
     assert calls.count("diga_bn_bwd_partials") == 8 and calls.count("diga_bn_bwd") == 1     # bn3 of the last block stays plain
     assert torch.equal(y0, y1)
     # the junction epilogues read the ReLU mask as one bit per element (relu_bits of diga_bn_fwd*); reading the BatchNorm
-    # output instead (DIGA_RELU_BITS=0) is the same mask: bit-identical gradients
-    monkeypatch.setenv("DIGA_RELU_BITS", "0")
+    # output instead (config.relu_bits = False) is the same mask: bit-identical gradients
+    monkeypatch.setattr(config.active(), "relu_bits", False)
     y2, dx2, gr2 = run()
-    monkeypatch.delenv("DIGA_RELU_BITS")
+    monkeypatch.setattr(config.active(), "relu_bits", True)
     assert torch.equal(y2, y1) and torch.equal(dx2, dx1)
     for k in gr1:
         assert torch.equal(gr1[k], gr2[k]), k
@@ -382,7 +384,7 @@ def test_fused_gradient_with_a_second_consumer_falls_back(bf16x3):
     side = torch.randn((1, 1024, 19, 17), generator=g).to(DEV)
     res = {}
     for fuse in ("1", "0"):
-        os.environ["DIGA_FUSE_BWD"] = fuse
+        config.active().fuse_bwd = fuse == "1"
         try:
             for b in blocks:
                 for p in b.parameters():
@@ -394,7 +396,7 @@ def test_fused_gradient_with_a_second_consumer_falls_back(bf16x3):
             torch.cuda.synchronize()
             res[fuse] = (xd.grad.clone(), {k: p.grad.clone() for k, p in blocks[0].named_parameters() if p.grad is not None})
         finally:
-            os.environ.pop("DIGA_FUSE_BWD", None)
+            config.active().fuse_bwd = True
     dx1, g1 = res["1"]
     dx0, g0 = res["0"]
     assert float((dx1 - dx0).abs().max()) <= 3e-5 * float(dx0.abs().max())
@@ -438,12 +440,12 @@ def test_whole_model_gradients_vs_float64_with_pinned_switches(conv_math, arch_n
             hooks.append(mod.register_forward_hook(lambda mo, i, o, n=names[mod]: seen.__setitem__(n, (o.detach() > 0).cpu().double())))
     hooks.append(m.layer0[3].register_forward_hook(lambda mo, i, o: seen.__setitem__("pool_in", i[0].detach().cpu().double())))
     hooks.append(m.final.bottleneck[0].se[1].register_forward_hook(lambda mo, i, o: seen.__setitem__("se", (o.detach() > 0).cpu().double())))
-    os.environ["DIGA_TWIN_ONLY"] = "0"
+    config.active().twin_only = False
     try:
         with torch.no_grad():
             out_plain = m(xd)[2]
     finally:
-        os.environ.pop("DIGA_TWIN_ONLY")
+        config.active().twin_only = True
         for h in hooks:
             h.remove()
     masks = {"layer0": seen["layer0.1"], "se": seen["se"],

@@ -91,100 +91,3 @@ def test_second_backward_through_a_gradient_chain_raises():
     assert x.grad is not None and float(x.grad.abs().sum()) > 0
     with pytest.raises(RuntimeError, match="second backward"):
         loss.backward()
-
-
-def test_deferred_bn1_apply_is_bit_identical(monkeypatch):
-    """fp32: bn1 of a bottleneck computes statistics and coefficients only and conv2's Winograd input transform applies
-    relu(fma(y1, a, b)) on load (diga_conv2d_winograd_f32_ab; the weight gradient reads the kept transform or re-applies the
-    coefficients): output, input gradient and every weight gradient equal the run with the stand-alone apply pass bit for bit."""
-    from diga_amd import _lib
-    from diga_amd.model import conv as _dconv
-    from diga_amd.model import seg_model_noaux as sm
-    torch.manual_seed(3)
-    blk = sm.Bottleneck(1024, 256, 1, dilation=2).to(DEV).train()
-    g = torch.Generator().manual_seed(8)
-    x0 = torch.randn((2, 1024, 19, 17), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
-    probe = torch.randn((2, 1024, 19, 17), generator=g).to(DEV)
-    prev = _lib.get_conv_math()
-    _lib.set_conv_math(0)
-    calls, real = [], _lib.call
-    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
-    try:
-        res = []
-        for fuse, keep in (("0", "1"), ("1", "1"), ("1", "0")):
-            monkeypatch.setattr(_dconv, "FUSE_BN1", fuse == "1")
-            monkeypatch.setattr(_dconv, "WINOGRAD_KEEP_V", keep == "1")
-            for p_ in blk.parameters():
-                p_.grad = None
-            sd = {k: v.clone() for k, v in blk.state_dict().items()}
-            calls.clear()
-            x = x0.clone().requires_grad_()
-            y = blk(x)
-            (y * probe).sum().backward()
-            assert ("diga_conv2d_winograd_f32_ab" in calls) == (fuse == "1"), calls
-            assert ("diga_conv2d_wgrad_winograd_f32_ab" in calls) == (fuse == "1"), calls
-            res.append([y.detach().clone(), x.grad.clone()] + [getattr(blk, c).weight.grad.clone() for c in ("conv1", "conv2", "conv3")]
-                       + [blk.bn1.running_mean.clone(), blk.bn1.running_var.clone()])
-            blk.load_state_dict(sd)              # (running statistics back to where they were)
-    finally:
-        _lib.set_conv_math(prev)
-    for other in res[1:]:
-        for a, b in zip(res[0], other):
-            assert torch.equal(a, b)
-
-
-def test_fused_residual_junction_is_bit_identical(monkeypatch):
-    """fp32: inside a whole-network forward (norm.junction_fusion) bn3 of a bottleneck leaves relu(bn3(y3) + skip) to conv1 of the next
-    block, whose persistent GEMM applies it while staging its operand and stores the activated tensor + ReLU mask bits
-    (diga_conv2d_junction_f32).  Three chained layer3-width blocks: outputs, input gradient, every weight gradient and the BatchNorm
-    running statistics equal the run with stand-alone apply passes bit for bit; a consumer that cannot fuse (here: the chain called
-    with a conv1 the GEMM does not take) falls back to the stand-alone pass."""
-    from diga_amd import _lib
-    from diga_amd.model import norm as dn
-    from diga_amd.model import seg_model_noaux as sm
-    monkeypatch.setattr(dn, "JUNCTION_FUSION", 2)              # every eligible consumer (the default fuses single-column-tile ones only)
-    torch.manual_seed(5)
-    blocks = torch.nn.Sequential(*[sm.Bottleneck(1024, 256, 1, dilation=2) for _ in range(3)]).to(DEV).train()
-    for b in blocks[:-1]:
-        b.defer_out, b.next_conv1 = True, (256, (1, 1))
-    g = torch.Generator().manual_seed(9)
-    x0 = torch.randn((8, 1024, 97, 97), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
-    probe = torch.randn((8, 1024, 97, 97), generator=g).to(DEV)
-    prev = _lib.get_conv_math()
-    _lib.set_conv_math(0)
-    calls, real = [], _lib.call
-    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
-    try:
-        res = []
-        for fused in (False, True):
-            for p_ in blocks.parameters():
-                p_.grad = None
-            sd = {k: v.clone() for k, v in blocks.state_dict().items()}
-            calls.clear()
-            x = x0.clone().requires_grad_()
-            if fused:
-                with dn.junction_fusion():
-                    y = blocks(x)
-            else:
-                y = blocks(x)
-            (y * probe).sum().backward()
-            assert calls.count("diga_conv2d_junction_f32") == (2 if fused else 0), calls.count("diga_conv2d_junction_f32")
-            assert calls.count("diga_bn_apply") == 0
-            res.append([y.detach().clone(), x.grad.clone()] + [p_.grad.clone() for p_ in blocks.parameters() if p_.grad is not None]
-                       + [v.clone() for k, v in blocks.state_dict().items() if "running" in k])
-            blocks.load_state_dict(sd)
-        for a, b in zip(res[0], res[1]):
-            assert torch.equal(a, b)
-        # a deferred junction whose consumer cannot fuse: materialised by the stand-alone pass, same bits
-        calls.clear()
-        with dn.junction_fusion():
-            mid = blocks[0](x0)
-            assert getattr(mid, "_diga_lazy_junction", None) is not None and not mid._diga_lazy_junction["filled"]
-            narrow = sm.Bottleneck(1024, 16, 1, dilation=2).to(DEV).train()          # conv1 into 16 channels: not a persistent-GEMM shape
-            narrow(mid)
-        assert calls.count("diga_bn_apply") == 1 and mid._diga_lazy_junction["filled"]
-        with torch.no_grad():
-            want = blocks[0](x0)
-        assert torch.equal(mid.detach(), want)
-    finally:
-        _lib.set_conv_math(prev)

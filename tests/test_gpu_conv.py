@@ -7,6 +7,8 @@ import zlib
 
 import pytest
 import torch
+
+from diga_amd import config
 import torch.nn.functional as F
 
 from conftest import WINO_TOL, assert_close, winograd_tile
@@ -51,7 +53,7 @@ def test_conv_fwd_bwd(case, tile_cap, monkeypatch):
     if tile_cap < 6:
         if default_tile <= tile_cap:
             pytest.skip("the default path is this one already")
-        monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", tile_cap)
+        monkeypatch.setattr(config.active(), "winograd_max_tile", tile_cap)
     tile = winograd_tile(n, cin, h, w, cout, k, stride, pad, dil)
     # absolute part of the bound, in units of the tensor's scale: y / dx / dw
     a_y, a_dx, a_dw = (WINO_TOL[tile][0], WINO_TOL[tile][0], WINO_TOL[tile][1]) if tile > 2 else (2e-6, 3e-6, 3e-6)
@@ -232,9 +234,9 @@ def test_twin_path_matches_register_staged_path_and_is_shared(bf16x3, monkeypatc
     convs = [DigaConv2d(256, 160, 3, padding=d, dilation=d, bias=True).to(DEV) for d in (1, 6)] + \
             [DigaConv2d(256, 128, 1, bias=False).to(DEV)]
     with torch.no_grad():
-        monkeypatch.setenv("DIGA_CONV_TWIN", "0")
+        monkeypatch.setattr(config.active(), "conv_twin", "0")
         ref = [c(x) for c in convs]
-        monkeypatch.setenv("DIGA_CONV_TWIN", "3")
+        monkeypatch.setattr(config.active(), "conv_twin", "3")
         calls = []
         orig = _lib.call
 
@@ -371,8 +373,8 @@ def test_winograd_output_transform_bn_statistics(case, tile, monkeypatch):
     name, n, cin, h, w, cout, dil = case
     if cout % 4 != 0:
         pytest.skip("statistics need Cout % 4 == 0")
-    monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", tile)
-    monkeypatch.setattr(dc, "WINOGRAD_RATIO", 10.0)
+    monkeypatch.setattr(config.active(), "winograd_max_tile", tile)
+    monkeypatch.setattr(config.active(), "winograd_ratio", 10.0)
     if winograd_tile(n, cin, h, w, cout, 3, 1, dil, dil) != tile:
         pytest.skip("this geometry does not take this tile")
     g = synth.gen(zlib.crc32(name.encode()) % 10000 + 11 + tile)
@@ -394,7 +396,7 @@ def test_winograd_output_transform_bn_statistics(case, tile, monkeypatch):
     part = getattr(y, "_diga_bn_partials", None)
     assert part is not None and part[1][0] == "records" and part[1][1] > 0
     fused = bn_a(y, relu=True)
-    monkeypatch.setattr(dc, "WINOGRAD_STATS", False)
+    monkeypatch.setattr(config.active(), "winograd_stats", False)
     y2 = conv(xd)
     assert not hasattr(y2, "_diga_bn_partials") and torch.equal(y2, y)
     plain = bn_b(y2, relu=True)
@@ -426,7 +428,7 @@ def test_winograd_f32_vs_float64(case, tile, monkeypatch):
     from diga_amd.model import conv as dc
     name, n, cin, h, w, cout, d = case
     monkeypatch.setattr(dc, "WINOGRAD", True)
-    monkeypatch.setattr(dc, "WINOGRAD_RATIO", 10.0)
+    monkeypatch.setattr(config.active(), "winograd_ratio", 10.0)
     monkeypatch.setattr(dc, "_wino_plan", lambda hi, wi, dd: (tile, 0.5))
     calls = []
     real = _lib.call
@@ -464,7 +466,7 @@ def test_winograd_f32_vs_float64(case, tile, monkeypatch):
         assert e < WINO_TOL[tile][1 if what == "dw" else 0], (what, e)
         print(f"winograd tile {tile} {name} {what}: max err / scale = {e:.2e}")
     if wide:                                           # ... and the same gradient when the backward recomputes V
-        monkeypatch.setattr(dc, "WINOGRAD_KEEP_V", False)
+        monkeypatch.setattr(config.active(), "winograd_keep_v", False)
         dw_kept = m.weight.grad.clone()
         m.weight.grad = None
         _lib.set_conv_math(0)
@@ -485,7 +487,7 @@ def test_persistent_gemm_bit_identical_to_per_tile_launch(tile, monkeypatch):
     from diga_amd.model import conv as dc
     from diga_amd.model.conv import DigaConv2d
     monkeypatch.setattr(dc, "WINOGRAD", True)
-    monkeypatch.setattr(dc, "WINOGRAD_RATIO", 10.0)
+    monkeypatch.setattr(config.active(), "winograd_ratio", 10.0)
     monkeypatch.setattr(dc, "_wino_plan", lambda hi, wi, dd: (tile, 0.5))
     prev = _lib.get_conv_math()
     _lib.set_conv_math(0)

@@ -151,6 +151,28 @@ def test_two_rank_selftraining_step_same_in_all_three_forms(tmp_path, conv_math)
 
 
 @pytest.mark.timeout(1500)
+def test_rccl_single_rank_runs_the_production_reducer_path():
+    """RCCL code in the driver's GPU test (round 6): a child process brings up a ONE-rank "nccl" process group on the box's GPU with
+    the reducer forced active (config.ddp_single_rank) and runs the warm-up step and the self-training step in all three forms --
+    hook-driven buckets on RCCL's stream next to the teacher / weight-gradient side streams, gradients living in the bucket slices,
+    the three-stream self-training form with the hooks held and per-bucket launches after the join, the class-sum all-gather --
+    against the same steps without a reducer: bit-identical students, centroid banks and losses (tests/rccl_single_rank_worker.py;
+    it exits non-zero on any difference).  What only > 1 rank can show -- that the sum over ranks is right -- is the gloo tests' job
+    above (`test_two_rank_*`)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("DIGA_DDP_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=1400, cwd=ROOT)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "rccl single-rank worker OK" in r.stdout and r.stdout.count("== plain run bit for bit") == 4
+
+
+@pytest.mark.timeout(1500)
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per device (the 1-GPU test box skips it)")
 def test_bench_two_ranks_over_rccl():
     """The distributed path as the driver launches it, on real RCCL: `bench.py --gpus 2 --lean` (two worker processes, one per

@@ -11,6 +11,8 @@ import ctypes
 import numpy as np
 import pytest
 import torch
+
+from diga_amd import config
 import torch.nn.functional as F
 
 from oracle import mit as om
@@ -504,6 +506,107 @@ def test_segformer_student_warmup_step_vs_oracle_composition(head):
         assert float(got["distil"]) == pytest.approx(float(di), rel=5e-3)
     finally:
         _lib.set_conv_math(prev)
+
+
+def _segformer_selftrain_setup(golden):
+    import random
+    from diga_amd.calc_centroids import Class_Features
+    from diga_amd.model.segformer import SegFormerStudent
+    from diga_amd.train_step import DigaTrainer
+    from oracle import deeplab as od
+    from oracle import detweights
+    sd_b = om.state_dict(om.MIT_B1)
+    head_shapes = {k: v for k, v in od.state_shapes(od.RESNET101).items() if k.startswith("final.")}
+    sd_h = {}
+    for k, (shp, kind) in head_shapes.items():
+        if k.startswith("final.conv2d_list.") and k.endswith(".0.weight"):
+            shp = (shp[0], 512, shp[2], shp[3])
+        sd_h[k[len("final."):]] = detweights.fill("seg." + k, shp, kind)
+
+    def make():
+        m = SegFormerStudent("mit_b1", head="aspp")
+        m.backbone.load_state_dict(sd_b)
+        m.final.load_state_dict(sd_h)
+        m.set_head_dropout(0.0)
+        m.backbone.reset_drop_path(0.0)
+        return m.to(DEV)
+
+    student, teacher = make(), make()
+    teacher.train()
+    tr = DigaTrainer(student, teacher, rng=random)
+    cf = Class_Features(numbers=19)
+    cf.objective_vectors = golden("selftrain").t("cents0").clone().to(DEV)
+    return student, teacher, tr, cf
+
+
+@pytest.mark.parametrize("overlap", [0, 2])
+def test_segformer_selftraining_step_keeps_an_overflow_of_the_first_graph(golden, monkeypatch, overlap):
+    """the overlapped self-training step runs the forward of student(cross_mix) next to / after the backward
+    of student(cat).  The MiT encoder used to clear its fp16-overflow flag in EVERY training forward, so the second forward could
+    erase an overflow the first graph's backward had raised and the optimizer applied inf / NaN gradients.  The flag is now cleared
+    only by the first training forward after an optimizer step has consumed it (_lib.take_consumed_flag).  Here the DISTILLATION
+    term -- part of the first graph only -- is scaled until its fp16 branch gradients overflow while CE_mix (second graph) stays
+    clean: the step must be skipped on the device (parameters and momentum untouched, flag raised, counted once), and the next
+    ordinary step must clear the flag and move the weights."""
+    import random
+    monkeypatch.setattr(config.active(), "c4_overlap", overlap)
+    student, teacher, tr, cf = _segformer_selftrain_setup(golden)
+    before = {k: p.detach().clone() for k, p in student.named_parameters()}
+    batch = [t.to(DEV) for t in synth.selftrain_batch(3100, 2, 128, 160, block=16)]
+    random.seed(11)
+    log = tr.selftrain_step(1, *batch, cf, lambda_distil=1.0e12)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(log["ce_mix"]).all())                       # the second graph's loss is an ordinary number
+    assert student.grad_overflow.cpu().tolist() == [1, 1]
+    for k, p in student.named_parameters():
+        assert torch.equal(p.detach(), before[k]), k
+    random.seed(12)
+    log = tr.selftrain_step(2, *batch, cf)
+    torch.cuda.synchronize()
+    assert student.grad_overflow.cpu().tolist() == [0, 1]
+    assert all(bool(torch.isfinite(p).all()) for p in student.parameters())
+    assert any(not torch.equal(p.detach(), before[k]) for k, p in student.named_parameters())
+
+
+def test_mit_overflow_flag_survives_a_forward_before_the_optimizer_step(golden):
+    """The unit form of the above: forward, overflowing backward, ANOTHER training forward (no optimizer step in between) -- the flag
+    stays up; after DigaSGD.step(found_inf=flag) the next forward clears it."""
+    from diga_amd.util import utils as U
+    g = golden("mit")
+    m = _model("mit_b1").eval()
+    x = g.t("x").to(DEV)
+    opt = U.DigaSGD([{"params": list(m.parameters())}], lr=1e-2, momentum=0.9, weight_decay=0.0)
+    outs = m(x)
+    (sum((o * g.t(f"probe{i + 1}").to(DEV)[:, : o.shape[1]]).sum() for i, o in enumerate(outs)) * 1.0e9).backward()
+    assert m.grad_overflow.cpu().tolist() == [1, 1]
+    m(x)                                                           # a second graph's forward: must not erase the verdict
+    assert m.grad_overflow.cpu().tolist() == [1, 1]
+    opt.step(found_inf=m.grad_overflow)                            # skipped on the device; the flag is consumed
+    m(x)
+    assert m.grad_overflow.cpu().tolist() == [0, 1]
+
+
+def test_mit_student_twice_in_one_backward_with_side_stream_weight_gradients(golden, monkeypatch):
+    """with the weight gradients on the side stream (`_lib.side_overlap`) a MiT student that enters ONE
+    backward pass twice (the one-backward self-training form) has two contributions per parameter summed by autograd on the main
+    stream; the second one must not be added to a first one that is still in flight.  Parameters after the step with the side
+    stream equal the in-line run."""
+    import random
+    monkeypatch.setattr(config.active(), "c4_overlap", 0)                         # student(cat) and student(cross_mix) in one backward pass
+    res = []
+    for side in (True, False):
+        student, teacher, tr, cf = _segformer_selftrain_setup(golden)
+        if not side:
+            monkeypatch.setattr(config.active(), "wgrad_stream", False)
+        batch = [t.to(DEV) for t in synth.selftrain_batch(3200, 2, 128, 160, block=16)]
+        random.seed(13)
+        for it in (1, 2):
+            tr.selftrain_step(it, *batch, cf)
+        torch.cuda.synchronize()
+        res.append({k: p.detach().clone() for k, p in student.named_parameters()})
+        monkeypatch.setattr(config.active(), "wgrad_stream", True)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
 
 
 def test_gemm_nt_256_row_tile_variant():

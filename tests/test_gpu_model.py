@@ -143,6 +143,63 @@ def test_tiny_model_train_step_vs_oracle():
         assert_close(teacher.state_dict()[k], otr.t[k], 2e-3, 2e-5, k)
 
 
+@pytest.mark.parametrize("arch_name", ["TINY", "RESNET101"])
+def test_warmup_step_live_dropout_vs_oracle(arch_name):
+    """The reference's student AND teacher run nn.Dropout2d(0.1) in train mode (G5/model/seg_model_noaux.py:171,207-208; the teacher
+    is never .eval()'d): a per-(image, channel) keep mask scales the head's GroupNorm output, `feat` is the dropped tensor, the
+    gradient flows through the mask.  Every other model-level pin forces p = 0 (the draws are not portable); here p = 0.1 stays
+    LIVE and the masks are drawn on the host and injected into both sides -- `Classifier_Module2._drop_scale` (-> `chan_scale` of
+    the GroupNorm apply kernel -> its backward) and the oracle's `keep_mask` (oracle/step.py) -- so the wiring bench.py times is
+    compared term by term: losses of two steps, the head / bottleneck / trunk weights after them, and that the masks were consumed
+    (2 B rows per pass and network)."""
+    from diga_amd.train_step import DigaTrainer
+    from oracle import step as ost
+    arch_o = getattr(od, arch_name)
+    student, teacher = _model(arch_name), _model(arch_name)
+    teacher.train()
+    assert student.final.head[0].p == pytest.approx(0.1) and teacher.final.head[0].p == pytest.approx(0.1)
+    B, H, W = 2, (96 if arch_name == "TINY" else 128), 128
+    width = arch_o.aspp_width
+    gm = synth.gen(4242)
+    drawn = {("student", it): (torch.rand((2 * B, width), generator=gm) >= 0.1).float() for it in range(2)}
+    drawn.update({("teacher", it): (torch.rand((2 * B, width), generator=gm) >= 0.1).float() for it in range(2)})
+    assert all(0.0 < float(1 - m.mean()) < 0.25 for m in drawn.values())          # channels ARE dropped
+    now = {"it": 0}
+    used = []
+
+    def inject(role, head):
+        def _drop_scale(n, c, device):
+            assert head.head[0].training and (n, c) == (2 * B, width)
+            used.append((role, now["it"]))
+            return (drawn[(role, now["it"])] / (1.0 - head.head[0].p)).to(device)
+        head._drop_scale = _drop_scale
+
+    inject("student", student.final)
+    inject("teacher", teacher.final)
+    otr = ost.Trainer(detweights.state_dict(arch_o), detweights.state_dict(arch_o), arch=arch_o, droprate_off=False,
+                      keep_masks=lambda role, n, w: drawn[(role, now["it"])])
+    for it in range(2):
+        now["it"] = it
+        batch = synth.warmup_batch(900 + it, B, H, W, block=16)
+        random.seed(it)
+        want = otr.warmup_step(it, *batch, random)
+        random.seed(it)
+        if it == 0:
+            first_want = want
+            tr = DigaTrainer(student, teacher, rng=random)
+        got = tr.warmup_step(it, *(t.to(DEV) for t in batch))
+        assert float(got["ce"]) == pytest.approx(want["ce"], rel=1e-3), it
+        assert float(got["distil"]) == pytest.approx(want["distil"], rel=1e-3), it
+    assert sorted(used) == sorted([("student", 0), ("teacher", 0), ("student", 1), ("teacher", 1)])
+    # and the masks matter: the same step without them gives another loss (the comparison above is not vacuous)
+    plain = ost.Trainer(detweights.state_dict(arch_o), detweights.state_dict(arch_o), arch=arch_o)
+    random.seed(0)
+    assert abs(plain.warmup_step(0, *synth.warmup_batch(900, B, H, W, block=16), random)["distil"] - first_want["distil"]) > 1e-4 * abs(first_want["distil"])
+    for k in ["layer0.0.weight", "layer3.1.conv2.weight", "final.head.1.weight", "final.bottleneck.1.weight", "final.conv2d_list.1.0.weight"]:
+        assert_close(student.state_dict()[k], otr.s[k], 2e-3, 2e-5, k)
+        assert_close(teacher.state_dict()[k], otr.t[k], 2e-3, 2e-5, k)
+
+
 def test_tiny_model_16_class_step_vs_oracle():
     """16-class mode of the Synthia tree: the same step with a 16-way head -- exercises the
     C = 16 instantiations of the fused loss block -- against the oracle."""

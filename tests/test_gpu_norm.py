@@ -236,6 +236,42 @@ def test_aspp_head_golden(golden, conv_math):
     assert seen_smooth == len(smooth)
 
 
+def test_aspp_head_live_dropout_golden(golden, conv_math):
+    """Classifier_Module2 in TRAIN mode with Dropout2d(0.1) live against the reference head's own run (tests/golden/aspp_dropout.npz):
+    the (image, channel) keep mask the reference drew is injected through `_drop_scale` -> `chan_scale` of the GroupNorm apply
+    kernel; logits, the dropped `feat`, the input gradient and the head-side weight gradients (through the mask) must be the
+    reference's."""
+    from diga_amd.model.seg_model_noaux import Classifier_Module2
+    g = golden("aspp_dropout")
+    head = Classifier_Module2(64, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    sd = {}
+    for k, v in head.state_dict().items():
+        kind = "conv" if v.dim() == 4 else "lin" if v.dim() == 2 else "gn_w" if k.endswith("weight") else "bias"
+        sd[k] = detweights.fill("aspp64." + k, tuple(v.shape), kind)
+    head.load_state_dict(sd)
+    head = head.to(DEV).train()
+    keep = g.t("keep")
+    assert head.head[0].p == pytest.approx(0.1)
+    head._drop_scale = lambda n, c, device: (keep / (1.0 - head.head[0].p)).to(device)
+    x = _cl(g.t("x")).requires_grad_()
+    res = head(x, get_feat=True)
+    assert_close(res["out"], g.t("out"), 1e-3, 1e-4, "head logits")
+    assert_close(res["feat"], g.t("feat"), 1e-3, 1e-4, "head feat (dropped)")
+    assert bool((res["feat"].detach().abs().amax(dim=(2, 3)) > 0).float().cpu().eq(keep).all())
+    ((res["out"] * g.t("probe").to(DEV)).sum() + (res["feat"] * g.t("probe_f").to(DEV)).sum()).backward()
+    frac, l2 = (1e-4, 1e-3) if conv_math == 0 else (1e-2, 1e-2)
+    assert_mostly_close(x.grad, g.t("gx"), 2e-3, 2e-5, frac, l2, "grad x")
+    for k in ("bottleneck.1.weight", "bottleneck.1.bias", "bottleneck.2.weight", "bottleneck.2.bias", "head.1.weight"):
+        gk = "gw_" + k.replace(".", "_")
+        ref = g.t(gk) if gk in g else g.t(gk + "__sample")
+        got = head.get_parameter(k).grad
+        got = got if gk in g else got.reshape(-1)[::97]
+        if conv_math == 0:
+            assert_close(got, ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, gk)
+        else:
+            assert_mostly_close(got, ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, frac, l2, gk)
+
+
 @pytest.mark.parametrize("n,k,o,act", [(16, 1280, 80, 1), (16, 80, 1280, 2), (3, 37, 5, 0), (1, 64, 64, 2)])
 def test_small_linear_forward_backward_vs_float64(n, k, o, act):
     """The SE block's dense layers (diga_small_linear_fwd / _bwd: Linear + none / ReLU / sigmoid) against torch in float64:

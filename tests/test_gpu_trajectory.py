@@ -8,7 +8,7 @@ step 0 (strided samples), BatchNorm running statistics of both networks and eval
 What this pins that the 3-step golden (test_gpu_model.py::test_warmup_three_steps_golden) cannot: that a per-layer arithmetic
 difference (the F(6x6,3x3) / F(4x4,3x3) Winograd tiles of the exact-fp32 path: 2.7e-5 of scale per layer against 7e-7 for
 F(2x2); the split-bf16 path: 3e-5) does not COMPOUND through batch-statistics BatchNorm + momentum SGD + the EMA teacher.  The
-test runs the same trajectory with the default tiles, with every layer capped at F(2x2) (conv.WINOGRAD_MAX_TILE = 2: the direct
+test runs the same trajectory with the default tiles, with every layer capped at F(2x2) (config.winograd_max_tile = 2: the direct
 kernels' error level) and in split bf16, prints the per-step deviation of each, and holds each to a small multiple of the trajectory's
 own rounding floor -- the distance between two runs of the REFERENCE that differ only in summation order, stored in the capture.  The deviation of the large tiles must not grow faster than
 F(2x2)'s: `growth` = mean deviation of the last five steps / mean of the first five.
@@ -20,6 +20,8 @@ import random
 import numpy as np
 import pytest
 import torch
+
+from diga_amd import config
 
 from oracle import deeplab as od
 from oracle import detweights, synth
@@ -80,12 +82,11 @@ def run_trajectory_once(name, g, mode):
 def run_trajectory(g, mode):
     """Runs the capture's trajectory through DigaTrainer; returns the deviations (a dict of floats / lists)."""
     from diga_amd import _lib
-    from diga_amd.model import conv as dc
     from diga_amd.train_step import DigaTrainer
     B, H, W, steps, seed0, block, mix_seed = (int(v) for v in g["geometry"])
-    prev_math, prev_tile = _lib.get_conv_math(), dc.WINOGRAD_MAX_TILE
+    prev_math, prev_tile = _lib.get_conv_math(), config.active().winograd_max_tile
     _lib.set_conv_math(1 if mode == "bf16x3" else 0)
-    dc.WINOGRAD_MAX_TILE = 2 if mode == "f32_tile2" else 6
+    config.active().winograd_max_tile = 2 if mode == "f32_tile2" else 6
     try:
         student, teacher = _model(), _model()
         for mdl in (student, teacher):
@@ -135,7 +136,7 @@ def run_trajectory(g, mode):
         return res
     finally:
         _lib.set_conv_math(prev_math)
-        dc.WINOGRAD_MAX_TILE = prev_tile
+        config.active().winograd_max_tile = prev_tile
         _lib.join_side()
 
 
@@ -196,9 +197,9 @@ def run_selftraining_trajectory(g, mode, overlap):
     from diga_amd import train_step as ts
     from diga_amd.calc_centroids import Class_Features
     B, H, W, steps, seed0, block, mix_seed = (int(v) for v in g["geometry"])
-    prev_math, prev_overlap = _lib.get_conv_math(), ts.C4_OVERLAP
+    prev_math, prev_overlap = _lib.get_conv_math(), config.active().c4_overlap
     _lib.set_conv_math(1 if mode == "bf16x3" else 0)
-    ts.C4_OVERLAP = overlap
+    config.active().c4_overlap = overlap
     try:
         student, teacher = _model(), _model()
         for mdl in (student, teacher):
@@ -239,7 +240,7 @@ def run_selftraining_trajectory(g, mode, overlap):
         return res
     finally:
         _lib.set_conv_math(prev_math)
-        ts.C4_OVERLAP = prev_overlap
+        config.active().c4_overlap = prev_overlap
         _lib.join_side()
 
 

@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 import torch
+
+from diga_amd import config
 import torch.multiprocessing as mp
 
 from conftest import ROOT
@@ -78,8 +80,6 @@ def test_abi_argument_errors_without_gpu():
     rc = _lib.lib.diga_conv2d_winograd_f32_opts(16, 16, None, 16, 16, 1 << 30, 1, 8, 8, 128, 128, 128, 128, 1, 6, ctypes.byref(opt), None, 0, None)
     assert rc == -1 and "reflect_pad" in _lib.last_error()
     assert _lib.lib.diga_bn_fwd_records(16, 4, 16, 4, None, 4, 16, 16, None, None, 16, 16, None, 8, 4, 0, 0, None, 0.1, 1e-5, 16, None, 4, 16, 1 << 20, None) == -1
-    assert _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 1024, 256) == 1 and _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 1024, 64) == 0
-    assert _lib.lib.diga_conv2d_junction_ok(4 * 97 * 97, 1024, 256) == 0 and _lib.lib.diga_conv2d_junction_ok(16 * 97 * 97, 4096, 256) == 0
     assert _lib.lib.diga_small_linear_fwd(None, None, None, None, 1, 1, 1, 0, None) == -1
     assert _lib.lib.diga_nonfinite_flag_f32(None, 4, None, None) == -1 and _lib.lib.diga_colsum_nhwc(None, 4, None, 4, 4, None, 0, None) == -1
 
@@ -484,17 +484,17 @@ def test_winograd_gate_and_tile_ratio(monkeypatch):
     25 x 25 at every dilation that divides 96 -- the tile choice (fewest multiplications, F(2x2) on a tie) and the gate: 3x3,
     stride 1, padding = dilation in either direction (forward / backward-data offsets), wide enough, not too many tiles."""
     from diga_amd.model import conv as dc
-    monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", 4)
+    monkeypatch.setattr(config.active(), "winograd_max_tile", 4)
     for d in (1, 2, 4, 6, 12, 24):
         assert dc._wino_plan(97, 97, d) == (4, pytest.approx(36 * 25 * 25 / (9 * 97 * 97)))
     assert dc._wino_plan(97, 97, 18) == (2, pytest.approx(16 * 54 * 54 / (9 * 97 * 97)))      # 36 x 36 tiles of 36 products: a tie
     assert dc._wino_plan(65, 129, 4) == (4, pytest.approx(36 * 17 * 33 / (9 * 65 * 129)))
-    monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", 6)
+    monkeypatch.setattr(config.active(), "winograd_max_tile", 6)
     for d in (1, 2, 4):
         assert dc._wino_plan(97, 97, d) == (6, pytest.approx(64 * 17 * 17 / (9 * 97 * 97)))
     assert dc._wino_plan(97, 97, 18) == (6, pytest.approx(64 * 18 * 18 / (9 * 97 * 97)))       # 6- and 5-wide sub-images: one tile each
     assert dc._wino_plan(97, 97, 12)[0] == 4 and dc._wino_plan(97, 97, 24)[0] == 4              # 9- / 5-wide sub-images: 4x4 tiles waste less
-    monkeypatch.setattr(dc, "WINOGRAD_MAX_TILE", 2)
+    monkeypatch.setattr(config.active(), "winograd_max_tile", 2)
     assert dc._wino_plan(97, 97, 2)[0] == 2
     assert dc._wino_ratio(97, 97, 6) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))
     assert dc._wino_ratio(97, 97, 12) == pytest.approx(16 * 49 * 49 / (9 * 97 * 97))

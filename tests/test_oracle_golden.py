@@ -258,6 +258,35 @@ def test_aspp_head(golden):
             assert_close(v.grad.reshape(-1)[::97], ref, 2e-3, 1e-4 * float(ref.abs().max()) + 1e-7, gk)
 
 
+def test_aspp_head_live_dropout(golden):
+    """The oracle's `keep_mask` against the reference head with nn.Dropout2d(0.1) LIVE (tests/golden/aspp_dropout.npz: the drawn
+    mask read back from the reference's own `feat`): scale 1 / (1 - p) on kept (image, channel) pairs, zero on dropped ones, `feat` is
+    the dropped tensor, gradients flow through the mask."""
+    g = golden("aspp_dropout")
+    arch, sd = _aspp64_sd()
+    for v in sd.values():
+        v.requires_grad_()
+    x = g.t("x").requires_grad_()
+    keep = g.t("keep")
+    assert arch.droprate == pytest.approx(0.1) and 0 < int((1 - keep).sum()) < keep.numel() // 4
+    out, feat = od.aspp_head(sd, x, arch, keep_mask=keep)
+    assert_close(out, g.t("out"), 1e-4, 1e-5, "out")
+    assert_close(feat, g.t("feat"), 1e-4, 1e-5, "feat")
+    assert bool((feat.detach().abs().amax(dim=(2, 3)) > 0).float().eq(keep).all())
+    ((out * g.t("probe")).sum() + (feat * g.t("probe_f")).sum()).backward()
+    assert_close(x.grad, g.t("gx"), 1e-3, 1e-5, "grad x")
+    for k, v in sd.items():
+        gk = "gw_" + k[len("final."):].replace(".", "_")
+        if gk in g:
+            ref = g.t(gk)
+            assert_close(v.grad, ref, 2e-3, 1e-4 * float(ref.abs().max()) + 1e-7, gk)
+        else:
+            cs, l1 = g[gk + "__sum"].tolist()
+            ref = g.t(gk + "__sample")
+            assert float(v.grad.abs().sum()) == pytest.approx(l1, rel=1e-3), gk
+            assert_close(v.grad.reshape(-1)[::97], ref, 2e-3, 1e-4 * float(ref.abs().max()) + 1e-7, gk)
+
+
 def test_model_structure_matches_reference(golden):
     g = golden("model")
     shapes = od.state_shapes(od.RESNET101)

@@ -6,6 +6,8 @@ import random
 import pytest
 import torch
 
+from diga_amd import config
+
 from conftest import assert_close
 from oracle import deeplab as od
 from oracle import detweights, synth
@@ -92,7 +94,7 @@ def test_selftrain_overlapped_tail_is_bit_identical(golden, conv_math, monkeypat
     g = golden("selftrain")
 
     def run(overlap):
-        monkeypatch.setattr(ts, "C4_OVERLAP", overlap)
+        monkeypatch.setattr(config.active(), "c4_overlap", overlap)
         def make():
             m = SegModel()
             m.load_state_dict(detweights.state_dict(od.RESNET101))

@@ -353,6 +353,37 @@ def gen_aspp():
     save("aspp", x=x, out=out, feat=feat, probe=probe, probe_f=probe_f, gx=x.grad, **grads)
 
 
+def gen_aspp_dropout():
+    """The reference head with nn.Dropout2d(0.1) LIVE (train mode; seg_model_noaux.py:171,207-208): the drawn (image, channel)
+    keep mask is read back from the module's own output (`feat` is the dropped tensor: a dropped channel is exactly zero, a kept
+    one is GroupNorm output / 0.9) and stored with input, logits, feat and the gradients, so that the oracle's `keep_mask` and
+    the HIP path's `chan_scale` can be held to the reference's Dropout2d semantics, not only to each other."""
+    torch.manual_seed(0)
+    head = Classifier_Module2(64, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    sd = _fill_module(head, "aspp64.")
+    head.train()
+    g = synth.gen(8)
+    x = torch.randn((4, 64, 17, 21), generator=g).requires_grad_()
+    torch.manual_seed(123)
+    res = head(x, get_feat=True)
+    out, feat = res["out"], res["feat"]
+    keep = (feat.detach().abs().amax(dim=(2, 3)) > 0).float()              # [4, 256]
+    assert 0.02 < float(1 - keep.mean()) < 0.25, float(1 - keep.mean())
+    probe = torch.randn(out.shape, generator=g)
+    probe_f = 0.1 * torch.randn(feat.shape, generator=g)
+    ((out * probe).sum() + (feat * probe_f).sum()).backward()
+    grads = {}
+    for k, p in head.named_parameters():
+        key = "gw_" + k.replace(".", "_")
+        if p.grad.numel() <= 20000:
+            grads[key] = p.grad
+        else:
+            grads[key + "__sum"] = np.array([synth.checksum(p.grad), float(p.grad.abs().sum())])
+            grads[key + "__sample"] = p.grad.reshape(-1)[::97].clone()
+    print("aspp_dropout: dropped", int((1 - keep).sum()), "of", keep.numel(), "channels")
+    save("aspp_dropout", x=x, out=out, feat=feat, keep=keep, probe=probe, probe_f=probe_f, gx=x.grad, **grads)
+
+
 # ------------------------------------------------------------------ G-model
 def _ref_model():
     m = SegModel()
@@ -1177,6 +1208,156 @@ def gen_valmiou():
          geometry=np.array([n_img, H, W]), seed0=np.array(7000))
 
 
+def gen_valmiou_full():
+    """The reference's validation pass at ITS geometry (G5/evaluate_val.py:60,73-93; warm_up.py:346-359): ONE 1024 x 2048 image
+    and its 512 x 1024 bilinear (align_corners) half through SegModel.eval() (running-statistics BatchNorm, N = 1: 129 x 257 and
+    65 x 129 maps = 33 153 / 8 385 rows per GEMM), both logit maps upsampled to 1024 x 2048, element-wise max, argmax,
+    runningScore.  Stored: the low-resolution logits of both scales in full (19 x 129 x 257 and 19 x 65 x 129 floats), the
+    prediction (uint8), a packed mask of the pixels whose top-2 margin of the fused logits is below 1e-3 of the logit scale (where a
+    rounding-level difference may flip the argmax), ground truth (the prediction with 30 % of 64 x 64 blocks re-drawn), the 19 x 19
+    confusion matrix and the scores.  The image is regenerated from its seed by the test."""
+    import contextlib
+    import io
+    m = _ref_model().eval()
+    H, W = 1024, 2048
+    up = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+    g = synth.gen(7100)
+    img = torch.rand((1, 3, H, W), generator=g) * 2.0 - 1.0 + 0.5 * torch.randn((1, 3, 1, 1), generator=g)
+    img_ds = F.interpolate(img, (H // 2, W // 2), mode="bilinear", align_corners=True)
+    with torch.no_grad():
+        lo = m(img)[2]
+        lo_ds = m(img_ds)[2]
+        fused = torch.max(up(lo), up(lo_ds))
+    top2 = fused.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])[0]
+    scale = float(fused.abs().max())
+    p = fused.max(1)[1]
+    noisy = synth.block_labels(g, 1, H, W, 64)
+    flip = (torch.rand((1, H // 64, W // 64), generator=g) < 0.3).repeat_interleave(64, 1).repeat_interleave(64, 2)
+    gt = torch.where(flip, noisy, p)
+    rs = runningScore(19)
+    rs.update(gt.numpy(), p.numpy())
+    with contextlib.redirect_stdout(io.StringIO()):
+        sc, cls_iu = rs.get_scores()
+    near = (margin < 1e-3 * scale).numpy()
+    print("valmiou_full: logits", tuple(lo.shape), tuple(lo_ds.shape), "scale", scale, "classes predicted", torch.unique(p).tolist(),
+          "near ties", int(near.sum()), "mIoU", sc["Mean IoU : \t"], flush=True)
+    save("valmiou_full", logits=lo[0], logits_ds=lo_ds[0], pred=p[0].to(torch.uint8), gt=gt[0].to(torch.uint8),
+         near_tie_bits=np.packbits(near), near_ties=np.array([int((margin < t * scale).sum()) for t in (1e-5, 1e-4, 1e-3)]),
+         logit_scale=np.array(scale), hist=rs.confusion_matrix, miou=np.array(sc["Mean IoU : \t"]), acc=np.array(sc["Overall Acc: \t"]),
+         iu=np.array([cls_iu[i] for i in range(19)]), geometry=np.array([H, W]), seed=np.array(7100))
+
+
+# ------------------------------------------------------------------ G-trainmiou (round 6: a TRAINED model's validation mIoU)
+TRAINMIOU = dict(B=2, H=128, W=128, steps=300, block=32, every=50, n_val=32, lr=2.5e-4, seeds=(0, 1, 2),
+                 data_seed0=20000, val_seed0=90000)
+
+
+def _two_scale_val(student, cfg):
+    """G5/evaluate_val.py:73-93 = warm_up.py:343-360 on `n_val` held-out images of the learnable task: eval() student on the
+    image and on its half-size bilinear (align_corners) downscale, both upsampled to label size, element-wise max, argmax,
+    runningScore."""
+    import contextlib
+    import io
+    H, W = cfg["H"], cfg["W"]
+    up = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+    rs = runningScore(19)
+    student.eval()
+    for i in range(cfg["n_val"]):
+        img, _, _, gt = synth.learnable_batch(cfg["val_seed0"] + i, 1, H, W, block=cfg["block"])
+        img_ds = F.interpolate(img, (H // 2, W // 2), mode="bilinear", align_corners=True)
+        with torch.no_grad():
+            pred = up(student(img)[2])
+            pred_ds = up(student(img_ds)[2])
+        p = torch.max(pred, pred_ds).max(1)[1]
+        rs.update(gt.numpy(), p.numpy())
+    with contextlib.redirect_stdout(io.StringIO()):
+        sc, cls_iu = rs.get_scores()
+    student.train()
+    return float(sc["Mean IoU : \t"]), float(sc["Overall Acc: \t"]), np.array([cls_iu[i] for i in range(19)]), rs.confusion_matrix.copy()
+
+
+def _train_and_validate(cfg, seed):
+    """The reference's warm-up loop (train_DiGA_gta2city_warm_up.py:197-305) with Dropout2d LIVE (torch's global RNG seeded with
+    `seed`), ClassMix drawn from Python's `random` seeded with `seed`, batches of the learnable task from data_seed0 +
+    1000 * seed + it; the reference's validation (:343-373) every `every` steps and at the end."""
+    import torch.optim as optim
+    B, H, W = cfg["B"], cfg["H"], cfg["W"]
+    torch.manual_seed(1234 + seed)
+    random.seed(4321 + seed)
+    student, teacher = _ref_model(), _ref_model()
+    opt = optim.SGD(student.optim_parameters(cfg["lr"]), lr=cfg["lr"], momentum=0.9, weight_decay=0.0005)
+    up = torch.nn.Upsample(size=[H, W], mode="bilinear", align_corners=True)
+    teacher = create_teacher_params(teacher, student)
+    curve, acc_curve, ce_log, di_log = [], [], [], []
+    for it in range(cfg["steps"]):
+        student.train()
+        adjust_learning_rate([opt], base_lr=cfg["lr"], i_iter=it, max_iter=80000, power=0.9)
+        with torch.no_grad():
+            teacher = update_teacher_params(teacher, student, it)
+        x, x_aug, rec, lab = synth.learnable_batch(cfg["data_seed0"] + 1000 * seed + it, B, H, W, block=cfg["block"])
+        mask = torch.zeros(lab.size())
+        for i in range(B):
+            present = torch.unique(lab[i]).tolist()
+            pick = random.sample(present, len(present) // 2)
+            if 255 not in pick:
+                pick.append(255)
+            for c in pick:
+                mask[i][lab[i] == c] = 1
+        mix = torch.zeros(rec.size())
+        for i in range(B):
+            mix[i] = torch.mul(rec[i], 1 - mask[i]) + torch.mul(x_aug[i], mask[i])
+        cat = torch.cat([x, mix])
+        _, _, s_cat, _ = student(cat)
+        s_cat = up(s_cat)
+        _, _, t_cat, _ = teacher(cat)
+        t_cat = up(t_cat)
+        ce = cross_entropy2d(s_cat[:B], lab)
+        di = distillation_loss(t_cat, s_cat)
+        total = 1.0 * ce + 0.5 * di
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        ce_log.append(float(ce)); di_log.append(float(di))
+        if (it + 1) % cfg["every"] == 0:
+            miou, acc, _, _ = _two_scale_val(student, cfg)
+            curve.append(miou); acc_curve.append(acc)
+            print(f"trainmiou seed {seed} step {it + 1}: CE {np.mean(ce_log[-cfg['every']:]):.4f} distil {np.mean(di_log[-cfg['every']:]):.4f} "
+                  f"val mIoU {100 * miou:.2f} acc {100 * acc:.2f}", flush=True)
+    miou, acc, iu, hist = _two_scale_val(student, cfg)
+    return dict(curve=np.array(curve), acc_curve=np.array(acc_curve), ce=np.array(ce_log), distil=np.array(di_log),
+                miou=miou, acc=acc, iu=iu, hist=hist)
+
+
+def gen_trainmiou():
+    """north_star's training-level criterion ('mIoU within 0.1 of reference on fixed seed'): after a few optimizer steps two fp32
+    implementations are no longer pointwise comparable (traj25: probe logits 9e-3 of scale apart after 25 steps, reference
+    against reference), so the criterion is checked the only way it can be -- statistically.  The reference's warm-up loop runs
+    `steps` iterations on a LEARNABLE synthetic task (oracle/synth.py::learnable_batch), Dropout2d live, for every seed of
+    `seeds`; the reference's two-scale validation gives the mIoU curve and the final mIoU on held-out images.  Stored: per-seed
+    curves, final mIoU / accuracy / per-class IoU / confusion matrix, loss logs, the mean and seed-to-seed spread of the final
+    mIoU -- what tests/test_gpu_trainmiou.py holds the HIP path's own runs against."""
+    cfg = dict(TRAINMIOU)
+    for k in ("steps", "every", "n_val", "block"):
+        if os.environ.get("TRAINMIOU_" + k.upper()):
+            cfg[k] = int(os.environ["TRAINMIOU_" + k.upper()])
+    if os.environ.get("TRAINMIOU_LR"):
+        cfg["lr"] = float(os.environ["TRAINMIOU_LR"])
+    if os.environ.get("TRAINMIOU_SEEDS"):
+        cfg["seeds"] = tuple(int(v) for v in os.environ["TRAINMIOU_SEEDS"].split(","))
+    runs = [_train_and_validate(cfg, s) for s in cfg["seeds"]]
+    final = np.array([r["miou"] for r in runs])
+    print("trainmiou final mIoU per seed", (100 * final).tolist(), "mean", 100 * final.mean(), "spread (max-min)", 100 * (final.max() - final.min()),
+          "std", 100 * final.std(ddof=1) if len(final) > 1 else 0.0, flush=True)
+    if os.environ.get("TRAINMIOU_DRY"):
+        return
+    save("trainmiou", seeds=np.array(cfg["seeds"]), curve=np.stack([r["curve"] for r in runs]), acc_curve=np.stack([r["acc_curve"] for r in runs]),
+         ce=np.stack([r["ce"] for r in runs]), distil=np.stack([r["distil"] for r in runs]), miou=final,
+         acc=np.array([r["acc"] for r in runs]), iu=np.stack([r["iu"] for r in runs]), hist=np.stack([r["hist"] for r in runs]),
+         geometry=np.array([cfg["B"], cfg["H"], cfg["W"], cfg["steps"], cfg["block"], cfg["every"], cfg["n_val"], cfg["data_seed0"], cfg["val_seed0"]]),
+         lr=np.array(cfg["lr"]))
+
+
 # ------------------------------------------------------------------ G-ohem ("next" row 4)
 def gen_ohem():
     """OhemCrossEntropy (G5/util/loss.py:65-122) in its three regimes: threshold = thresh (many uncertain
@@ -1212,7 +1393,7 @@ def gen_ohem():
     save("ohem", **out)
 
 
-ALL = dict(full768b8=gen_full768b8, full512x1024b8=gen_full512x1024b8, traj25=gen_traj25, traj768=gen_traj768, selftraj10=gen_selftraj10, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
+ALL = dict(trainmiou=gen_trainmiou, aspp_dropout=gen_aspp_dropout, valmiou_full=gen_valmiou_full, full768b8=gen_full768b8, full512x1024b8=gen_full512x1024b8, traj25=gen_traj25, traj768=gen_traj768, selftraj10=gen_selftraj10, mit=gen_mit, segformer_head=gen_segformer_head, mit768bwd=gen_mit768bwd, full768=gen_full768, full512x1024=gen_full512x1024, ohem=gen_ohem, ce=gen_ce, distill=gen_distill, upsample=gen_upsample, ema=gen_ema, sgd=gen_sgd,
            classmix=gen_classmix, centroid=gen_centroid, meanvec=gen_meanvec, aspp=gen_aspp,
            model=gen_model, step=gen_step, selftrain=gen_selftrain, translator=gen_translator, miou=gen_miou, valmiou=gen_valmiou)
 
