@@ -16,76 +16,86 @@ namespace diga {
 constexpr int kKMax = 32;
 
 // ------------------------------------------------------------------------------------------
-// PX pixels per lane (block = 64 * PX pixels): the 20 KB centroid image is staged once per 128 pixels, every centroid
-// value read from LDS serves PX pixels, and PX * 4 plane loads are in flight per lane.  Per pixel the arithmetic (channel
-// order inside a wave's quarter of D, then the four partials in wave order) does not depend on PX.
-template <int K, int PX>
-__global__ __launch_bounds__(256) void centroid_weights_kernel(const float* __restrict__ feat,
+// Round 6.  Block = 64 pixels (one per lane) x 4 waves that split the D channels; what bounds this kernel is NOT bandwidth alone:
+//   * arithmetic: (c - x)^2 accumulated per (pixel, channel, class) is 2 VALU operations -- 17.2 M pixel-channels x 19 classes at C4 =
+//     10.2 M wave instructions, 40 k cycles per SIMD = 17 us of pure issue.  The classes are therefore processed in PAIRS on the packed
+//     fp32 pipe (v_pk_add_f32 / v_pk_fma_f32: a centroid pair from one 8-byte LDS read against the pixel's value broadcast to both
+//     halves): 9 us;
+//   * latency: a wave's channels are a chain of dependent load rounds -- 16 plane loads per lane and round (round 5: 8 with two pixels
+//     per lane), and the FIRST round is issued before the centroids are staged and the block meets at its barrier;
+//   * occupancy: the partial distances reuse the centroids' LDS (20 KB per block instead of 40) and the kernel is held to 64 VGPRs:
+//     eight blocks per CU = eight waves per SIMD, all 1056 blocks of C4 resident at once.
+// Per pixel the arithmetic is round 5's: fma chain in channel order inside a wave's quarter of D, the four partials added in wave order.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int K>
+__global__ __launch_bounds__(256, 6) void centroid_weights_kernel(const float* __restrict__ feat,
                                                                const float* __restrict__ cent,
                                                                float* __restrict__ weights,
                                                                float* __restrict__ neg_dist, int D, int Krt,
                                                                int64_t HW) {
     constexpr int KP = (K + 3) & ~3;
-    constexpr int BP = 64 * PX;       // pixels per block
+    constexpr int U = 16;             // plane loads in flight per lane
     extern __shared__ __align__(16) float smem[];
-    float* cT = smem;                 // [D][KP]  transposed centroids
-    float* part = smem + (size_t)D * KP;  // [4][K][BP] per-wave partial squared distances
+    float* cT = smem;                 // [D][KP]  transposed centroids; afterwards [4][K][64] per-wave partial squared distances
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+    const int dper = (D + 3) / 4;
+    const int d0 = wv * dper, d1 = (d0 + dper < D) ? d0 + dper : D;
+    const float* f = feat + ((int64_t)n * D + d0) * HW + (p < HW ? p : 0);
+    const int nd = d1 > d0 ? d1 - d0 : 0;
+    const int full = nd / U;          // rounds of U channels (+ a tail of nd % U)
+    float x[U];
+    if (full > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = f[(int64_t)u * HW];
+    }
     // coalesced read of the [K][D] centroids (consecutive threads = consecutive d), transposed on the LDS write
     for (int i = threadIdx.x; i < KP * D; i += 256) {
         const int k = i / D, d = i - k * D;
         cT[d * KP + k] = (k < Krt) ? cent[(int64_t)k * D + d] : 0.f;
     }
     __syncthreads();
-    const int64_t p0 = (int64_t)blockIdx.x * BP + lane;
-    const int dper = (D + 3) / 4;
-    const int d0 = wv * dper, d1 = (d0 + dper < D) ? d0 + dper : D;
-    float acc[PX][K];
+    f32x2 acc[KP / 2];
 #pragma unroll
-    for (int u = 0; u < PX; ++u)
+    for (int q = 0; q < KP / 2; ++q) acc[q] = (f32x2){0.f, 0.f};
+    auto channel = [&](int d, float xv) {
+        const f32x2* c2 = reinterpret_cast<const f32x2*>(cT + (size_t)d * KP);
+        const f32x2 xx = (f32x2){xv, xv};
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[u][k] = 0.f;
-    const float* f[PX];
-#pragma unroll
-    for (int u = 0; u < PX; ++u) f[u] = feat + ((int64_t)n * D) * HW + (p0 + 64 * u < HW ? p0 + 64 * u : 0);
-    // 8 channels x PX plane loads in flight per lane: a wave's 64 channels are 8 dependent rounds (4-deep: 16 rounds, and the
-    // kernel is nothing but that latency chain: 68.7 MB of features at C4)
-#pragma unroll 8
-    for (int d = d0; d < d1; ++d) {
-        float x[PX];
-#pragma unroll
-        for (int u = 0; u < PX; ++u) x[u] = f[u][(int64_t)d * HW];
-        const float4* c4 = reinterpret_cast<const float4*>(cT + (size_t)d * KP);
-#pragma unroll
-        for (int q = 0; q < KP / 4; ++q) {
-            const float4 c = c4[q];
-#pragma unroll
-            for (int u = 0; u < PX; ++u) {
-                const float e0 = c.x - x[u], e1 = c.y - x[u], e2 = c.z - x[u], e3 = c.w - x[u];
-                if (q * 4 + 0 < K) acc[u][q * 4 + 0] += e0 * e0;
-                if (q * 4 + 1 < K) acc[u][q * 4 + 1] += e1 * e1;
-                if (q * 4 + 2 < K) acc[u][q * 4 + 2] += e2 * e2;
-                if (q * 4 + 3 < K) acc[u][q * 4 + 3] += e3 * e3;
-            }
+        for (int q = 0; q < KP / 2; ++q) {
+            const f32x2 e = c2[q] - xx;
+            acc[q] = __builtin_elementwise_fma(e, e, acc[q]);
         }
+    };
+    for (int r = 0; r < full; ++r) {
+        if (r > 0) {
+            // (no register double-buffering: 16 + 20 live values keep the kernel at eight waves per SIMD, and the other seven waves
+            //  cover this round trip -- the double-buffered form needed 112 VGPRs = four waves, one block too few per CU for C4)
+            const float* fr = f + (int64_t)r * U * HW;
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = fr[(int64_t)u * HW];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) channel(d0 + r * U + u, x[u]);
     }
+    for (int d = d0 + full * U; d < d1; ++d) channel(d, f[(int64_t)(d - d0) * HW]);
+    __syncthreads();                  // every wave is done with the centroids: their LDS becomes the partials' [4][K][64]
+    float* part = smem;
 #pragma unroll
-    for (int u = 0; u < PX; ++u)
-#pragma unroll
-        for (int k = 0; k < K; ++k) part[(wv * K + k) * BP + 64 * u + lane] = acc[u][k];
+    for (int q = 0; q < KP / 2; ++q) {
+        if (2 * q < K) part[(wv * K + 2 * q) * 64 + lane] = acc[q].x;
+        if (2 * q + 1 < K) part[(wv * K + 2 * q + 1) * 64 + lane] = acc[q].y;
+    }
     __syncthreads();
-    // softmax over classes: wave w finishes the pixels lane + 64 * u with u % 4 == w (PX <= 4: one group per wave)
-    if (wv >= PX) return;
-    const int64_t p = p0 + 64 * wv;
-    if (p >= HW) return;
-    const int col = 64 * wv + lane;
+    if (wv != 0 || p >= HW) return;
     float dist[K];
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float s = part[(0 * K + k) * BP + col] + part[(1 * K + k) * BP + col] +
-                        part[(2 * K + k) * BP + col] + part[(3 * K + k) * BP + col];
+        const float s = part[(0 * K + k) * 64 + lane] + part[(1 * K + k) * 64 + lane] +
+                        part[(2 * K + k) * 64 + lane] + part[(3 * K + k) * 64 + lane];
         dist[k] = -sqrtf(s);
         if (k < Krt) m = fmaxf(m, dist[k]);
     }
@@ -188,6 +198,99 @@ __global__ __launch_bounds__(256) void argmax_consensus_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 6: the consensus kernel for upsampling factors >= 4 (the path's x8), built for what bounds it.  Round 5's kernel above spends
+// ~250 VALU + 76 LDS instructions per output pixel (19 classes x 4 taps read one float at a time, 7 scalar flops each): 4.2 M pixels at
+// C4 = 26 us of issue alone, next to 72 MB of traffic worth 12 us -- it is ALU-bound, not bandwidth-bound.  Here:
+//   * the staged low-res weights lie CLASS-FASTEST in LDS ([row][col][KP]): a tap's 20 classes are five 16-byte reads, not 19 reads;
+//   * two classes per instruction on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32): 6 packed operations per class pair;
+//   * int64 labels travel as 16-byte pairs: a thread owns two horizontally adjacent pixels on two rows (block = 128 x 8 pixels).
+// Same expression tree per class as torch's upsample_bilinear2d, h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d), with the inner and the
+// outer sum contracted to fma; strict first-maximum argmax.
+constexpr int kCons8Rows = 6, kCons8Cols = 36;
+template <int K>
+__global__ __launch_bounds__(256) void argmax_consensus_pairs_kernel(const float* __restrict__ wts, const long long* __restrict__ pseudo_in,
+                                                                     long long* __restrict__ pseudo_out, long long* __restrict__ feat_pseudo,
+                                                                     int h, int w, int H, int W, float sy, float sx) {
+    constexpr int KP = (K + 3) & ~3;
+    __shared__ __align__(16) float tile[kCons8Rows * kCons8Cols * KP];          // [row][col][KP]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int X0 = blockIdx.x * 128, Y0 = blockIdx.y * 8;
+    const int X = X0 + 2 * lane;
+    const int n = blockIdx.z;
+    longlong2 pin[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int Y = Y0 + wv + 4 * r;
+        pin[r] = (X < W && Y < H) ? *reinterpret_cast<const longlong2*>(pseudo_in + ((int64_t)n * H + Y) * W + X) : make_longlong2(0, 0);
+    }
+    int ia, ib, ja, jb;
+    float t_;
+    bilinear_cell(Y0, sy, h, ia, t_);
+    bilinear_cell(min(Y0 + 7, H - 1), sy, h, ib, t_);
+    bilinear_cell(X0, sx, w, ja, t_);
+    bilinear_cell(min(X0 + 127, W - 1), sx, w, jb, t_);
+    const int rows = min(ib + 1, h - 1) - ia + 1, cols = min(jb + 1, w - 1) - ja + 1;      // <= kCons8Rows x kCons8Cols (checked by the host)
+    const float* base_n = wts + ((int64_t)n * K) * h * w;
+    const int per = rows * cols;
+    for (int i = threadIdx.x; i < KP * per; i += 256) {
+        const int k = i / per, rc = i - k * per;
+        const int r = rc / cols, c = rc - r * cols;
+        tile[rc * KP + k] = k < K ? base_n[(int64_t)k * h * w + (int64_t)(ia + r) * w + ja + c] : -INFINITY;
+    }
+    __syncthreads();
+    if (X >= W) return;
+    int j0[2];
+    float wx[2];
+    bilinear_cell(X, sx, w, j0[0], wx[0]);
+    bilinear_cell(X + 1, sx, w, j0[1], wx[1]);
+    const int dj = (w > 1) ? KP : 0, di = (h > 1) ? cols * KP : 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int Y = Y0 + wv + 4 * r;
+        if (Y >= H) continue;
+        int i0;
+        float wy;
+        bilinear_cell(Y, sy, h, i0, wy);
+        long long res[2], arg64[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float* t0 = tile + ((i0 - ia) * cols + (j0[e] - ja)) * KP;
+            const f32x2 w0 = (f32x2){1.f - wx[e], 1.f - wx[e]}, w1 = (f32x2){wx[e], wx[e]};
+            const f32x2 h0 = (f32x2){1.f - wy, 1.f - wy}, h1 = (f32x2){wy, wy};
+            float best = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int q = 0; q < KP / 4; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4*>(t0 + 4 * q), b4 = *reinterpret_cast<const float4*>(t0 + dj + 4 * q);
+                const float4 c4 = *reinterpret_cast<const float4*>(t0 + di + 4 * q), d4 = *reinterpret_cast<const float4*>(t0 + di + dj + 4 * q);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x2 a = hh ? (f32x2){a4.z, a4.w} : (f32x2){a4.x, a4.y}, b = hh ? (f32x2){b4.z, b4.w} : (f32x2){b4.x, b4.y};
+                    const f32x2 c = hh ? (f32x2){c4.z, c4.w} : (f32x2){c4.x, c4.y}, d = hh ? (f32x2){d4.z, d4.w} : (f32x2){d4.x, d4.y};
+                    const f32x2 top = __builtin_elementwise_fma(w1, b, w0 * a), bot = __builtin_elementwise_fma(w1, d, w0 * c);
+                    const f32x2 v = __builtin_elementwise_fma(h1, bot, h0 * top);
+                    const int k0 = 4 * q + 2 * hh;
+                    if (k0 < K && v.x > best) {            // strict: first maximum wins, as torch.max (padding classes hold -inf)
+                        best = v.x;
+                        arg = k0;
+                    }
+                    if (k0 + 1 < K && v.y > best) {
+                        best = v.y;
+                        arg = k0 + 1;
+                    }
+                }
+            }
+            const long long pl = e ? pin[r].y : pin[r].x;
+            res[e] = (pl == (long long)arg) ? pl : (long long)DIGA_IGNORE_LABEL;
+            arg64[e] = (long long)arg;
+        }
+        const int64_t o = ((int64_t)n * H + Y) * W + X;
+        *reinterpret_cast<longlong2*>(pseudo_out + o) = make_longlong2(res[0], res[1]);
+        if (feat_pseudo) *reinterpret_cast<longlong2*>(feat_pseudo + o) = make_longlong2(arg64[0], arg64[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // ids[n,p] = argmax_k out[n,k,p] if it agrees with the label (or no labels), else K (dead bucket)
 __global__ __launch_bounds__(256) void class_ids_kernel(const float* __restrict__ out,
                                                         const float* __restrict__ labels_lr,
@@ -231,40 +334,43 @@ __global__ __launch_bounds__(256) void class_ids_kernel(const float* __restrict_
     if (threadIdx.x < K && cnt[threadIdx.x]) atomicAdd(&counts[(int64_t)n * K + threadIdx.x], cnt[threadIdx.x]);
 }
 
-// one wave per (image, channel): lane-private class bins in LDS, then a cross-lane sum per class
+// one block per (image, channel): its four waves take a quarter of the plane each (round 5: one wave per plane, four planes per block --
+// 2048 waves for the whole chip, each a chain of 131 dependent load rounds at C4), 16 plane loads + 16 id loads in flight per lane and
+// round, lane-private class bins in LDS (no float atomics), then a cross-wave + cross-lane sum per class.  A lane's additions keep their
+// pixel order; the plane's total is (lanes of quarter 0) + ... + (lanes of quarter 3) per class, a fixed order.
 __global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict__ feat,
                                                          const uint8_t* __restrict__ ids, float* __restrict__ sums,
                                                          int D, int K, int64_t hw) {
-    __shared__ float bins[4][kKMax + 1][64];
+    extern __shared__ float bins_raw[];           // [4][K + 1][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int d = blockIdx.x * 4 + wv;
+    const int d = blockIdx.x;
     const int n = blockIdx.y;
-    for (int k = 0; k <= K; ++k) bins[wv][k][lane] = 0.f;
-    if (d < D) {
-        const float* f = feat + ((int64_t)n * D + d) * hw;
-        const uint8_t* id = ids + (int64_t)n * hw;
-        // (8 pixels per round: the loads of a round are issued before its first LDS update -- the loop was one dependent
-        //  load -> read-modify-write chain per pixel, 131 rounds at C4; a lane's additions keep their order)
-        int64_t p = lane;
-        for (; p + 7 * 64 < hw; p += 8 * 64) {
-            float v[8];
-            int c[8];
+    float* bins = bins_raw + (size_t)wv * (K + 1) * 64;
+    for (int k = 0; k <= K; ++k) bins[k * 64 + lane] = 0.f;
+    const float* f = feat + ((int64_t)n * D + d) * hw;
+    const uint8_t* id = ids + (int64_t)n * hw;
+    const int64_t quarter = ((hw + 255) / 256) * 64;
+    const int64_t end = (wv + 1) * quarter < hw ? (wv + 1) * quarter : hw;
+    int64_t p = wv * quarter + lane;
+    constexpr int U = 16;
+    for (; p + (U - 1) * 64 < end; p += U * 64) {
+        float v[U];
+        int c[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                c[u] = id[p + 64 * u];
-                v[u] = f[p + 64 * u];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) bins[wv][c[u]][lane] += v[u];
+        for (int u = 0; u < U; ++u) {
+            c[u] = id[p + 64 * u];
+            v[u] = f[p + 64 * u];
         }
-        for (; p < hw; p += 64) bins[wv][id[p]][lane] += f[p];
+#pragma unroll
+        for (int u = 0; u < U; ++u) bins[c[u] * 64 + lane] += v[u];
     }
+    for (; p < end; p += 64) bins[id[p] * 64 + lane] += f[p];
     __syncthreads();
-    if (d < D) {
-        for (int k = 0; k < K; ++k) {
-            const float t = wave_sum(bins[wv][k][lane]);
-            if (lane == 0) sums[((int64_t)n * K + k) * D + d] = t;
-        }
+    for (int k = wv; k < K; k += 4) {
+        const float* b = bins_raw + (size_t)k * 64 + lane;
+        const size_t ws = (size_t)(K + 1) * 64;
+        const float t = wave_sum(((b[0] + b[ws]) + b[2 * ws]) + b[3 * ws]);
+        if (lane == 0) sums[((int64_t)n * K + k) * D + d] = t;
     }
 }
 
@@ -329,47 +435,18 @@ extern "C" int diga_centroid_softmax_weights(const float* feat, const float* cen
     hipStream_t st = (hipStream_t)stream;
     // D*4 B of features per low-res pixel in, K*4 B of weights out (+ K*4 with distances)
     ProfScope prof(DIGA_PROF_CENTROID_WEIGHTS, st, (double)N * HW * (D * 4.0 + K * 4.0 * (neg_dist ? 2.0 : 1.0)));
-    // pixels per lane: the smallest PX whose blocks all fit on the chip at once (256 CUs x the blocks the LDS footprint allows per CU) --
-    // at C4 (8 x 8385 pixels) PX = 2 gives 528 blocks for 512 slots: a second, almost empty round doubled the kernel's time
-    auto pick_px = [&](int kp) {
-        for (int px = 1; px <= 4; ++px) {
-            const size_t sh = ((size_t)D * kp + (size_t)4 * kp * 64 * px) * sizeof(float);
-            const int64_t per_cu = std::min<int64_t>(8, (160 * 1024) / (int64_t)sh);
-            if (per_cu >= 1 && ceil_div(HW, 64 * px) * N <= 256 * per_cu) return px;
-        }
-        return 4;
-    };
-#define DIGA_CW_LAUNCH(KT_, KP_, PX_)                                                                                        \
+#define DIGA_CW_LAUNCH(KT_, KP_)                                                                                             \
     do {                                                                                                                    \
-        dim3 grid((unsigned)ceil_div(HW, 64 * PX_), (unsigned)N);                                                           \
-        const size_t sh = ((size_t)D * KP_ + (size_t)4 * KT_ * 64 * PX_) * sizeof(float);                                    \
+        dim3 grid((unsigned)ceil_div(HW, 64), (unsigned)N);                                                                 \
+        const size_t sh = std::max((size_t)D * KP_, (size_t)4 * KT_ * 64) * sizeof(float);                                   \
         DIGA_REQUIRE(sh <= 160 * 1024, DIGA_EINVAL, "centroid_softmax_weights: D too large for LDS");                        \
-        (void)hipFuncSetAttribute((const void*)centroid_weights_kernel<KT_, PX_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((centroid_weights_kernel<KT_, PX_>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist, (int)D,     \
+        (void)hipFuncSetAttribute((const void*)centroid_weights_kernel<KT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((centroid_weights_kernel<KT_>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist, (int)D,     \
                            (int)K, HW);                                                                                     \
     } while (0)
-    if (K <= 19 && K > 16) {
-        switch (pick_px(20)) {
-            case 1: DIGA_CW_LAUNCH(19, 20, 1); break;
-            case 2: DIGA_CW_LAUNCH(19, 20, 2); break;
-            case 3: DIGA_CW_LAUNCH(19, 20, 3); break;
-            default: DIGA_CW_LAUNCH(19, 20, 4); break;
-        }
-    } else if (K <= 16) {
-        switch (pick_px(16)) {
-            case 1: DIGA_CW_LAUNCH(16, 16, 1); break;
-            case 2: DIGA_CW_LAUNCH(16, 16, 2); break;
-            case 3: DIGA_CW_LAUNCH(16, 16, 3); break;
-            default: DIGA_CW_LAUNCH(16, 16, 4); break;
-        }
-    } else {
-        dim3 grid((unsigned)ceil_div(HW, 64), (unsigned)N);
-        const size_t sh = ((size_t)D * 32 + 4 * 32 * 64) * sizeof(float);
-        DIGA_REQUIRE(sh <= 160 * 1024, DIGA_EINVAL, "centroid_softmax_weights: D*K too large for LDS");
-        (void)hipFuncSetAttribute((const void*)centroid_weights_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((centroid_weights_kernel<32, 1>), grid, dim3(256), sh, st, feat, centroids, weights, neg_dist,
-                           (int)D, (int)K, HW);
-    }
+    if (K <= 19 && K > 16) DIGA_CW_LAUNCH(19, 20);
+    else if (K <= 16) DIGA_CW_LAUNCH(16, 16);
+    else DIGA_CW_LAUNCH(32, 32);
 #undef DIGA_CW_LAUNCH
     return launch_status("diga_centroid_softmax_weights");
 }
@@ -383,9 +460,24 @@ extern "C" int diga_upsample_argmax_consensus(const float* weights, const int64_
     // low-res weights in, int64 label map read and written [, second map written]
     ProfScope prof(DIGA_PROF_CONSENSUS, (hipStream_t)stream,
                    (double)N * (h * w * K * 4.0 + (double)H * W * (feat_pseudo ? 24.0 : 16.0)));
+    const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+    // the pair kernel: even W, 16-byte aligned label maps, and an upsampling factor that keeps a 128 x 8 block's taps inside its LDS tile
+    // (8 rows span <= 7 * sy + 2 low-res rows, 128 columns <= 127 * sx + 2 columns)
+    const bool pairs = (K == 19 || K == 16) && W % 2 == 0 && W >= 2 && h >= 2 && w >= 2 && aligned16(pseudo_in) && aligned16(pseudo_out) &&
+                       (!feat_pseudo || aligned16(feat_pseudo)) && 7.f * sy + 3.f <= (float)kCons8Rows && 127.f * sx + 3.f <= (float)kCons8Cols;
+    if (pairs) {
+        dim3 g2((unsigned)ceil_div(W, 128), (unsigned)ceil_div(H, 8), (unsigned)N);
+        if (K == 19)
+            hipLaunchKernelGGL((argmax_consensus_pairs_kernel<19>), g2, dim3(256), 0, (hipStream_t)stream, weights, (const long long*)pseudo_in,
+                               (long long*)pseudo_out, (long long*)feat_pseudo, (int)h, (int)w, (int)H, (int)W, sy, sx);
+        else
+            hipLaunchKernelGGL((argmax_consensus_pairs_kernel<16>), g2, dim3(256), 0, (hipStream_t)stream, weights, (const long long*)pseudo_in,
+                               (long long*)pseudo_out, (long long*)feat_pseudo, (int)h, (int)w, (int)H, (int)W, sy, sx);
+        return launch_status("diga_upsample_argmax_consensus");
+    }
     hipLaunchKernelGGL(argmax_consensus_kernel, grid, dim3(256), (size_t)K * kConsRows * kConsCols * sizeof(float), (hipStream_t)stream, weights,
                        (const long long*)pseudo_in, (long long*)pseudo_out, (long long*)feat_pseudo, (int)K, (int)h,
-                       (int)w, (int)H, (int)W, ac_scale(h, H), ac_scale(w, W));
+                       (int)w, (int)H, (int)W, sy, sx);
     return launch_status("diga_upsample_argmax_consensus");
 }
 
@@ -413,8 +505,8 @@ extern "C" int diga_class_mean_vectors(const float* feat, const float* out, cons
     const float ry = labels_full ? (float)H / (float)h : 0.f, rx = labels_full ? (float)W / (float)w : 0.f;
     hipLaunchKernelGGL(class_ids_kernel, dim3((unsigned)ceil_div(hw, 256), (unsigned)N), dim3(256), 0, st, out, labels_lr,
                        (const long long*)labels_full, ids, counts, (int)K, (int)h, (int)w, (int)H, (int)W, ry, rx);
-    hipLaunchKernelGGL(class_sums_kernel, dim3((unsigned)ceil_div(D, 4), (unsigned)N), dim3(256), 0, st, feat, ids, sums,
-                       (int)D, (int)K, hw);
+    hipLaunchKernelGGL(class_sums_kernel, dim3((unsigned)D, (unsigned)N), dim3(256), (size_t)4 * (K + 1) * 64 * sizeof(float), st, feat, ids,
+                       sums, (int)D, (int)K, hw);
     return launch_status("diga_class_mean_vectors");
 }
 

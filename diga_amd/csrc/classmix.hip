@@ -17,31 +17,45 @@ __global__ __launch_bounds__(256) void label_hist256_kernel(const long long* __r
     __syncthreads();
     const int b = blockIdx.y;
     const long long* lab = labels + (int64_t)b * HW;
+    // Round 6: labels as 16-byte PAIRS (two int64 per load, four loads = 64 B per lane in flight per round; round 5: eight 8-byte loads),
+    // a wave's pairs are 1 KB contiguous.  An odd HW leaves one label for the tail.
+    const int64_t pairs = HW >> 1;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    // eight labels per thread and round, all eight loads in flight before the first is counted (the loop used to be one dependent
-    // load -> ballot chain per label: eight latencies per block for a 37 MB pass)
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < HW; base += 8 * stride) {
-        long long vv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t i = base + u * stride + threadIdx.x;
-            vv[u] = i < HW ? lab[i] : -1;
+    auto count = [&](long long v) {
+        bool todo = (v >= 0 && v < 256);
+        // wave-aggregated increment: one LDS atomic per distinct value per wave
+        while (true) {
+            const unsigned long long pending = __ballot(todo);
+            if (pending == 0ull) break;
+            const int leader = __ffsll((long long)pending) - 1;
+            const int lv = __shfl((int)v, leader, 64);
+            const bool same = todo && ((int)v == lv);
+            const unsigned long long grp = __ballot(same);
+            if ((threadIdx.x & 63) == leader) atomicAdd(&sh[lv], (uint32_t)__popcll(grp));
+            todo = todo && !same;
         }
+    };
+    const bool aligned = (reinterpret_cast<uintptr_t>(lab) & 15u) == 0;
+    if (aligned) {
+        const longlong2* lab2 = reinterpret_cast<const longlong2*>(lab);
+        for (int64_t base = (int64_t)blockIdx.x * 256; base < pairs; base += 4 * stride) {
+            longlong2 vv[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long long v = vv[u];
-            bool todo = (v >= 0 && v < 256);
-            // wave-aggregated increment: one LDS atomic per distinct value per wave
-            while (true) {
-                const unsigned long long pending = __ballot(todo);
-                if (pending == 0ull) break;
-                const int leader = __ffsll((long long)pending) - 1;
-                const int lv = __shfl((int)v, leader, 64);
-                const bool same = todo && ((int)v == lv);
-                const unsigned long long grp = __ballot(same);
-                if ((threadIdx.x & 63) == leader) atomicAdd(&sh[lv], (uint32_t)__popcll(grp));
-                todo = todo && !same;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = base + u * stride + threadIdx.x;
+                vv[u] = i < pairs ? lab2[i] : make_longlong2(-1, -1);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                count(vv[u].x);
+                count(vv[u].y);
+            }
+        }
+        if ((HW & 1) && blockIdx.x == 0) count(threadIdx.x == 0 ? lab[HW - 1] : -1);
+    } else {
+        for (int64_t base = (int64_t)blockIdx.x * 256; base < HW; base += stride) {
+            const int64_t i = base + threadIdx.x;
+            count(i < HW ? lab[i] : -1);
         }
     }
     __syncthreads();

@@ -361,7 +361,10 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
     int n_ce /* images that carry a CE term */, int h, int w, int H, int W, float sy, float sx, float k_ce,
     float k_di, float scale, int cpw /* cells per wave: 1, 2, 4 or 8 neighbours along x, 64 / cpw lanes each */) {
     constexpr int ROWS = cell_rows<C>();
-    __shared__ float red[ROWS * 65];
+    // (round 6) the wave's 4 C + 2 sums are folded over each lane quad with two DPP steps BEFORE they cross LDS: 17 columns instead of
+    // 65 -- 5.3 KB instead of 20 KB per one-wave block, which had capped the kernel at 8 waves per CU (two per SIMD) under ~57
+    // dependent transcendentals per pixel
+    __shared__ float red[ROWS * 17];
     // small cells (logits at 1/4 scale: 4 x 4 full-resolution pixels per cell) would leave most of a wave idle and pay the LDS fold
     // per 16 pixels: `cpw` neighbouring cells share the wave, lane group `sub` owns cell blockIdx.x * cpw + sub
     const int lpc = 64 / cpw;
@@ -409,15 +412,18 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
             }
         }
         float zs = 0.f, zt = 0.f;
+        float es[C];                       // exp(s - max): softmax(s) = es / zs below (round 5 evaluated exp(s - lse) again: C more expf per pixel)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            zs += expf(s[c] - ms);
+            es[c] = expf(s[c] - ms);
+            zs += es[c];
             if (DISTILL) {
                 q[c] = expf(q[c] - mt);
                 zt += q[c];
             }
         }
         const float lse = ms + logf(zs);
+        const float rzs = 1.f / zs;
         const float rzt = DISTILL ? 1.f / zt : 0.f;
         int tc = -1;
         bool valid = false;
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
         float di_px = 0.f, xt = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float p = expf(s[c] - lse);
+            const float p = es[c] * rzs;
             float g = gce * (p - ((c == tc) ? 1.f : 0.f));
             xt = (c == tc) ? s[c] : xt;
             if (DISTILL) {
@@ -447,21 +453,38 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
         ce_sum += valid ? (lse - xt) : 0.f;
         if (DISTILL && live) di_sum += wgt * di_px;
     }
-    // transposed wave reduction through LDS: row r = value index, column = lane (of the whole wave); each cell folds its lane group
+    // transposed wave reduction: quad sums by DPP (a lane group is >= 8 lanes: a quad never spans two cells), then through LDS:
+    // row r = value index, column = quad (of the whole wave); each cell folds the quads of its lane group
     const int wl = threadIdx.x;
+    auto quad_sum = [](float v) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+        return v;
+    };
+    const bool lead = (wl & 3) == 0;
+    const int qcol = wl >> 2;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < C; ++c) red[(k * C + c) * 65 + wl] = acc[k][c];
-    red[(4 * C) * 65 + wl] = ce_sum;
-    red[(4 * C + 1) * 65 + wl] = di_sum;
+        for (int c = 0; c < C; ++c) {
+            const float v = quad_sum(acc[k][c]);
+            if (lead) red[(k * C + c) * 17 + qcol] = v;
+        }
+    {
+        const float v0 = quad_sum(ce_sum), v1 = quad_sum(di_sum);
+        if (lead) {
+            red[(4 * C) * 17 + qcol] = v0;
+            red[(4 * C + 1) * 17 + qcol] = v1;
+        }
+    }
     __syncthreads();
     float* out = cellpart + (((int64_t)n * (h - 1) + ci) * (w - 1) + (int64_t)blockIdx.x * cpw) * ROWS;
     const int ncell = min(cpw, (w - 1) - (int)blockIdx.x * cpw);
+    const int qpc = lpc >> 2;              // quads per cell
     for (int o = wl; o < ROWS * ncell; o += 64) {
         const int sc = o / ROWS, r = o - sc * ROWS;
         float t = 0.f;
-        for (int k = 0; k < lpc; ++k) t += red[r * 65 + sc * lpc + k];
+        for (int k = 0; k < qpc; ++k) t += red[r * 17 + sc * qpc + k];
         out[(int64_t)sc * ROWS + r] = t;
     }
 }

@@ -40,9 +40,8 @@ class SegModel(nn.Module):
         if self.training:
             dn.bump_batches_tracked(self)                     # one launch for the 104 BatchNorm step counters
         conv1, bn1, _relu, maxpool = self.layer0              # ReLU is fused into the BN kernel
-        with dn.junction_fusion():                            # (residual junctions applied inside the next block's conv1 GEMM)
-            shallow = self.layer2(self.layer1(maxpool(bn1(conv1(x), relu=True))))
-            deep = self.layer4(self.layer3(shallow))
+        shallow = self.layer2(self.layer1(maxpool(bn1(conv1(x), relu=True))))
+        deep = self.layer4(self.layer3(shallow))
         if self.bn_clr:
             deep = self.bn_pretrain(deep)
         res = self.final(deep)

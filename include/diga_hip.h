@@ -471,21 +471,26 @@ int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const floa
                 void* stream);
 
 /* Train-mode diga_bn_fwd whose statistics pass is replaced by partials the producing conv already wrote
- * (`partial` = stats_partial of diga_conv2d_nhwc_*, `chunk_rows` = 128). */
+ * (`partial` = stats_partial of diga_conv2d_nhwc_*, `chunk_rows` = 128).
+ * tickets (nullable): ceil(C / 64) int32 counters, ZERO on entry and left zero on exit, owned by the caller and used by ONE stream at a
+ * time.  With it, layers whose partials are folded first (more than 128 chunks) fold and finalise in one launch -- the last-arriving
+ * fold block of a 64-channel slab finalises it -- instead of two; results are identical.  NULL: the two-launch form. */
 int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
                          int y_twin, unsigned char* relu_bits, float momentum, float eps, const float* partial,
-                         int64_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
+                         int64_t chunk_rows, void* workspace, size_t workspace_bytes, int32_t* tickets, void* stream);
 
 /* ... replaced by RECORDS of unequal size: partial [n_records][3][C] {sum (x - s), sum (x - s)^2, s}, counts [n_records] = the rows
  * behind each record (0 allowed), sum of counts = M -- what the Winograd forward's output transform writes (stats_partial of
- * diga_conv2d_winograd_f32: its tile groups hold different numbers of in-image pixels).  workspace as diga_bn_fwd_partials + 96 floats. */
+ * diga_conv2d_winograd_f32: its tile groups hold different numbers of in-image pixels).  workspace as diga_bn_fwd_partials + 96 floats;
+ * tickets as diga_bn_fwd_partials. */
 int diga_bn_fwd_records(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                         const float* gamma, const float* beta, float* running_mean, float* running_var,
                         float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
                         int y_twin, unsigned char* relu_bits, float momentum, float eps, const float* partial,
-                        const float* counts, int64_t n_records, void* workspace, size_t workspace_bytes, void* stream);
+                        const float* counts, int64_t n_records, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                        void* stream);
 
 /* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*mask, mask = [y>0] when y is given,
  * [fma(x, a, b) > 0] when relu_ab = save_ab of the forward is given instead (BN without residual), 1 when both are

@@ -188,7 +188,7 @@ def test_conv_epilogue_bn_statistics(case, math, monkeypatch):
     from diga_amd.model import conv as _dc
     from diga_amd.model.conv import DigaConv2d
     from diga_amd.model.norm import DigaBatchNorm2d
-    monkeypatch.setattr(_dc, "WINOGRAD", False)
+    monkeypatch.setattr(config.active(), "winograd", False)
     name, n, cin, h, w, cout, k, stride, pad, dil, _ = case
     g = synth.gen(zlib.crc32(name.encode()) % 10000 + 7)
     x = torch.randn((n, cin, h, w), generator=g) + 3.0
@@ -327,7 +327,7 @@ def test_f32_dma_and_persistent_kernels_bit_identical_to_register_staged_kernel(
     halves of the input channels (a backward-data convolution into < 256 channels).  Direct kernels only (Winograd off)."""
     from diga_amd import _lib
     from diga_amd.model import conv as dc
-    monkeypatch.setattr(dc, "WINOGRAD", False)
+    monkeypatch.setattr(config.active(), "winograd", False)
     name, n, cin, h, w, cout, k, s, p, d = case
     g = torch.Generator().manual_seed(4321)
     x = torch.randn((n, cin, h, w), generator=g)
@@ -427,7 +427,7 @@ def test_winograd_f32_vs_float64(case, tile, monkeypatch):
     from diga_amd import _lib
     from diga_amd.model import conv as dc
     name, n, cin, h, w, cout, d = case
-    monkeypatch.setattr(dc, "WINOGRAD", True)
+    monkeypatch.setattr(config.active(), "winograd", True)
     monkeypatch.setattr(config.active(), "winograd_ratio", 10.0)
     monkeypatch.setattr(dc, "_wino_plan", lambda hi, wi, dd: (tile, 0.5))
     calls = []
@@ -486,7 +486,7 @@ def test_persistent_gemm_bit_identical_to_per_tile_launch(tile, monkeypatch):
     from diga_amd import _lib
     from diga_amd.model import conv as dc
     from diga_amd.model.conv import DigaConv2d
-    monkeypatch.setattr(dc, "WINOGRAD", True)
+    monkeypatch.setattr(config.active(), "winograd", True)
     monkeypatch.setattr(config.active(), "winograd_ratio", 10.0)
     monkeypatch.setattr(dc, "_wino_plan", lambda hi, wi, dd: (tile, 0.5))
     prev = _lib.get_conv_math()

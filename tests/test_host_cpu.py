@@ -79,7 +79,7 @@ def test_abi_argument_errors_without_gpu():
     opt = _lib.ConvOptions(1, 1, 0)
     rc = _lib.lib.diga_conv2d_winograd_f32_opts(16, 16, None, 16, 16, 1 << 30, 1, 8, 8, 128, 128, 128, 128, 1, 6, ctypes.byref(opt), None, 0, None)
     assert rc == -1 and "reflect_pad" in _lib.last_error()
-    assert _lib.lib.diga_bn_fwd_records(16, 4, 16, 4, None, 4, 16, 16, None, None, 16, 16, None, 8, 4, 0, 0, None, 0.1, 1e-5, 16, None, 4, 16, 1 << 20, None) == -1
+    assert _lib.lib.diga_bn_fwd_records(16, 4, 16, 4, None, 4, 16, 16, None, None, 16, 16, None, 8, 4, 0, 0, None, 0.1, 1e-5, 16, None, 4, 16, 1 << 20, None, None) == -1
     assert _lib.lib.diga_small_linear_fwd(None, None, None, None, 1, 1, 1, 0, None) == -1
     assert _lib.lib.diga_nonfinite_flag_f32(None, 4, None, None) == -1 and _lib.lib.diga_colsum_nhwc(None, 4, None, 4, 4, None, 0, None) == -1
 
@@ -569,3 +569,37 @@ def test_segformer_head_fresh_initialisation_is_mmcvs():
     assert torch.equal(head.linear_fuse.bn.weight.detach(), torch.ones(768)) and torch.equal(head.linear_fuse.bn.bias.detach(), torch.zeros(768))
     assert head.linear_fuse.bn.weight.requires_grad and head.linear_fuse.bn.bias.requires_grad
     assert float(head.linear_pred.weight.std()) == pytest.approx(0.01, rel=0.05) and float(head.linear_pred.bias.abs().max()) == 0.0
+
+
+def test_package_modules_reference_only_attributes_that_exist():
+    """A refactoring guard that needs no GPU: every `<module alias>.<attribute>` the package's own sources (and bench.py) read from
+    another module of the package must exist there (round 6 removed module-level switches and two fused paths; one leftover
+    `dn.junction_fusion()` cost a full GPU suite run)."""
+    import ast
+    import glob
+    import importlib
+    import types
+    files = glob.glob(os.path.join(ROOT, "diga_amd", "**", "*.py"), recursive=True) + [os.path.join(ROOT, "bench.py")]
+    missing = []
+    for f in files:
+        tree = ast.parse(open(f).read())
+        alias = {}
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.startswith("diga_amd"):
+                pkg = importlib.import_module(node.module)
+                for a in node.names:
+                    obj = getattr(pkg, a.name, None)
+                    if obj is None:
+                        try:
+                            obj = importlib.import_module(node.module + "." + a.name)
+                        except ImportError:
+                            missing.append((os.path.relpath(f, ROOT), node.lineno, f"from {node.module} import {a.name}"))
+                            continue
+                    if isinstance(obj, types.ModuleType):
+                        alias[a.asname or a.name] = obj
+        assigned = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store)}
+        for node in ast.walk(tree):
+            if (isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and isinstance(node.ctx, ast.Load)
+                    and node.value.id in alias and node.value.id not in assigned and not hasattr(alias[node.value.id], node.attr)):
+                missing.append((os.path.relpath(f, ROOT), node.lineno, f"{node.value.id}.{node.attr}"))
+    assert not missing, missing
