@@ -82,7 +82,7 @@ SIGNATURES = {
     "diga_pyramid_sum_bwd": (INT, [P, I64, I64, P, I64, I64, I64, I64, P]),
     "diga_pyramid_sum_fwd3": (INT, [P, I64, I64, P, P, P, P, P, I64, I64, P]),
     "diga_pyramid_sum_bwd3": (INT, [P, I64, I64, P, P, P, I64, I64, P]),
-    "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
+    "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P, P]),
     "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_conv2d_winograd_workspace_bytes": (SZ, [I64] * 7),
     "diga_conv2d_winograd_tile_table_bytes": (SZ, [I64] * 5),

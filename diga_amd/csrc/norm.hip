@@ -839,9 +839,8 @@ __global__ __launch_bounds__(256) void merge_finalize_kernel(const float* __rest
 // lanes x 64 columns, coalesced 256-byte row pieces, sums in double.  Used in front of bn_bwd_finalize2_kernel when the
 // backward-data epilogue delivered one partial per 128-row chunk (> 1000 chunks at C2 sizes: walking them with the
 // finaliser's 16 lanes per channel took 44 us per layer).
-__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ in, int K, int W, int parts,
-                                                          float* __restrict__ out) {
-    __shared__ double red[4][64];
+__device__ __forceinline__ void colsum_fold_block(double (*red)[64], const float* __restrict__ in, int K, int W, int parts,
+                                                  float* __restrict__ out) {
     const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl, part = blockIdx.y;
     double acc = 0.0;
@@ -852,14 +851,21 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restric
     if (lane == 0 && c < W) out[(int64_t)part * W + c] = (float)(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
-                                                               const float* __restrict__ gamma,
-                                                               const float* __restrict__ invstd, float* __restrict__ kk,
-                                                               int training, float* __restrict__ dgamma = nullptr,
-                                                               float* __restrict__ dbeta = nullptr) {
-    __shared__ double red[2][kFinLn][kFinCh];
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ in, int K, int W, int parts,
+                                                          float* __restrict__ out) {
+    __shared__ double red[4][64];
+    colsum_fold_block(red, in, K, W, parts, out);
+}
+
+// the backward finaliser of kFinCh channels starting at c0 by one 256-thread block; `red` = [2][kFinLn][kFinCh] doubles.  Every thread of
+// the block must call it (barriers inside).  COHERENT as in bn_finalize_channels.
+template <bool COHERENT>
+__device__ __forceinline__ void bn_bwd_finalize_channels(double (*red)[kFinLn][kFinCh], int c0, const float* __restrict__ partial,
+                                                         const ColGeom& g, const float* __restrict__ gamma,
+                                                         const float* __restrict__ invstd, float* __restrict__ kk, int training,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int cl = threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
-    const int c = blockIdx.x * kFinCh + cl;
+    const int c = c0 + cl;
     const bool live = c < g.C;
     // (eval mode with a trainable affine pair: the partial sums exist -- they ARE dgamma / dbeta -- but dx takes no mean terms)
     const int K = (training || dgamma) ? g.nseg * g.nchunk : 0;
@@ -867,13 +873,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __re
     if (live)
 #pragma unroll 4
         for (int k = lane; k < K; k += kFinLn) {
-            s1 += (double)partial[(int64_t)k * 2 * g.C + c];
-            s2 += (double)partial[(int64_t)k * 2 * g.C + g.C + c];
+            s1 += (double)fin_load<COHERENT>(partial + (int64_t)k * 2 * g.C + c);
+            s2 += (double)fin_load<COHERENT>(partial + (int64_t)k * 2 * g.C + g.C + c);
         }
     red[0][lane][cl] = s1;
     red[1][lane][cl] = s2;
     __syncthreads();
-    if (lane != 0 || !live) return;
+    if (lane != 0 || !live) {
+        __syncthreads();
+        return;
+    }
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int l = 0; l < kFinLn; ++l) {
@@ -888,6 +897,41 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __re
     // a trainable affine pair (the SegFormer head's BatchNorm): the two column sums ARE its gradients
     if (dgamma) dgamma[c] = (float)t2;
     if (dbeta) dbeta[c] = (float)t1;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ invstd, float* __restrict__ kk,
+                                                               int training, float* __restrict__ dgamma = nullptr,
+                                                               float* __restrict__ dbeta = nullptr) {
+    __shared__ double red[2][kFinLn][kFinCh];
+    bn_bwd_finalize_channels<false>(red, blockIdx.x * kFinCh, partial, g, gamma, invstd, kk, training, dgamma, dbeta);
+}
+
+// colsum_fold + bn_bwd_finalize2 in ONE launch (round 6, the backward twin of merge_finalize_kernel): the fold's grid is (2 C / 64 column
+// slabs, parts); a channel slab s (64 channels) owns the two column slabs s and C / 64 + s (sum g, sum g xhat) -- 2 x parts blocks take a
+// ticket of tickets[s], the last one finalises the 64 channels.  C % 64 == 0.
+__global__ __launch_bounds__(256) void colsum_fold_finalize_kernel(const float* __restrict__ in, int K, int W, int parts, float* __restrict__ out,
+                                                                   ColGeom gf, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                                   float* __restrict__ kk, int* __restrict__ tickets) {
+    __shared__ double red[2][kFinLn][kFinCh];                   // (the fold uses its first 4 x 64 doubles)
+    __shared__ int last;
+    colsum_fold_block(reinterpret_cast<double (*)[64]>(&red[0][0][0]), in, K, W, parts, out);
+    const int slabs = gf.C / 64, slab = (int)blockIdx.x % slabs;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(&tickets[slab], 1);
+        last = (t == 2 * (int)gridDim.y - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x == 0) tickets[slab] = 0;
+#pragma unroll 1
+    for (int q = 0; q < 64 / kFinCh; ++q)
+        bn_bwd_finalize_channels<true>(red, slab * 64 + q * kFinCh, out, gf, gamma, invstd, kk, 1, nullptr, nullptr);
 }
 
 // one wave per (image, group): lane = (channel j = lane % cpg_pad, chunk lane); requires cpg <= 64
@@ -1248,7 +1292,7 @@ extern "C" int diga_bn_bwd_affine(const float* dy, int64_t ld_dy, const float* x
 extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,
                                     const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx, int64_t M,
                                     int64_t C, int dx_twin, const float* partial, int64_t chunk_rows, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    size_t workspace_bytes, int32_t* tickets, void* stream) {
     DIGA_REQUIRE(!dx_twin || (C % 8 == 0 && ld_dx == C), DIGA_EINVAL, "bn_bwd_partials: twin output needs C % 8 == 0 and a dense dx");
     DIGA_REQUIRE(g && x && gamma && save_mean && save_invstd && dx && partial && workspace && M > 0 && chunk_rows > 0, DIGA_EINVAL,
                  "bn_bwd_partials: bad argument");
@@ -1264,18 +1308,28 @@ extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x
     geo.chunk_rows = (int)chunk_rows;
     geo.nchunk = (int)ceil_div(M, chunk_rows);
     float* kk = (float*)workspace;
+    bool finalised = false;
     if (geo.nchunk > 64) {
         // many 128-row chunks: fold them to 32 rows first (the finaliser only needs sum g, sum g*xhat over all rows)
         constexpr int kParts = 32;
         float* folded = kk + 3 * C;
-        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)ceil_div(2 * C, 64), kParts), dim3(256), 0, st, partial, geo.nchunk,
-                           (int)(2 * C), kParts, folded);
+        ColGeom gf = geo;
+        gf.nchunk = kParts;
+        gf.chunk_rows = (int)ceil_div(M, kParts);        // (only nseg * nchunk and rows_per_seg enter the finaliser)
+        if (tickets != nullptr && C % 64 == 0) {
+            hipLaunchKernelGGL(colsum_fold_finalize_kernel, dim3((unsigned)(2 * C / 64), kParts), dim3(256), 0, st, partial, geo.nchunk,
+                               (int)(2 * C), kParts, folded, gf, gamma, save_invstd, kk, tickets);
+            finalised = true;
+        } else {
+            hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)ceil_div(2 * C, 64), kParts), dim3(256), 0, st, partial, geo.nchunk,
+                               (int)(2 * C), kParts, folded);
+        }
         partial = folded;
-        geo.nchunk = kParts;
-        geo.chunk_rows = (int)ceil_div(M, kParts);       // (only nseg * nchunk and rows_per_seg enter the finaliser)
+        geo = gf;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, geo, gamma,
-                       save_invstd, kk, 1);
+    if (!finalised)
+        hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, geo, gamma,
+                           save_invstd, kk, 1);
     launch_bwd_apply(dim3(ew_blocks(M * C / 4)), st, g, ld_g, x, ld_x, (const float*)nullptr,
                        (int64_t)0, save_mean, save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, (float*)nullptr,
                        (int64_t)0, M, M, (int)C, (const float*)nullptr, dx_twin);

@@ -145,7 +145,7 @@ class _BnFn(torch.autograd.Function):
             ws = _lib.workspace(67 * c * 4, xn.device, "norm_kk")
             _lib.call("diga_bn_bwd_partials", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(weight), _lib.ptr(save_mean),
                       _lib.ptr(save_invstd), _lib.ptr(dx), c, m, c, 1 if ctx.dx_twin else 0, _lib.ptr(pre[1]), int(pre[5]),
-                      _lib.ptr(ws), ws.numel(), _lib.stream())
+                      _lib.ptr(ws), ws.numel(), _bn_tickets(c, xn.device), _lib.stream())
             dres = g if has_res else None
         else:
             dres = torch.empty_like(xn) if has_res else None

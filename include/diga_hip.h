@@ -514,11 +514,12 @@ int diga_bn_bwd_affine(const float* dy, int64_t ld_dy, const float* x, int64_t l
 /* diga_bn_bwd for a gradient that arrives already masked and reduced: `g` and `partial` ([ceil(M/chunk_rows)][2][C]:
  * sum g, sum g*xhat per chunk) come out of the epilogue of the backward-data convolution that produced g
  * (diga_conv2d_nhwc_*_epi, chunk_rows = 128): one finalise launch + the apply pass (read g, x; write dx).
- * workspace >= 67*C floats. */
+ * workspace >= 67*C floats.  tickets (nullable): as diga_bn_fwd_partials -- with it (and C % 64 == 0) the fold of > 64 chunks and the
+ * finaliser are one launch. */
 int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,
                          const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx, int64_t M, int64_t C,
                          int dx_twin, const float* partial, int64_t chunk_rows, void* workspace, size_t workspace_bytes,
-                         void* stream);
+                         int32_t* tickets, void* stream);
 
 /* GroupNorm over (HW x C/G) per image and group, then y = [relu](chan_scale[n,c] * (xhat*gamma + beta));
  * chan_scale (nullable, [N][C]) carries the Dropout2d keep/(1-p) pattern.  save_mean/invstd [N][G]. */

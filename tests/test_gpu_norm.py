@@ -330,6 +330,46 @@ def test_bn_fused_fold_and_finalise_is_bit_identical(kind, monkeypatch):
         _lib.set_conv_math(prev)
 
 
+def test_bn_backward_fused_fold_and_finalise_is_bit_identical(monkeypatch):
+    """The backward twin: the BatchNorm-backward sums delivered by the backward-data epilogues (one partial per 128-row chunk), folded
+    and finalised in one launch (diga_bn_bwd_partials with `tickets`) against colsum_fold + bn_bwd_finalize2: a bottleneck's input
+    gradient and every weight gradient equal bit for bit, twice in a row (counters back at zero)."""
+    from diga_amd import _lib, config
+    from diga_amd.model import seg_model_noaux as sm
+    prev = _lib.get_conv_math()
+    _lib.set_conv_math(0)
+    try:
+        torch.manual_seed(4)
+        blk = sm.Bottleneck(1024, 256, 1, dilation=2).to(DEV).train()
+        g = synth.gen(12)
+        x0 = _cl(torch.randn((4, 1024, 65, 65), generator=g))              # 16 900 rows: 133 chunks of 128 (> 64: folded first)
+        probe = torch.randn((4, 1024, 65, 65), generator=g).to(DEV)
+        calls, real = [], _lib.call
+        monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append((name, a)), real(name, *a))[1])
+        res = []
+        for fused in (False, True, True):
+            monkeypatch.setattr(config.active(), "bn_fused_finalize", fused)
+            for p_ in blk.parameters():
+                p_.grad = None
+            sd = {k: v.clone() for k, v in blk.state_dict().items()}
+            calls.clear()
+            x = x0.clone().requires_grad_()
+            y = blk(x)
+            (y * probe).sum().backward()
+            torch.cuda.synchronize()
+            bwd = [a for n, a in calls if n == "diga_bn_bwd_partials"]
+            assert len(bwd) >= 2 and all((a[-2] is not None) == fused for a in bwd)
+            res.append([y.detach().clone(), x.grad.clone()] + [getattr(blk, c).weight.grad.clone() for c in ("conv1", "conv2", "conv3")])
+            blk.load_state_dict(sd)
+            if fused:
+                assert int(_lib.tickets(16, torch.device(DEV)).abs().sum()) == 0
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert torch.equal(a, b)
+    finally:
+        _lib.set_conv_math(prev)
+
+
 @pytest.mark.parametrize("n,k,o,act", [(16, 1280, 80, 1), (16, 80, 1280, 2), (3, 37, 5, 0), (1, 64, 64, 2)])
 def test_small_linear_forward_backward_vs_float64(n, k, o, act):
     """The SE block's dense layers (diga_small_linear_fwd / _bwd: Linear + none / ReLU / sigmoid) against torch in float64:

@@ -175,8 +175,19 @@ def test_large_tiles_do_not_drift_faster_than_f2x2(golden):
     big, small = run_trajectory_once("traj25", g, "f32"), run_trajectory_once("traj25", g, "f32_tile2")
     _report("traj25_growth", big)
     last = lambda r: float(np.mean([max(a, b) for a, b in zip(r["ce_dev"], r["distil_dev"])][-5:]))      # noqa: E731
-    print(f"\nlast-5-step mean loss deviation: default tiles {last(big):.2e}, F(2x2) {last(small):.2e}; growth {big['growth']:.2f} vs {small['growth']:.2f}")
-    assert big["growth"] < max(3.0, 3.0 * small["growth"])
+    # the yardstick for "no faster": the growth of the REFERENCE against itself over the same 25 steps (two runs of the reference that
+    # differ in summation order only, `floor_*_dev` of the capture: 25.4 with this formula) and of the F(2x2)-only run (23.1 measured in
+    # round 5, default tiles 31.4).  Round 5's bound was 3 x F(2x2)'s growth -- 36 % faster passed unnoticed; now 1.5 x the larger of the two.
+    floor = np.maximum(np.asarray(g["floor_ce_dev"]), np.asarray(g["floor_distil_dev"]))
+    ref_growth = float(floor[-5:].mean() / max(floor[:5].mean(), 1e-12))
+    print(f"\nlast-5-step mean loss deviation: default tiles {last(big):.2e}, F(2x2) {last(small):.2e}; growth: default tiles {big['growth']:.2f}, "
+          f"F(2x2) {small['growth']:.2f}, reference vs reference {ref_growth:.2f}")
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and os.access(out, os.W_OK):
+        with open(os.path.join(out, "traj_growth.json"), "w") as f:
+            json.dump(dict(default_tiles=big["growth"], f2x2=small["growth"], reference_vs_reference=ref_growth,
+                           last5_default=last(big), last5_f2x2=last(small)), f)
+    assert big["growth"] < 1.5 * max(small["growth"], ref_growth), (big["growth"], small["growth"], ref_growth)
     assert last(big) < max(4.0 * last(small), 2e-6)
     assert big["head_delta"] < max(4.0 * small["head_delta"], 1e-4)
 
