@@ -49,7 +49,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak
 SERIAL_STEPS = 2          # steps of the serialised-stream pass that times kernels for the roofline
 FWD_GFLOP_768 = 1232.9           # model forward, one 768x768 image
 FWD_GFLOP_256 = 142.6
-PROFILE_TAGS = ("r05", "r04", "r03", "r02")    # profiles/<tag>_<precision>_serial_pmc_summary.json feeds roofline.traffic (newest first)
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02")    # profiles/<tag>_<precision>_serial_pmc_summary.json feeds roofline.traffic (newest first)
 
 CONFIGS = {
     # name: (arch, batch per GPU, H, W, label block, BASELINE.json entry, description)
@@ -210,12 +210,14 @@ def cpu_baseline_subprocess():
     return out
 
 
-def miou_parity_subprocess(limit_s=300):
+def miou_parity_subprocess(limit_s=420):
     """Fixed-seed validation mIoU of the build (both conv arithmetics) against the capture of the reference
-    (tests/golden/valmiou.npz): the checker lives with the tests (it needs the oracle's deterministic weights), so it
+    (tests/golden/valmiou.npz), and -- north_star's training-level criterion -- ONE seed of the trained-model experiment
+    (tests/golden/trainmiou.npz: 300 steps of the warm-up loop on a learnable task, then the two-scale validation) next to the
+    reference's three training runs: the checker lives with the tests (it needs the oracle's deterministic weights), so it
     runs as a child process, after the timed regions."""
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "miou_parity.py")], capture_output=True, text=True,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "miou_parity.py"), "--trained"], capture_output=True, text=True,
                            timeout=limit_s)
         for ln in reversed(r.stdout.splitlines()):
             if ln.startswith("{"):
@@ -852,6 +854,14 @@ def compact(line):
                      "parallelism": cfg["parallelism"]}
     pm = line.get("peak_mem_gb") or {}
     out["peak_mem_gb"] = {k: num(v, 4) for k, v in pm.items()} or None
+    mp = line.get("miou_parity") or {}
+    tm = mp.get("trained_model") or {}
+    if mp and "error" not in mp:
+        # val mIoU half of the metric: fixed weights (argmax parity of the validation pass) and a TRAINED model (one seed run live;
+        # reference = three training runs of the reference's own loop, tests/golden/trainmiou.npz)
+        out["miou_parity"] = {"fixed_weights_delta_points": num((mp.get("f32") or {}).get("miou_delta_points"), 3),
+                              "trained_hip_miou": num(tm.get("hip_final_miou"), 4), "trained_reference_same_seed": num(tm.get("reference_same_seed"), 4),
+                              "trained_reference_mean": num(tm.get("reference_mean"), 4), "trained_reference_seed_spread": num(tm.get("reference_seed_spread"), 3)}
     out.update(rccl_ranks=line["rccl_ranks"], backend=line.get("backend"), ranks_agree=line.get("ranks_agree"), roofline=roof, cpu_baseline=cpu, target=line.get("target"),
                second_precision=leg(line.get("second_precision")), c4_selftrain=leg(oc.get("c4")), c5_segformer=leg(oc.get("c5")),
                detail=line.get("detail_file"))

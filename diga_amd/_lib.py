@@ -74,15 +74,15 @@ SIGNATURES = {
     "diga_im2col_nchw": (INT, [P, P] + [I64] * 11 + [P]),
     "diga_norm_workspace_bytes": (SZ, [I64, I64, I64]),
     "diga_bn_fwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, INT, P, F32, F32, P, SZ, P]),
-    "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, I64, P, SZ, P, P]),
-    "diga_bn_fwd_records": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, P, I64, P, SZ, P, P]),
+    "diga_bn_fwd_partials": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, I64, P, SZ, P]),
+    "diga_bn_fwd_records": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, P, P, I64, I64, INT, INT, P, F32, F32, P, P, I64, P, SZ, P]),
     "diga_bn_bwd": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, I64, I64, I64, INT, INT, P, SZ, P]),
     "diga_bn_bwd_affine": (INT, [P, I64, P, I64, P, I64, P, P, P, P, P, I64, P, P, I64, I64, INT, P, SZ, P]),
     "diga_pyramid_sum_fwd": (INT, [P, I64, I64, P, P, I64, I64, P, I64, I64, P, I64, I64, I64, I64, P]),
     "diga_pyramid_sum_bwd": (INT, [P, I64, I64, P, I64, I64, I64, I64, P]),
     "diga_pyramid_sum_fwd3": (INT, [P, I64, I64, P, P, P, P, P, I64, I64, P]),
     "diga_pyramid_sum_bwd3": (INT, [P, I64, I64, P, P, P, I64, I64, P]),
-    "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P, P]),
+    "diga_bn_bwd_partials": (INT, [P, I64, P, I64, P, P, P, P, I64, I64, I64, INT, P, I64, P, SZ, P]),
     "diga_conv2d_nhwc_f32_epi": (INT, [P, P, P] + [I64] * 17 + [P, INT, P]),
     "diga_conv2d_winograd_workspace_bytes": (SZ, [I64] * 7),
     "diga_conv2d_winograd_tile_table_bytes": (SZ, [I64] * 5),
@@ -291,21 +291,6 @@ def join_side():
     for idx in list(_side_dirty):
         torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
     _side_dirty.clear()
-
-
-_tickets = {}
-
-
-def tickets(n, device):
-    """A zero-initialised int32 counter array of >= n entries for the CURRENT stream of `device` (the last-arriving-block kernels take
-    their tickets from it and leave it zeroed: include/diga_hip.h, `tickets`).  One per device and stream: two streams must never share
-    a counter array, a stream's own launches are ordered."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    buf = _tickets.get(key)
-    if buf is None or buf.numel() < n:
-        buf = torch.zeros(max(int(n), 64), dtype=torch.int32, device=device)
-        _tickets[key] = buf
-    return buf
 
 
 def workspace(nbytes, device, tag="default"):

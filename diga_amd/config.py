@@ -56,7 +56,6 @@ class StepConfig:
     relu_bits: bool = True               # ReLU masks as bit planes instead of reading the activated tensor in backward
     fuse_bwd: bool = True                # residual-junction add + ReLU mask + BN-backward reduce in the backward-data epilogue
     junction_chain: bool = True
-    bn_fused_finalize: bool = True       # BatchNorm statistics: fold + finalise in one launch (last-arriving block per channel slab)
     # ---- data parallelism (diga_amd/ddp.py)
     ddp_bucket_mb: int = 25
     ddp_grad_views: bool = True          # gradients live in the all-reduce buckets
@@ -92,7 +91,6 @@ class StepConfig:
         c.relu_bits = _flag("DIGA_RELU_BITS", c.relu_bits)
         c.fuse_bwd = _flag("DIGA_FUSE_BWD", c.fuse_bwd)
         c.junction_chain = _flag("DIGA_JUNCTION_CHAIN", c.junction_chain)
-        c.bn_fused_finalize = _flag("DIGA_BN_FUSED_FINALIZE", c.bn_fused_finalize)
         c.ddp_bucket_mb = int(e("DIGA_DDP_BUCKET_MB", c.ddp_bucket_mb))
         c.ddp_grad_views = _flag("DIGA_DDP_GRAD_VIEWS", c.ddp_grad_views)
         c.ddp_overlap = _flag("DIGA_DDP_OVERLAP", c.ddp_overlap)

@@ -354,13 +354,21 @@ constexpr int cell_rows() {
     return 4 * C + 2;
 }
 
-template <int C, bool DISTILL>
+// ONE (round 6): the launch's cells hold at most 64 pixels each and every wave owns ONE cell (cpw == 1: the x8 / x7.98 upsampling of
+// the DeepLab path).  Then (a) the cell index is uniform over the wave, so the 4 x C x 2 corner logits are wave-uniform loads (scalar
+// loads: the generic form issued 118 vector loads per lane for them), and (b) there is one pixel per lane and no loop, so the 4 C
+// gradient sums need no accumulators -- each product goes straight into its cross-lane reduction.  The generic form's 76 accumulators
+// + 57 logit / exponential values + 152 gathered corners made it a 315-VGPR kernel: ONE wave per SIMD under ~60 dependent
+// transcendentals and a chain of global round trips per block (1.0 ms per C2 step; the round-6 counter pass showed the occupancy, not
+// the arithmetic, to be the bound).
+template <int C, bool DISTILL, bool ONE>
 __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
     const float* __restrict__ stu_lr, const float* __restrict__ tea_lr, const long long* __restrict__ labels,
     const int* __restrict__ ystart, const int* __restrict__ xstart, float* __restrict__ cellpart, int B,
     int n_ce /* images that carry a CE term */, int h, int w, int H, int W, float sy, float sx, float k_ce,
-    float k_di, float scale, int cpw /* cells per wave: 1, 2, 4 or 8 neighbours along x, 64 / cpw lanes each */) {
+    float k_di, float scale, int cpw_rt /* cells per wave: 1, 2, 4 or 8 neighbours along x, 64 / cpw lanes each */) {
     constexpr int ROWS = cell_rows<C>();
+    const int cpw = ONE ? 1 : cpw_rt;
     // (round 6) the wave's 4 C + 2 sums are folded over each lane quad with two DPP steps BEFORE they cross LDS: 17 columns instead of
     // 65 -- 5.3 KB instead of 20 KB per one-wave block, which had capped the kernel at 8 waves per CU (two per SIMD) under ~57
     // dependent transcendentals per pixel
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
     // small cells (logits at 1/4 scale: 4 x 4 full-resolution pixels per cell) would leave most of a wave idle and pay the LDS fold
     // per 16 pixels: `cpw` neighbouring cells share the wave, lane group `sub` owns cell blockIdx.x * cpw + sub
     const int lpc = 64 / cpw;
-    const int lane = threadIdx.x % lpc, sub = threadIdx.x / lpc;
+    const int lane = ONE ? (int)threadIdx.x : (int)threadIdx.x % lpc, sub = ONE ? 0 : (int)threadIdx.x / lpc;
     const int cj_raw = blockIdx.x * cpw + sub, ci = blockIdx.y, n = blockIdx.z;
     const bool cell_ok = cj_raw < w - 1;
     const int cj = cell_ok ? cj_raw : w - 2;
@@ -381,14 +389,24 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
     const float wgt = n < B ? scale : 1.f;
     const bool has_ce = n < n_ce;
 
-    float acc[4][C];
+    float acc[ONE ? 1 : 4][ONE ? 1 : C];
+    if constexpr (!ONE) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
+            for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
+    }
     float ce_sum = 0.f, di_sum = 0.f;
+    const int wl = threadIdx.x;
+    auto quad_sum = [](float v) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+        return v;
+    };
+    const bool lead = (wl & 3) == 0;
+    const int qcol = wl >> 2;
 
-    for (int base = 0; base < npx; base += lpc) {
+    for (int base = 0; base < (ONE ? 1 : npx); base += lpc) {
         const int idx = base + lane;
         const bool live = idx < npx;
         const int py = ylo + (live ? idx / nx : 0), px = xlo + (live ? idx % nx : 0);
@@ -445,31 +463,36 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
                 di_px -= qq * (s[c] - lse);
                 g += gdi * (p - qq);
             }
-            acc[0][c] += w00 * g;
-            acc[1][c] += w01 * g;
-            acc[2][c] += w10 * g;
-            acc[3][c] += w11 * g;
+            if constexpr (ONE) {
+                // (dead lanes carry g = 0: gce and gdi are zero there)
+                const float r0 = quad_sum(w00 * g), r1 = quad_sum(w01 * g), r2 = quad_sum(w10 * g), r3 = quad_sum(w11 * g);
+                if (lead) {
+                    red[(0 * C + c) * 17 + qcol] = r0;
+                    red[(1 * C + c) * 17 + qcol] = r1;
+                    red[(2 * C + c) * 17 + qcol] = r2;
+                    red[(3 * C + c) * 17 + qcol] = r3;
+                }
+            } else {
+                acc[0][c] += w00 * g;
+                acc[1][c] += w01 * g;
+                acc[2][c] += w10 * g;
+                acc[3][c] += w11 * g;
+            }
         }
         ce_sum += valid ? (lse - xt) : 0.f;
         if (DISTILL && live) di_sum += wgt * di_px;
     }
     // transposed wave reduction: quad sums by DPP (a lane group is >= 8 lanes: a quad never spans two cells), then through LDS:
     // row r = value index, column = quad (of the whole wave); each cell folds the quads of its lane group
-    const int wl = threadIdx.x;
-    auto quad_sum = [](float v) {
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
-        return v;
-    };
-    const bool lead = (wl & 3) == 0;
-    const int qcol = wl >> 2;
+    if constexpr (!ONE) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float v = quad_sum(acc[k][c]);
-            if (lead) red[(k * C + c) * 17 + qcol] = v;
-        }
+            for (int c = 0; c < C; ++c) {
+                const float v = quad_sum(acc[k][c]);
+                if (lead) red[(k * C + c) * 17 + qcol] = v;
+            }
+    }
     {
         const float v0 = quad_sum(ce_sum), v1 = quad_sum(di_sum);
         if (lead) {
@@ -660,14 +683,21 @@ int run_upsample_loss(const float* stu_lr, const float* tea_lr, const int64_t* l
     const double cell_px = ((double)H / (double)(h - 1)) * ((double)W / (double)(w - 1));
     const int cpw = cell_px >= 48.0 ? 1 : cell_px >= 24.0 ? 2 : cell_px >= 12.0 ? 4 : 8;
     dim3 grid((unsigned)ceil_div(w - 1, cpw), (unsigned)(h - 1), (unsigned)N);
-    if (distill)
-        hipLaunchKernelGGL((upsample_loss_cells_kernel<C, true>), grid, dim3(64), 0, st, stu_lr, tea_lr,
-                           (const long long*)labels, cw.ystart, cw.xstart, cw.cellpart, (int)B, (int)n_ce, (int)h,
-                           (int)w, (int)H, (int)W, sy, sx, k_ce, k_di, scale, cpw);
-    else
-        hipLaunchKernelGGL((upsample_loss_cells_kernel<C, false>), grid, dim3(64), 0, st, stu_lr, tea_lr,
-                           (const long long*)labels, cw.ystart, cw.xstart, cw.cellpart, (int)B, (int)n_ce, (int)h,
-                           (int)w, (int)H, (int)W, sy, sx, k_ce, k_di, scale, cpw);
+    // one cell per wave and no cell larger than a wave: a cell spans at most ceil(1 / s) + 1 pixels per axis (s = (in - 1) / (out - 1))
+    const double cy = sy > 0.f ? std::ceil(1.0 / (double)sy) + 1.0 : (double)H, cx = sx > 0.f ? std::ceil(1.0 / (double)sx) + 1.0 : (double)W;
+    const bool one = cpw == 1 && cy * cx <= 64.0;
+#define DIGA_UL_LAUNCH(D_, O_)                                                                                             \
+    hipLaunchKernelGGL((upsample_loss_cells_kernel<C, D_, O_>), grid, dim3(64), 0, st, stu_lr, tea_lr, (const long long*)labels, \
+                       cw.ystart, cw.xstart, cw.cellpart, (int)B, (int)n_ce, (int)h, (int)w, (int)H, (int)W, sy, sx, k_ce, k_di,  \
+                       scale, cpw)
+    if (distill) {
+        if (one) DIGA_UL_LAUNCH(true, true);
+        else DIGA_UL_LAUNCH(true, false);
+    } else {
+        if (one) DIGA_UL_LAUNCH(false, true);
+        else DIGA_UL_LAUNCH(false, false);
+    }
+#undef DIGA_UL_LAUNCH
     const int64_t total = N * C * h * w;
     hipLaunchKernelGGL((upsample_loss_gather_kernel<C>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st,
                        cw.cellpart, grad_lr, (int)N, (int)h, (int)w);

@@ -657,25 +657,17 @@ __device__ __forceinline__ ChunkInv chunk_inv(const ColGeom& g) {
 
 // block = kFinCh channels x kFinLn lanes; all (segment, chunk) partials of a channel form one population
 constexpr int kFinCh = 16, kFinLn = 16;
-// COHERENT: the partials were written by OTHER blocks of the running kernel (merge_finalize_kernel's last-arriving block): every read
-// is an agent-scope atomic load, which no per-XCD L2 / per-CU vector cache can serve from a stale line.
-template <bool COHERENT>
-__device__ __forceinline__ float fin_load(const float* p) {
-    if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-// the finaliser of kFinCh channels starting at c0 by one 256-thread block (kFinCh channels x kFinLn record lanes); `red` = the block's
-// [kFinLn][kFinCh] doubles.  Every thread of the block must call it (barriers inside).
-template <bool COHERENT>
-__device__ __forceinline__ void bn_finalize_channels(double (*red)[kFinCh], int c0, const float* __restrict__ partial, const ColGeom& g,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                     float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                     float* __restrict__ ab, float momentum, float eps, const float* __restrict__ counts) {
+__global__ __launch_bounds__(256) void bn_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           float* __restrict__ ab, float momentum, float eps,
+                                                           const float* __restrict__ counts = nullptr) {
     // counts (nullable): rows of every record when they are not g.chunk_rows-sized row chunks (the Winograd output transform's
     // per-tile-group records, diga_bn_fwd_records); a record may be empty (count 0)
+    __shared__ double red[kFinLn][kFinCh];
     const int cl = threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
-    const int c = c0 + cl;
+    const int c = blockIdx.x * kFinCh + cl;
     const bool live = c < g.C;
     const ChunkInv ci = chunk_inv(g);
     const int K = g.nseg * g.nchunk;
@@ -684,8 +676,8 @@ __device__ __forceinline__ void bn_finalize_channels(double (*red)[kFinCh], int 
 #pragma unroll 4
         for (int k = lane; k < K; k += kFinLn) {
             const float* p = partial + (int64_t)k * 3 * g.C;
-            const double nk = counts != nullptr ? (double)fin_load<COHERENT>(counts + k) : ((k % g.nchunk) == g.nchunk - 1) ? ci.n_last : ci.n_full;
-            s += nk * (double)fin_load<COHERENT>(p + 2 * g.C + c) + (double)fin_load<COHERENT>(p + c);
+            const double nk = counts != nullptr ? (double)counts[k] : ((k % g.nchunk) == g.nchunk - 1) ? ci.n_last : ci.n_full;
+            s += nk * (double)p[2 * g.C + c] + (double)p[c];
         }
     red[lane][cl] = s;
     __syncthreads();
@@ -703,19 +695,16 @@ __device__ __forceinline__ void bn_finalize_channels(double (*red)[kFinCh], int 
             const bool last = (k % g.nchunk) == g.nchunk - 1;
             double nk = last ? ci.n_last : ci.n_full, ik = last ? ci.inv_last : ci.inv_full;
             if (counts != nullptr) {
-                nk = (double)fin_load<COHERENT>(counts + k);
+                nk = (double)counts[k];
                 ik = nk > 0.0 ? 1.0 / nk : 0.0;
             }
-            const double sd = fin_load<COHERENT>(p + c), sd2 = fin_load<COHERENT>(p + g.C + c), sh = fin_load<COHERENT>(p + 2 * g.C + c);
+            const double sd = p[c], sd2 = p[g.C + c], sh = p[2 * g.C + c];
             const double d = sh + sd * ik - mean;
             m2 += sd2 - sd * sd * ik + nk * d * d;
         }
     red[lane][cl] = m2;
     __syncthreads();
-    if (lane != 0 || !live) {
-        __syncthreads();          // (pairs with the barrier at the end: `red` is reused by the caller's next group of channels)
-        return;
-    }
+    if (lane != 0 || !live) return;
     double M2 = 0.0;
 #pragma unroll
     for (int l = 0; l < kFinLn; ++l) M2 += red[l][cl];
@@ -732,27 +721,16 @@ __device__ __forceinline__ void bn_finalize_channels(double (*red)[kFinCh], int 
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void bn_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                           float* __restrict__ ab, float momentum, float eps,
-                                                           const float* __restrict__ counts = nullptr) {
-    __shared__ double red[kFinLn][kFinCh];
-    bn_finalize_channels<false>(red, blockIdx.x * kFinCh, partial, g, gamma, beta, running_mean, running_var, save_mean, save_invstd, ab,
-                                momentum, eps, counts);
 }
 
 // Folds `group` consecutive row-chunk partials {sum d, sum d^2, shift} (each over `g.chunk_rows` rows, the last
 // one ragged) into one partial per group, re-based on the shift of the group's first chunk.  Block = 4 chunk
 // lanes x 64 channels, so every load is a coalesced 256-byte row piece; sums are formed in double.
-__device__ __forceinline__ void merge_partials_block(double (*red)[4][64], const float* __restrict__ partial, const ColGeom& g, int group,
-                                                     float* __restrict__ merged, const float* __restrict__ counts,
-                                                     float* __restrict__ mcounts, bool every_slab) {
+__global__ __launch_bounds__(256) void merge_partials_kernel(const float* __restrict__ partial, ColGeom g, int group,
+                                                             float* __restrict__ merged, const float* __restrict__ counts = nullptr,
+                                                             float* __restrict__ mcounts = nullptr) {
     // counts / mcounts (nullable): per-record row counts in, per-group sums out (records of unequal size, see bn_finalize2_kernel)
+    __shared__ double red[2][4][64];
     const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
     const bool live = c < g.C;
@@ -761,9 +739,7 @@ __device__ __forceinline__ void merge_partials_block(double (*red)[4][64], const
     const ChunkInv ci = chunk_inv(g);
     double s1 = 0.0, s2 = 0.0;
     float base = 0.f;
-    // (every_slab: the fused kernel's last-arriving block of a channel slab reads mcounts right after ITS slab's tickets -- every slab
-    //  writes the group's count, the same value, before its ticket)
-    if (counts != nullptr && threadIdx.x == 0 && (blockIdx.y == 0 || every_slab)) {
+    if (counts != nullptr && threadIdx.x == 0 && blockIdx.y == 0) {
         float tot = 0.f;                                   // (integers < 2^24: exact in fp32)
         for (int k = k0; k < k1; ++k) tot += counts[k];
         mcounts[blockIdx.x] = tot;
@@ -788,59 +764,13 @@ __device__ __forceinline__ void merge_partials_block(double (*red)[4][64], const
     o[2 * g.C + c] = base;
 }
 
-__global__ __launch_bounds__(256) void merge_partials_kernel(const float* __restrict__ partial, ColGeom g, int group,
-                                                             float* __restrict__ merged, const float* __restrict__ counts = nullptr,
-                                                             float* __restrict__ mcounts = nullptr) {
-    __shared__ double red[2][4][64];
-    merge_partials_block(red, partial, g, group, merged, counts, mcounts, false);
-}
-
-// Round 6: merge + finalise in ONE launch.  The two-launch chain (merge_partials 6.6 us, bn_finalize2 7.7 us and the gap between them)
-// sits on its stream's critical path in front of every BatchNorm apply pass -- 208 times per C2 step, and round 5 measured that chain at
-// ~1 : 1 in the step.  Here every merge block takes a ticket for its 64-channel slab after its merged partial is
-// out (release fence, agent-scope atomic); the block that draws the LAST ticket of a slab finalises those 64 channels -- the same
-// arithmetic as bn_finalize2_kernel, 16 channels x 16 record lanes at a time, four times -- reading the other blocks' partials with
-// agent-scope loads (the per-XCD L2s are not coherent with each other for plain loads), and puts the ticket counter back to zero for the
-// next call on this stream.  `tickets`: ceil(C / 64) int32, zero on entry, zero on exit (caller-owned, one per stream).
-struct FinArgs {
-    const float* gamma;
-    const float* beta;
-    float* running_mean;
-    float* running_var;
-    float* save_mean;
-    float* save_invstd;
-    float* ab;
-    float momentum, eps;
-};
-__global__ __launch_bounds__(256) void merge_finalize_kernel(const float* __restrict__ partial, ColGeom g, int group, float* __restrict__ merged,
-                                                             const float* __restrict__ counts, float* __restrict__ mcounts, ColGeom gm,
-                                                             FinArgs f, int* __restrict__ tickets) {
-    __shared__ double red[2][4][64];
-    __shared__ int last;
-    merge_partials_block(red, partial, g, group, merged, counts, mcounts, true);
-    __threadfence();                                            // this block's merged partial (and mcounts) before its ticket
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(&tickets[blockIdx.y], 1);
-        last = (t == (int)gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    if (threadIdx.x == 0) tickets[blockIdx.y] = 0;              // (nobody else touches this slab's counter any more in this launch)
-    double (*fred)[kFinCh] = reinterpret_cast<double (*)[kFinCh]>(&red[0][0][0]);      // 16 x 16 doubles of the 2 x 4 x 64
-#pragma unroll 1
-    for (int q = 0; q < 64 / kFinCh; ++q)
-        bn_finalize_channels<true>(fred, blockIdx.y * 64 + q * kFinCh, merged, gm, f.gamma, f.beta, f.running_mean, f.running_var, f.save_mean,
-                                   f.save_invstd, f.ab, f.momentum, f.eps, mcounts);
-}
-
 // Folds K rows of a [K][W] matrix of partial sums into `parts` rows (part p sums rows p, p + parts, ...): block = 4 row
 // lanes x 64 columns, coalesced 256-byte row pieces, sums in double.  Used in front of bn_bwd_finalize2_kernel when the
 // backward-data epilogue delivered one partial per 128-row chunk (> 1000 chunks at C2 sizes: walking them with the
 // finaliser's 16 lanes per channel took 44 us per layer).
-__device__ __forceinline__ void colsum_fold_block(double (*red)[64], const float* __restrict__ in, int K, int W, int parts,
-                                                  float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ in, int K, int W, int parts,
+                                                          float* __restrict__ out) {
+    __shared__ double red[4][64];
     const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl, part = blockIdx.y;
     double acc = 0.0;
@@ -851,21 +781,14 @@ __device__ __forceinline__ void colsum_fold_block(double (*red)[64], const float
     if (lane == 0 && c < W) out[(int64_t)part * W + c] = (float)(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
-__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ in, int K, int W, int parts,
-                                                          float* __restrict__ out) {
-    __shared__ double red[4][64];
-    colsum_fold_block(red, in, K, W, parts, out);
-}
-
-// the backward finaliser of kFinCh channels starting at c0 by one 256-thread block; `red` = [2][kFinLn][kFinCh] doubles.  Every thread of
-// the block must call it (barriers inside).  COHERENT as in bn_finalize_channels.
-template <bool COHERENT>
-__device__ __forceinline__ void bn_bwd_finalize_channels(double (*red)[kFinLn][kFinCh], int c0, const float* __restrict__ partial,
-                                                         const ColGeom& g, const float* __restrict__ gamma,
-                                                         const float* __restrict__ invstd, float* __restrict__ kk, int training,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ invstd, float* __restrict__ kk,
+                                                               int training, float* __restrict__ dgamma = nullptr,
+                                                               float* __restrict__ dbeta = nullptr) {
+    __shared__ double red[2][kFinLn][kFinCh];
     const int cl = threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
-    const int c = c0 + cl;
+    const int c = blockIdx.x * kFinCh + cl;
     const bool live = c < g.C;
     // (eval mode with a trainable affine pair: the partial sums exist -- they ARE dgamma / dbeta -- but dx takes no mean terms)
     const int K = (training || dgamma) ? g.nseg * g.nchunk : 0;
@@ -873,16 +796,13 @@ __device__ __forceinline__ void bn_bwd_finalize_channels(double (*red)[kFinLn][k
     if (live)
 #pragma unroll 4
         for (int k = lane; k < K; k += kFinLn) {
-            s1 += (double)fin_load<COHERENT>(partial + (int64_t)k * 2 * g.C + c);
-            s2 += (double)fin_load<COHERENT>(partial + (int64_t)k * 2 * g.C + g.C + c);
+            s1 += (double)partial[(int64_t)k * 2 * g.C + c];
+            s2 += (double)partial[(int64_t)k * 2 * g.C + g.C + c];
         }
     red[0][lane][cl] = s1;
     red[1][lane][cl] = s2;
     __syncthreads();
-    if (lane != 0 || !live) {
-        __syncthreads();
-        return;
-    }
+    if (lane != 0 || !live) return;
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int l = 0; l < kFinLn; ++l) {
@@ -897,41 +817,6 @@ __device__ __forceinline__ void bn_bwd_finalize_channels(double (*red)[kFinLn][k
     // a trainable affine pair (the SegFormer head's BatchNorm): the two column sums ARE its gradients
     if (dgamma) dgamma[c] = (float)t2;
     if (dbeta) dbeta[c] = (float)t1;
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ partial, ColGeom g,
-                                                               const float* __restrict__ gamma,
-                                                               const float* __restrict__ invstd, float* __restrict__ kk,
-                                                               int training, float* __restrict__ dgamma = nullptr,
-                                                               float* __restrict__ dbeta = nullptr) {
-    __shared__ double red[2][kFinLn][kFinCh];
-    bn_bwd_finalize_channels<false>(red, blockIdx.x * kFinCh, partial, g, gamma, invstd, kk, training, dgamma, dbeta);
-}
-
-// colsum_fold + bn_bwd_finalize2 in ONE launch (round 6, the backward twin of merge_finalize_kernel): the fold's grid is (2 C / 64 column
-// slabs, parts); a channel slab s (64 channels) owns the two column slabs s and C / 64 + s (sum g, sum g xhat) -- 2 x parts blocks take a
-// ticket of tickets[s], the last one finalises the 64 channels.  C % 64 == 0.
-__global__ __launch_bounds__(256) void colsum_fold_finalize_kernel(const float* __restrict__ in, int K, int W, int parts, float* __restrict__ out,
-                                                                   ColGeom gf, const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                                   float* __restrict__ kk, int* __restrict__ tickets) {
-    __shared__ double red[2][kFinLn][kFinCh];                   // (the fold uses its first 4 x 64 doubles)
-    __shared__ int last;
-    colsum_fold_block(reinterpret_cast<double (*)[64]>(&red[0][0][0]), in, K, W, parts, out);
-    const int slabs = gf.C / 64, slab = (int)blockIdx.x % slabs;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(&tickets[slab], 1);
-        last = (t == 2 * (int)gridDim.y - 1);
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    if (threadIdx.x == 0) tickets[slab] = 0;
-#pragma unroll 1
-    for (int q = 0; q < 64 / kFinCh; ++q)
-        bn_bwd_finalize_channels<true>(red, slab * 64 + q * kFinCh, out, gf, gamma, invstd, kk, 1, nullptr, nullptr);
 }
 
 // one wave per (image, group): lane = (channel j = lane % cpg_pad, chunk lane); requires cpg <= 64
@@ -1167,7 +1052,7 @@ static int bn_fwd_from_partials(const char* who, const float* x, int64_t ld_x, f
                                 float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
                                 int64_t C, int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps,
                                 const float* partial, int64_t chunk_rows, const float* counts, int64_t n_records,
-                                void* workspace, size_t workspace_bytes, int32_t* tickets, void* stream) {
+                                void* workspace, size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(!relu_bits || (relu && C % 32 == 0), DIGA_EINVAL, "%s: relu_bits needs relu and C %% 32 == 0", who);
     DIGA_REQUIRE(x && gamma && beta && save_mean && save_invstd && partial && workspace && M > 0, DIGA_EINVAL, "%s: bad argument", who);
     DIGA_REQUIRE(counts ? (n_records > 0 && n_records < (1 << 30)) : chunk_rows > 0, DIGA_EINVAL, "%s: bad chunk_rows / record count", who);
@@ -1191,29 +1076,18 @@ static int bn_fwd_from_partials(const char* who, const float* x, int64_t ld_x, f
     const size_t need = ((group > 1 ? (size_t)ngroup * 3 * C + (counts ? ngroup : 0) : 0) + (size_t)2 * C) * sizeof(float);
     DIGA_REQUIRE(workspace_bytes >= need, DIGA_EWORKSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, need);
     float* ab = save_ab != nullptr ? save_ab : (float*)workspace;
-    bool finalised = false;
     if (group > 1) {
         float* merged = (float*)workspace + 2 * C;
         float* mcounts = counts ? merged + (size_t)ngroup * 3 * C : nullptr;
-        ColGeom gm = g;
-        gm.chunk_rows = counts ? 1 : (int)(chunk_rows * group);
-        gm.nchunk = ngroup;
-        if (tickets != nullptr) {
-            FinArgs f{gamma, beta, running_mean, running_var, save_mean, save_invstd, ab, momentum, eps};
-            hipLaunchKernelGGL(merge_finalize_kernel, dim3(ngroup, (unsigned)ceil_div(C, 64)), dim3(256), 0, st, partial, g, group, merged,
-                               counts, mcounts, gm, f, tickets);
-            finalised = true;
-        } else {
-            hipLaunchKernelGGL(merge_partials_kernel, dim3(ngroup, (unsigned)ceil_div(C, 64)), dim3(256), 0, st, partial, g, group,
-                               merged, counts, mcounts);
-        }
+        hipLaunchKernelGGL(merge_partials_kernel, dim3(ngroup, (unsigned)ceil_div(C, 64)), dim3(256), 0, st, partial, g, group,
+                           merged, counts, mcounts);
         partial = merged;
         counts = mcounts;
-        g = gm;
+        g.chunk_rows = counts ? 1 : (int)(chunk_rows * group);
+        g.nchunk = ngroup;
     }
-    if (!finalised)
-        hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
-                           running_mean, running_var, save_mean, save_invstd, ab, momentum, eps, counts);
+    hipLaunchKernelGGL(bn_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, g, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, ab, momentum, eps, counts);
     if (y != nullptr)
         launch_affine(dim3(ew_blocks(M * C / 4)), st, x, ld_x, y, ld_y, residual, ld_r, ab,
                            ab + C, (int64_t)0, M, M, (int)C, relu, y_twin, relu_bits);
@@ -1225,10 +1099,10 @@ extern "C" int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int6
                                     float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
                                     int64_t C, int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps,
                                     const float* partial, int64_t chunk_rows,
-                                    void* workspace, size_t workspace_bytes, int32_t* tickets, void* stream) {
+                                    void* workspace, size_t workspace_bytes, void* stream) {
     return bn_fwd_from_partials("diga_bn_fwd_partials", x, ld_x, y, ld_y, residual, ld_r, gamma, beta, running_mean, running_var, save_mean,
                                 save_invstd, save_ab, M, C, relu, y_twin, relu_bits, momentum, eps, partial, chunk_rows, nullptr, 0,
-                                workspace, workspace_bytes, tickets, stream);
+                                workspace, workspace_bytes, stream);
 }
 
 extern "C" int diga_bn_fwd_records(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual,
@@ -1236,11 +1110,11 @@ extern "C" int diga_bn_fwd_records(const float* x, int64_t ld_x, float* y, int64
                                    float* running_var, float* save_mean, float* save_invstd, float* save_ab, int64_t M,
                                    int64_t C, int relu, int y_twin, unsigned char* relu_bits, float momentum, float eps,
                                    const float* partial, const float* counts, int64_t n_records,
-                                   void* workspace, size_t workspace_bytes, int32_t* tickets, void* stream) {
+                                   void* workspace, size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(counts != nullptr, DIGA_EINVAL, "diga_bn_fwd_records: null counts");
     return bn_fwd_from_partials("diga_bn_fwd_records", x, ld_x, y, ld_y, residual, ld_r, gamma, beta, running_mean, running_var, save_mean,
                                 save_invstd, save_ab, M, C, relu, y_twin, relu_bits, momentum, eps, partial, 0, counts, n_records,
-                                workspace, workspace_bytes, tickets, stream);
+                                workspace, workspace_bytes, stream);
 }
 
 static int bn_bwd_impl(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, const float* y, int64_t ld_y,
@@ -1292,7 +1166,7 @@ extern "C" int diga_bn_bwd_affine(const float* dy, int64_t ld_dy, const float* x
 extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,
                                     const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx, int64_t M,
                                     int64_t C, int dx_twin, const float* partial, int64_t chunk_rows, void* workspace,
-                                    size_t workspace_bytes, int32_t* tickets, void* stream) {
+                                    size_t workspace_bytes, void* stream) {
     DIGA_REQUIRE(!dx_twin || (C % 8 == 0 && ld_dx == C), DIGA_EINVAL, "bn_bwd_partials: twin output needs C % 8 == 0 and a dense dx");
     DIGA_REQUIRE(g && x && gamma && save_mean && save_invstd && dx && partial && workspace && M > 0 && chunk_rows > 0, DIGA_EINVAL,
                  "bn_bwd_partials: bad argument");
@@ -1308,28 +1182,18 @@ extern "C" int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x
     geo.chunk_rows = (int)chunk_rows;
     geo.nchunk = (int)ceil_div(M, chunk_rows);
     float* kk = (float*)workspace;
-    bool finalised = false;
     if (geo.nchunk > 64) {
         // many 128-row chunks: fold them to 32 rows first (the finaliser only needs sum g, sum g*xhat over all rows)
         constexpr int kParts = 32;
         float* folded = kk + 3 * C;
-        ColGeom gf = geo;
-        gf.nchunk = kParts;
-        gf.chunk_rows = (int)ceil_div(M, kParts);        // (only nseg * nchunk and rows_per_seg enter the finaliser)
-        if (tickets != nullptr && C % 64 == 0) {
-            hipLaunchKernelGGL(colsum_fold_finalize_kernel, dim3((unsigned)(2 * C / 64), kParts), dim3(256), 0, st, partial, geo.nchunk,
-                               (int)(2 * C), kParts, folded, gf, gamma, save_invstd, kk, tickets);
-            finalised = true;
-        } else {
-            hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)ceil_div(2 * C, 64), kParts), dim3(256), 0, st, partial, geo.nchunk,
-                               (int)(2 * C), kParts, folded);
-        }
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)ceil_div(2 * C, 64), kParts), dim3(256), 0, st, partial, geo.nchunk,
+                           (int)(2 * C), kParts, folded);
         partial = folded;
-        geo = gf;
+        geo.nchunk = kParts;
+        geo.chunk_rows = (int)ceil_div(M, kParts);       // (only nseg * nchunk and rows_per_seg enter the finaliser)
     }
-    if (!finalised)
-        hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, geo, gamma,
-                           save_invstd, kk, 1);
+    hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((unsigned)ceil_div(C, kFinCh)), dim3(256), 0, st, partial, geo, gamma,
+                       save_invstd, kk, 1);
     launch_bwd_apply(dim3(ew_blocks(M * C / 4)), st, g, ld_g, x, ld_x, (const float*)nullptr,
                        (int64_t)0, save_mean, save_invstd, 0, 1, kk, (int64_t)0, (int64_t)C, dx, ld_dx, (float*)nullptr,
                        (int64_t)0, M, M, (int)C, (const float*)nullptr, dx_twin);

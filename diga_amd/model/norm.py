@@ -51,11 +51,6 @@ def _ws(rows_per_seg, nseg, c, device):
     return _lib.workspace(_lib.lib.diga_norm_workspace_bytes(rows_per_seg, nseg, c), device, "norm")
 
 
-def _bn_tickets(c, device):
-    """The counter array of the one-launch fold + finalise (config.bn_fused_finalize; None = the two-launch form)."""
-    return _lib.ptr(_lib.tickets((c + 63) // 64, device)) if config.active().bn_fused_finalize else None
-
-
 # --------------------------------------------------------------------------------------------- BatchNorm
 class _BnFn(torch.autograd.Function):
     """Train-mode BatchNorm (+ReLU, +residual).  `box` (a dict, or None) ties this BN to the convolution that consumes its
@@ -91,15 +86,14 @@ class _BnFn(torch.autograd.Function):
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
                       _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
                       _lib.ptr(bits), float(momentum), float(eps), _lib.ptr(partials[0]),
-                      _lib.C.c_void_p(partials[0].data_ptr() + recs * 3 * c * 4), recs, _lib.ptr(wsr), wsr.numel(), _bn_tickets(c, xn.device),
-                      _lib.stream())
+                      _lib.C.c_void_p(partials[0].data_ptr() + recs * 3 * c * 4), recs, _lib.ptr(wsr), wsr.numel(), _lib.stream())
         elif partials is not None and training:
             # the producing conv already reduced its output tile by tile: finalise + apply only
             _lib.call("diga_bn_fwd_partials", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight),
                       _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean),
                       _lib.ptr(save_invstd), _lib.ptr(save_ab), m, c, 1 if relu else 0, 1 if twin_out else 0,
                       _lib.ptr(bits),
-                      float(momentum), float(eps), _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(), _bn_tickets(c, xn.device),
+                      float(momentum), float(eps), _lib.ptr(partials[0]), int(partials[1]), _lib.ptr(ws), ws.numel(),
                       _lib.stream())
         else:
             _lib.call("diga_bn_fwd", _lib.ptr(xn), c, _lib.ptr(y), c, _lib.ptr(rn), c, _lib.ptr(weight), _lib.ptr(bias),
@@ -145,7 +139,7 @@ class _BnFn(torch.autograd.Function):
             ws = _lib.workspace(67 * c * 4, xn.device, "norm_kk")
             _lib.call("diga_bn_bwd_partials", _lib.ptr(g), ld_g, _lib.ptr(xn), c, _lib.ptr(weight), _lib.ptr(save_mean),
                       _lib.ptr(save_invstd), _lib.ptr(dx), c, m, c, 1 if ctx.dx_twin else 0, _lib.ptr(pre[1]), int(pre[5]),
-                      _lib.ptr(ws), ws.numel(), _bn_tickets(c, xn.device), _lib.stream())
+                      _lib.ptr(ws), ws.numel(), _lib.stream())
             dres = g if has_res else None
         else:
             dres = torch.empty_like(xn) if has_res else None

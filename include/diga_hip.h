@@ -471,26 +471,21 @@ int diga_bn_fwd(const float* x, int64_t ld_x, float* y, int64_t ld_y, const floa
                 void* stream);
 
 /* Train-mode diga_bn_fwd whose statistics pass is replaced by partials the producing conv already wrote
- * (`partial` = stats_partial of diga_conv2d_nhwc_*, `chunk_rows` = 128).
- * tickets (nullable): ceil(C / 64) int32 counters, ZERO on entry and left zero on exit, owned by the caller and used by ONE stream at a
- * time.  With it, layers whose partials are folded first (more than 128 chunks) fold and finalise in one launch -- the last-arriving
- * fold block of a 64-channel slab finalises it -- instead of two; results are identical.  NULL: the two-launch form. */
+ * (`partial` = stats_partial of diga_conv2d_nhwc_*, `chunk_rows` = 128). */
 int diga_bn_fwd_partials(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
                          int y_twin, unsigned char* relu_bits, float momentum, float eps, const float* partial,
-                         int64_t chunk_rows, void* workspace, size_t workspace_bytes, int32_t* tickets, void* stream);
+                         int64_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ... replaced by RECORDS of unequal size: partial [n_records][3][C] {sum (x - s), sum (x - s)^2, s}, counts [n_records] = the rows
  * behind each record (0 allowed), sum of counts = M -- what the Winograd forward's output transform writes (stats_partial of
- * diga_conv2d_winograd_f32: its tile groups hold different numbers of in-image pixels).  workspace as diga_bn_fwd_partials + 96 floats;
- * tickets as diga_bn_fwd_partials. */
+ * diga_conv2d_winograd_f32: its tile groups hold different numbers of in-image pixels).  workspace as diga_bn_fwd_partials + 96 floats. */
 int diga_bn_fwd_records(const float* x, int64_t ld_x, float* y, int64_t ld_y, const float* residual, int64_t ld_r,
                         const float* gamma, const float* beta, float* running_mean, float* running_var,
                         float* save_mean, float* save_invstd, float* save_ab, int64_t M, int64_t C, int relu,
                         int y_twin, unsigned char* relu_bits, float momentum, float eps, const float* partial,
-                        const float* counts, int64_t n_records, void* workspace, size_t workspace_bytes, int32_t* tickets,
-                        void* stream);
+                        const float* counts, int64_t n_records, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the above wrt x (gamma/beta are frozen on this path): g = dy*mask, mask = [y>0] when y is given,
  * [fma(x, a, b) > 0] when relu_ab = save_ab of the forward is given instead (BN without residual), 1 when both are
@@ -514,12 +509,11 @@ int diga_bn_bwd_affine(const float* dy, int64_t ld_dy, const float* x, int64_t l
 /* diga_bn_bwd for a gradient that arrives already masked and reduced: `g` and `partial` ([ceil(M/chunk_rows)][2][C]:
  * sum g, sum g*xhat per chunk) come out of the epilogue of the backward-data convolution that produced g
  * (diga_conv2d_nhwc_*_epi, chunk_rows = 128): one finalise launch + the apply pass (read g, x; write dx).
- * workspace >= 67*C floats.  tickets (nullable): as diga_bn_fwd_partials -- with it (and C % 64 == 0) the fold of > 64 chunks and the
- * finaliser are one launch. */
+ * workspace >= 67*C floats. */
 int diga_bn_bwd_partials(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* gamma,
                          const float* save_mean, const float* save_invstd, float* dx, int64_t ld_dx, int64_t M, int64_t C,
                          int dx_twin, const float* partial, int64_t chunk_rows, void* workspace, size_t workspace_bytes,
-                         int32_t* tickets, void* stream);
+                         void* stream);
 
 /* GroupNorm over (HW x C/G) per image and group, then y = [relu](chan_scale[n,c] * (xhat*gamma + beta));
  * chan_scale (nullable, [N][C]) carries the Dropout2d keep/(1-p) pattern.  save_mean/invstd [N][G]. */

@@ -275,101 +275,6 @@ def test_aspp_head_live_dropout_golden(golden, conv_math):
             assert_mostly_close(got, ref, 3e-3, 2e-4 * float(ref.abs().max()) + 1e-7, frac, l2, gk)
 
 
-@pytest.mark.parametrize("kind", ["gemm_partials", "winograd_records"])
-def test_bn_fused_fold_and_finalise_is_bit_identical(kind, monkeypatch):
-    """Round 6: BatchNorm statistics from the producing convolution's partials, folded and finalised in ONE launch (the last-arriving
-    fold block of a 64-channel slab finalises it: diga_bn_fwd_partials / diga_bn_fwd_records with `tickets`) against the two-launch
-    form: output, saved statistics / coefficients and running statistics equal bit for bit, call after call (the ticket counters are
-    left zeroed), on both kinds of partials -- the persistent GEMM's 64-row chunks (1176 of them at 8 x 97 x 97) and the Winograd
-    output transform's records of unequal size."""
-    from diga_amd import _lib, config
-    from diga_amd.model.conv import DigaConv2d
-    from diga_amd.model.norm import DigaBatchNorm2d
-    prev = _lib.get_conv_math()
-    _lib.set_conv_math(0)
-    try:
-        g = synth.gen(31)
-        if kind == "gemm_partials":
-            conv = DigaConv2d(256, 512, 1, bias=False)
-            x = torch.randn((8, 256, 97, 97), generator=g)
-        else:
-            conv = DigaConv2d(256, 256, 3, padding=2, dilation=2, bias=False)
-            x = torch.randn((8, 256, 97, 97), generator=g)
-        conv.emit_bn_stats = True
-        conv = conv.to(DEV).train()
-        xd = _cl(x)
-        res = {}
-        calls, real = [], _lib.call
-        monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append((name, a)), real(name, *a))[1])
-        for fused in (False, True, True):
-            monkeypatch.setattr(config.active(), "bn_fused_finalize", fused)
-            bn = DigaBatchNorm2d(conv.out_channels)
-            for p in bn.parameters():
-                p.requires_grad = False
-            with torch.no_grad():
-                bn.weight.copy_(torch.rand(conv.out_channels, generator=synth.gen(5)) + 0.5)
-                bn.bias.copy_(torch.randn(conv.out_channels, generator=synth.gen(6)))
-            bn = bn.to(DEV).train()
-            calls.clear()
-            with torch.no_grad():
-                y = bn(conv(xd), relu=True)
-            name, args = [c for c in calls if c[0].startswith("diga_bn_fwd")][0]
-            assert name == ("diga_bn_fwd_partials" if kind == "gemm_partials" else "diga_bn_fwd_records"), name
-            assert (args[-2] is not None) == fused                   # the tickets pointer
-            torch.cuda.synchronize()
-            res.setdefault(fused, []).append((y.clone(), bn.running_mean.clone(), bn.running_var.clone()))
-            if fused:
-                assert int(_lib.tickets(8, torch.device(DEV)).abs().sum()) == 0     # every counter back at zero
-        want = res[False][0]
-        for got in res[True]:
-            for a, b in zip(want, got):
-                assert torch.equal(a, b)
-        yd = conv(xd).detach().double().cpu()
-        assert_close(want[1], 0.1 * yd.mean((0, 2, 3)), 1e-4, 1e-6, "running mean")
-    finally:
-        _lib.set_conv_math(prev)
-
-
-def test_bn_backward_fused_fold_and_finalise_is_bit_identical(monkeypatch):
-    """The backward twin: the BatchNorm-backward sums delivered by the backward-data epilogues (one partial per 128-row chunk), folded
-    and finalised in one launch (diga_bn_bwd_partials with `tickets`) against colsum_fold + bn_bwd_finalize2: a bottleneck's input
-    gradient and every weight gradient equal bit for bit, twice in a row (counters back at zero)."""
-    from diga_amd import _lib, config
-    from diga_amd.model import seg_model_noaux as sm
-    prev = _lib.get_conv_math()
-    _lib.set_conv_math(0)
-    try:
-        torch.manual_seed(4)
-        blk = sm.Bottleneck(1024, 256, 1, dilation=2).to(DEV).train()
-        g = synth.gen(12)
-        x0 = _cl(torch.randn((4, 1024, 65, 65), generator=g))              # 16 900 rows: 133 chunks of 128 (> 64: folded first)
-        probe = torch.randn((4, 1024, 65, 65), generator=g).to(DEV)
-        calls, real = [], _lib.call
-        monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append((name, a)), real(name, *a))[1])
-        res = []
-        for fused in (False, True, True):
-            monkeypatch.setattr(config.active(), "bn_fused_finalize", fused)
-            for p_ in blk.parameters():
-                p_.grad = None
-            sd = {k: v.clone() for k, v in blk.state_dict().items()}
-            calls.clear()
-            x = x0.clone().requires_grad_()
-            y = blk(x)
-            (y * probe).sum().backward()
-            torch.cuda.synchronize()
-            bwd = [a for n, a in calls if n == "diga_bn_bwd_partials"]
-            assert len(bwd) >= 2 and all((a[-2] is not None) == fused for a in bwd)
-            res.append([y.detach().clone(), x.grad.clone()] + [getattr(blk, c).weight.grad.clone() for c in ("conv1", "conv2", "conv3")])
-            blk.load_state_dict(sd)
-            if fused:
-                assert int(_lib.tickets(16, torch.device(DEV)).abs().sum()) == 0
-        for other in res[1:]:
-            for a, b in zip(res[0], other):
-                assert torch.equal(a, b)
-    finally:
-        _lib.set_conv_math(prev)
-
-
 @pytest.mark.parametrize("n,k,o,act", [(16, 1280, 80, 1), (16, 80, 1280, 2), (3, 37, 5, 0), (1, 64, 64, 2)])
 def test_small_linear_forward_backward_vs_float64(n, k, o, act):
     """The SE block's dense layers (diga_small_linear_fwd / _bwd: Linear + none / ReLU / sigmoid) against torch in float64:

@@ -16,68 +16,19 @@ offset moves them by points).
 """
 import json
 import os
-import random
 
 import numpy as np
 import pytest
 import torch
-
-from oracle import deeplab as od
-from oracle import detweights, synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _model():
-    from diga_amd.model import seg_model_noaux as sm
-    from diga_amd.model.model_noaux import SegModel
-    m = SegModel(arch=sm.RESNET101)
-    m.load_state_dict(detweights.state_dict(od.RESNET101))
-    return m.to(DEV)
-
-
-def _validate(student, B, H, W, block, n_val, val_seed0):
-    from diga_amd import evaluate as ev
-    from diga_amd.util.metrics import runningScore
-    rs = runningScore(19, verbose=False)
-    student.eval()
-    for i in range(n_val):
-        img, _, _, gt = synth.learnable_batch(val_seed0 + i, 1, H, W, block=block)
-        ev.evaluate_two_scale(student, img.to(DEV), gt.to(DEV), rs)
-    student.train()
-    sc, _ = rs.get_scores()
-    return float(sc["Mean IoU : \t"])
-
-
 def train_and_validate(g, seed, conv_math):
-    """One seed of the capture's experiment on the HIP path; returns (mIoU curve, final mIoU, mean CE of the last `every` steps)."""
-    from diga_amd import _lib
-    from diga_amd.train_step import DigaTrainer
-    B, H, W, steps, block, every, n_val, data_seed0, val_seed0 = (int(v) for v in g["geometry"])
-    lr = float(g["lr"])
-    prev = _lib.get_conv_math()
-    _lib.set_conv_math(conv_math)
-    try:
-        torch.manual_seed(1234 + seed)                            # the device's Dropout2d stream (the reference drew from the CPU generator)
-        random.seed(4321 + seed)                                  # ClassMix: the same draws as the capture
-        student, teacher = _model(), _model()                     # Dropout2d(0.1) LIVE in both heads, as in the reference
-        teacher.train()
-        tr = DigaTrainer(student, teacher, base_lr=lr, rng=random)
-        curve, ce = [], []
-        for it in range(steps):
-            batch = synth.learnable_batch(data_seed0 + 1000 * seed + it, B, H, W, block=block)
-            log = tr.warmup_step(it, *(t.to(DEV) for t in batch))
-            ce.append(log["ce"])
-            if (it + 1) % every == 0:
-                curve.append(_validate(student, B, H, W, block, n_val, val_seed0))
-        final = _validate(student, B, H, W, block, n_val, val_seed0)
-        tail = float(torch.stack(ce[-every:]).mean())
-        return np.array(curve), final, tail
-    finally:
-        _lib.set_conv_math(prev)
-        _lib.join_side()
+    import miou_parity
+    return miou_parity.train_and_validate(g, seed, conv_math, DEV)
 
 
 @pytest.mark.timeout(1500)

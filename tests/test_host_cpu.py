@@ -79,7 +79,7 @@ def test_abi_argument_errors_without_gpu():
     opt = _lib.ConvOptions(1, 1, 0)
     rc = _lib.lib.diga_conv2d_winograd_f32_opts(16, 16, None, 16, 16, 1 << 30, 1, 8, 8, 128, 128, 128, 128, 1, 6, ctypes.byref(opt), None, 0, None)
     assert rc == -1 and "reflect_pad" in _lib.last_error()
-    assert _lib.lib.diga_bn_fwd_records(16, 4, 16, 4, None, 4, 16, 16, None, None, 16, 16, None, 8, 4, 0, 0, None, 0.1, 1e-5, 16, None, 4, 16, 1 << 20, None, None) == -1
+    assert _lib.lib.diga_bn_fwd_records(16, 4, 16, 4, None, 4, 16, 16, None, None, 16, 16, None, 8, 4, 0, 0, None, 0.1, 1e-5, 16, None, 4, 16, 1 << 20, None) == -1
     assert _lib.lib.diga_small_linear_fwd(None, None, None, None, 1, 1, 1, 0, None) == -1
     assert _lib.lib.diga_nonfinite_flag_f32(None, 4, None, None) == -1 and _lib.lib.diga_colsum_nhwc(None, 4, None, 4, 4, None, 0, None) == -1
 
