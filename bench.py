@@ -800,7 +800,11 @@ def main():
             "target": target_statement(a.config, a.precision, families, B, H, W, n_stu, n_tea),
             "config": {"workload": f"{CONFIGS[a.config][5]}: {CONFIGS[a.config][6]} {H}x{W}, batch {B} per GPU",
                        "global_batch": world * B, "crop": [H, W], "parallelism": f"dp{world}",
-                       "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea}},
+                       "images_per_step_per_gpu": {"student_fwd_bwd": n_stu, "teacher_fwd": n_tea},
+                       # what pins this geometry to the reference: the reference's own forward / backward at 768 x 768 on
+                       # 2 and on 8 images (75 272 rows per GEMM; the step's 16-image pass, 150 544 rows, does not fit a CPU capture in this
+                       # container's 62 GB) and a 3-step training trajectory at 768 x 768
+                       "reference_pins": "full768 (2 img), full768b8 (8 img: half the step's 16-image pass), traj768 (3 steps), trainmiou (300 steps @128)"},
             "rccl_ranks": world, "backend": backend if world > 1 else "none (single process)",
             "ranks_agree": losses.pop("_ranks_agree", None), "peak_mem_gb": losses.pop("_peak_mem_gb", None), "host": host,
             "roofline": roof, "roofline_other_kernels": other, "bandwidth_kernels": bw, "cpu_baseline": cpu_line,

@@ -305,13 +305,20 @@ __global__ __launch_bounds__(256) void class_ids_kernel(const float* __restrict_
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p < hw) {
         const float* o = out + ((int64_t)n * K) * hw + p;
-        float best = o[0];
+        // (round 6: the K plane loads of a pixel in flight together, eight at a time -- the run-time-K loop issued them one by one,
+        //  a chain of K dependent round trips for a 5 MB pass)
+        float best = -INFINITY;
         int arg = 0;
-        for (int k = 1; k < K; ++k) {
-            const float v = o[(int64_t)k * hw];
-            if (v > best) {
-                best = v;
-                arg = k;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (k0 + u < K) ? o[(int64_t)(k0 + u) * hw] : -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u < K && (v[u] > best || (k0 + u == 0))) {      // strict: first maximum wins (k = 0 starts the chain, NaN-safe as before)
+                    best = v[u];
+                    arg = k0 + u;
+                }
             }
         }
         int id = arg;

@@ -683,9 +683,21 @@ int run_upsample_loss(const float* stu_lr, const float* tea_lr, const int64_t* l
     const double cell_px = ((double)H / (double)(h - 1)) * ((double)W / (double)(w - 1));
     const int cpw = cell_px >= 48.0 ? 1 : cell_px >= 24.0 ? 2 : cell_px >= 12.0 ? 4 : 8;
     dim3 grid((unsigned)ceil_div(w - 1, cpw), (unsigned)(h - 1), (unsigned)N);
-    // one cell per wave and no cell larger than a wave: a cell spans at most ceil(1 / s) + 1 pixels per axis (s = (in - 1) / (out - 1))
-    const double cy = sy > 0.f ? std::ceil(1.0 / (double)sy) + 1.0 : (double)H, cx = sx > 0.f ? std::ceil(1.0 / (double)sx) + 1.0 : (double)W;
-    const bool one = cpw == 1 && cy * cx <= 64.0;
+    // one cell per wave and no cell larger than a wave: the largest cell per axis, counted with the kernels' own float arithmetic
+    // (bilinear_cell: i0 = min(int(scale * dst), n_in - 2); 8 x 8 at the DeepLab path's x7.99 -- a bound like ceil(1 / s) + 1 says 9)
+    auto max_cell = [](int64_t n_in, int64_t n_out, float sc) {
+        int best = 0, run = 0, prev = -1;
+        for (int64_t d = 0; d < n_out; ++d) {
+            int i = (int)(sc * (float)d);
+            if (i > (int)n_in - 2) i = (int)n_in - 2;
+            if (i < 0) i = 0;
+            run = (i == prev) ? run + 1 : 1;
+            prev = i;
+            best = run > best ? run : best;
+        }
+        return best;
+    };
+    const bool one = cpw == 1 && H <= 16384 && W <= 16384 && max_cell(h, H, sy) * max_cell(w, W, sx) <= 64;
 #define DIGA_UL_LAUNCH(D_, O_)                                                                                             \
     hipLaunchKernelGGL((upsample_loss_cells_kernel<C, D_, O_>), grid, dim3(64), 0, st, stu_lr, tea_lr, (const long long*)labels, \
                        cw.ystart, cw.xstart, cw.cellpart, (int)B, (int)n_ce, (int)h, (int)w, (int)H, (int)W, sy, sx, k_ce, k_di,  \
