@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 6) void centroid_weights_kernel(const float* _
                                                                float* __restrict__ neg_dist, int D, int Krt,
                                                                int64_t HW) {
     constexpr int KP = (K + 3) & ~3;
-    constexpr int U = 16;             // plane loads in flight per lane
+    constexpr int U = 16;             // plane loads in flight per lane (32 at five waves per SIMD measured slower: 45.3 vs 40.7 us)
     extern __shared__ __align__(16) float smem[];
     float* cT = smem;                 // [D][KP]  transposed centroids; afterwards [4][K][64] per-wave partial squared distances
     const int n = blockIdx.y;

@@ -51,9 +51,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// Stage 1 of a two-level sum: block b reduces its slice of `partials` (k < 2 interleaved values at
-// `stride`) to stage[b*2 + k]; finished by finalize_sums_kernel over the gridDim.x stage entries.
-__global__ __launch_bounds__(256) void stage_sums_kernel(const float* __restrict__ partials, int64_t n, int stride,
+// Stage 1 of a two-level sum: block b reduces its slice of `partials` (value k < 2 of entry i at partials[i * stride + k * koff])
+// to stage[b*2 + k]; finished by finalize_sums_kernel over the gridDim.x stage entries.
+__global__ __launch_bounds__(256) void stage_sums_kernel(const float* __restrict__ partials, int64_t n, int stride, int64_t koff,
                                                          int kcount, float* __restrict__ stage) {
     __shared__ float sm[4];
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void stage_sums_kernel(const float* __restrict
     float a0 = 0.f, a1 = 0.f;
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
         a0 += partials[i * stride];
-        if (kcount > 1) a1 += partials[i * stride + 1];
+        if (kcount > 1) a1 += partials[i * stride + koff];
     }
     const float t0 = block_sum<4>(a0, sm);
     const float t1 = block_sum<4>(a1, sm);
@@ -501,14 +501,17 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
         }
     }
     __syncthreads();
-    float* out = cellpart + (((int64_t)n * (h - 1) + ci) * (w - 1) + (int64_t)blockIdx.x * cpw) * ROWS;
+    // cellpart is PLANAR (round 6): value r of cell q at cellpart[r * ncells + q] -- the gather kernel's four reads per gradient element
+    // and the loss sums then walk contiguous memory (the cell-major layout made every one of them a 312-byte-strided access: 80 us)
+    const int64_t ncells = (int64_t)gridDim.z * (h - 1) * (w - 1);
+    float* out = cellpart + ((int64_t)n * (h - 1) + ci) * (w - 1) + (int64_t)blockIdx.x * cpw;
     const int ncell = min(cpw, (w - 1) - (int)blockIdx.x * cpw);
     const int qpc = lpc >> 2;              // quads per cell
     for (int o = wl; o < ROWS * ncell; o += 64) {
-        const int sc = o / ROWS, r = o - sc * ROWS;
+        const int r = o / ncell, sc = o - r * ncell;
         float t = 0.f;
         for (int k = 0; k < qpc; ++k) t += red[r * 17 + sc * qpc + k];
-        out[(int64_t)sc * ROWS + r] = t;
+        out[(int64_t)r * ncells + sc] = t;
     }
 }
 
@@ -516,7 +519,6 @@ template <int C>
 __global__ __launch_bounds__(256) void upsample_loss_gather_kernel(const float* __restrict__ cellpart,
                                                                    float* __restrict__ grad_lr, int N, int h,
                                                                    int w) {
-    constexpr int ROWS = cell_rows<C>();
     const int64_t total = (int64_t)N * C * h * w;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -524,13 +526,14 @@ __global__ __launch_bounds__(256) void upsample_loss_gather_kernel(const float* 
     const int i = (int)((t / w) % h);
     const int c = (int)((t / ((int64_t)w * h)) % C);
     const int n = (int)(t / ((int64_t)w * h * C));
-    const float* base = cellpart + ((int64_t)n * (h - 1)) * (w - 1) * ROWS;
+    const int64_t ncells = (int64_t)N * (h - 1) * (w - 1);
+    const float* base = cellpart + ((int64_t)n * (h - 1)) * (w - 1);       // planar: value r of cell q at [r * ncells + q]
     float g = 0.f;
     // fixed order: (i-1,j-1) corner 11, (i-1,j) corner 10, (i,j-1) corner 01, (i,j) corner 00
-    if (i > 0 && j > 0) g += base[(((int64_t)(i - 1)) * (w - 1) + (j - 1)) * ROWS + 3 * C + c];
-    if (i > 0 && j < w - 1) g += base[(((int64_t)(i - 1)) * (w - 1) + j) * ROWS + 2 * C + c];
-    if (i < h - 1 && j > 0) g += base[(((int64_t)i) * (w - 1) + (j - 1)) * ROWS + 1 * C + c];
-    if (i < h - 1 && j < w - 1) g += base[(((int64_t)i) * (w - 1) + j) * ROWS + c];
+    if (i > 0 && j > 0) g += base[(int64_t)(3 * C + c) * ncells + ((int64_t)(i - 1)) * (w - 1) + (j - 1)];
+    if (i > 0 && j < w - 1) g += base[(int64_t)(2 * C + c) * ncells + ((int64_t)(i - 1)) * (w - 1) + j];
+    if (i < h - 1 && j > 0) g += base[(int64_t)(1 * C + c) * ncells + ((int64_t)i) * (w - 1) + (j - 1)];
+    if (i < h - 1 && j < w - 1) g += base[(int64_t)c * ncells + ((int64_t)i) * (w - 1) + j];
     grad_lr[t] = g;
 }
 
@@ -714,8 +717,8 @@ int run_upsample_loss(const float* stu_lr, const float* tea_lr, const int64_t* l
     hipLaunchKernelGGL((upsample_loss_gather_kernel<C>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st,
                        cw.cellpart, grad_lr, (int)N, (int)h, (int)w);
     const int64_t ncells = N * (h - 1) * (w - 1);
-    hipLaunchKernelGGL(stage_sums_kernel, dim3(kStageBlocks), dim3(256), 0, st, cw.cellpart + 4 * C, ncells,
-                       4 * C + 2, distill ? 2 : 1, cw.stage);
+    hipLaunchKernelGGL(stage_sums_kernel, dim3(kStageBlocks), dim3(256), 0, st, cw.cellpart + (int64_t)(4 * C) * ncells, ncells,
+                       1, ncells, distill ? 2 : 1, cw.stage);
     hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(1024), 0, st, cw.stage, (int64_t)kStageBlocks, 2,
                        distill ? 2 : 1, losses_out, ce_norm, di_norm);
     return launch_status("diga_upsample_loss");
