@@ -354,21 +354,21 @@ constexpr int cell_rows() {
     return 4 * C + 2;
 }
 
-// ONE (round 6): the launch's cells hold at most 64 pixels each and every wave owns ONE cell (cpw == 1: the x8 / x7.98 upsampling of
-// the DeepLab path).  Then (a) the cell index is uniform over the wave, so the 4 x C x 2 corner logits are wave-uniform loads (scalar
-// loads: the generic form issued 118 vector loads per lane for them), and (b) there is one pixel per lane and no loop, so the 4 C
-// gradient sums need no accumulators -- each product goes straight into its cross-lane reduction.  The generic form's 76 accumulators
-// + 57 logit / exponential values + 152 gathered corners made it a 315-VGPR kernel: ONE wave per SIMD under ~60 dependent
-// transcendentals and a chain of global round trips per block (1.0 ms per C2 step; the round-6 counter pass showed the occupancy, not
-// the arithmetic, to be the bound).
-template <int C, bool DISTILL, bool ONE>
+// SINGLE (round 6): no cell of the launch holds more pixels than its lane group has lanes (64 / cpw), so there is ONE pixel per lane and
+// no loop: the 4 C gradient sums need no accumulators -- each product goes straight into its cross-lane reduction.  UNI (cpw == 1, the
+// x8 upsampling of the DeepLab path): the cell index is uniform over the wave, so the 4 x C x 2 corner logits are wave-uniform loads
+// (scalar loads: the generic form issued 118 vector loads per lane for them).  The generic form's 76 accumulators + 57 logit /
+// exponential values + 152 gathered corners made it a 315-VGPR kernel: ONE wave per SIMD under ~60 dependent transcendentals and a chain
+// of global round trips per block (1.0 ms per C2 step; the round-6 counter pass showed the occupancy, not the arithmetic, to be the bound).
+template <int C, bool DISTILL, bool SINGLE, bool UNI>
 __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
     const float* __restrict__ stu_lr, const float* __restrict__ tea_lr, const long long* __restrict__ labels,
     const int* __restrict__ ystart, const int* __restrict__ xstart, float* __restrict__ cellpart, int B,
     int n_ce /* images that carry a CE term */, int h, int w, int H, int W, float sy, float sx, float k_ce,
     float k_di, float scale, int cpw_rt /* cells per wave: 1, 2, 4 or 8 neighbours along x, 64 / cpw lanes each */) {
     constexpr int ROWS = cell_rows<C>();
-    const int cpw = ONE ? 1 : cpw_rt;
+    constexpr bool ONE = SINGLE;            // (one pixel per lane, no accumulators)
+    const int cpw = UNI ? 1 : cpw_rt;
     // (round 6) the wave's 4 C + 2 sums are folded over each lane quad with two DPP steps BEFORE they cross LDS: 17 columns instead of
     // 65 -- 5.3 KB instead of 20 KB per one-wave block, which had capped the kernel at 8 waves per CU (two per SIMD) under ~57
     // dependent transcendentals per pixel
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64) void upsample_loss_cells_kernel(
     // small cells (logits at 1/4 scale: 4 x 4 full-resolution pixels per cell) would leave most of a wave idle and pay the LDS fold
     // per 16 pixels: `cpw` neighbouring cells share the wave, lane group `sub` owns cell blockIdx.x * cpw + sub
     const int lpc = 64 / cpw;
-    const int lane = ONE ? (int)threadIdx.x : (int)threadIdx.x % lpc, sub = ONE ? 0 : (int)threadIdx.x / lpc;
+    const int lane = UNI ? (int)threadIdx.x : (int)threadIdx.x % lpc, sub = UNI ? 0 : (int)threadIdx.x / lpc;
     const int cj_raw = blockIdx.x * cpw + sub, ci = blockIdx.y, n = blockIdx.z;
     const bool cell_ok = cj_raw < w - 1;
     const int cj = cell_ok ? cj_raw : w - 2;
@@ -682,12 +682,8 @@ int run_upsample_loss(const float* stu_lr, const float* tea_lr, const int64_t* l
     const int tmax = (int)(h > w ? h : w);
     hipLaunchKernelGGL(cell_starts_kernel, dim3((tmax + 255) / 256), dim3(256), 0, st, cw.ystart, cw.xstart, (int)h,
                        (int)w, (int)H, (int)W, sy, sx);
-    // cells per wave from the mean cell size (8 x 8 pixels at DeepLab's 1/8 scale: 1; 4 x 4 at SegFormer's 1/4 scale: 4)
-    const double cell_px = ((double)H / (double)(h - 1)) * ((double)W / (double)(w - 1));
-    const int cpw = cell_px >= 48.0 ? 1 : cell_px >= 24.0 ? 2 : cell_px >= 12.0 ? 4 : 8;
-    dim3 grid((unsigned)ceil_div(w - 1, cpw), (unsigned)(h - 1), (unsigned)N);
-    // one cell per wave and no cell larger than a wave: the largest cell per axis, counted with the kernels' own float arithmetic
-    // (bilinear_cell: i0 = min(int(scale * dst), n_in - 2); 8 x 8 at the DeepLab path's x7.99 -- a bound like ceil(1 / s) + 1 says 9)
+    // the largest cell per axis, counted with the kernels' own float arithmetic (bilinear_cell: i0 = min(int(scale * dst), n_in - 2);
+    // 8 x 8 at the DeepLab path's x7.99 -- a bound like ceil(1 / s) + 1 says 9)
     auto max_cell = [](int64_t n_in, int64_t n_out, float sc) {
         int best = 0, run = 0, prev = -1;
         for (int64_t d = 0; d < n_out; ++d) {
@@ -700,17 +696,30 @@ int run_upsample_loss(const float* stu_lr, const float* tea_lr, const int64_t* l
         }
         return best;
     };
-    const bool one = cpw == 1 && H <= 16384 && W <= 16384 && max_cell(h, H, sy) * max_cell(w, W, sx) <= 64;
-#define DIGA_UL_LAUNCH(D_, O_)                                                                                             \
-    hipLaunchKernelGGL((upsample_loss_cells_kernel<C, D_, O_>), grid, dim3(64), 0, st, stu_lr, tea_lr, (const long long*)labels, \
+    // cells per wave: as many neighbouring cells along x as fit a wave with ONE pixel per lane (the accumulator-free form: 8 x 8 cells of
+    // the DeepLab path -> 1; the 4 x 4 / 4 x 5 / 5 x 5 cells of logits at 1/4 scale -> 2); cells beyond 64 pixels: the looping form
+    const int mc = (H <= 16384 && W <= 16384) ? max_cell(h, H, sy) * max_cell(w, W, sx) : 1 << 30;
+    const bool single = mc <= 64;
+    int cpw;
+    if (single) {
+        cpw = mc <= 8 ? 8 : mc <= 16 ? 4 : mc <= 32 ? 2 : 1;
+    } else {
+        const double cell_px = ((double)H / (double)(h - 1)) * ((double)W / (double)(w - 1));
+        cpw = cell_px >= 48.0 ? 1 : cell_px >= 24.0 ? 2 : cell_px >= 12.0 ? 4 : 8;
+    }
+    dim3 grid((unsigned)ceil_div(w - 1, cpw), (unsigned)(h - 1), (unsigned)N);
+#define DIGA_UL_LAUNCH(D_, S_, U_)                                                                                         \
+    hipLaunchKernelGGL((upsample_loss_cells_kernel<C, D_, S_, U_>), grid, dim3(64), 0, st, stu_lr, tea_lr, (const long long*)labels, \
                        cw.ystart, cw.xstart, cw.cellpart, (int)B, (int)n_ce, (int)h, (int)w, (int)H, (int)W, sy, sx, k_ce, k_di,  \
                        scale, cpw)
     if (distill) {
-        if (one) DIGA_UL_LAUNCH(true, true);
-        else DIGA_UL_LAUNCH(true, false);
+        if (single && cpw == 1) DIGA_UL_LAUNCH(true, true, true);
+        else if (single) DIGA_UL_LAUNCH(true, true, false);
+        else DIGA_UL_LAUNCH(true, false, false);
     } else {
-        if (one) DIGA_UL_LAUNCH(false, true);
-        else DIGA_UL_LAUNCH(false, false);
+        if (single && cpw == 1) DIGA_UL_LAUNCH(false, true, true);
+        else if (single) DIGA_UL_LAUNCH(false, true, false);
+        else DIGA_UL_LAUNCH(false, false, false);
     }
 #undef DIGA_UL_LAUNCH
     const int64_t total = N * C * h * w;
