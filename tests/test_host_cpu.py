@@ -603,3 +603,36 @@ def test_package_modules_reference_only_attributes_that_exist():
                     and node.value.id in alias and node.value.id not in assigned and not hasattr(alias[node.value.id], node.attr)):
                 missing.append((os.path.relpath(f, ROOT), node.lineno, f"{node.value.id}.{node.attr}"))
     assert not missing, missing
+
+
+def test_step_config_is_explicit_and_reads_the_environment_once(monkeypatch):
+    """diga_amd/config.py: environment variables give DEFAULTS (read once at import), `use` / `override` scope a configuration, a trainer's
+    config is plain data (copying never touches the original), invalid values are refused, and nothing under diga_amd/ writes os.environ."""
+    import dataclasses
+    import glob
+    import re
+    from diga_amd import config
+    assert config.active() is config.DEFAULTS
+    base = config.DEFAULTS
+    with config.override(c4_overlap=0, teacher_stream=False) as c:
+        assert config.active() is c and c.c4_overlap == 0 and not c.teacher_stream
+        assert base.c4_overlap == config.DEFAULTS.c4_overlap            # the defaults are untouched
+        with config.use(base.replace(winograd_max_tile=2)) as inner:
+            assert config.active() is inner and inner.winograd_max_tile == 2
+        assert config.active() is c
+    assert config.active() is config.DEFAULTS
+    s = base.serial_streams()
+    assert (s.teacher_stream, s.wgrad_stream, s.c4_overlap) == (False, False, 0) and s is not base
+    with pytest.raises(ValueError):
+        base.replace(c4_overlap=3)
+    with pytest.raises(ValueError):
+        base.replace(centroid_exchange="broadcast")
+    # the environment is a source of defaults only: a variable set AFTER import changes nothing, from_env() sees it
+    monkeypatch.setenv("DIGA_C4_OVERLAP", "1")
+    assert config.active().c4_overlap == base.c4_overlap
+    assert config.StepConfig.from_env().c4_overlap == 1
+    assert len(dataclasses.fields(config.StepConfig)) >= 25
+    # no module of the package assigns to os.environ (ddp.init_from_env only .setdefault()s MASTER_ADDR / MASTER_PORT)
+    for f in glob.glob(os.path.join(ROOT, "diga_amd", "**", "*.py"), recursive=True):
+        src = open(f).read()
+        assert not re.search(r"os\.environ\[[^\]]+\]\s*=", src) and "os.environ.update" not in src and "os.environ.pop" not in src, f

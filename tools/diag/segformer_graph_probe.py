@@ -36,6 +36,7 @@ def run(graph):
 
 
 print("eager, side streams:", run(False))
-os.environ.update(DIGA_TEACHER_STREAM="0", DIGA_WGRAD_STREAM="0")
+from diga_amd import config as _cfg
+_cfg.DEFAULTS.teacher_stream = _cfg.DEFAULTS.wgrad_stream = False      # (round 6: fields, not environment variables)
 print("eager, one stream  :", run(False))
 print("graph              :", run(True))
