@@ -501,6 +501,52 @@ def test_consensus_vs_oracle_large(mods):
     assert float(safe.float().mean()) > 0.999
 
 
+@pytest.mark.parametrize("N,D,hw,HW", [(1, 256, (17, 23), (130, 182)),      # ragged block edges of the pair kernel (182 = 128 + 54, 130 = 16 * 8 + 2)
+                                       (2, 256, (17, 23), (129, 181)),      # odd width: the one-pixel-per-thread kernel
+                                       (1, 100, (9, 10), (36, 40)),         # D = 100: a wave's quarter is 25 channels (one 16-deep round + a tail of 9), x4 upsampling
+                                       (2, 64, (33, 65), (66, 130)),        # x2 upsampling: outside the pair kernel's tile (falls back)
+                                       (1, 256, (5, 7), (5, 7))])           # identity geometry
+def test_centroid_weights_and_consensus_edge_shapes_vs_oracle(mods, N, D, hw, HW):
+    """Round 6 rebuilt the centroid-weights kernel (packed class pairs, 16-deep load rounds + a channel tail) and the consensus kernel
+    (128 x 8 blocks of pixel pairs, class-fastest LDS tile, with the round-5 kernel as the fall-back for odd widths / small upsampling
+    factors): geometries that hit the ragged edges, the tail loop and both fall-backs, against the oracle away from argmax near-ties."""
+    g = synth.gen(N * 1000 + D + hw[0] + HW[1])
+    cents = torch.randn((19, D), generator=g)
+    cls_map = torch.randint(0, 19, (N, *hw), generator=g)
+    feat = cents[cls_map].permute(0, 3, 1, 2).contiguous() * 0.6 + 0.7 * torch.randn((N, D, *hw), generator=g)
+    pseudo_prob = synth.block_labels(g, N, HW[0], HW[1], block=8, ignore_frac=0.05)
+    w = oc.centroid_weight(feat, cents)
+    want, want_fp = oc.consensus_filter(w, pseudo_prob)
+    up = ol.upsample_bilinear_ac(w, HW)
+    top2 = up.topk(2, dim=1)[0]
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-5
+    cf = mods["cc"].Class_Features(numbers=19, feat_dim=D)
+    cf.objective_vectors = cents.to(DEV)
+    assert_close(cf.get_centroid_weight(feat.to(DEV)), w, 3e-4, 1e-9, "weights")
+    got, fp = cf.consensus_pseudo_labels(feat.to(DEV), pseudo_prob.to(DEV), return_feat_pseudo=True)
+    assert bool((fp.cpu() == want_fp)[safe].all()) and bool((got.cpu() == want)[safe].all())
+    assert float(safe.float().mean()) > 0.99
+
+
+@pytest.mark.parametrize("N,D,hw", [(2, 256, (65, 129)), (1, 64, (7, 9)), (3, 100, (33, 31)), (1, 256, (16, 16))])
+def test_class_sums_edge_shapes_vs_float64(mods, N, D, hw):
+    """class_ids (plane loads eight at a time) + class_sums (a plane per block, four waves a quarter each, 16-deep rounds + tail): planes
+    shorter than a round (63 pixels), exactly four rounds (256), ragged (8385), D not a multiple of anything -- per-class sums and counts
+    against a float64 scatter."""
+    g = synth.gen(N * 77 + D + hw[0])
+    h, w = hw
+    feat = torch.randn((N, D, h, w), generator=g)
+    out = torch.randn((N, 19, h, w), generator=g)
+    cf = mods["cc"].Class_Features(numbers=19, feat_dim=D)
+    sums, counts = cf._class_sums(feat.to(DEV), out.to(DEV))[:2]
+    arg = out.argmax(1)                                              # [N, h, w]
+    want = torch.zeros((N, 19, D), dtype=torch.float64)
+    want.scatter_add_(1, arg.reshape(N, -1, 1).expand(N, h * w, D), feat.double().permute(0, 2, 3, 1).reshape(N, h * w, D))
+    wc = torch.zeros((N, 19), dtype=torch.int64).scatter_add_(1, arg.reshape(N, -1), torch.ones((N, h * w), dtype=torch.int64))
+    assert torch.equal(counts.cpu().long(), wc)
+    assert_close(sums, want, 2e-5, 2e-5, "class sums")
+
+
 # ----------------------------------------------------------------------------- mIoU
 def test_running_score(mods, golden):
     g = golden("miou")
