@@ -3,6 +3,7 @@
 There is no CPU fallback: importing this module without the built library, or calling an op
 with non-GPU tensors, raises.  Build with `python -m diga_amd.build`.
 """
+import collections
 import ctypes as C
 import os
 
@@ -265,6 +266,7 @@ def take_consumed_flag(flag):
 # ---- optional second stream for work that is off the critical path (weight gradients during backward)
 _side_streams = {}
 _side_dirty = set()
+_side_holds = collections.deque()   # (event on the side stream, owning stream, tensors): release_to_side
 side_overlap = False          # switched on by the step driver around backward(); plain autograd users stay in line
 
 
@@ -286,11 +288,43 @@ def active_side_stream(device):
     return _side_streams.get(idx) if idx in _side_dirty else None
 
 
+def release_to_side(side, tensors):
+    """Hand `tensors` (allocated on the CURRENT stream, just read or written by work enqueued on `side`) over for the side stream's use.
+
+    `Tensor.record_stream` would do: the caching allocator then returns a freed block to its pool only once an event on the side stream
+    has completed -- polled from the HOST at the next allocation.  The host runs a backward pass far ahead of the device, so those
+    events are never complete when it asks, every such block (an activation, an output gradient, a kept transform) stays out of the
+    pool until well into the next step, and the pool opens new segments instead: 126 GB reserved on the main stream for tensors that
+    peak at 104 GB (profiles/r06_memory_by_stream.txt).  Instead the tensors are kept alive HERE for `wgrad_hold` more layers, and the
+    stream that owns them is made to wait (on the device) for the side stream's event of that time before the reference is dropped:
+    the block is then free in stream order, reusable by the very next allocation, and the wait is on work the side stream finished
+    layers ago.  wgrad_hold = 0, and stream capture, keep record_stream.
+
+    NEVER pass a tensor that is returned from backward as a gradient: AccumulateGrad takes a gradient over without a copy only while
+    nobody else holds it; with a second reference it CLONES it on the main stream -- while the side stream is still writing it (found
+    the hard way: bit-identity of the self-training step's stream forms).  Gradients keep record_stream (they live until the next
+    zero_grad anyway)."""
+    hold = config.active().wgrad_hold
+    if hold <= 0 or torch.cuda.is_current_stream_capturing():
+        for t in tensors:
+            t.record_stream(side)
+        return
+    ev = torch.cuda.Event()
+    ev.record(side)
+    _side_holds.append((ev, torch.cuda.current_stream(side.device), tensors))
+    while len(_side_holds) > hold:
+        ev0, owner, _ = _side_holds.popleft()
+        owner.wait_event(ev0)
+
+
 def join_side():
     """Make the current stream of every device that used its side stream wait for it."""
     for idx in list(_side_dirty):
         torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
     _side_dirty.clear()
+    while _side_holds:
+        ev0, owner, _ = _side_holds.popleft()
+        owner.wait_event(ev0)
 
 
 def workspace(nbytes, device, tag="default"):

@@ -33,6 +33,7 @@ class StepConfig:
     teacher_stream: bool = True          # teacher forward(s) on a second HIP stream next to the student's forward
     teacher_offset: str = "layer1"       # the student stage behind which the teacher is enqueued ("" / "0": both at once)
     wgrad_stream: bool = True            # weight gradients on a side stream next to the backward-data / BatchNorm chain
+    wgrad_hold: int = 4                  # ... whose inputs are held for this many layers and released behind an event (0: record_stream)
     c4_overlap: int = 2                  # self-training step: 0 one backward pass; 1 cross-mixed fwd/bwd on a third stream; 2 the whole target branch
     c4_overlap_gloo: bool = False        # keep the overlapped forms under the gloo smoke-test backend (slow there, not wrong)
     step_graph: bool = False             # replay the static part of the warm-up step from a HIP graph (launch-bound configurations)
@@ -71,6 +72,7 @@ class StepConfig:
         c.teacher_stream = _flag("DIGA_TEACHER_STREAM", c.teacher_stream)
         c.teacher_offset = e("DIGA_TEACHER_OFFSET", c.teacher_offset)
         c.wgrad_stream = _flag("DIGA_WGRAD_STREAM", c.wgrad_stream)
+        c.wgrad_hold = int(e("DIGA_WGRAD_HOLD", c.wgrad_hold))
         c.c4_overlap = int(e("DIGA_C4_OVERLAP", c.c4_overlap))
         c.c4_overlap_gloo = _flag("DIGA_C4_OVERLAP_GLOO", c.c4_overlap_gloo)
         c.step_graph = _flag("DIGA_STEP_GRAPH", c.step_graph)
@@ -104,6 +106,8 @@ class StepConfig:
             raise ValueError(f"centroid_exchange must be 'allgather' or 'allreduce', not {self.centroid_exchange!r}")
         if self.c4_overlap not in (0, 1, 2):
             raise ValueError(f"c4_overlap must be 0, 1 or 2, not {self.c4_overlap!r}")
+        if self.wgrad_hold < 0:
+            raise ValueError(f"wgrad_hold must be >= 0, not {self.wgrad_hold!r}")
         if self.conv_math not in (0, 1):
             raise ValueError(f"conv_math must be 0 (fp32) or 1 (split bf16), not {self.conv_math!r}")
         if self.winograd_max_tile not in (2, 4, 6):

@@ -680,8 +680,9 @@ class _Conv2dFn(torch.autograd.Function):
                 side.wait_stream(torch.cuda.current_stream(w.device))
                 with torch.cuda.stream(side):
                     run()
-                for tns in (gyp, xn, dwp, dw) + ((dy_twin, x_twin) if use_tw else ()) + ((wino_v,) if wino_v is not None else ()):
-                    tns.record_stream(side)
+                dw.record_stream(side)          # (a returned gradient: never held, see _lib.release_to_side)
+                _lib.release_to_side(side, (gyp, xn) + (() if alias else (dwp,)) + ((dy_twin, x_twin) if use_tw else ())
+                                     + ((wino_v,) if wino_v is not None else ()))
         if has_bias and ctx.needs_input_grad[2]:
             db = _bias_grad(gy)
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None

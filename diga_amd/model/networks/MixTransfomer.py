@@ -154,8 +154,7 @@ class _Ops:
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
                 res = self._wgrad_launch(dy, x, scale, bias, m, n, k)
-            for t in (dy, x):
-                t.record_stream(side)
+            _lib.release_to_side(side, (dy, x))
             return res
         return self._wgrad_launch(dy, x, scale, bias, m, n, k)
 

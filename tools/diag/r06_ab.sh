@@ -15,7 +15,7 @@ for round in $(seq 1 $N); do
     for item in $rest; do
       case "$item" in +*) flags="$flags ${item#+}";; *) envs="$envs $item";; esac
     done
-    line=$(env $envs python $R/bench.py --lean $BASE $flags --steps 12 --warmup 3 2>/dev/null | tail -1)
+    line=$(env $envs python $R/bench.py --lean $BASE $flags --steps 12 --warmup 3 2>$R/gpurun_out/r06_ab_last_stderr.txt | tail -1)
     ms=$(echo "$line" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'alloc', round(d.get('peak_mem_gb',{}).get('allocated',0),1), 'resv', round(d.get('peak_mem_gb',{}).get('reserved',0),1))" 2>/dev/null)
     echo "$round $name $ms" | tee -a $OUT
   done
