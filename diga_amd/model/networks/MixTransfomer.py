@@ -154,7 +154,8 @@ class _Ops:
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
                 res = self._wgrad_launch(dy, x, scale, bias, m, n, k)
-            _lib.release_to_side(side, (dy, x))
+            for t in (dy, x):                   # (small tensors, hundreds of launches: the allocator's deferred reuse costs nothing here and
+                t.record_stream(side)           #  _lib.release_to_side's event per launch measured +2 ms of host time on the eager step)
             return res
         return self._wgrad_launch(dy, x, scale, bias, m, n, k)
 
