@@ -266,7 +266,7 @@ def take_consumed_flag(flag):
 # ---- optional second stream for work that is off the critical path (weight gradients during backward)
 _side_streams = {}
 _side_dirty = set()
-_side_holds = collections.deque()   # (event on the side stream, owning stream, tensors): release_to_side
+_side_holds = {}                    # owning stream -> deque of (event on the side stream, owning stream, tensors): release_to_side
 side_overlap = False          # switched on by the step driver around backward(); plain autograd users stay in line
 
 
@@ -295,7 +295,7 @@ def release_to_side(side, tensors):
     has completed -- polled from the HOST at the next allocation.  The host runs a backward pass far ahead of the device, so those
     events are never complete when it asks, every such block (an activation, an output gradient, a kept transform) stays out of the
     pool until well into the next step, and the pool opens new segments instead: 126 GB reserved on the main stream for tensors that
-    peak at 104 GB (profiles/r06_memory_by_stream.txt).  Instead the tensors are kept alive HERE for `wgrad_hold` more layers, and the
+    peak at 104 GB (profiles/r06_memory_by_stream.txt).  Instead the tensors are kept alive HERE for `wgrad_hold` (+ up to `wgrad_hold_batch`) more layers, and the
     stream that owns them is made to wait (on the device) for the side stream's event of that time before the reference is dropped:
     the block is then free in stream order, reusable by the very next allocation, and the wait is on work the side stream finished
     layers ago.  wgrad_hold = 0, and stream capture, keep record_stream.
@@ -311,10 +311,25 @@ def release_to_side(side, tensors):
         return
     ev = torch.cuda.Event()
     ev.record(side)
-    _side_holds.append((ev, torch.cuda.current_stream(side.device), tensors))
-    while len(_side_holds) > hold:
-        ev0, owner, _ = _side_holds.popleft()
-        owner.wait_event(ev0)
+    owner = torch.cuda.current_stream(side.device)
+    key = (owner.device.index, owner.cuda_stream)        # one queue per owning stream: the self-training step feeds the side stream from two
+    queue = _side_holds.get(key)
+    if queue is None:
+        queue = _side_holds[key] = collections.deque()
+    queue.append((ev, owner, tensors))
+    # released in batches: every device-side wait is a barrier packet in the owner's queue (one per layer measured +6 ms on the
+    # self-training step's 2 x 105 layers); events of one stream complete in order, so the batch's LAST event covers the batch
+    batch = max(1, config.active().wgrad_hold_batch)
+    if len(queue) >= hold + batch:
+        ev0, owner0, _ = queue[batch - 1]
+        owner0.wait_event(ev0)
+        for _ in range(batch):
+            queue.popleft()
+
+
+def held_for_side():
+    """Number of entries release_to_side is holding (tests)."""
+    return sum(len(q) for q in _side_holds.values())
 
 
 def join_side():
@@ -322,9 +337,11 @@ def join_side():
     for idx in list(_side_dirty):
         torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
     _side_dirty.clear()
-    while _side_holds:
-        ev0, owner, _ = _side_holds.popleft()
-        owner.wait_event(ev0)
+    for queue in _side_holds.values():
+        if queue:
+            ev0, owner, _ = queue[-1]
+            owner.wait_event(ev0)
+            queue.clear()
 
 
 def workspace(nbytes, device, tag="default"):

@@ -34,6 +34,7 @@ class StepConfig:
     teacher_offset: str = "layer1"       # the student stage behind which the teacher is enqueued ("" / "0": both at once)
     wgrad_stream: bool = True            # weight gradients on a side stream next to the backward-data / BatchNorm chain
     wgrad_hold: int = 4                  # ... whose inputs are held for this many layers and released behind an event (0: record_stream)
+    wgrad_hold_batch: int = 4            # ... that many at a time (one device-side wait per batch)
     c4_overlap: int = 2                  # self-training step: 0 one backward pass; 1 cross-mixed fwd/bwd on a third stream; 2 the whole target branch
     c4_overlap_gloo: bool = False        # keep the overlapped forms under the gloo smoke-test backend (slow there, not wrong)
     step_graph: bool = False             # replay the static part of the warm-up step from a HIP graph (launch-bound configurations)
@@ -73,6 +74,7 @@ class StepConfig:
         c.teacher_offset = e("DIGA_TEACHER_OFFSET", c.teacher_offset)
         c.wgrad_stream = _flag("DIGA_WGRAD_STREAM", c.wgrad_stream)
         c.wgrad_hold = int(e("DIGA_WGRAD_HOLD", c.wgrad_hold))
+        c.wgrad_hold_batch = int(e("DIGA_WGRAD_HOLD_BATCH", c.wgrad_hold_batch))
         c.c4_overlap = int(e("DIGA_C4_OVERLAP", c.c4_overlap))
         c.c4_overlap_gloo = _flag("DIGA_C4_OVERLAP_GLOO", c.c4_overlap_gloo)
         c.step_graph = _flag("DIGA_STEP_GRAPH", c.step_graph)

@@ -27,7 +27,7 @@ def test_release_to_side_holds_then_releases_behind_an_event():
     main = torch.cuda.current_stream(dev)
     _lib.side_overlap = True
     try:
-        with config.override(wgrad_stream=True, wgrad_hold=2):
+        with config.override(wgrad_stream=True, wgrad_hold=2, wgrad_hold_batch=1):
             side = _lib.side_stream(dev)
             assert side is not None
             sums = []
@@ -44,7 +44,7 @@ def test_release_to_side_holds_then_releases_behind_an_event():
                     sums.append(t.sum())                         # the side stream reads t
                 _lib.release_to_side(side, (t,))
                 del t
-                assert len(_lib._side_holds) == min(i + 1, 2)    # never more than `wgrad_hold` entries
+                assert _lib.held_for_side() == min(i + 1, 2)    # never more than `wgrad_hold` entries
                 # a released block is free in stream order -- back in its pool the moment the queue drops it, not parked behind an event the
                 # host has yet to see complete: only the held tensors (and the few bytes of the sums) are active
                 assert abs(active() - base - min(i + 1, 2) * nbytes) < (64 << 10), (i, active() - base)
@@ -52,13 +52,27 @@ def test_release_to_side_holds_then_releases_behind_an_event():
                 again.fill_(-1.0)
                 del again
             _lib.join_side()
-            assert len(_lib._side_holds) == 0
+            assert _lib.held_for_side() == 0
             torch.cuda.synchronize()
             assert [float(v) for v in sums] == [float(i) * (1 << 20) for i in range(5)]
+            del sums[:]
+        with config.override(wgrad_stream=True, wgrad_hold=2, wgrad_hold_batch=3):   # released three at a time behind ONE wait
+            seen = []
+            for i in range(9):
+                t = torch.full((1 << 20,), 1.0, device=dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    sums.append(t.sum())
+                _lib.release_to_side(side, (t,))
+                del t
+                seen.append(_lib.held_for_side())
+            assert seen == [1, 2, 3, 4, 2, 3, 4, 2, 3], seen
+            _lib.join_side()
+            assert _lib.held_for_side() == 0
         with config.override(wgrad_stream=True, wgrad_hold=0):      # 0: the allocator's record_stream, nothing held
             t = torch.ones((1 << 20,), device=dev)
             _lib.release_to_side(_lib.side_stream(dev), (t,))
-            assert len(_lib._side_holds) == 0
+            assert _lib.held_for_side() == 0
             _lib.join_side()
     finally:
         _lib.side_overlap = False
@@ -95,7 +109,7 @@ def test_warmup_steps_do_not_move_by_a_bit_under_the_hold(arch, conv_math):
         return losses, {k: v.clone() for k, v in student.state_dict().items()}
 
     la, sa = run(0)
-    for hold in (config.StepConfig().wgrad_hold, 1000):
+    for hold in (config.StepConfig().wgrad_hold, 1, 1000):
         lb, sb = run(hold)
         assert la == lb, (hold, la, lb)
         for k in sa:
