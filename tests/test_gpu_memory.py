@@ -120,6 +120,7 @@ def test_warmup_steps_do_not_move_by_a_bit_under_the_hold(arch, conv_math):
 def test_c2_reserved_memory_within_1p2_of_allocated():
     """BASELINE configs[1] (ResNet-101, B = 8 crops of 768 x 768, fp32, default streams) in a fresh process: the peak the caching
     allocator holds from the driver over the timed steps stays within 1.2 x the peak of the step's tensors.  (Round 5: 1.54 x.)"""
+    torch.cuda.empty_cache()                      # (this process's cache of earlier tests must not crowd the child's 125 GB)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lean", "--steps", "3", "--warmup", "2"],
                        capture_output=True, text=True, timeout=800, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -137,6 +138,7 @@ def test_c4_three_stream_form_holds_no_more_than_the_one_backward_form_needs():
     `reserved` above 1.2 x ITS OWN `allocated` -- it frees the first student graph while the second still runs, 106 GB at the high-water
     mark where the one-backward form has 146 GB -- but what it holds from the driver must stay within 1.2 x of what the one-backward form's
     tensors occupy (measured 169.9 GB against 1.2 x 145.6 = 174.7; with record_stream it was 210 GB)."""
+    torch.cuda.empty_cache()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lean", "--config", "c4", "--steps", "2", "--warmup", "2"],
                        capture_output=True, text=True, timeout=800, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
