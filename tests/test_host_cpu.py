@@ -632,6 +632,14 @@ def test_step_config_is_explicit_and_reads_the_environment_once(monkeypatch):
     assert config.active().c4_overlap == base.c4_overlap
     assert config.StepConfig.from_env().c4_overlap == 1
     assert len(dataclasses.fields(config.StepConfig)) >= 25
+    # round 6: the weight-gradient hold (how long a side-stream kernel's inputs are kept before their stream-ordered release)
+    assert (base.wgrad_hold, base.wgrad_hold_batch) == (4, 4)
+    monkeypatch.setenv("DIGA_WGRAD_HOLD", "0")
+    monkeypatch.setenv("DIGA_WGRAD_HOLD_BATCH", "2")
+    e = config.StepConfig.from_env()
+    assert (e.wgrad_hold, e.wgrad_hold_batch) == (0, 2)
+    with pytest.raises(ValueError):
+        base.replace(wgrad_hold=-1)
     # no module of the package assigns to os.environ (ddp.init_from_env only .setdefault()s MASTER_ADDR / MASTER_PORT)
     for f in glob.glob(os.path.join(ROOT, "diga_amd", "**", "*.py"), recursive=True):
         src = open(f).read()
